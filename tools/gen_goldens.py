@@ -1,0 +1,326 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, where /root/reference exists).
+
+Imports the reference's own hot-path modules (read-only, no bytecode written) with `sys.modules`
+stubs for packages that are imported but never called on the path (cv2, omegaconf, easydict;
+SURVEY.md Appendix C), runs them on small seeded inputs and writes inputs + expected outputs as
+`.npz` fixtures under tests/golden/.  The fixtures are data only; no reference source travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
+
+Reference entry points executed here:
+  utils/pcd.py        pdist('inv_norm_cosine'), nn_correspondences, lift_pcd
+  utils/coordinates.py scale_coords, get_valid_coords
+  models/pointdsc/common.py   rigid_transform_3d, knn
+  models/pointdsc/PointDSC.py PointDSC (encoder, classification, pick_seeds, cal_seed_trans,
+                              cal_leading_eigenvector, post_refinement, forward)
+  utils/pointdsc/init.py      get_pointdsc_pose
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+for _name, _attrs in {"cv2": {}, "omegaconf": {"DictConfig": dict, "OmegaConf": object},
+                      "easydict": {"EasyDict": dict}}.items():
+    _m = types.ModuleType(_name)
+    _m.__dict__.update(_attrs)
+    sys.modules[_name] = _m
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from utils.pcd import nn_correspondences, lift_pcd, pdist  # noqa: E402  (reference)
+from utils import coordinates  # noqa: E402  (reference)
+from utils.pointdsc.init import get_pointdsc_pose  # noqa: E402  (reference)
+from models.pointdsc.PointDSC import PointDSC  # noqa: E402  (reference)
+from models.pointdsc.common import rigid_transform_3d, knn  # noqa: E402  (reference)
+
+from oracle.oryon_oracle import analytic_pointdsc_params  # noqa: E402  (ours: closed-form weights)
+from oryon_amd.synth import make_pair  # noqa: E402  (ours: synthetic pair)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **conv)
+    print(f"wrote {name}.npz  ({sum(a.nbytes for a in conv.values()) / 1024:.1f} KiB raw)")
+
+
+# ---------------------------------------------------------------------------------------------- G1
+def matcher_case(tag, C, H, W, seed, mask_kind, threshold=0.25, ties=False, zero_desc=False, correlated=True):
+    g = torch.Generator().manual_seed(seed)
+    f1 = torch.randn(C, H, W, generator=g)
+    f2 = torch.randn(C, H, W, generator=g)
+    if correlated:  # make a share of query pixels near-copies of anchor pixels so some rows pass the threshold
+        perm = torch.randperm(H * W, generator=g)
+        n = (H * W) // 2
+        f2v = f2.view(C, -1)
+        f2v[:, perm[:n]] = f1.view(C, -1)[:, perm[n:2 * n]] + 0.15 * torch.randn(C, n, generator=g)
+    m1 = torch.zeros(H, W, dtype=torch.int32)
+    m2 = torch.zeros(H, W, dtype=torch.int32)
+    if mask_kind == "boxes":
+        m1[H // 4:3 * H // 4, W // 5:4 * W // 5] = 1
+        m2[H // 6:5 * H // 6, W // 6:5 * W // 6] = 1
+    elif mask_kind == "ones":
+        m1[:] = 1
+        m2[:] = 1
+    elif mask_kind == "random":
+        m1 = (torch.rand(H, W, generator=g) > 0.6).to(torch.int32)
+        m2 = (torch.rand(H, W, generator=g) > 0.4).to(torch.int32)
+    elif mask_kind == "empty_a":
+        m2[:] = 1
+    elif mask_kind == "single":
+        m1[H // 2, W // 2] = 1
+        m2[H // 3, W // 3] = 1
+        m2[H // 3, W // 3 + 1] = 1
+    elif mask_kind == "values":   # mask holding values other than {0,1}: only ==1 counts
+        m1 = torch.randint(0, 3, (H, W), generator=g, dtype=torch.int32)
+        m2 = torch.randint(0, 3, (H, W), generator=g, dtype=torch.int32)
+    if ties:       # duplicate query descriptors -> exact ties, first index must win
+        f2v = f2.view(C, -1)
+        f2v[:, 1::2] = f2v[:, 0::2][:, : f2v[:, 1::2].shape[1]]
+    if zero_desc:  # all-zero descriptors exercise the eps clamp
+        f1[:, H // 2, :] = 0
+        f2[:, :, W // 2] = 0
+    roi1 = torch.nonzero(m1 == 1)
+    roi2 = torch.nonzero(m2 == 1)
+    out = dict(feats1=f1, feats2=f2, mask1=m1, mask2=m2, threshold=np.float32(threshold), roi1=roi1, roi2=roi2)
+    if roi1.shape[0] and roi2.shape[0]:
+        a = f1[:, roi1[:, 0], roi1[:, 1]].T.to(torch.float32)
+        b = f2[:, roi2[:, 0], roi2[:, 1]].T.to(torch.float32)
+        dist = pdist(a, b, "inv_norm_cosine")                       # reference utils/pcd.py:202
+        min_dist = torch.amin(dist, dim=1)                          # :203
+        arg = torch.argmin(dist, dim=1)                             # :204
+        if dist.shape[1] > 1:
+            top2 = torch.topk(dist, 2, dim=1, largest=False)[0]
+            gap = top2[:, 1] - top2[:, 0]
+        else:
+            gap = torch.full_like(min_dist, float("inf"))
+        # a row is an exact tie if another column holds exactly the minimum
+        ntie = (dist == min_dist[:, None]).sum(dim=1)
+        out.update(min_dist=min_dist, argmin=arg, valid=(min_dist < threshold), gap=gap, n_at_min=ntie)
+    torch.manual_seed(1)
+    corrs = nn_correspondences(f1.clone(), f2.clone(), m1, m2, threshold, 500, 5000, "cpu")   # full reference call
+    out["sampled_is_none"] = np.bool_(corrs is None)
+    if corrs is not None:
+        out["sampled_corrs"] = corrs
+    save(f"g1_matcher_{tag}", **out)
+
+
+def gen_matcher():
+    matcher_case("c32_24", 32, 24, 24, 11, "boxes")
+    matcher_case("c256_16", 256, 16, 16, 12, "ones")
+    matcher_case("c32_48", 32, 48, 48, 13, "random")
+    matcher_case("ties", 16, 20, 20, 14, "ones", ties=True)
+    matcher_case("zero", 8, 16, 16, 15, "ones", zero_desc=True)
+    matcher_case("empty_a", 8, 12, 12, 16, "empty_a")
+    matcher_case("single", 8, 12, 12, 17, "single")
+    matcher_case("values", 24, 20, 28, 18, "values")
+    matcher_case("nomatch", 64, 16, 16, 19, "ones", correlated=False)      # nothing under threshold -> None
+    matcher_case("subsample", 8, 80, 80, 20, "ones")                        # N1 = 6400 > 5000 -> first RNG draw
+
+
+# ---------------------------------------------------------------------------------------------- G2
+def lift_case(tag, HA, WA, HQ, WQ, FH, FW, K_a, K_q, seed, depth_dtype):
+    g = torch.Generator().manual_seed(seed)
+    n = 300
+    corrs = torch.stack([torch.randint(0, FH, (n,), generator=g), torch.randint(0, FW, (n,), generator=g),
+                         torch.randint(0, FH, (n,), generator=g), torch.randint(0, FW, (n,), generator=g)], dim=1)
+    corrs[:4] = torch.tensor([[0, 0, 0, 0], [FH - 1, FW - 1, FH - 1, FW - 1], [0, FW - 1, FH - 1, 0], [FH - 1, 0, 0, FW - 1]])
+    depth_a = torch.randint(300, 3000, (HA, WA), generator=g).to(depth_dtype)
+    depth_q = torch.randint(300, 3000, (HQ, WQ), generator=g).to(depth_dtype)
+    depth_a[torch.rand(HA, WA, generator=g) < 0.1] = 0     # zero-depth pixels are NOT filtered by the reference
+    depth_q[torch.rand(HQ, WQ, generator=g) < 0.1] = 0
+    cam_a = torch.tensor(K_a, dtype=torch.float64).reshape(9)
+    cam_q = torch.tensor(K_q, dtype=torch.float64).reshape(9)
+    sizes_a, sizes_q = torch.tensor([HA, WA]), torch.tensor([HQ, WQ])
+    HAt, WAt = sizes_a     # 0-dim int64 tensors, exactly what pipeline.py:438-439 holds
+    HQt, WQt = sizes_q
+    ca, cq = corrs[:, :2].clone(), corrs[:, 2:].clone()
+    ca = coordinates.scale_coords(ca, (FH, FW), (HAt, WAt))          # pipeline.py:447
+    cq = coordinates.scale_coords(cq, (FH, FW), (HQt, WQt))          # :448
+    va = coordinates.get_valid_coords(ca, (HAt, WAt))                # :449
+    vq = coordinates.get_valid_coords(cq, (HQt, WQt))                # :450
+    valid = torch.logical_and(va, vq)
+    ca, cq = ca[valid].to(torch.long), cq[valid].to(torch.long)      # :453-456
+    pcd_a = lift_pcd(depth_a.unsqueeze(-1), cam_a, (ca[:, 1], ca[:, 0])) / 1000.   # :459
+    pcd_q = lift_pcd(depth_q.unsqueeze(-1), cam_q, (cq[:, 1], cq[:, 0])) / 1000.   # :460
+    save(f"g2_lift_{tag}", corrs=corrs.to(torch.int16), depth_a=depth_a.to(torch.int16), depth_q=depth_q.to(torch.int16),
+         depth_is_float=np.bool_(depth_dtype == torch.float32),
+         cam_a=cam_a, cam_q=cam_q, feat_hw=np.array([FH, FW]), size_a=np.array([HA, WA]), size_q=np.array([HQ, WQ]),
+         valid=valid, pix_a=ca.to(torch.int16), pix_q=cq.to(torch.int16), pcd_a=pcd_a, pcd_q=pcd_q,
+         pcd_dtype=str(pcd_a.dtype))
+
+
+def gen_lift():
+    K_nocs = [[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]]        # datasets.py:398
+    K_toyl = [[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]]  # datasets.py:573
+    lift_case("nocs", 480, 640, 480, 640, 192, 192, K_nocs, K_nocs, 21, torch.int32)
+    lift_case("toyl", 480, 640, 480, 640, 192, 192, K_toyl, K_toyl, 22, torch.float32)
+    lift_case("nonsquare", 375, 501, 240, 320, 192, 192, K_nocs, K_toyl, 23, torch.int32)
+    lift_case("feat224", 224, 224, 224, 224, 224, 224, [[280.0, 0, 112.0], [0, 280.0, 112.0], [0, 0, 1]],
+              [[280.0, 0, 112.0], [0, 280.0, 112.0], [0, 0, 1]], 24, torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------- G3
+def _rand_rot(g):
+    q = torch.randn(4, generator=g, dtype=torch.float64)
+    q = q / q.norm()
+    w, x, y, z = q
+    return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=torch.float64)
+
+
+def gen_kabsch():
+    g = torch.Generator().manual_seed(31)
+    bs, m = 12, 40
+    A = torch.randn(bs, m, 3, generator=g) * 0.2
+    B = torch.zeros_like(A)
+    for b in range(bs):
+        R = _rand_rot(g).float()
+        t = torch.randn(3, generator=g) * 0.3
+        B[b] = A[b] @ R.T + t + 0.002 * torch.randn(m, 3, generator=g)
+    w = torch.rand(bs, m, generator=g)
+    w[0] = 1.0
+    w[1, ::2] = 0.0                       # zero weights
+    w[2, :5] = -0.5                       # negative weights are clipped (common.py:20)
+    A[3, :, 2] = 0.0                      # coplanar source
+    B[3] = A[3] @ _rand_rot(g).float().T + 0.1
+    B[4] = A[4] * torch.tensor([1.0, 1.0, -1.0])   # reflection: det correction must kick in
+    w[5] = 0.0
+    w[5, 3] = 1.0                         # single effective point
+    w_in = w.clone()
+    T = rigid_transform_3d(A.clone(), B.clone(), w_in)              # reference common.py:7-45 (mutates w_in)
+    T_now = rigid_transform_3d(A.clone(), B.clone(), None)
+    save("g3_kabsch", A=A, B=B, w=w, T=T, T_noweights=T_now)
+
+
+# ---------------------------------------------------------------------------------------------- G4
+def synthetic_corr_set(n, seed, inlier_ratio=0.6, extent=0.15, dup=0):
+    """n putative 3D-3D correspondences on an object-sized cloud, a share of them outliers."""
+    g = torch.Generator().manual_seed(seed)
+    src = (torch.rand(n, 3, generator=g) - 0.5) * 2 * extent + torch.tensor([0.0, 0.0, 0.8])
+    R = _rand_rot(g).float()
+    t = torch.randn(3, generator=g) * 0.1
+    tgt = src @ R.T + t + 0.001 * torch.randn(n, 3, generator=g)
+    n_out = int(n * (1 - inlier_ratio))
+    out_idx = torch.randperm(n, generator=g)[:n_out]
+    tgt[out_idx] = (torch.rand(n_out, 3, generator=g) - 0.5) * 2 * extent + tgt.mean(0)
+    if dup:
+        src[-dup:] = src[:dup]
+        tgt[-dup:] = tgt[:dup]
+    T = torch.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return src, tgt, T
+
+
+def pointdsc_case(tag, n, num_layers, C, seed, extent=0.15, inlier_ratio=0.6, dup=0, pseed=0):
+    cfg = dict(num_layers=num_layers, num_channels=C, num_iterations=10, ratio=0.1, sigma_d=0.1, k=40, nms_radius=0.1,
+               inlier_threshold=0.1)
+    model = PointDSC(in_dim=6, num_layers=num_layers, num_channels=C, num_iterations=10, ratio=0.1, sigma_d=0.1,
+                     k=40, nms_radius=0.1)                     # exactly the kwargs init.py:41-50 forwards
+    model.load_state_dict(analytic_pointdsc_params(num_layers, C, seed=pseed), strict=True)
+    model.eval()
+    src, tgt, T_gt = synthetic_corr_set(n, seed, inlier_ratio, extent, dup)
+    with torch.no_grad():
+        corr_pos = torch.cat([src, tgt], dim=-1)
+        corr_pos = corr_pos - corr_pos.mean(0)                 # init.py:18-19
+        s, t_ = src[None], tgt[None]
+        src_dist = torch.norm((s[:, :, None, :] - s[:, None, :, :]), dim=-1)                     # PointDSC.py:151
+        comp = src_dist - torch.norm((t_[:, :, None, :] - t_[:, None, :, :]), dim=-1)
+        comp = torch.clamp(1.0 - comp ** 2 / model.sigma_spat ** 2, min=0)                        # :153
+        feats = model.encoder(corr_pos[None].permute(0, 2, 1), comp).permute(0, 2, 1)            # :155
+        nfeats = F.normalize(feats, p=2, dim=-1)                                                   # :156
+        conf = model.classification(feats.permute(0, 2, 1)).squeeze(1)                            # :171
+        rel = (conf.T >= conf) | (src_dist[0] >= model.nms_radius)
+        is_local_max = rel.min(-1)[0]                                                              # :212-216
+        seeds = model.pick_seeds(src_dist, conf, R=model.nms_radius, max_num=int(n * model.ratio))  # :174
+        k = min(model.k, n - 1)
+        knn_all = knn(nfeats, k=k, ignore_self=True, normalized=True)                             # :250
+        seed_trans, seed_fit, init_trans, labels = model.cal_seed_trans(seeds, nfeats, s, t_)    # :182
+        final = model.post_refinement(init_trans, s, t_)                                          # :186
+        full = model({"corr_pos": corr_pos[None], "src_keypts": s, "tgt_keypts": t_, "testing": True})
+        pose = get_pointdsc_pose(model, src, tgt, "cpu")                                          # init.py:10-29
+        # number of strictly positive local maxima -> are the seeds well-defined (no zero-key ties)?
+        n_pos_max = int(((conf[0] > 0) & is_local_max.bool()).sum())
+    assert torch.equal(full["final_trans"][0], final[0])
+    save(f"g4_pointdsc_{tag}", src=src, tgt=tgt, T_gt=T_gt, n=n, num_layers=num_layers, C=C, pseed=pseed,
+         SC_rows=comp[0, :32], src_dist_rows=src_dist[0, :32], feat=feats[0], confidence=conf[0],
+         is_local_max=is_local_max, seeds=seeds[0].to(torch.int16), n_pos_max=n_pos_max, knn_all=knn_all[0].to(torch.int16),
+         seed_trans=seed_trans[0], seed_fitness=seed_fit[0], init_trans=init_trans[0], init_labels=labels[0],
+         final_trans=final[0], final_labels=full["final_labels"][0], pose=pose)
+
+
+def gen_pointdsc():
+    pointdsc_case("l2c32_n41", 41, 2, 32, 41)
+    pointdsc_case("l2c32_n128", 128, 2, 32, 42)
+    pointdsc_case("l12c128_n128", 128, 12, 128, 43)
+    pointdsc_case("l12c128_n500", 500, 12, 128, 44, extent=0.4)   # scene-sized: many local maxima
+    pointdsc_case("l12c128_n500_obj", 500, 12, 128, 45, extent=0.12, dup=60)  # object-sized + duplicate rows
+    pointdsc_case("l6c128_n200", 200, 6, 128, 46, inlier_ratio=0.3, pseed=1)
+
+
+# ---------------------------------------------------------------------------------------------- G6
+def gen_end_to_end():
+    H = W = 48
+    C = 32
+    p = make_pair(3, H, W, C)
+    cfg = dict(num_layers=2, C=32)
+    model = PointDSC(in_dim=6, num_layers=2, num_channels=32, num_iterations=10, ratio=0.1, sigma_d=0.1, k=40, nms_radius=0.1)
+    model.load_state_dict(analytic_pointdsc_params(2, 32), strict=True)
+    model.eval()
+    f1, f2, m1, m2 = p["feat_a"], p["feat_q"], p["mask_a"], p["mask_q"]
+    roi1 = torch.nonzero(m1 == 1)
+    roi2 = torch.nonzero(m2 == 1)
+    a = f1[:, roi1[:, 0], roi1[:, 1]].T
+    b = f2[:, roi2[:, 0], roi2[:, 1]].T
+    dist = pdist(a, b, "inv_norm_cosine")
+    min_dist, arg = torch.amin(dist, 1), torch.argmin(dist, 1)
+    top2 = torch.topk(dist, 2, dim=1, largest=False)[0]
+    torch.manual_seed(1)
+    corrs = nn_correspondences(f1.clone(), f2.clone(), m1, m2, 0.25, 500, 5000, "cpu")
+    sizes = torch.tensor([H, W])
+    Ht, Wt = sizes
+    ca = coordinates.scale_coords(corrs[:, :2].clone(), (H, W), (Ht, Wt))
+    cq = coordinates.scale_coords(corrs[:, 2:].clone(), (H, W), (Ht, Wt))
+    valid = torch.logical_and(coordinates.get_valid_coords(ca, (Ht, Wt)), coordinates.get_valid_coords(cq, (Ht, Wt)))
+    ca, cq = ca[valid].to(torch.long), cq[valid].to(torch.long)
+    cam = p["camera"].reshape(9)
+    pcd_a = lift_pcd(p["depth_a"].unsqueeze(-1), cam, (ca[:, 1], ca[:, 0])) / 1000.
+    pcd_q = lift_pcd(p["depth_q"].unsqueeze(-1), cam, (cq[:, 1], cq[:, 0])) / 1000.
+    pose = get_pointdsc_pose(model, pcd_a, pcd_q, "cpu")
+    anchor_pose = torch.eye(4)
+    anchor_pose[:3, 3] = torch.tensor([0.01, -0.02, 0.8])
+    pred_q = pose @ anchor_pose                                         # pipeline.py:320
+    save("g6_end_to_end", pair_index=3, H=H, W=W, C=C, roi1=roi1, roi2=roi2, min_dist=min_dist, argmin=arg,
+         gap=top2[:, 1] - top2[:, 0], valid=min_dist < 0.25, sampled_corrs=corrs, lift_valid=valid,
+         pcd_a=pcd_a, pcd_q=pcd_q, pose=pose, pose_gt=p["pose"], anchor_pose=anchor_pose, pred_q=pred_q)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e"]
+    if "matcher" in which:
+        gen_matcher()
+    if "lift" in which:
+        gen_lift()
+    if "kabsch" in which:
+        gen_kabsch()
+    if "pointdsc" in which:
+        gen_pointdsc()
+    if "e2e" in which:
+        gen_end_to_end()
