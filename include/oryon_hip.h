@@ -1,0 +1,179 @@
+/* liboryon_hip.so — C ABI of the MI355X-native Oryon hot path (gfx950 only).
+ *
+ * The reference (jcorsetti/oryon) is pure Python/PyTorch and has no FFI; its boundary for this path is a
+ * set of Python callables.  Each entry point below replaces the PyTorch expression(s) cited next to it
+ * (file:line into the reference tree) and is what a ctypes binding on the reference side would load
+ * (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller owns all buffers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are asynchronous on
+ *     it, never synchronise, never allocate (except oryon_pointdsc_create/_finalize);
+ *   - return value: ORYON_OK or a negative ORYON_ERR_*; nothing throws; oryon_last_error() gives text;
+ *   - per-pair outcomes (no mask / no correspondences) are DATA, reported in `status` arrays with the
+ *     reference's own failure semantics (pipeline.py:335-350), not error codes;
+ *   - thread-safe for distinct streams; no global state besides the last-error string (thread local).
+ */
+#ifndef ORYON_HIP_H
+#define ORYON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORYON_OK 0
+#define ORYON_ERR_INVALID_ARG (-1)
+#define ORYON_ERR_HIP (-2)
+#define ORYON_ERR_WORKSPACE (-3)
+#define ORYON_ERR_NO_DEVICE (-4)
+#define ORYON_ERR_STATE (-5)
+
+/* per-pair status values (pipeline.py:316-350: invalid detection / matcher returned None / pose ok) */
+#define ORYON_PAIR_OK 0
+#define ORYON_PAIR_NO_MASK 1
+#define ORYON_PAIR_NO_CORR 2
+
+/* matcher tile geometry the padded capacities must respect */
+#define ORYON_MATCH_TILE 128
+
+const char *oryon_version(void);
+const char *oryon_last_error(void);
+/* ORYON_OK iff device `device` exists and is gfx950. */
+int oryon_device_check(int device);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K0  mask -> ROI.   Replaces torch.nonzero(mask == 1) (utils/pcd.py:184-185) and the validity test
+ *     count_nonzero(mask == 1) > 0 (pipeline.py:391-393).
+ * mask  [n_maps, HW] int32        roi [n_maps, HW] int32 (linear pixel index y*W+x, row-major order)
+ * count [n_maps] int32
+ */
+int oryon_roi_compact(const int32_t *mask, int n_maps, int HW, int32_t *roi, int32_t *count, void *stream);
+
+/* K0  sigmoid(logit) > threshold -> {0,1} int32 mask.  Replaces losses.py:58-59 (test.mask == predicted). */
+int oryon_mask_from_logits(const float *logits, int64_t n, float threshold, int32_t *mask, void *stream);
+
+/* K0  legacy-nearest resize of an integer mask to the feature-map grid (src = floor(dst * in/out) computed
+ *     with the fp32 scale, as torch F.interpolate(mode='nearest') does).  Replaces pipeline.py:408-411. */
+int oryon_mask_resize_nearest(const uint8_t *mask_in, int n_maps, int HI, int WI, int HO, int WO,
+                              int32_t *mask_out, void *stream);
+
+/* K0  device-side subsample WITHOUT replacement to at most max_keep entries per map, keeping row-major
+ *     order.  Counter-based RNG keyed by (seed, map_key[m], element) so the result is independent of how
+ *     maps are sharded over GPUs.  Stands in for torch_sample_select (utils/misc.py:242-254, called at
+ *     utils/pcd.py:187-190) in the batched path; the drop-in Python facade keeps the host torch RNG.
+ * map_key [n_maps] int64 (e.g. global pair index), may be NULL (then the map index is used). */
+int oryon_roi_subsample(int32_t *roi, int32_t *count, int n_maps, int roi_stride, int max_keep, uint64_t seed,
+                        const int64_t *map_key, void *stream);
+
+/* K0  gather the ROI descriptors of channel-planar maps and L2-normalise them.
+ *     Replaces feats[:, roi[:,0], roi[:,1]].T (utils/pcd.py:192-193) and the x / max(|x|, 1e-8) half of
+ *     cosine_similarity (utils/pcd.py:28).
+ * feat [n_maps, C, HW] fp32; roi [n_maps, roi_stride]; out [n_maps, rows_cap, C_pad] fp32, row-major; rows
+ * >= count[m] up to the next multiple of 256 and columns C..C_pad-1 are zero-filled (zero columns do not
+ * change the fmaf chain).  C_pad is a multiple of 32 (>= C), rows_cap a multiple of 256. */
+int oryon_gather_normalise_f32(const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride,
+                               const int32_t *count, int rows_cap, int C_pad, float *out, void *stream);
+
+/* K1  cosine nearest neighbour: for every anchor row the query row minimising 0.5*(1 - a^.q^).
+ *     Replaces pdist(...,'inv_norm_cosine') + amin + argmin + (min_dist < th) (utils/pcd.py:202-205)
+ *     without materialising [N1,N2] (the reference materialises [N1,N2,C]).
+ * a_hat [B, cap_a, C], q_hat [B, cap_q, C]  (outputs of oryon_gather_normalise_f32; caps multiples of
+ * ORYON_MATCH_TILE), n_a/n_q [B] int32 on device.
+ * min_dist [B,cap_a] fp32, argmin [B,cap_a] int32 (first index on ties), valid [B,cap_a] uint8.
+ * Arithmetic: exact fp32 — dot = k-ordered fmaf chain (v_mfma_f32_32x32x2_f32), dist = fma(-0.5,dot,0.5).
+ * workspace: oryon_match_workspace_bytes(B, cap_a) bytes (used only when the launch splits the query range). */
+size_t oryon_match_workspace_bytes(int B, int cap_a);
+int oryon_match_f32(const float *a_hat, const float *q_hat, int B, int C, int cap_a, int cap_q,
+                    const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist, int32_t *argmin,
+                    uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream);
+
+/* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).
+ *     Replaces utils/pcd.py:205-214: keep rows with valid, need more than one, sample exactly max_corrs
+ *     (with replacement iff fewer are available).
+ * corrs [B, max_corrs, 4] int32 (y1,x1,y2,x2 in feature-map coordinates), n_valid [B], status [B]
+ * (ORYON_PAIR_OK / ORYON_PAIR_NO_MASK when n_a or n_q is 0 / ORYON_PAIR_NO_CORR when <= 1 valid row).
+ * scratch [B, cap_a] int32 (ordered list of valid anchor rows). */
+int oryon_select_corrs(const int32_t *roi_a, const int32_t *roi_q, int roi_stride_a, int roi_stride_q,
+                       const int32_t *n_a, const int32_t *n_q, const int32_t *argmin, const uint8_t *valid, int cap_a,
+                       int B, int W, int max_corrs, uint64_t seed, const int64_t *pair_key, int32_t *scratch,
+                       int32_t *corrs, int32_t *n_valid, int32_t *status, void *stream);
+
+/* K2  scale (y,x) to the original image, keep rows inside both images, truncate, gather depth, pin-hole
+ *     lift, /1000.  Replaces pipeline.py:447-460 + utils/coordinates.py:5-48 + utils/pcd.py:44-74.
+ * corrs [B, n_cap, 4] int32; n_corr [B] or NULL (then n_cap rows each); depth_* [B,H*,W*] fp32 millimetres;
+ * cam_* [B,9] fp32 (row-major K, already rounded from the reference's fp64); status [B] may be NULL
+ * (pairs whose status != ORYON_PAIR_OK are skipped and get n_out = 0).
+ * pcd_a/pcd_q [B, n_cap, 3] fp32 metres, compacted over valid rows in order; n_out [B]. */
+int oryon_lift_pairs(const int32_t *corrs, const int32_t *n_corr, int B, int n_cap, int FH, int FW,
+                     const float *depth_a, int HA, int WA, const float *depth_q, int HQ, int WQ,
+                     const float *cam_a, const float *cam_q, const int32_t *status, float *pcd_a, float *pcd_q,
+                     int32_t *n_out, void *stream);
+
+/* K2' lift_pcd itself (utils/pcd.py:35-81 with xy_idxs): selected pixels of ONE depth map [H,W] fp32 ->
+ *     [n,3] fp32 in the depth's unit (millimetres), X = ((x - cx) * z) / fx etc., no fma contraction.
+ *     x_idx / y_idx [n] int32 must be inside the image (the reference would raise an IndexError). */
+int oryon_lift_points(const float *depth, int H, int W, const float *cam9, const int32_t *x_idx, const int32_t *y_idx,
+                      int n, float *out, void *stream);
+
+/* K8  batched weighted Kabsch with an in-kernel 3x3 SVD (one-sided Jacobi, fp64 internal).
+ *     Replaces rigid_transform_3d (models/pointdsc/common.py:7-45) incl. its H.cpu() -> LAPACK round trip.
+ * A,B [nb, m, 3] fp32; w [nb, m] fp32 or NULL (all ones); negative weights count as 0 (common.py:20).
+ * T [nb, 16] fp32 row-major 4x4. */
+int oryon_kabsch_batched(const float *A, const float *B, const float *w, int nb, int m, float *T, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K3-K10  PointDSC registration (models/pointdsc/PointDSC.py:128-197, inference branch, wrapped as
+ *         utils/pointdsc/init.py:10-29 does: corr_pos = cat(src,tgt) - mean).
+ */
+typedef struct oryon_pointdsc oryon_pointdsc_t;
+
+typedef struct {
+    int in_dim;             /* 6 */
+    int num_layers;         /* release config: 12 */
+    int num_channels;       /* 128 (32, 64 or 128 supported) */
+    int num_iterations;     /* power-iteration cap, 10 */
+    float ratio;            /* seeds = int(n * ratio), 0.1 */
+    float inlier_threshold; /* 0.10 */
+    float sigma_d;          /* 0.10 (sigma_spat) */
+    int k;                  /* 40 */
+    float nms_radius;       /* 0.10 */
+} oryon_pointdsc_config_t;
+
+int oryon_pointdsc_create(oryon_pointdsc_t **handle, const oryon_pointdsc_config_t *cfg);
+void oryon_pointdsc_destroy(oryon_pointdsc_t *handle);
+/* Load one tensor by its reference state-dict name (models/pointdsc/PointDSC.py:9-25,49-63,97-113), fp32
+ * host data.  Unknown names -> ORYON_ERR_INVALID_ARG; num_batches_tracked is accepted and ignored. */
+int oryon_pointdsc_load_param(oryon_pointdsc_t *handle, const char *name, const float *data_host, int64_t numel);
+/* Fold eval-mode BatchNorm into the preceding conv, upload to the current device. */
+int oryon_pointdsc_finalize(oryon_pointdsc_t *handle, void *stream);
+size_t oryon_pointdsc_workspace_bytes(const oryon_pointdsc_t *handle, int B, int n_cap);
+/* src,tgt [B, n_cap, 3] fp32 metres; n [B] int32 (rows actually used, <= n_cap); status_in [B] or NULL.
+ * T [B,16] fp32 (identity for pairs that fail, as pipeline.py:341/350), labels [B,n_cap] uint8 or NULL,
+ * status_out [B] int32 or NULL. */
+int oryon_pointdsc_register(oryon_pointdsc_t *handle, const float *src, const float *tgt, const int32_t *n, int B,
+                            int n_cap, const int32_t *status_in, void *workspace, size_t workspace_bytes, float *T,
+                            uint8_t *labels, int32_t *status_out, void *stream);
+/* Stage-level views for parity tests (same kernels as oryon_pointdsc_register):
+ *   encode : corr features [B,n_cap,C] + confidence [B,n_cap]
+ *   seeds  : NMS seeds [B, S_cap] int32 + n_seeds [B]
+ *   hypotheses : given seeds, per-seed transforms [B,S_cap,16], fitness [B,S_cap], best [B]
+ *   refine : post_refinement of given transforms */
+int oryon_pointdsc_encode(oryon_pointdsc_t *handle, const float *src, const float *tgt, const int32_t *n, int B,
+                          int n_cap, void *workspace, size_t workspace_bytes, float *feat, float *confidence,
+                          void *stream);
+int oryon_pointdsc_seeds(oryon_pointdsc_t *handle, const float *src, const float *confidence, const int32_t *n, int B,
+                         int n_cap, int S_cap, int32_t *seeds, int32_t *n_seeds, void *stream);
+int oryon_pointdsc_hypotheses(oryon_pointdsc_t *handle, const float *src, const float *tgt, const float *feat,
+                              const int32_t *n, const int32_t *seeds, const int32_t *n_seeds, int B, int n_cap,
+                              int S_cap, void *workspace, size_t workspace_bytes, float *seed_T, float *fitness,
+                              int32_t *best, void *stream);
+int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const float *tgt, const int32_t *n, int B,
+                          int n_cap, const float *T_in, float *T_out, uint8_t *labels, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORYON_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of liboryon_hip.so (the C ABI declared in include/oryon_hip.h).
+
+The product path has NO fallback: if the shared library is missing or the device is not gfx950, every
+operator raises.  torch is used only as plumbing (device memory, streams)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboryon_hip.so")
+_lib = None
+
+
+class OryonError(RuntimeError):
+    pass
+
+
+class PointDSCConfig(ctypes.Structure):
+    _fields_ = [("in_dim", c_int), ("num_layers", c_int), ("num_channels", c_int), ("num_iterations", c_int),
+                ("ratio", c_float), ("inlier_threshold", c_float), ("sigma_d", c_float), ("k", c_int),
+                ("nms_radius", c_float)]
+
+
+_P = c_void_p
+_PROTOS = {
+    "oryon_version": (c_char_p, []),
+    "oryon_last_error": (c_char_p, []),
+    "oryon_device_check": (c_int, [c_int]),
+    "oryon_roi_compact": (c_int, [_P, c_int, c_int, _P, _P, _P]),
+    "oryon_mask_from_logits": (c_int, [_P, c_int64, c_float, _P, _P]),
+    "oryon_mask_resize_nearest": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "oryon_roi_subsample": (c_int, [_P, _P, c_int, c_int, c_int, c_uint64, _P, _P]),
+    "oryon_gather_normalise_f32": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P]),
+    "oryon_match_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "oryon_match_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "oryon_select_corrs": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_uint64, _P, _P,
+                                   _P, _P, _P, _P]),
+    "oryon_lift_pairs": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,
+                                 _P, _P, _P]),
+    "oryon_lift_points": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
+    "oryon_kabsch_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "oryon_pointdsc_create": (c_int, [POINTER(c_void_p), POINTER(PointDSCConfig)]),
+    "oryon_pointdsc_destroy": (None, [c_void_p]),
+    "oryon_pointdsc_load_param": (c_int, [c_void_p, c_char_p, _P, c_int64]),
+    "oryon_pointdsc_finalize": (c_int, [c_void_p, _P]),
+    "oryon_pointdsc_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "oryon_pointdsc_register": (c_int, [c_void_p, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, _P, _P, _P]),
+    "oryon_pointdsc_encode": (c_int, [c_void_p, _P, _P, _P, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+    "oryon_pointdsc_seeds": (c_int, [c_void_p, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "oryon_pointdsc_hypotheses": (c_int, [c_void_p, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P, _P,
+                                          _P, _P]),
+    "oryon_pointdsc_refine": (c_int, [c_void_p, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+def lib():
+    """Load liboryon_hip.so (once).  Raises OryonError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OryonError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C oryon_amd/csrc` - there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        missing = [name for name in _PROTOS if not hasattr(L, name)]
+        if missing:
+            raise OryonError(f"{LIB_PATH} lacks symbols declared in include/oryon_hip.h: {missing} (stale build?)")
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        raise OryonError(f"{what or 'liboryon_hip'} failed ({code}): {lib().oryon_last_error().decode()}")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C ABI takes contiguous buffers"
+    return t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    """The current torch HIP stream of `device` as a raw hipStream_t."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise OryonError("oryon_amd operators run on an MI355X (torch device 'cuda'); no CPU fallback exists")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    check(lib().oryon_device_check(idx), "oryon_device_check")
+    return torch.device("cuda", idx)

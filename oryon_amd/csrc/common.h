@@ -1,0 +1,55 @@
+// Shared helpers for the gfx950 kernels of liboryon_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/oryon_hip.h"
+
+namespace oryon {
+
+void set_error(const char *fmt, ...);
+
+#define ORYON_CHECK_ARG(cond)                                                           \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            oryon::set_error("%s: invalid argument: %s", __func__, #cond);              \
+            return ORYON_ERR_INVALID_ARG;                                               \
+        }                                                                               \
+    } while (0)
+
+#define ORYON_CHECK_LAUNCH()                                                            \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            oryon::set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return ORYON_ERR_HIP;                                                       \
+        }                                                                               \
+    } while (0)
+
+#define ORYON_CHECK_HIP(expr)                                                           \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            oryon::set_error("%s: %s failed: %s", __func__, #expr, hipGetErrorString(e_)); \
+            return ORYON_ERR_HIP;                                                       \
+        }                                                                               \
+    } while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// 64-bit mix (splitmix64 finaliser): the counter-based RNG of the batched sampling kernels.
+__host__ __device__ static inline uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ static inline uint32_t rng_u32(uint64_t seed, uint64_t key, uint32_t stream, uint32_t i)
+{
+    return (uint32_t)(mix64(mix64(seed ^ (key * 0xD1B54A32D192ED03ull)) + ((uint64_t)stream << 32 | i)) >> 32);
+}
+
+}  // namespace oryon

@@ -1,0 +1,242 @@
+// K0 family: masks -> ROI lists -> (subsample) -> gathered, L2-normalised descriptor rows.
+// Replaces utils/pcd.py:184-193, losses.py:58-59, pipeline.py:408-411 of the reference (see include/oryon_hip.h).
+// All of this is HBM-bound integer/gather work: coalesced row-major scans, wave ballots for the ordered
+// compaction, an LDS transpose so the [N,C] descriptor rows are written in 128-byte runs.
+#include "common.h"
+
+namespace oryon {
+
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_WAVES = SCAN_THREADS / 64;
+
+// Ordered (stable) block compaction step: every thread contributes `flag`; returns this thread's output
+// slot (valid when flag) relative to the chunk start and the chunk total through `total`.
+__device__ __forceinline__ int block_rank(bool flag, int *s_wave /*[SCAN_WAVES]*/, int &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long b = __ballot(flag);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    __syncthreads();                       // previous user of s_wave is done
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_WAVES; ++w) {
+        const int c = s_wave[w];
+        base += (w < wave) ? c : 0;
+        tot += c;
+    }
+    total = tot;
+    return base + before;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void roi_compact_kernel(const int32_t *__restrict__ mask, int HW,
+                                                                    int32_t *__restrict__ roi, int32_t *__restrict__ count)
+{
+    __shared__ int s_wave[SCAN_WAVES];
+    const int m = blockIdx.x;
+    const int32_t *mk = mask + (size_t)m * HW;
+    int32_t *out = roi + (size_t)m * HW;
+    int base = 0;
+    for (int p0 = 0; p0 < HW; p0 += SCAN_THREADS) {
+        const int p = p0 + threadIdx.x;
+        const bool flag = (p < HW) && (mk[p] == 1);
+        int total;
+        const int r = block_rank(flag, s_wave, total);
+        if (flag) out[base + r] = p;
+        base += total;
+    }
+    if (threadIdx.x == 0) count[m] = base;
+}
+
+__global__ void mask_from_logits_kernel(const float *__restrict__ logits, int64_t n, float thr, int32_t *__restrict__ mask)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = 1.0f / (1.0f + expf(-logits[i]));
+        mask[i] = s > thr ? 1 : 0;
+    }
+}
+
+__global__ void mask_resize_nearest_kernel(const uint8_t *__restrict__ in, int HI, int WI, int HO, int WO,
+                                           int32_t *__restrict__ out)
+{
+    const int m = blockIdx.y;
+    const float sy = (float)HI / (float)HO, sx = (float)WI / (float)WO;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HO * WO; p += gridDim.x * blockDim.x) {
+        const int y = p / WO, x = p % WO;
+        int ys = (int)floorf((float)y * sy), xs = (int)floorf((float)x * sx);
+        ys = ys < HI - 1 ? ys : HI - 1;
+        xs = xs < WI - 1 ? xs : WI - 1;
+        out[(size_t)m * HO * WO + p] = (int32_t)in[((size_t)m * HI + ys) * WI + xs];
+    }
+}
+
+// Subsample without replacement: keep the max_keep smallest 32-bit keys (ties by index), in ROI order.
+__global__ __launch_bounds__(SCAN_THREADS) void roi_subsample_kernel(int32_t *__restrict__ roi, int32_t *__restrict__ count,
+                                                                      int roi_stride, int max_keep, uint64_t seed,
+                                                                      const int64_t *__restrict__ map_key)
+{
+    __shared__ int s_wave[SCAN_WAVES];
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_prefix, s_remaining;
+    const int m = blockIdx.x;
+    const int n = count[m];
+    if (n <= max_keep) return;
+    const uint64_t key = map_key ? (uint64_t)map_key[m] : (uint64_t)m;
+    int32_t *r = roi + (size_t)m * roi_stride;
+
+    if (threadIdx.x == 0) { s_prefix = 0u; s_remaining = (unsigned)max_keep; }
+    // radix select, most significant byte first
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (threadIdx.x < 256) s_hist[threadIdx.x] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+            const unsigned k = rng_u32(seed, key, 0u, (uint32_t)i);
+            if ((k & hi_mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned rem = s_remaining, cum = 0u;
+            int b = 0;
+            for (; b < 256; ++b) {
+                if (cum + s_hist[b] >= rem) break;
+                cum += s_hist[b];
+            }
+            s_remaining = rem - cum;
+            s_prefix = prefix | ((unsigned)b << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned T = s_prefix;
+    const int ties_to_take = (int)s_remaining;
+    int kept = 0, ties_seen = 0;
+    for (int i0 = 0; i0 < n; i0 += SCAN_THREADS) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < n;
+        const unsigned k = in ? rng_u32(seed, key, 0u, (uint32_t)i) : 0xFFFFFFFFu;
+        const int32_t v = in ? r[i] : 0;
+        const bool tie = in && (k == T);
+        int tie_total;
+        const int tie_rank = block_rank(tie, s_wave, tie_total);
+        const bool keep = in && (k < T || (tie && (ties_seen + tie_rank) < ties_to_take));
+        int keep_total;
+        const int pos = block_rank(keep, s_wave, keep_total);
+        // all reads of this chunk (v) happened before block_rank's barriers -> in-place write is safe
+        if (keep) r[kept + pos] = v;
+        kept += keep_total;
+        ties_seen += tie_total;
+    }
+    if (threadIdx.x == 0) count[m] = kept;
+}
+
+// Gather + normalise.  One thread per ROI row for the (canonical, k-ordered) norm; the scaled values go
+// through an LDS transpose so global stores are 128-byte runs of one descriptor row.
+constexpr int GN_ROWS = 256;
+constexpr int GN_KT = 32;
+__global__ __launch_bounds__(GN_ROWS) void gather_normalise_kernel(const float *__restrict__ feat, int C, int HW,
+                                                                    const int32_t *__restrict__ roi, int roi_stride,
+                                                                    const int32_t *__restrict__ count, int rows_cap,
+                                                                    int Cp, float *__restrict__ out)
+{
+    __shared__ float tile[GN_ROWS * (GN_KT + 1)];
+    const int m = blockIdx.y;
+    const int n = count[m];
+    const int row0 = blockIdx.x * GN_ROWS;
+    if (row0 >= n) return;                       // only the last partially filled block zero-fills
+    const int t = threadIdx.x;
+    const int row = row0 + t;
+    const bool live = row < n;
+    const float *f = feat + (size_t)m * C * HW;
+    const int pix = live ? roi[(size_t)m * roi_stride + row] : 0;
+    float n2 = 0.0f;
+    if (live)
+        for (int k = 0; k < C; ++k) {
+            const float v = f[(size_t)k * HW + pix];
+            n2 = __fmaf_rn(v, v, n2);
+        }
+    float d = __fsqrt_rn(n2);
+    d = d < 1e-8f ? 1e-8f : d;
+    float *o = out + ((size_t)m * rows_cap + row0) * Cp;
+    for (int k0 = 0; k0 < Cp; k0 += GN_KT) {
+#pragma unroll 8
+        for (int kk = 0; kk < GN_KT; ++kk) {
+            const float v = (live && k0 + kk < C) ? __fdiv_rn(f[(size_t)(k0 + kk) * HW + pix], d) : 0.0f;
+            tile[t * (GN_KT + 1) + kk] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (GN_ROWS * GN_KT / 4) / GN_ROWS; ++i) {
+            const int fidx = t + GN_ROWS * i;
+            const int r = fidx / (GN_KT / 4), c4 = fidx % (GN_KT / 4);
+            float4 v;
+            v.x = tile[r * (GN_KT + 1) + c4 * 4 + 0];
+            v.y = tile[r * (GN_KT + 1) + c4 * 4 + 1];
+            v.z = tile[r * (GN_KT + 1) + c4 * 4 + 2];
+            v.w = tile[r * (GN_KT + 1) + c4 * 4 + 3];
+            *reinterpret_cast<float4 *>(o + (size_t)r * Cp + k0 + c4 * 4) = v;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace oryon
+
+using namespace oryon;
+
+extern "C" int oryon_roi_compact(const int32_t *mask, int n_maps, int HW, int32_t *roi, int32_t *count, void *stream)
+{
+    ORYON_CHECK_ARG(mask && roi && count && n_maps >= 0 && HW > 0);
+    if (n_maps == 0) return ORYON_OK;
+    hipLaunchKernelGGL(roi_compact_kernel, dim3(n_maps), dim3(SCAN_THREADS), 0, as_stream(stream), mask, HW, roi, count);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_mask_from_logits(const float *logits, int64_t n, float threshold, int32_t *mask, void *stream)
+{
+    ORYON_CHECK_ARG(logits && mask && n >= 0);
+    if (n == 0) return ORYON_OK;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(mask_from_logits_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), logits, n, threshold, mask);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_mask_resize_nearest(const uint8_t *mask_in, int n_maps, int HI, int WI, int HO, int WO,
+                                         int32_t *mask_out, void *stream)
+{
+    ORYON_CHECK_ARG(mask_in && mask_out && n_maps >= 0 && HI > 0 && WI > 0 && HO > 0 && WO > 0);
+    if (n_maps == 0) return ORYON_OK;
+    const int bx = ceil_div(HO * WO, 256) < 64 ? ceil_div(HO * WO, 256) : 64;
+    hipLaunchKernelGGL(mask_resize_nearest_kernel, dim3(bx, n_maps), dim3(256), 0, as_stream(stream), mask_in, HI, WI, HO,
+                       WO, mask_out);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_roi_subsample(int32_t *roi, int32_t *count, int n_maps, int roi_stride, int max_keep, uint64_t seed,
+                                   const int64_t *map_key, void *stream)
+{
+    ORYON_CHECK_ARG(roi && count && n_maps >= 0 && roi_stride > 0 && max_keep > 0);
+    if (n_maps == 0) return ORYON_OK;
+    hipLaunchKernelGGL(roi_subsample_kernel, dim3(n_maps), dim3(SCAN_THREADS), 0, as_stream(stream), roi, count, roi_stride,
+                       max_keep, seed, map_key);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_gather_normalise_f32(const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride,
+                                          const int32_t *count, int rows_cap, int C_pad, float *out, void *stream)
+{
+    ORYON_CHECK_ARG(feat && roi && count && out && n_maps >= 0 && C > 0 && HW > 0 && roi_stride > 0);
+    ORYON_CHECK_ARG(C_pad >= C && C_pad % GN_KT == 0);
+    ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % GN_ROWS == 0);
+    if (n_maps == 0) return ORYON_OK;
+    hipLaunchKernelGGL(gather_normalise_kernel, dim3(rows_cap / GN_ROWS, n_maps), dim3(GN_ROWS), 0, as_stream(stream), feat,
+                       C, HW, roi, roi_stride, count, rows_cap, C_pad, out);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}

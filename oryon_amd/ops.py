@@ -1,0 +1,147 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point of include/oryon_hip.h).
+
+Every wrapper takes torch CUDA tensors, allocates outputs with torch (plumbing) and launches the HIP
+kernel on the current torch stream.  Nothing here computes: the arithmetic lives in liboryon_hip.so."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+MATCH_TILE = 128
+ROW_PAD = 256      # oryon_gather_normalise_f32 zero-fills / requires multiples of 256 rows
+K_PAD = 32
+
+
+def round_up(x: int, m: int) -> int:
+    return ((int(x) + m - 1) // m) * m
+
+
+def roi_compact(mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mask [n_maps, H, W] (or [H,W]) int32 -> (roi [n_maps, HW] int32 linear indices, count [n_maps] int32)."""
+    if mask.dim() == 2:
+        mask = mask[None]
+    _lib.require_gpu(mask.device)
+    mask = mask.to(torch.int32).contiguous()
+    n_maps, HW = mask.shape[0], mask.shape[1] * mask.shape[2]
+    roi = torch.empty((n_maps, HW), dtype=torch.int32, device=mask.device)
+    count = torch.empty((n_maps,), dtype=torch.int32, device=mask.device)
+    check(lib().oryon_roi_compact(ptr(mask), n_maps, HW, ptr(roi), ptr(count), stream_ptr(mask.device)), "oryon_roi_compact")
+    return roi, count
+
+
+def mask_from_logits(logits: torch.Tensor, threshold: float) -> torch.Tensor:
+    _lib.require_gpu(logits.device)
+    logits = logits.to(torch.float32).contiguous()
+    out = torch.empty(logits.shape, dtype=torch.int32, device=logits.device)
+    check(lib().oryon_mask_from_logits(ptr(logits), logits.numel(), float(threshold), ptr(out), stream_ptr(logits.device)),
+          "oryon_mask_from_logits")
+    return out
+
+
+def mask_resize_nearest(mask: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
+    """uint8 masks [n,HI,WI] -> int32 [n,HO,WO] with torch's legacy 'nearest' index rule."""
+    if mask.dim() == 2:
+        mask = mask[None]
+    _lib.require_gpu(mask.device)
+    m = mask.to(torch.uint8).contiguous()
+    n, HI, WI = m.shape
+    out = torch.empty((n, int(out_hw[0]), int(out_hw[1])), dtype=torch.int32, device=m.device)
+    check(lib().oryon_mask_resize_nearest(ptr(m), n, HI, WI, int(out_hw[0]), int(out_hw[1]), ptr(out), stream_ptr(m.device)),
+          "oryon_mask_resize_nearest")
+    return out
+
+
+def roi_subsample_(roi: torch.Tensor, count: torch.Tensor, max_keep: int, seed: int, map_key: Optional[torch.Tensor] = None) -> None:
+    """In-place device-RNG subsample of every ROI list to at most max_keep entries (order preserved)."""
+    _lib.require_gpu(roi.device)
+    check(lib().oryon_roi_subsample(ptr(roi), ptr(count), roi.shape[0], roi.shape[1], int(max_keep), int(seed) & (2**64 - 1),
+                                    ptr(map_key), stream_ptr(roi.device)), "oryon_roi_subsample")
+
+
+def gather_normalise(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int) -> torch.Tensor:
+    """feat [n_maps,C,H,W] fp32, roi [n_maps, stride] -> [n_maps, rows_cap, C_pad] unit rows (rows_cap % 256 == 0)."""
+    _lib.require_gpu(feat.device)
+    assert feat.dtype == torch.float32 and feat.is_contiguous()
+    n_maps, C = feat.shape[0], feat.shape[1]
+    HW = feat.shape[2] * feat.shape[3]
+    Cp = round_up(C, K_PAD)
+    out = torch.empty((n_maps, rows_cap, Cp), dtype=torch.float32, device=feat.device)
+    check(lib().oryon_gather_normalise_f32(ptr(feat), n_maps, C, HW, ptr(roi), roi.shape[1], ptr(count), rows_cap, Cp,
+                                           ptr(out), stream_ptr(feat.device)), "oryon_gather_normalise_f32")
+    return out
+
+
+def match(a_hat: torch.Tensor, q_hat: torch.Tensor, n_a: torch.Tensor, n_q: torch.Tensor, threshold: float):
+    """a_hat [B,cap_a,Cp], q_hat [B,cap_q,Cp] -> (min_dist [B,cap_a] f32, argmin [B,cap_a] i32, valid [B,cap_a] u8)."""
+    dev = _lib.require_gpu(a_hat.device)
+    B, cap_a, Cp = a_hat.shape
+    cap_q = q_hat.shape[1]
+    assert q_hat.shape[0] == B and q_hat.shape[2] == Cp
+    min_dist = torch.empty((B, cap_a), dtype=torch.float32, device=dev)
+    argmin = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
+    valid = torch.empty((B, cap_a), dtype=torch.uint8, device=dev)
+    wsb = lib().oryon_match_workspace_bytes(B, cap_a)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+    check(lib().oryon_match_f32(ptr(a_hat), ptr(q_hat), B, Cp, cap_a, cap_q, ptr(n_a), ptr(n_q), float(threshold),
+                                ptr(min_dist), ptr(argmin), ptr(valid), ptr(ws), wsb, stream_ptr(dev)), "oryon_match_f32")
+    return min_dist, argmin, valid
+
+
+def select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, W: int, max_corrs: int, seed: int, pair_key=None):
+    """Device-RNG correspondence sampling -> (corrs [B,max_corrs,4] i32, n_valid [B] i32, status [B] i32)."""
+    dev = _lib.require_gpu(roi_a.device)
+    B, cap_a = argmin.shape
+    corrs = torch.zeros((B, max_corrs, 4), dtype=torch.int32, device=dev)
+    n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    scratch = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
+    check(lib().oryon_select_corrs(ptr(roi_a), ptr(roi_q), roi_a.shape[1], roi_q.shape[1], ptr(n_a), ptr(n_q), ptr(argmin),
+                                   ptr(valid), cap_a, B, int(W), int(max_corrs), int(seed) & (2**64 - 1), ptr(pair_key),
+                                   ptr(scratch), ptr(corrs), ptr(n_valid), ptr(status), stream_ptr(dev)), "oryon_select_corrs")
+    return corrs, n_valid, status
+
+
+def lift_pairs(corrs: torch.Tensor, n_corr: Optional[torch.Tensor], feat_hw, depth_a: torch.Tensor, depth_q: torch.Tensor,
+               cam_a: torch.Tensor, cam_q: torch.Tensor, status: Optional[torch.Tensor] = None):
+    """corrs [B,n_cap,4] i32, depth_* [B,H,W] f32 (mm), cam_* [B,9] f32 -> (pcd_a, pcd_q [B,n_cap,3] metres, n_out [B])."""
+    dev = _lib.require_gpu(corrs.device)
+    B, n_cap = corrs.shape[0], corrs.shape[1]
+    assert corrs.dtype == torch.int32 and depth_a.dtype == torch.float32 and depth_q.dtype == torch.float32
+    assert cam_a.dtype == torch.float32 and cam_a.shape == (B, 9) and cam_q.shape == (B, 9)
+    pa = torch.zeros((B, n_cap, 3), dtype=torch.float32, device=dev)
+    pq = torch.zeros((B, n_cap, 3), dtype=torch.float32, device=dev)
+    n_out = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(lib().oryon_lift_pairs(ptr(corrs), ptr(n_corr), B, n_cap, int(feat_hw[0]), int(feat_hw[1]),
+                                 ptr(depth_a.contiguous()), depth_a.shape[1], depth_a.shape[2],
+                                 ptr(depth_q.contiguous()), depth_q.shape[1], depth_q.shape[2],
+                                 ptr(cam_a.contiguous()), ptr(cam_q.contiguous()), ptr(status), ptr(pa), ptr(pq), ptr(n_out),
+                                 stream_ptr(dev)), "oryon_lift_pairs")
+    return pa, pq, n_out
+
+
+def lift_points(depth: torch.Tensor, cam9: torch.Tensor, x_idx: torch.Tensor, y_idx: torch.Tensor) -> torch.Tensor:
+    """depth [H,W] f32, cam9 [9] f32, pixel indices [n] -> [n,3] f32 in the depth's unit."""
+    dev = _lib.require_gpu(depth.device)
+    n = x_idx.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    xi = x_idx.to(torch.int32).contiguous()
+    yi = y_idx.to(torch.int32).contiguous()
+    check(lib().oryon_lift_points(ptr(depth), depth.shape[0], depth.shape[1], ptr(cam9.contiguous()), ptr(xi), ptr(yi), n,
+                                  ptr(out), stream_ptr(dev)), "oryon_lift_points")
+    return out
+
+
+def kabsch_batched(A: torch.Tensor, B: torch.Tensor, w: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[nb,m,3] x2 (+ [nb,m]) fp32 -> [nb,4,4] fp32."""
+    dev = _lib.require_gpu(A.device)
+    A = A.to(torch.float32).contiguous()
+    B = B.to(torch.float32).contiguous()
+    w = None if w is None else w.to(torch.float32).contiguous()
+    nb, m = A.shape[0], A.shape[1]
+    T = torch.empty((nb, 4, 4), dtype=torch.float32, device=dev)
+    check(lib().oryon_kabsch_batched(ptr(A), ptr(B), ptr(w), nb, m, ptr(T), stream_ptr(dev)), "oryon_kabsch_batched")
+    return T

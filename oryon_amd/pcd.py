@@ -1,0 +1,100 @@
+"""Drop-in counterparts of the reference's utils/pcd.py entry points on the hot path.
+
+    nn_correspondences(feats1, feats2, mask1, mask2, threshold, max_corrs, subsample_source, corrs_device)
+    lift_pcd(depth, camera, xy_idxs)
+    torch_sample_select(t, n)
+
+Same names, argument meaning, return types and failure behaviour as utils/pcd.py:177-216, :35-81 and
+utils/misc.py:242-254; the arithmetic runs in liboryon_hip.so (K0 + K1 + K2').  The two random draws keep
+the reference's host-side torch.multinomial on the global CPU generator, in the same order, so a seeded
+run consumes the RNG stream exactly as the reference does with corrs_device='cpu'.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from ._lib import require_gpu
+
+
+def torch_sample_select(t: Tensor, n: int) -> Tensor:
+    """Exactly n indices into t's first dimension; replacement only when n > N (utils/misc.py:242-254).
+    Always drawn from the global CPU generator (the reference's default corrs_device)."""
+    N = t.shape[0]
+    w = torch.ones(N, dtype=torch.float64)
+    return torch.multinomial(w, n, replacement=(n > N))
+
+
+def match_presample(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor, threshold: float,
+                    subsample_source: Optional[int] = None):
+    """Deterministic half of the matcher (utils/pcd.py:184-205) on the GPU.
+
+    Returns dict(roi1 [N1,2] i64 (y,x), roi2 [N2,2] i64, min_dist [N1] f32, argmin [N1] i64, valid [N1] bool).
+    When subsample_source is given and N1 exceeds it, the first RNG draw is made exactly as the reference does."""
+    dev = require_gpu(feats1.device)
+    W = feats1.shape[2]
+    W2 = feats2.shape[2]
+    f1 = feats1.to(torch.float32).contiguous()[None]
+    f2 = feats2.to(torch.float32).contiguous()[None]
+    roi1_lin, c1 = ops.roi_compact(mask1.to(dev))
+    roi2_lin, c2 = ops.roi_compact(mask2.to(dev))
+    n1, n2 = int(c1.item()), int(c2.item())          # the reference syncs here as well (shape of nonzero)
+    roi1_lin = roi1_lin[:, :n1]
+    if subsample_source is not None and n1 > subsample_source:
+        idxs = torch_sample_select(roi1_lin[0], subsample_source).to(dev)
+        roi1_lin = roi1_lin[:, idxs]
+        n1 = subsample_source
+        c1 = torch.full((1,), n1, dtype=torch.int32, device=dev)
+    roi1_lin = roi1_lin.contiguous()
+    out = dict(
+        roi1=torch.stack((roi1_lin[0] // W, roi1_lin[0] % W), dim=1).to(torch.int64),
+        roi2=torch.stack((roi2_lin[0, :n2] // W2, roi2_lin[0, :n2] % W2), dim=1).to(torch.int64))
+    if n1 == 0 or n2 == 0:
+        out.update(min_dist=torch.zeros(n1, device=dev), argmin=torch.zeros(n1, dtype=torch.int64, device=dev),
+                   valid=torch.zeros(n1, dtype=torch.bool, device=dev))
+        return out
+    a_hat = ops.gather_normalise(f1, roi1_lin, c1, ops.round_up(n1, ops.ROW_PAD))
+    q_hat = ops.gather_normalise(f2, roi2_lin, c2, ops.round_up(n2, ops.ROW_PAD))
+    min_dist, argmin, valid = ops.match(a_hat, q_hat, c1, c2, threshold)
+    out.update(min_dist=min_dist[0, :n1], argmin=argmin[0, :n1].to(torch.int64), valid=valid[0, :n1].bool())
+    return out
+
+
+def nn_correspondences(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor, threshold: float, max_corrs: int,
+                       subsample_source: Optional[int], corrs_device: str = "cuda") -> Optional[Tensor]:
+    """Matches between two [D,H,W] feature maps restricted to mask==1; int64 [max_corrs,4] rows
+    (y1,x1,y2,x2) on feats1.device, or None when at most one anchor pixel finds a match under the
+    threshold (utils/pcd.py:177-216).  `corrs_device` is accepted for signature compatibility; the
+    contraction always runs in fp32 on the GPU (the reference's 'cpu' numerics)."""
+    orig_device = feats1.device
+    pre = match_presample(feats1, feats2, mask1, mask2, threshold, subsample_source)
+    valid_corr = torch.nonzero(pre["valid"]).squeeze(1)
+    if valid_corr.shape[0] > 1:
+        roi2 = pre["roi2"][pre["argmin"]]
+        final_corrs = torch.cat((pre["roi1"][valid_corr], roi2[valid_corr]), dim=1)
+        idxs = torch_sample_select(final_corrs, max_corrs).to(final_corrs.device)
+        return final_corrs[idxs].to(orig_device)
+    return None
+
+
+def lift_pcd(depth: Tensor, camera: Tensor, xy_idxs: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
+    """Depth [H,W,1] (millimetres) + flattened K [9] -> [N,3] points (millimetres), fp32
+    (utils/pcd.py:35-81).  With xy_idxs=(x_idx, y_idx) only those pixels are lifted; the caller divides
+    by 1000 as pipeline.py:459-460 does."""
+    dev = require_gpu(depth.device)
+    H, W, D = depth.shape
+    if D != 1:
+        raise NotImplementedError("RGB-D lifting (D > 1) is off the registration path (utils/pcd.py:76-80)")
+    d = depth[:, :, 0].to(torch.float32).contiguous()
+    if xy_idxs is None:
+        ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+        x_idx, y_idx = xs.reshape(-1), ys.reshape(-1)
+    else:
+        x_idx, y_idx = xy_idxs[0].to(dev), xy_idxs[1].to(dev)
+        if x_idx.numel() and (int(x_idx.min()) < 0 or int(x_idx.max()) >= W or int(y_idx.min()) < 0 or int(y_idx.max()) >= H):
+            raise IndexError("lift_pcd: pixel index out of the depth image")
+    cam = camera.reshape(9).to(torch.float32).to(dev)
+    return ops.lift_points(d, cam, x_idx, y_idx)
