@@ -1,0 +1,65 @@
+// Internal structures shared by the PointDSC translation units.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace oryon {
+
+struct PdscLayer {
+    const float *w_pcn, *b_pcn;   // [C,C] BN-folded, [C]
+    const float *w_qkv, *b_qkv;   // [3C,C], [3C]
+    const float *w_m1, *b_m1;     // [C/2,C] BN-folded
+    const float *w_m2, *b_m2;     // [C/2,C/2] BN-folded
+    const float *w_m3, *b_m3;     // [C,C/2]
+};
+
+struct PdscModel {
+    oryon_pointdsc_config_t cfg;
+    float sigma;      // feature-consistency sigma (learnable scalar, PointDSC.py:97)
+    float sigma_d;    // sigma_spat (PointDSC.py:98)
+    const float *w0, *b0;             // layer0 [C,in_dim]
+    std::vector<PdscLayer> layers;
+    const float *w_c1, *b_c1, *w_c2, *b_c2, *w_c3, *b_c3;
+};
+
+struct PdscWorkspace {
+    float *corr_pos;  // [B,n_cap,8]
+    float *feat;      // [B,n_cap,C]
+    float *feat1;     // [B,n_cap,C]
+    float *qkv;       // [B,n_cap,3C]
+    float *msg;       // [B,n_cap,C]
+    float *h1, *h2;   // [B,n_cap,max(C/2,32)]
+    float *feat_n;    // [B,n_cap,C]
+    float *conf;      // [B,n_cap]
+    int32_t *seeds;   // [B,S_cap]
+    int32_t *n_seeds; // [B]
+    int32_t *knn;     // [B,S_cap,k]
+    float *Mmat;      // [B,S_cap,k,k]
+    float *seed_w;    // [B,S_cap,k]
+    float *seed_T;    // [B,S_cap,16]
+    float *fitness;   // [B,S_cap]
+    int32_t *best;    // [B]
+    float *T0;        // [B,16]
+    int S_cap, k;
+};
+
+inline int pdsc_seed_cap(const oryon_pointdsc_config_t &cfg, int n_cap)
+{
+    return (int)((double)n_cap * (double)cfg.ratio) + 1;
+}
+
+void pdsc_launch_normalise(const float *feat, int C, int n_cap, int B, const int32_t *n_rows, float *out, hipStream_t st);
+int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *src, const float *tgt, const int32_t *n_rows,
+                     int B, int n_cap, hipStream_t st);
+int pdsc_run_seeds(const PdscModel &M, const float *src, const float *conf, const int32_t *n_rows, int B, int n_cap, int S_cap,
+                   int32_t *seeds, int32_t *n_seeds, hipStream_t st);
+int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float *src, const float *tgt, const float *feat_n,
+                        const int32_t *n_rows, const int32_t *seeds, const int32_t *n_seeds, int B, int n_cap, float *seed_T,
+                        float *fitness, int32_t *best, float *T_best, uint8_t *labels, hipStream_t st);
+int pdsc_run_refine(const PdscModel &M, const float *src, const float *tgt, const int32_t *n_rows, int B, int n_cap,
+                    const float *T_in, const int32_t *status_in, const int32_t *n_seeds, float *T_out, int32_t *status_out,
+                    hipStream_t st);
+
+}  // namespace oryon

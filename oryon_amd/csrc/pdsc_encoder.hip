@@ -1,0 +1,358 @@
+// K3 + K4: PointDSC feature encoder (NonLocalNet) on the fp32 matrix cores.
+//
+// Replaces models/pointdsc/PointDSC.py:150-156 (+ NonLocalBlock.forward :27-45, NonLocalNet.forward :65-77):
+//   SC_ij   = clamp(1 - (|s_i-s_j| - |t_i-t_j|)^2 / sigma_d^2, 0)
+//   layer   : feat = relu(BN(conv(feat)));  q,k,v = conv(feat);
+//             w = softmax_j(SC_ij * q_i.k_j / sqrt(C));  msg = sum_j w_ij v_j;  feat += mlp(msg)
+// The reference materialises SC [n,n] and the [n,n] attention matrix; here
+//   * every 1x1 conv (+ folded eval-mode BatchNorm, ReLU, residual) is one LDS-tiled MFMA GEMM
+//     (pdsc_linear_kernel), and
+//   * the attention is a flash-style kernel that never stores an n x n object: SC is recomputed per
+//     (query,key) from the six coordinates (keys' coordinates sit in LDS next to the K/V tiles) and the
+//     softmax is online.  It works on TRANSPOSED tiles, S^T = K Q^T and O^T = V^T P^T: in the 32x32 MFMA
+//     C/D layout a lane then owns ONE query column, so max / sum / rescale are lane-local, and the P
+//     registers feed the second MFMA directly as its B operand (no LDS round trip, no shuffles).
+#include "common.h"
+#include "pdsc.h"
+
+namespace oryon {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// row index inside a 32x32 MFMA C/D block held by (register r, lane half hi)
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ------------------------------------------------------------------------------------------------
+// corr_pos = cat(src, tgt) - mean over the n rows (utils/pointdsc/init.py:18-19); rows >= n are zeroed.
+// One workgroup per pair.
+__global__ __launch_bounds__(256) void pdsc_center_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                           const int32_t *__restrict__ n_rows, int n_cap,
+                                                           float *__restrict__ corr_pos /*[B,n_cap,8]*/)
+{
+    __shared__ double s_part[4][6];
+    __shared__ float s_mean[6];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = n_rows[b];
+    const float *s = src + (size_t)b * n_cap * 3, *g = tgt + (size_t)b * n_cap * 3;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = t; i < n; i += 256) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { acc[d] += s[3 * i + d]; acc[3 + d] += g[3 * i + d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        double v = acc[d];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) s_part[wave][d] = v;
+    }
+    __syncthreads();
+    if (t < 6) s_mean[t] = (float)((s_part[0][t] + s_part[1][t] + s_part[2][t] + s_part[3][t]) / (double)(n > 0 ? n : 1));
+    __syncthreads();
+    float *o = corr_pos + (size_t)b * n_cap * 8;
+    for (int i = t; i < n_cap; i += 256) {
+        float v[8];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            v[d] = i < n ? s[3 * i + d] - s_mean[d] : 0.0f;
+            v[3 + d] = i < n ? g[3 * i + d] - s_mean[3 + d] : 0.0f;
+        }
+        v[6] = v[7] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[(size_t)i * 8 + d] = v[d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Y[b, rows, :N] = act(X[b, rows, :K] W^T + bias) (+ R[b, rows, :N]);   W is [N, K] row-major.
+// Tile: 64 rows x 128 columns per workgroup, k-tiles of 32 staged in LDS (LD = 33: conflict-free
+// ds_read_b32 of a 32-row column); 4 waves as 2 (row halves) x 2 (column halves of 64 = two 32x32 blocks).
+constexpr int LIN_ROWS = 64, LIN_COLS = 128, LIN_BK = 32, LIN_LD = LIN_BK + 1;
+
+template <bool RELU, bool RESID>
+__global__ __launch_bounds__(256) void pdsc_linear_kernel(const float *__restrict__ X, int ldx, size_t x_batch,
+                                                           const float *__restrict__ W, const float *__restrict__ bias,
+                                                           const float *__restrict__ R, int ldr, size_t r_batch,
+                                                           float *__restrict__ Y, int ldy, size_t y_batch, int K, int N,
+                                                           const int32_t *__restrict__ n_rows)
+{
+    __shared__ float Xs[LIN_ROWS * LIN_LD];
+    __shared__ float Ws[LIN_COLS * LIN_LD];
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.x * LIN_ROWS, n0 = blockIdx.y * LIN_COLS;
+    if (n_rows && m0 >= n_rows[b]) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const float *x = X + (size_t)b * x_batch + (size_t)m0 * ldx;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    for (int k0 = 0; k0 < K; k0 += LIN_BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (LIN_ROWS * LIN_BK) / 256; ++i) {
+            const int e = t + 256 * i, row = e >> 5, kk = e & 31;
+            Xs[row * LIN_LD + kk] = (k0 + kk < K) ? x[(size_t)row * ldx + k0 + kk] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < (LIN_COLS * LIN_BK) / 256; ++i) {
+            const int e = t + 256 * i, col = e >> 5, kk = e & 31;
+            Ws[col * LIN_LD + kk] = (n0 + col < N && k0 + kk < K) ? W[(size_t)(n0 + col) * K + k0 + kk] : 0.0f;
+        }
+        __syncthreads();
+        const float *xa = Xs + (wm * 32 + l31) * LIN_LD + hi;
+        const float *wb = Ws + (wn * 64 + l31) * LIN_LD + hi;
+#pragma unroll
+        for (int ks = 0; ks < LIN_BK / 2; ++ks) {
+            const float a = xa[2 * ks];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[2 * ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[32 * LIN_LD + 2 * ks], acc[1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = n0 + wn * 64 + j * 32 + l31;
+        if (c >= N) continue;
+        const float bv = bias ? bias[c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + crow(r, hi);
+            float v = acc[j][r] + bv;
+            if (RELU) v = v > 0.0f ? v : 0.0f;
+            if (RESID) v += R[(size_t)b * r_batch + (size_t)row * ldr + c];
+            Y[(size_t)b * y_batch + (size_t)row * ldy + c] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flash-style SC-modulated attention.  One workgroup = 128 queries (4 waves x 32), key tiles of 64.
+// QKV: [B, n_cap, 3C] (q | k | v), coords: src,tgt [B, n_cap, 3];  msg: [B, n_cap, C].
+constexpr int ATT_Q = 128, ATT_KT = 64;
+
+template <int C>
+__global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__restrict__ QKV, const float *__restrict__ src,
+                                                              const float *__restrict__ tgt,
+                                                              const int32_t *__restrict__ n_rows, int n_cap,
+                                                              float inv_sigma2, float inv_sqrt_c, float *__restrict__ msg)
+{
+    constexpr int LD = C + 1;
+    constexpr int CB = C / 32;
+    __shared__ float Ks[ATT_KT * LD];
+    __shared__ float Vs[ATT_KT * LD];
+    __shared__ float Cs[ATT_KT * 6];
+    const int b = blockIdx.y;
+    const int n = n_rows[b];
+    const int q0 = blockIdx.x * ATT_Q;
+    if (q0 >= n) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int qrow = q0 + wave * 32 + l31;  // this lane's query (< n_cap always)
+    const float *base = QKV + (size_t)b * n_cap * 3 * C;
+    const float *sp = src + (size_t)b * n_cap * 3, *tp = tgt + (size_t)b * n_cap * 3;
+
+    // Q^T as B operand: lane (query l31, half hi) holds Q[query][2ks + hi]
+    float qreg[C / 2];
+    {
+        const float2 *qv = reinterpret_cast<const float2 *>(base + (size_t)qrow * 3 * C);
+#pragma unroll
+        for (int ks = 0; ks < C / 2; ++ks) {
+            const float2 v = qv[ks];
+            qreg[ks] = hi ? v.y : v.x;
+        }
+    }
+    float sq[3], tq[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sq[d] = sp[(size_t)qrow * 3 + d]; tq[d] = tp[(size_t)qrow * 3 + d]; }
+
+    f32x16 acc_o[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    for (int j0 = 0; j0 < n; j0 += ATT_KT) {
+        __syncthreads();
+        // stage K, V rows j0..j0+63 (k-contiguous rows, coalesced along channels) and the keys' coordinates
+        for (int e = t; e < ATT_KT * C; e += 256) {
+            const int row = e / C, c = e % C;
+            const float *rp = base + (size_t)(j0 + row) * 3 * C;
+            const bool in = j0 + row < n_cap;
+            Ks[row * LD + c] = in ? rp[C + c] : 0.0f;
+            Vs[row * LD + c] = in ? rp[2 * C + c] : 0.0f;
+        }
+        for (int e = t; e < ATT_KT * 3; e += 256) {
+            const int row = e / 3, d = e % 3;
+            const bool in = j0 + row < n_cap;
+            Cs[row * 6 + d] = in ? sp[(size_t)(j0 + row) * 3 + d] : 0.0f;
+            Cs[row * 6 + 3 + d] = in ? tp[(size_t)(j0 + row) * 3 + d] : 0.0f;
+        }
+        __syncthreads();
+
+        // S^T = K Q^T : rows = keys (two blocks of 32), columns = this wave's 32 queries
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+            const float *ka = Ks + (kb * 32 + l31) * LD + hi;
+#pragma unroll
+            for (int ks = 0; ks < C / 2; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * ks], qreg[ks], s[kb], 0, 0, 0);
+        }
+        // logits = SC * (q.k) / sqrt(C);  running max
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kb * 32 + crow(r, hi);
+                const float *kc = Cs + kk * 6;
+                const float dx = sq[0] - kc[0], dy = sq[1] - kc[1], dz = sq[2] - kc[2];
+                const float ex = tq[0] - kc[3], ey = tq[1] - kc[4], ez = tq[2] - kc[5];
+                const float ds = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+                const float dt = __fsqrt_rn(ex * ex + ey * ey + ez * ez);
+                const float df = ds - dt;
+                float sc = 1.0f - df * df * inv_sigma2;
+                sc = sc > 0.0f ? sc : 0.0f;
+                float v = sc * (s[kb][r] * inv_sqrt_c);
+                v = (j0 + kk < n) ? v : -INFINITY;
+                s[kb][r] = v;
+                m_tile = fmaxf(m_tile, v);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);        // finite: key j0 < n is always live
+        const float alpha = __expf(m_run - m_new);       // exp(-inf) = 0 on the first tile
+        float l_tile = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = expf(s[kb][r] - m_new);
+                s[kb][r] = p;
+                l_tile += p;
+            }
+        l_run = l_run * alpha + l_tile;
+        m_run = m_new;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
+        // O^T += V^T P^T : A = V^T (lane (channel l31, half hi) reads V[key(r,hi)][channel]), B = own P registers
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *va = Vs + (kb * 32 + crow(r, hi)) * LD + l31;
+                const float p = s[kb][r];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[cb * 32], p, acc_o[cb], 0, 0, 0);
+            }
+    }
+    const float inv_l = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    float *mo = msg + ((size_t)b * n_cap + qrow) * C;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = acc_o[cb][4 * g + 0] * inv_l;
+            v.y = acc_o[cb][4 * g + 1] * inv_l;
+            v.z = acc_o[cb][4 * g + 2] * inv_l;
+            v.w = acc_o[cb][4 * g + 3] * inv_l;
+            *reinterpret_cast<float4 *>(mo + cb * 32 + 8 * g + 4 * hi) = v;
+        }
+}
+
+// F.normalize(feat, p=2, dim=-1) (PointDSC.py:156): one wave per row.
+__global__ __launch_bounds__(256) void pdsc_normalise_kernel(const float *__restrict__ feat, int C, int n_cap,
+                                                              const int32_t *__restrict__ n_rows, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_cap) return;
+    const float *f = feat + ((size_t)b * n_cap + row) * C;
+    float *o = out + ((size_t)b * n_cap + row) * C;
+    float s = 0.0f;
+    for (int c = lane; c < C; c += 64) s += f[c] * f[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    float d = __fsqrt_rn(s);
+    d = d < 1e-12f ? 1e-12f : d;
+    const bool live = row < n_rows[b];
+    for (int c = lane; c < C; c += 64) o[c] = live ? f[c] / d : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int launch_linear(bool relu, bool resid, const float *X, int ldx, size_t xb, const float *W, const float *bias,
+                         const float *R, int ldr, size_t rb, float *Y, int ldy, size_t yb, int K, int N, int B, int n_cap,
+                         const int32_t *n_rows, hipStream_t st)
+{
+    dim3 grid(n_cap / LIN_ROWS, ceil_div(N, LIN_COLS), B), block(256);
+    if (relu && !resid)
+        hipLaunchKernelGGL((pdsc_linear_kernel<true, false>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
+    else if (!relu && resid)
+        hipLaunchKernelGGL((pdsc_linear_kernel<false, true>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
+    else if (!relu && !resid)
+        hipLaunchKernelGGL((pdsc_linear_kernel<false, false>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
+    else
+        hipLaunchKernelGGL((pdsc_linear_kernel<true, true>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
+    return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+}
+
+void pdsc_launch_normalise(const float *feat, int C, int n_cap, int B, const int32_t *n_rows, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(pdsc_normalise_kernel, dim3(n_cap / 4, B), dim3(256), 0, st, feat, C, n_cap, n_rows, out);
+}
+
+// Runs the whole encoder: features [B,n_cap,C] (un-normalised) into ws.feat, confidence into ws.conf.
+int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *src, const float *tgt, const int32_t *n_rows,
+                     int B, int n_cap, hipStream_t st)
+{
+    const int C = M.cfg.num_channels, H = C / 2;
+    const size_t fb = (size_t)n_cap * C, qb = (size_t)n_cap * 3 * C, hb = (size_t)n_cap * H;
+    hipLaunchKernelGGL(pdsc_center_kernel, dim3(B), dim3(256), 0, st, src, tgt, n_rows, n_cap, ws.corr_pos);
+    // layer0: conv 6 -> C (PointDSC.py:72)
+    int rc = launch_linear(false, false, ws.corr_pos, 8, (size_t)n_cap * 8, M.w0, M.b0, nullptr, 0, 0, ws.feat, C, fb, M.cfg.in_dim, C,
+                           B, n_cap, n_rows, st);
+    if (rc) return rc;
+    const float inv_sigma2 = 1.0f / (M.sigma_d * M.sigma_d);
+    const float inv_sqrt_c = 1.0f / sqrtf((float)C);
+    for (int l = 0; l < M.cfg.num_layers; ++l) {
+        const PdscLayer &L = M.layers[l];
+        // PointCN: conv + BN + ReLU (BN folded)
+        rc = launch_linear(true, false, ws.feat, C, fb, L.w_pcn, L.b_pcn, nullptr, 0, 0, ws.feat1, C, fb, C, C, B, n_cap, n_rows, st);
+        if (rc) return rc;
+        // q | k | v projections as one GEMM with N = 3C
+        rc = launch_linear(false, false, ws.feat1, C, fb, L.w_qkv, L.b_qkv, nullptr, 0, 0, ws.qkv, 3 * C, qb, C, 3 * C, B, n_cap, n_rows, st);
+        if (rc) return rc;
+        dim3 ag(n_cap / ATT_Q, B);
+        if (C == 128)
+            hipLaunchKernelGGL((pdsc_attention_kernel<128>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg);
+        else if (C == 64)
+            hipLaunchKernelGGL((pdsc_attention_kernel<64>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg);
+        else
+            hipLaunchKernelGGL((pdsc_attention_kernel<32>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg);
+        if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
+        // fc_message: C -> C/2 -> C/2 -> C, residual onto the PointCN output
+        rc = launch_linear(true, false, ws.msg, C, fb, L.w_m1, L.b_m1, nullptr, 0, 0, ws.h1, H, hb, C, H, B, n_cap, n_rows, st);
+        if (rc) return rc;
+        rc = launch_linear(true, false, ws.h1, H, hb, L.w_m2, L.b_m2, nullptr, 0, 0, ws.h2, H, hb, H, H, B, n_cap, n_rows, st);
+        if (rc) return rc;
+        rc = launch_linear(false, true, ws.h2, H, hb, L.w_m3, L.b_m3, ws.feat1, C, fb, ws.feat, C, fb, H, C, B, n_cap, n_rows, st);
+        if (rc) return rc;
+    }
+    // confidence head C -> 32 -> 32 -> 1 (PointDSC.py:107-113)
+    rc = launch_linear(true, false, ws.feat, C, fb, M.w_c1, M.b_c1, nullptr, 0, 0, ws.h1, 32, (size_t)n_cap * 32, C, 32, B, n_cap, n_rows, st);
+    if (rc) return rc;
+    rc = launch_linear(true, false, ws.h1, 32, (size_t)n_cap * 32, M.w_c2, M.b_c2, nullptr, 0, 0, ws.h2, 32, (size_t)n_cap * 32, 32, 32, B, n_cap, n_rows, st);
+    if (rc) return rc;
+    rc = launch_linear(false, false, ws.h2, 32, (size_t)n_cap * 32, M.w_c3, M.b_c3, nullptr, 0, 0, ws.conf, 1, (size_t)n_cap, 32, 1, B, n_cap, n_rows, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pdsc_normalise_kernel, dim3(n_cap / 4, B), dim3(256), 0, st, ws.feat, C, n_cap, n_rows, ws.feat_n);
+    return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+}
+
+}  // namespace oryon

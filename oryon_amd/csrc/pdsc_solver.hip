@@ -1,0 +1,382 @@
+// K5-K10: PointDSC seed selection, per-seed consensus sets, power iteration, weighted Kabsch, hypothesis
+// scoring and the iterative refinement - all device-side, no host synchronisation.
+//
+// Replaces models/pointdsc/PointDSC.py:199-217 (pick_seeds), :234-336 (cal_seed_trans), :338-358
+// (cal_leading_eigenvector, incl. the joint allclose early exit over all seeds of a pair), :403-438
+// (post_refinement; the reference syncs to the host every iteration through int(inlier_num - previous) and
+// ships every 3x3 covariance to the CPU for LAPACK), and models/pointdsc/common.py:48-69 (knn, evaluated
+// only for the seed rows that are consumed).
+//
+// Ordering semantics: torch.argsort / topk tie order is implementation-defined in the reference
+// (SURVEY.md §7); here every ranking is "by value, ties by ascending index" (rank counting), which is what
+// a stable sort gives.
+#include "common.h"
+#include "kabsch.h"
+#include "pdsc.h"
+
+namespace oryon {
+
+// ------------------------------------------------------------------------------------------------ K5
+// is_local_max_i = AND_j (score_i >= score_j  OR  |s_i - s_j| >= R);  seeds = first S of the descending
+// order of score * is_local_max.  One workgroup per pair; O(n^2) compares out of LDS.
+__global__ __launch_bounds__(512) void pdsc_seeds_kernel(const float *__restrict__ src, const float *__restrict__ conf,
+                                                          const int32_t *__restrict__ n_rows, int n_cap, int S_cap,
+                                                          float radius, float ratio, int32_t *__restrict__ seeds,
+                                                          int32_t *__restrict__ n_seeds)
+{
+    extern __shared__ float sm[];
+    float *px = sm, *py = sm + n_cap, *pz = sm + 2 * n_cap, *sc = sm + 3 * n_cap, *key = sm + 4 * n_cap;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int n = n_rows[b];
+    int S = (int)((double)n * (double)ratio);
+    S = S < S_cap ? S : S_cap;
+    for (int i = t; i < n; i += blockDim.x) {
+        px[i] = src[((size_t)b * n_cap + i) * 3 + 0];
+        py[i] = src[((size_t)b * n_cap + i) * 3 + 1];
+        pz[i] = src[((size_t)b * n_cap + i) * 3 + 2];
+        sc[i] = conf[(size_t)b * n_cap + i];
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += blockDim.x) {
+        const float x = px[i], y = py[i], z = pz[i], s = sc[i];
+        bool lm = true;
+        for (int j = 0; j < n; ++j) {
+            const float dx = x - px[j], dy = y - py[j], dz = z - pz[j];
+            const float d = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+            lm = lm && ((s >= sc[j]) || (d >= radius));
+        }
+        key[i] = s * (lm ? 1.0f : 0.0f);
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += blockDim.x) {
+        const float k = key[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float kj = key[j];
+            rank += (kj > k || (kj == k && j < i)) ? 1 : 0;
+        }
+        if (rank < S) seeds[(size_t)b * S_cap + rank] = i;
+    }
+    if (t == 0) n_seeds[b] = S;
+}
+
+// ------------------------------------------------------------------------------------------------ K6 + K7a
+// One workgroup per (seed, pair): feature-space kNN of the seed row, then the k x k compatibility matrix
+//   M_ab = clamp(1 - (1 - f_a.f_b)/sigma^2, 0) * clamp(1 - (|s_a-s_b| - |t_a-t_b|)^2/sigma_d^2, 0),  M_aa = 0.
+constexpr int KNN_MAX_K = 64;
+__global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__restrict__ feat_n, const float *__restrict__ src,
+                                                               const float *__restrict__ tgt,
+                                                               const int32_t *__restrict__ n_rows, int n_cap, int C,
+                                                               const int32_t *__restrict__ seeds,
+                                                               const int32_t *__restrict__ n_seeds, int S_cap, int k_cfg,
+                                                               float inv_sigma2, float inv_sigma_d2,
+                                                               int32_t *__restrict__ knn_out, float *__restrict__ M_out)
+{
+    extern __shared__ float sm[];
+    const int b = blockIdx.y, s = blockIdx.x;
+    if (s >= n_seeds[b]) return;
+    const int n = n_rows[b];
+    const int k = k_cfg < n - 1 ? k_cfg : n - 1;
+    float *dist = sm;                       // [n_cap]
+    float *fs = dist + n_cap;               // [C] seed feature
+    float *kf = fs + C;                     // [KNN_MAX_K][C+1]
+    float *kc = kf + KNN_MAX_K * (C + 1);   // [KNN_MAX_K][6]
+    int *kidx = reinterpret_cast<int *>(kc + KNN_MAX_K * 6);  // [KNN_MAX_K]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int seed_row = seeds[(size_t)b * S_cap + s];
+    const float *F = feat_n + (size_t)b * n_cap * C;
+    for (int c = t; c < C; c += 256) fs[c] = F[(size_t)seed_row * C + c];
+    __syncthreads();
+    // 2 - 2 f_seed.f_j : one wave per row, lanes over channels
+    for (int j = wave; j < n; j += 4) {
+        float acc = 0.0f;
+        for (int c = lane; c < C; c += 64) acc = fmaf(fs[c], F[(size_t)j * C + c], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) dist[j] = 2.0f - 2.0f * acc;
+    }
+    __syncthreads();
+    // ascending rank (ties by index); rank 0 is dropped, ranks 1..k are the neighbours (common.py:68)
+    for (int j = t; j < n; j += 256) {
+        const float d = dist[j];
+        int rank = 0;
+        for (int m = 0; m < n; ++m) {
+            const float dm = dist[m];
+            rank += (dm < d || (dm == d && m < j)) ? 1 : 0;
+        }
+        if (rank >= 1 && rank <= k) kidx[rank - 1] = j;
+    }
+    __syncthreads();
+    for (int e = t; e < k * C; e += 256) {
+        const int a = e / C, c = e % C;
+        kf[a * (C + 1) + c] = F[(size_t)kidx[a] * C + c];
+    }
+    for (int e = t; e < k * 3; e += 256) {
+        const int a = e / 3, d = e % 3;
+        kc[a * 6 + d] = src[((size_t)b * n_cap + kidx[a]) * 3 + d];
+        kc[a * 6 + 3 + d] = tgt[((size_t)b * n_cap + kidx[a]) * 3 + d];
+    }
+    if (t < k) knn_out[((size_t)b * S_cap + s) * k_cfg + t] = kidx[t];
+    __syncthreads();
+    float *Mo = M_out + ((size_t)b * S_cap + s) * k_cfg * k_cfg;
+    for (int e = t; e < k * k; e += 256) {
+        const int a = e / k, c2 = e % k;
+        float v = 0.0f;
+        if (a != c2) {
+            float dot = 0.0f;
+            const float *fa = kf + a * (C + 1), *fb = kf + c2 * (C + 1);
+            for (int c = 0; c < C; ++c) dot = fmaf(fa[c], fb[c], dot);
+            float fm = 1.0f - (1.0f - dot) * inv_sigma2;
+            fm = fm > 0.0f ? fm : 0.0f;
+            const float *pa = kc + a * 6, *pb = kc + c2 * 6;
+            const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+            const float ex = pa[3] - pb[3], ey = pa[4] - pb[4], ez = pa[5] - pb[5];
+            const float df = __fsqrt_rn(dx * dx + dy * dy + dz * dz) - __fsqrt_rn(ex * ex + ey * ey + ez * ez);
+            float smv = 1.0f - df * df * inv_sigma_d2;
+            smv = smv > 0.0f ? smv : 0.0f;
+            v = fm * smv;
+        }
+        Mo[a * k_cfg + c2] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K7b + K8 + K9
+// One workgroup per pair (16 waves, one wave per seed at a time): joint power iteration, weight
+// normalisation, weighted Kabsch per seed, fitness over all correspondences, first-argmax, labels.
+constexpr int HYP_THREADS = 1024, HYP_WAVES = HYP_THREADS / 64;
+__global__ __launch_bounds__(HYP_THREADS) void pdsc_hypotheses_kernel(
+    const float *__restrict__ src, const float *__restrict__ tgt, const int32_t *__restrict__ n_rows, int n_cap,
+    const int32_t *__restrict__ n_seeds, int S_cap, int k_cfg, int num_iterations, float inlier_thr,
+    const int32_t *__restrict__ knn, const float *__restrict__ Mmat, float *__restrict__ seed_T, float *__restrict__ fitness,
+    int32_t *__restrict__ best, float *__restrict__ T_best, uint8_t *__restrict__ labels)
+{
+    extern __shared__ float sm[];
+    float *v_cur = sm;                          // [S_cap][64]
+    float *v_last = v_cur + S_cap * KNN_MAX_K;  // [S_cap][64]
+    float *s_fit = v_last + S_cap * KNN_MAX_K;  // [S_cap]
+    int *s_flag = reinterpret_cast<int *>(s_fit + S_cap);  // [S_cap] closeness per seed
+    float *s_T = s_fit + 2 * S_cap;             // [S_cap][16] per-seed transforms
+    __shared__ int s_all_close;
+    __shared__ int s_best;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = n_rows[b], S = n_seeds[b];
+    if (S <= 0) {
+        if (t == 0) best[b] = -1;
+        return;
+    }
+    const int k = k_cfg < n - 1 ? k_cfg : n - 1;
+    const float *sp = src + (size_t)b * n_cap * 3, *tp = tgt + (size_t)b * n_cap * 3;
+    for (int e = t; e < S * KNN_MAX_K; e += HYP_THREADS) { v_cur[e] = 1.0f; v_last[e] = 1.0f; }
+    __syncthreads();
+    // power iteration (PointDSC.py:347-357); the allclose test is over ALL seeds of the pair jointly
+    for (int it = 0; it < num_iterations; ++it) {
+        for (int s = wave; s < S; s += HYP_WAVES) {
+            const float *Ms = Mmat + ((size_t)b * S_cap + s) * k_cfg * k_cfg;
+            float u = 0.0f;
+            if (lane < k)
+                for (int c = 0; c < k; ++c) u = fmaf(Ms[lane * k_cfg + c], v_last[s * KNN_MAX_K + c], u);
+            float sq = (lane < k) ? u * u : 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+            const float vn = u / (__fsqrt_rn(sq) + 1e-6f);
+            const float vl = v_last[s * KNN_MAX_K + (lane < k ? lane : 0)];
+            const bool close = (lane >= k) || (fabsf(vn - vl) <= 1e-8f + 1e-5f * fabsf(vl));
+            const bool all = __all(close);
+            if (lane < k) v_cur[s * KNN_MAX_K + lane] = vn;
+            if (lane == 0) s_flag[s] = all ? 1 : 0;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int ok = 1;
+            for (int s = 0; s < S; ++s) ok &= s_flag[s];
+            s_all_close = ok;
+        }
+        for (int e = t; e < S * KNN_MAX_K; e += HYP_THREADS) v_last[e] = v_cur[e];
+        __syncthreads();
+        if (s_all_close) break;
+    }
+    // per seed: normalise weights, weighted Kabsch on the k neighbours, fitness over all n correspondences
+    for (int s = wave; s < S; s += HYP_WAVES) {
+        const float vv = lane < k ? v_last[s * KNN_MAX_K + lane] : 0.0f;
+        float sum = vv;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        float w = vv / (sum + 1e-6f);
+        w = w < 0.0f ? 0.0f : w;
+        KabschAcc acc;
+        acc.clear();
+        if (lane < k) {
+            const int j = knn[((size_t)b * S_cap + s) * k_cfg + lane];
+            acc.add(sp[3 * j], sp[3 * j + 1], sp[3 * j + 2], tp[3 * j], tp[3 * j + 1], tp[3 * j + 2], w);
+        }
+        acc.wave_reduce();
+        float T[16];
+        acc.solve(T);   // every lane solves the same 3x3 (keeps T in registers for the fitness pass)
+        int cnt = 0;
+        for (int j = lane; j < n; j += 64) {
+            const float x = sp[3 * j], y = sp[3 * j + 1], z = sp[3 * j + 2];
+            const float dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - tp[3 * j];
+            const float dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - tp[3 * j + 1];
+            const float dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - tp[3 * j + 2];
+            cnt += (__fsqrt_rn(dx * dx + dy * dy + dz * dz) < inlier_thr) ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane == 0) {
+            const float f = (float)cnt / (float)n;
+            s_fit[s] = f;
+            fitness[(size_t)b * S_cap + s] = f;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s_T[s * 16 + i] = T[i];
+                seed_T[((size_t)b * S_cap + s) * 16 + i] = T[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        int bi = 0;
+        float bf = s_fit[0];
+        for (int s = 1; s < S; ++s)
+            if (s_fit[s] > bf) { bf = s_fit[s]; bi = s; }   // first maximum, as torch.argmax
+        s_best = bi;
+        best[b] = bi;
+    }
+    __syncthreads();
+    float T[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = s_T[s_best * 16 + i];
+    if (t < 16) T_best[(size_t)b * 16 + t] = T[t];
+    if (labels)
+        for (int j = t; j < n_cap; j += HYP_THREADS) {
+            uint8_t lab = 0;
+            if (j < n) {
+                const float x = sp[3 * j], y = sp[3 * j + 1], z = sp[3 * j + 2];
+                const float dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - tp[3 * j];
+                const float dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - tp[3 * j + 1];
+                const float dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - tp[3 * j + 2];
+                lab = (__fsqrt_rn(dx * dx + dy * dy + dz * dz) < inlier_thr) ? 1 : 0;
+            }
+            labels[(size_t)b * n_cap + j] = lab;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ K10
+// post_refinement: <= 20 rounds of {warp, inliers, stop if the count repeats, weighted Kabsch on inliers}.
+__global__ __launch_bounds__(256) void pdsc_refine_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                           const int32_t *__restrict__ n_rows, int n_cap, float tau,
+                                                           const float *__restrict__ T_in, const int32_t *__restrict__ status_in,
+                                                           const int32_t *__restrict__ n_seeds, float *__restrict__ T_out,
+                                                           int32_t *__restrict__ status_out)
+{
+    __shared__ float sT[16];
+    __shared__ double s_red[4][17];
+    __shared__ int s_cnt[4];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = n_rows[b];
+    int st = status_in ? status_in[b] : ORYON_PAIR_OK;
+    if (st == ORYON_PAIR_OK && ((n_seeds && n_seeds[b] <= 0) || n < 2)) st = ORYON_PAIR_NO_CORR;
+    if (st != ORYON_PAIR_OK) {   // failure path of the reference: identity pose (pipeline.py:341,350)
+        if (t < 16) T_out[(size_t)b * 16 + t] = (t % 5 == 0) ? 1.0f : 0.0f;
+        if (t == 0 && status_out) status_out[b] = st;
+        return;
+    }
+    if (t < 16) sT[t] = T_in[(size_t)b * 16 + t];
+    __syncthreads();
+    const float *sp = src + (size_t)b * n_cap * 3, *tp = tgt + (size_t)b * n_cap * 3;
+    int prev = 0;
+    for (int it = 0; it < 20; ++it) {
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = sT[i];
+        KabschAcc acc;
+        acc.clear();
+        int cnt = 0;
+        for (int j = t; j < n; j += 256) {
+            const float x = sp[3 * j], y = sp[3 * j + 1], z = sp[3 * j + 2];
+            const float bx = tp[3 * j], by = tp[3 * j + 1], bz = tp[3 * j + 2];
+            const float dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - bx;
+            const float dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - by;
+            const float dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - bz;
+            const float d = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+            if (d < tau) {
+                ++cnt;
+                const float q = d / tau;
+                acc.add(x, y, z, bx, by, bz, 1.0f / (1.0f + q * q));
+            }
+        }
+        acc.wave_reduce();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        __syncthreads();
+        if (lane == 0) {
+            s_cnt[wave] = cnt;
+            s_red[wave][0] = acc.sw;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { s_red[wave][1 + i] = acc.sa[i]; s_red[wave][4 + i] = acc.sb[i]; }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s_red[wave][7 + i] = acc.sab[i];
+        }
+        __syncthreads();
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (total == prev) break;      // abs(int(inlier_num - previous)) < 1  (PointDSC.py:426)
+        prev = total;
+        if (t == 0) {
+            KabschAcc a;
+            a.sw = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a.sa[i] = s_red[0][1 + i] + s_red[1][1 + i] + s_red[2][1 + i] + s_red[3][1 + i];
+                a.sb[i] = s_red[0][4 + i] + s_red[1][4 + i] + s_red[2][4 + i] + s_red[3][4 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a.sab[i] = s_red[0][7 + i] + s_red[1][7 + i] + s_red[2][7 + i] + s_red[3][7 + i];
+            float Tn[16];
+            a.solve(Tn);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sT[i] = Tn[i];
+        }
+        __syncthreads();
+    }
+    if (t < 16) T_out[(size_t)b * 16 + t] = sT[t];
+    if (t == 0 && status_out) status_out[b] = ORYON_PAIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int pdsc_run_seeds(const PdscModel &M, const float *src, const float *conf, const int32_t *n_rows, int B, int n_cap, int S_cap,
+                   int32_t *seeds, int32_t *n_seeds, hipStream_t st)
+{
+    const size_t sh = (size_t)5 * n_cap * sizeof(float);
+    hipLaunchKernelGGL(pdsc_seeds_kernel, dim3(B), dim3(512), sh, st, src, conf, n_rows, n_cap, S_cap, M.cfg.nms_radius,
+                       M.cfg.ratio, seeds, n_seeds);
+    return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+}
+
+int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float *src, const float *tgt, const float *feat_n,
+                        const int32_t *n_rows, const int32_t *seeds, const int32_t *n_seeds, int B, int n_cap, float *seed_T,
+                        float *fitness, int32_t *best, float *T_best, uint8_t *labels, hipStream_t st)
+{
+    const int C = M.cfg.num_channels, k = M.cfg.k, S_cap = ws.S_cap;
+    const size_t sh1 = ((size_t)n_cap + C + (size_t)KNN_MAX_K * (C + 1) + KNN_MAX_K * 6 + KNN_MAX_K) * sizeof(float);
+    hipLaunchKernelGGL(pdsc_knn_matrix_kernel, dim3(S_cap, B), dim3(256), sh1, st, feat_n, src, tgt, n_rows, n_cap, C, seeds,
+                       n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat);
+    if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
+    const size_t sh2 = ((size_t)2 * S_cap * KNN_MAX_K + 2 * S_cap + 16 * S_cap) * sizeof(float);
+    hipLaunchKernelGGL(pdsc_hypotheses_kernel, dim3(B), dim3(HYP_THREADS), sh2, st, src, tgt, n_rows, n_cap, n_seeds, S_cap, k,
+                       M.cfg.num_iterations, M.cfg.inlier_threshold, ws.knn, ws.Mmat, seed_T, fitness, best, T_best, labels);
+    return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+}
+
+int pdsc_run_refine(const PdscModel &M, const float *src, const float *tgt, const int32_t *n_rows, int B, int n_cap,
+                    const float *T_in, const int32_t *status_in, const int32_t *n_seeds, float *T_out, int32_t *status_out,
+                    hipStream_t st)
+{
+    const float tau = (M.cfg.inlier_threshold == 0.10f) ? 0.10f : 1.2f;   // PointDSC.py:415-418
+    hipLaunchKernelGGL(pdsc_refine_kernel, dim3(B), dim3(256), 0, st, src, tgt, n_rows, n_cap, tau, T_in, status_in, n_seeds,
+                       T_out, status_out);
+    return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+}
+
+}  // namespace oryon
