@@ -93,13 +93,14 @@ int oryon_match_f32(const float *a_hat, const float *q_hat, int B, int C, int ca
 /* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).
  *     Replaces utils/pcd.py:205-214: keep rows with valid, need more than one, sample exactly max_corrs
  *     (with replacement iff fewer are available).
- * corrs [B, max_corrs, 4] int32 (y1,x1,y2,x2 in feature-map coordinates), n_valid [B], status [B]
- * (ORYON_PAIR_OK / ORYON_PAIR_NO_MASK when n_a or n_q is 0 / ORYON_PAIR_NO_CORR when <= 1 valid row).
- * scratch [B, cap_a] int32 (ordered list of valid anchor rows). */
+ * corrs [B, corr_rows, 4] int32 (y1,x1,y2,x2 in feature-map coordinates; corr_rows >= max_corrs is the row
+ * stride per pair, rows >= max_corrs are left untouched), n_valid [B] (rows under the threshold), n_sel [B]
+ * (max_corrs or 0; may be NULL), status [B] (ORYON_PAIR_OK / ORYON_PAIR_NO_MASK when n_a or n_q is 0 /
+ * ORYON_PAIR_NO_CORR when <= 1 valid row).  scratch [B, cap_a] int32 (ordered list of valid anchor rows). */
 int oryon_select_corrs(const int32_t *roi_a, const int32_t *roi_q, int roi_stride_a, int roi_stride_q,
                        const int32_t *n_a, const int32_t *n_q, const int32_t *argmin, const uint8_t *valid, int cap_a,
-                       int B, int W, int max_corrs, uint64_t seed, const int64_t *pair_key, int32_t *scratch,
-                       int32_t *corrs, int32_t *n_valid, int32_t *status, void *stream);
+                       int B, int W, int max_corrs, int corr_rows, uint64_t seed, const int64_t *pair_key,
+                       int32_t *scratch, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status, void *stream);
 
 /* K2  scale (y,x) to the original image, keep rows inside both images, truncate, gather depth, pin-hole
  *     lift, /1000.  Replaces pipeline.py:447-460 + utils/coordinates.py:5-48 + utils/pcd.py:44-74.

@@ -34,17 +34,18 @@ __device__ __forceinline__ int block_rank_sel(bool flag, int *s_wave, int &total
 __global__ __launch_bounds__(SEL_THREADS) void select_corrs_kernel(
     const int32_t *__restrict__ roi_a, const int32_t *__restrict__ roi_q, int stride_a, int stride_q,
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, const int32_t *__restrict__ argmin,
-    const uint8_t *__restrict__ valid, int cap_a, int W, int max_corrs, uint64_t seed, const int64_t *__restrict__ pair_key,
-    int32_t *__restrict__ scratch, int32_t *__restrict__ corrs, int32_t *__restrict__ n_valid, int32_t *__restrict__ status)
+    const uint8_t *__restrict__ valid, int cap_a, int W, int max_corrs, int corr_rows, uint64_t seed,
+    const int64_t *__restrict__ pair_key, int32_t *__restrict__ scratch, int32_t *__restrict__ corrs,
+    int32_t *__restrict__ n_valid, int32_t *__restrict__ n_sel, int32_t *__restrict__ status)
 {
     __shared__ int s_wave[SEL_WAVES];
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_prefix, s_remaining;
     const int p = blockIdx.x;
     const int na = n_a[p], nq = n_q[p];
-    int32_t *out = corrs + (size_t)p * max_corrs * 4;
+    int32_t *out = corrs + (size_t)p * corr_rows * 4;
     if (na <= 0 || nq <= 0) {
-        if (threadIdx.x == 0) { n_valid[p] = 0; status[p] = ORYON_PAIR_NO_MASK; }
+        if (threadIdx.x == 0) { n_valid[p] = 0; status[p] = ORYON_PAIR_NO_MASK; if (n_sel) n_sel[p] = 0; }
         return;
     }
     const uint8_t *v = valid + (size_t)p * cap_a;
@@ -60,7 +61,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_corrs_kernel(
         nv += tot;
     }
     __syncthreads();
-    if (threadIdx.x == 0) { n_valid[p] = nv; status[p] = nv > 1 ? ORYON_PAIR_OK : ORYON_PAIR_NO_CORR; }
+    if (threadIdx.x == 0) {
+        n_valid[p] = nv;
+        status[p] = nv > 1 ? ORYON_PAIR_OK : ORYON_PAIR_NO_CORR;
+        if (n_sel) n_sel[p] = nv > 1 ? max_corrs : 0;
+    }
     if (nv <= 1) return;
     const uint64_t key = pair_key ? (uint64_t)pair_key[p] : (uint64_t)p;
     const int32_t *ra = roi_a + (size_t)p * stride_a, *rq = roi_q + (size_t)p * stride_q;
@@ -219,15 +224,16 @@ using namespace oryon;
 
 extern "C" int oryon_select_corrs(const int32_t *roi_a, const int32_t *roi_q, int roi_stride_a, int roi_stride_q,
                                   const int32_t *n_a, const int32_t *n_q, const int32_t *argmin, const uint8_t *valid,
-                                  int cap_a, int B, int W, int max_corrs, uint64_t seed, const int64_t *pair_key,
-                                  int32_t *scratch, int32_t *corrs, int32_t *n_valid, int32_t *status, void *stream)
+                                  int cap_a, int B, int W, int max_corrs, int corr_rows, uint64_t seed,
+                                  const int64_t *pair_key, int32_t *scratch, int32_t *corrs, int32_t *n_valid,
+                                  int32_t *n_sel, int32_t *status, void *stream)
 {
     ORYON_CHECK_ARG(roi_a && roi_q && n_a && n_q && argmin && valid && scratch && corrs && n_valid && status);
-    ORYON_CHECK_ARG(B >= 0 && cap_a > 0 && W > 0 && max_corrs > 0 && roi_stride_a > 0 && roi_stride_q > 0);
+    ORYON_CHECK_ARG(B >= 0 && cap_a > 0 && W > 0 && max_corrs > 0 && corr_rows >= max_corrs && roi_stride_a > 0 && roi_stride_q > 0);
     if (B == 0) return ORYON_OK;
     hipLaunchKernelGGL(select_corrs_kernel, dim3(B), dim3(SEL_THREADS), 0, as_stream(stream), roi_a, roi_q, roi_stride_a,
-                       roi_stride_q, n_a, n_q, argmin, valid, cap_a, W, max_corrs, seed, pair_key, scratch, corrs, n_valid,
-                       status);
+                       roi_stride_q, n_a, n_q, argmin, valid, cap_a, W, max_corrs, corr_rows, seed, pair_key, scratch, corrs,
+                       n_valid, n_sel, status);
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

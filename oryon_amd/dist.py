@@ -1,0 +1,56 @@
+"""Multi-GPU layout of the path: pairs are independent (the reference loops `for i_b in range(BS)`,
+pipeline.py:313), so a batch is block-partitioned over ranks with NO data-path collective; one
+all_gather of [B_r, 17] fp32 rows (16 pose values + status) collates the result.
+The reference itself has no collation step (each rank writes its own CSV, pipeline.py:480-484).
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm (xGMI), "gloo" on CPU for tests."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type: str = "cuda") -> Tuple[int, int, int]:
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank).  A single process without those variables is world 1 and needs no group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition: rank r owns [start, stop) with ceil(total/world) items per rank (last ones short)."""
+    per = (total + world - 1) // world
+    start = min(rank * per, total)
+    return start, min(start + per, total)
+
+
+def gather_poses(pose_local: torch.Tensor, status_local: torch.Tensor, total: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Collate per-rank results into the global order.  pose_local [B_r,4,4] fp32, status_local [B_r] int32 ->
+    (pose [total,4,4], status [total]) on every rank.  Ranks may hold fewer than ceil(total/world) pairs: rows are
+    padded to equal size for the collective and cut afterwards."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return pose_local[:total], status_local[:total]
+    per = (total + world - 1) // world
+    dev = pose_local.device
+    packed = torch.zeros((per, 17), dtype=torch.float32, device=dev)
+    b = pose_local.shape[0]
+    packed[:b, :16] = pose_local.reshape(b, 16)
+    packed[:b, 16] = status_local.to(torch.float32)
+    out = torch.empty((world * per, 17), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, packed)
+    out = out[:total]
+    return out[:, :16].reshape(total, 4, 4).contiguous(), out[:, 16].to(torch.int32)

@@ -1,0 +1,76 @@
+"""Batched match -> lift -> registration engine: the whole per-sample loop of FPM_Pipeline.test_step
+(pipeline.py:313-355) for B pairs at once, with no host synchronisation between stages.
+
+    masks -> ROI (K0) -> subsample <=5000 (K0, device RNG) -> gather+normalise (K0) -> cosine NN (K1)
+          -> sample 500 correspondences (K1b, device RNG) -> scale/validate/lift (K2) -> PointDSC (K3-K10)
+
+Differences from the drop-in per-sample facade (oryon_amd.pcd / oryon_amd.pointdsc), by design:
+  * the two random draws use a counter-based device RNG keyed by (seed, global pair index), so results do
+    not depend on how pairs are sharded over GPUs; the reference's host torch.multinomial stream is kept
+    only in the per-sample facade;
+  * failures are reported as per-pair status codes (ORYON_PAIR_*) with an identity pose, exactly the values
+    pipeline.py:335-350 writes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib, ops
+from .pointdsc import PointDSC
+
+PAIR_OK, PAIR_NO_MASK, PAIR_NO_CORR = 0, 1, 2
+
+
+@dataclass
+class MatchPoseConfig:
+    """Flag names follow configs/config.yaml of the reference (test.* section)."""
+    dist_th: float = 0.25          # test.dist_th
+    n_corrs: int = 500             # test.n_corrs (= dataset.max_corrs)
+    src_sampling: Optional[int] = 5000   # test.src_sampling
+    seed: int = 1                  # seed (pipeline.py:296-299)
+
+
+class MatchPoseEngine:
+    def __init__(self, solver: PointDSC, cfg: Optional[MatchPoseConfig] = None):
+        self.solver = solver
+        self.cfg = cfg or MatchPoseConfig()
+        self.n_cap = ops.round_up(self.cfg.n_corrs, 128)
+
+    @torch.no_grad()
+    def run(self, feat_a: Tensor, feat_q: Tensor, mask_a: Tensor, mask_q: Tensor, depth_a: Tensor, depth_q: Tensor,
+            cam_a: Tensor, cam_q: Tensor, pair_key: Optional[Tensor] = None, keep: bool = False) -> Dict[str, Tensor]:
+        """feat_* [B,C,FH,FW] fp32, mask_* [B,FH,FW] int (==1 selects), depth_* [B,H,W] fp32 mm, cam_* [B,3,3] or [B,9].
+        Returns pose [B,4,4] fp32 (identity on failure), status [B] int32, n_valid [B], n_lifted [B]."""
+        dev = _lib.require_gpu(feat_a.device)
+        cfg = self.cfg
+        B, C, FH, FW = feat_a.shape
+        if pair_key is None:
+            pair_key = torch.arange(B, dtype=torch.int64, device=dev)
+        masks = torch.cat((mask_a.reshape(B, FH, FW), mask_q.reshape(B, FH, FW)), dim=0)
+        roi, cnt = ops.roi_compact(masks)
+        roi_a, roi_q = roi[:B], roi[B:]
+        n_a, n_q = cnt[:B], cnt[B:]
+        if cfg.src_sampling is not None:
+            ops.roi_subsample_(roi_a, n_a, cfg.src_sampling, cfg.seed, pair_key)
+            cap_a = ops.round_up(min(cfg.src_sampling, FH * FW), ops.ROW_PAD)
+        else:
+            cap_a = ops.round_up(FH * FW, ops.ROW_PAD)
+        cap_q = ops.round_up(FH * FW, ops.ROW_PAD)
+        a_hat = ops.gather_normalise(feat_a, roi_a, n_a, cap_a)
+        q_hat = ops.gather_normalise(feat_q, roi_q, n_q, cap_q)
+        min_dist, argmin, valid = ops.match(a_hat, q_hat, n_a, n_q, cfg.dist_th)
+        corrs, n_valid, n_sel, status = ops.select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, FW, cfg.n_corrs, cfg.seed,
+                                                         pair_key, corr_rows=self.n_cap)
+        cam_a = cam_a.reshape(B, 9).to(torch.float32).contiguous()
+        cam_q = cam_q.reshape(B, 9).to(torch.float32).contiguous()
+        pcd_a, pcd_q, n_lift = ops.lift_pairs(corrs, n_sel, (FH, FW), depth_a, depth_q, cam_a, cam_q, status)
+        pose, _, status_out = self.solver.register(pcd_a, pcd_q, n_lift, status)
+        out = dict(pose=pose, status=status_out, n_valid=n_valid, n_lifted=n_lift)
+        if keep:
+            out.update(roi_a=roi_a, roi_q=roi_q, n_a=n_a, n_q=n_q, min_dist=min_dist, argmin=argmin, valid=valid, corrs=corrs,
+                       pcd_a=pcd_a, pcd_q=pcd_q)
+        return out

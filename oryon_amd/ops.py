@@ -91,18 +91,22 @@ def match(a_hat: torch.Tensor, q_hat: torch.Tensor, n_a: torch.Tensor, n_q: torc
     return min_dist, argmin, valid
 
 
-def select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, W: int, max_corrs: int, seed: int, pair_key=None):
-    """Device-RNG correspondence sampling -> (corrs [B,max_corrs,4] i32, n_valid [B] i32, status [B] i32)."""
+def select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, W: int, max_corrs: int, seed: int, pair_key=None,
+                 corr_rows: Optional[int] = None):
+    """Device-RNG correspondence sampling -> (corrs [B,corr_rows,4] i32, n_valid [B], n_sel [B], status [B])."""
     dev = _lib.require_gpu(roi_a.device)
     B, cap_a = argmin.shape
-    corrs = torch.zeros((B, max_corrs, 4), dtype=torch.int32, device=dev)
+    corr_rows = int(corr_rows or max_corrs)
+    corrs = torch.zeros((B, corr_rows, 4), dtype=torch.int32, device=dev)
     n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
+    n_sel = torch.empty((B,), dtype=torch.int32, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     scratch = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
     check(lib().oryon_select_corrs(ptr(roi_a), ptr(roi_q), roi_a.shape[1], roi_q.shape[1], ptr(n_a), ptr(n_q), ptr(argmin),
-                                   ptr(valid), cap_a, B, int(W), int(max_corrs), int(seed) & (2**64 - 1), ptr(pair_key),
-                                   ptr(scratch), ptr(corrs), ptr(n_valid), ptr(status), stream_ptr(dev)), "oryon_select_corrs")
-    return corrs, n_valid, status
+                                   ptr(valid), cap_a, B, int(W), int(max_corrs), corr_rows, int(seed) & (2**64 - 1),
+                                   ptr(pair_key), ptr(scratch), ptr(corrs), ptr(n_valid), ptr(n_sel), ptr(status),
+                                   stream_ptr(dev)), "oryon_select_corrs")
+    return corrs, n_valid, n_sel, status
 
 
 def lift_pairs(corrs: torch.Tensor, n_corr: Optional[torch.Tensor], feat_hw, depth_a: torch.Tensor, depth_q: torch.Tensor,

@@ -43,7 +43,7 @@ def main():
         ev[3].record()
         md, am, va = ops.match(a_hat, q_hat, na, nq, 0.25)
         ev[4].record()
-        corrs, nv, st = ops.select_corrs(roi_a, roi_q, na, nq, am, va, a.H, 500, 1)
+        corrs, nv, _, st = ops.select_corrs(roi_a, roi_q, na, nq, am, va, a.H, 500, 1)
         ev[5].record()
         torch.cuda.synchronize()
         return [ev[i].elapsed_time(ev[i + 1]) for i in range(5)], na, nq, nv, st
