@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd SQLite database (`*_results.db`) into a per-kernel stats table
+(the same content as `--stats` CSV output): calls, total / average / min / max duration, share.
+Optionally also dumps PMC counter sums per kernel.
+
+    python tools/rocpd_summary.py gpurun_out/prof/bench_results.db > profiles/r01_bench_kernel_stats.md
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = c.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                     f"from kernels group by {name_col} order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    print(f"# rocprofv3 kernel-trace summary of `{path.split('/')[-1]}`\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % of GPU time |")
+    print("|---|---:|---:|---:|---:|---:|---:|")
+    for n, k, tot, avg, mn, mx in rows:
+        short = n if len(n) < 90 else n[:87] + "..."
+        print(f"| `{short}` | {k} | {tot / 1e6:.3f} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100.0 * tot / total:.2f} |")
+    try:
+        pm = c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection "
+                       "group by 1, 2 order by 1, 2").fetchall()
+    except sqlite3.Error:
+        pm = []
+    if pm:
+        print("\n## PMC counters (sum over dispatches)\n")
+        print("| kernel | counter | sum | dispatches | per dispatch |")
+        print("|---|---|---:|---:|---:|")
+        for n, cn, v, k in pm:
+            short = n if len(n) < 70 else n[:67] + "..."
+            print(f"| `{short}` | {cn} | {v:.6g} | {k} | {v / k:.6g} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
