@@ -171,11 +171,13 @@ __global__ __launch_bounds__(GN_ROWS) void gather_normalise_kernel(const float *
         for (int i = 0; i < (GN_ROWS * GN_KT / 4) / GN_ROWS; ++i) {
             const int fidx = t + GN_ROWS * i;
             const int r = fidx / (GN_KT / 4), c4 = fidx % (GN_KT / 4);
+            // k-permuted row layout consumed by K1: position 8g + 4h + j holds k = 8g + 2j + h  (c4 = 2g + h)
+            const int kb = 8 * (c4 >> 1) + (c4 & 1);
             float4 v;
-            v.x = tile[r * (GN_KT + 1) + c4 * 4 + 0];
-            v.y = tile[r * (GN_KT + 1) + c4 * 4 + 1];
-            v.z = tile[r * (GN_KT + 1) + c4 * 4 + 2];
-            v.w = tile[r * (GN_KT + 1) + c4 * 4 + 3];
+            v.x = tile[r * (GN_KT + 1) + kb + 0];
+            v.y = tile[r * (GN_KT + 1) + kb + 2];
+            v.z = tile[r * (GN_KT + 1) + kb + 4];
+            v.w = tile[r * (GN_KT + 1) + kb + 6];
             *reinterpret_cast<float4 *>(o + (size_t)r * Cp + k0 + c4 * 4) = v;
         }
         __syncthreads();

@@ -75,6 +75,18 @@ def gather_normalise(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor,
     return out
 
 
+def unpermute_k(x: torch.Tensor) -> torch.Tensor:
+    """K0 stores every descriptor row with k permuted inside groups of 8 (position 8g+4h+j holds k = 8g+2j+h, the order
+    the MFMA A/B operands consume 16-byte chunks in).  Returns the rows in natural k order (tests / debugging only)."""
+    Cp = x.shape[-1]
+    pos = torch.arange(Cp, device=x.device)
+    g, r = pos // 8, pos % 8
+    k_at_pos = 8 * g + 2 * (r % 4) + r // 4
+    out = torch.empty_like(x)
+    out[..., k_at_pos] = x
+    return out
+
+
 def match(a_hat: torch.Tensor, q_hat: torch.Tensor, n_a: torch.Tensor, n_q: torch.Tensor, threshold: float):
     """a_hat [B,cap_a,Cp], q_hat [B,cap_q,Cp] -> (min_dist [B,cap_a] f32, argmin [B,cap_a] i32, valid [B,cap_a] u8)."""
     dev = _lib.require_gpu(a_hat.device)

@@ -32,7 +32,8 @@ def test_argument_validation_without_gpu():
     assert L.oryon_roi_compact(None, 1, 16, None, None, None) == -1          # ORYON_ERR_INVALID_ARG, no launch attempted
     assert b"invalid argument" in L.oryon_last_error()
     assert L.oryon_match_f32(None, None, 1, 32, 128, 128, None, None, 0.25, None, None, None, None, 0, None) == -1
-    assert L.oryon_match_workspace_bytes(64, 5120) == 0                       # batch fills the chip: no split workspace
+    assert L.oryon_match_workspace_bytes(512, 5120) == 0                      # batch alone gives >= 16 rounds: no query split
+    assert L.oryon_match_workspace_bytes(64, 5120) == 64 * 4 * 5120 * 8       # cfg2: 4 splits x (fp32 + int32) per anchor row
     assert L.oryon_match_workspace_bytes(1, 2048) > 0
 
 

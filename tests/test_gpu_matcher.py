@@ -111,9 +111,10 @@ def test_gather_normalise_bit_exact():
     assert np.array_equal(roi[0, :n].cpu().numpy(), ref_roi)
     out = ops.gather_normalise(torch.from_numpy(f).cuda()[None], roi, cnt, ops.round_up(n, 256))
     ref = c_oracle.gather_normalise(f, ref_roi)
-    got = out[0, :n, :C].cpu().numpy()
+    nat = ops.unpermute_k(out)                                   # rows are stored k-permuted for the MFMA operands
+    got = nat[0, :n, :C].cpu().numpy()
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
-    assert float(out[0, :n, C:].abs().max()) == 0.0
+    assert float(nat[0, :n, C:].abs().max()) == 0.0
     assert float(out[0, n:ops.round_up(n, 256)].abs().max()) == 0.0
 
 
