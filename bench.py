@@ -202,7 +202,7 @@ def main():
                 "max_trans_err_m_vs_gt": float(trans_err.max()) if trans_err.numel() else None,
             },
             "roofline": {
-                "bound": "mfma", "kernel": "match_f32_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                "bound": "mfma", "kernel": "match_f32_regb_kernel<256>", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                 "flops_per_launch": flops, "avg_launch_ms": match_ms,
                 "share_of_step": match_ms / (elapsed / a.steps * 1e3),

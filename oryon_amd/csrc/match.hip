@@ -350,18 +350,32 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_f32_regb_kernel(
                 } else {
                     const int qlane = qt * ROWS + 4 * hi;
                     const bool full = (qt + 1) * ROWS <= nq;
+                    // dist = fma(-0.5, dot, 0.5) is monotone in dot, so the tile's smallest distance is the image of its
+                    // largest dot product: one max tree + one fma decide whether ANY lane of the wave improves.  Only then
+                    // (ever rarer as the running minimum settles) is the exact first-index search below executed.
+                    float mx = acc[0][0];
 #pragma unroll
                     for (int m = 0; m < NACC; ++m)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int q = qlane + m * 32 + (r & 3) + 8 * (r >> 2);
-                            float d = __fmaf_rn(-0.5f, acc[m][r], 0.5f);
-                            if (!full) d = (q < nq) ? d : INFINITY;
-                            const bool better = d < best;     // strict: first (smallest) query index wins ties
-                            best = better ? d : best;
-                            bidx = better ? q : bidx;
-                            acc[m][r] = 0.0f;
-                        }
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[m][r]);
+                    const bool improves = __fmaf_rn(-0.5f, mx, 0.5f) < best;
+                    if (!full || __any(improves)) {
+#pragma unroll
+                        for (int m = 0; m < NACC; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int q = qlane + m * 32 + (r & 3) + 8 * (r >> 2);
+                                float d = __fmaf_rn(-0.5f, acc[m][r], 0.5f);
+                                if (!full) d = (q < nq) ? d : INFINITY;
+                                const bool better = d < best;     // strict: first (smallest) query index wins ties
+                                best = better ? d : best;
+                                bidx = better ? q : bidx;
+                            }
+                    }
+#pragma unroll
+                    for (int m = 0; m < NACC; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
                 }
             }
             if (!(VAR & 2)) {

@@ -1,0 +1,112 @@
+"""GPU tests of the callers (oryon_amd.pipeline.Pipeline / engine): reference-shaped per-sample loop, batched
+engine, failure statuses, partition invariance (sharded == unsharded bit for bit)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(L=2, C=32):
+    from oracle import oryon_oracle as orc
+    from oryon_amd.pointdsc import PointDSC
+    m = PointDSC(in_dim=6, num_layers=L, num_channels=C, num_iterations=10, ratio=0.1, sigma_d=0.1, k=40, nms_radius=0.1)
+    m.load_state_dict(orc.analytic_pointdsc_params(L, C), strict=True)
+    return m.cuda().eval()
+
+
+def _batch(idx, H=48, C=32, dev="cuda"):
+    from oryon_amd.synth import make_pair
+    pairs = [make_pair(i, H, H, C) for i in idx]
+    B = len(pairs)
+    st = lambda k: torch.stack([p[k] for p in pairs])
+    anchor_pose = torch.eye(4).repeat(B, 1, 1)
+    anchor_pose[:, :3, 3] = torch.tensor([0.01, -0.02, 0.8])
+    batch = {
+        "featmap_a": st("feat_a").to(dev), "featmap_q": st("feat_q").to(dev),
+        "anchor": {"mask": st("mask_a").to(torch.uint8), "orig_depth": [p["depth_a"] for p in pairs], "camera": st("camera"),
+                   "pose": anchor_pose, "instance_id": [f"s {i} a" for i in idx], "sizes": torch.tensor([[H, H]] * B)},
+        "query": {"mask": st("mask_q").to(torch.uint8), "orig_depth": [p["depth_q"] for p in pairs], "camera": st("camera"),
+                  "pose": st("pose").float(), "instance_id": [f"s {i} q" for i in idx], "sizes": torch.tensor([[H, H]] * B)},
+        "instance_id": [f"s {i}" for i in idx], "cls_id": [1] * B,
+    }
+    return batch, pairs
+
+
+def _pipeline(H=48):
+    from oryon_amd.pipeline import Pipeline, default_args
+    args = default_args(**{"test.mask": "oracle", "model.image_encoder.img_size": [H, H], "dataset.img_size": [H, H]})
+    return Pipeline(args, pointdsc_solver=_solver())
+
+
+def test_test_step_reference_shaped_loop():
+    pl = _pipeline()
+    batch, pairs = _batch([3, 4, 5])
+    batch["query"]["mask"][1] = 0                      # pair 1: empty query mask -> invalid detection
+    torch.manual_seed(1)
+    recs = pl.test_step(batch, 0)
+    assert [r["status"] for r in recs] == [0, 1, 0]
+    assert torch.equal(recs[1]["pred_pose_rel"], torch.eye(4)) and recs[1]["pred_pose"] is None
+    assert len(pl.pred_lines) == 3 and pl.pred_lines[1].split(",")[2].split(" ")[0] == "1.0"
+    for b in (0, 2):
+        T = recs[b]["pred_pose_rel"].numpy()
+        gt = pairs[b]["pose"].numpy()
+        assert np.abs(T[:3, :3] - gt[:3, :3]).max() < 1e-2 and np.abs(T[:3, 3] - gt[:3, 3]).max() < 5e-3
+        np.testing.assert_allclose(recs[b]["pred_pose"].numpy(), T @ batch["anchor"]["pose"][b].numpy(), atol=1e-6)
+
+
+def test_unknown_solver_raises_runtime_error():
+    pl = _pipeline()
+    pl.args.test.solver = "ransac"
+    batch, _ = _batch([3])
+    with pytest.raises(RuntimeError):
+        pl.get_pose(batch, torch.zeros((500, 4), dtype=torch.int64), 0)
+
+
+def test_batched_step_statuses_and_ground_truth():
+    pl = _pipeline()
+    batch, pairs = _batch([3, 4, 5, 6])
+    batch["anchor"]["mask"][2] = 0                     # NO_MASK
+    batch["featmap_q"][3] = 0.0                          # null descriptors: cos = 0 -> dist 0.5, nothing under 0.25 -> NO_CORR
+    out = pl.test_step_batched(batch)
+    st = out["status"].cpu().tolist()
+    assert st == [0, 0, 1, 2]
+    eye = torch.eye(4)
+    assert torch.equal(out["pose"][2].cpu(), eye) and torch.equal(out["pose"][3].cpu(), eye)
+    for b in (0, 1):
+        T = out["pose"][b].cpu().numpy()
+        gt = pairs[b]["pose"].numpy()
+        assert np.abs(T[:3, :3] - gt[:3, :3]).max() < 1e-2 and np.abs(T[:3, 3] - gt[:3, 3]).max() < 5e-3
+    np.testing.assert_allclose(out["pred_q"][0].cpu().numpy(), out["pose"][0].cpu().numpy() @ batch["anchor"]["pose"][0].numpy(), atol=1e-6)
+
+
+def test_partition_invariance_bit_for_bit():
+    """Processing pairs [0..5] in one batch == processing them as the shards a 2- or 3-rank job would own
+    (global pair index keys the device RNG)."""
+    from oryon_amd.dist import shard_range
+    pl = _pipeline()
+    idx = list(range(10, 16))
+    batch, _ = _batch(idx)
+    full = pl.test_step_batched(batch, first_pair_index=10)
+    for world in (2, 3):
+        poses = []
+        for r in range(world):
+            s, e = shard_range(len(idx), r, world)
+            sub, _ = _batch(idx[s:e])
+            poses.append(pl.test_step_batched(sub, first_pair_index=10 + s)["pose"])
+        assert torch.equal(torch.cat(poses), full["pose"])
+
+
+def test_predicted_mask_path():
+    from oryon_amd.pipeline import Pipeline, default_args
+    H = 48
+    args = default_args(**{"test.mask": "predicted", "model.image_encoder.img_size": [H, H]})
+    pl = Pipeline(args, pointdsc_solver=_solver())
+    batch, pairs = _batch([3, 4])
+    for key, mk in (("mask_a", "anchor"), ("mask_q", "query")):
+        batch[key] = (batch[mk]["mask"].float().cuda() * 8.0 - 4.0)[:, None]      # logits: +4 inside, -4 outside
+    res = pl.mask_results(batch, pl.model.forward(batch))
+    assert torch.equal(res["mask_a"].cpu(), batch["anchor"]["mask"].int())
+    assert float(res["iou_a"].min()) == 1.0
+    out = pl.test_step_batched(batch)
+    assert out["status"].cpu().tolist() == [0, 0]
