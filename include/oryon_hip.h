@@ -73,9 +73,13 @@ int oryon_roi_subsample(int32_t *roi, int32_t *count, int n_maps, int roi_stride
  *     cosine_similarity (utils/pcd.py:28).
  * feat [n_maps, C, HW] fp32; roi [n_maps, roi_stride]; out [n_maps, rows_cap, C_pad] fp32, row-major; rows
  * >= count[m] up to the next multiple of 256 and columns C..C_pad-1 are zero-filled (zero columns do not
- * change the fmaf chain).  C_pad is a multiple of 32 (>= C), rows_cap a multiple of 256. */
+ * change the fmaf chain).  C_pad is a multiple of 32 (>= C), rows_cap a multiple of 256.
+ * Layout note: inside every group of 8 columns the fp32 rows are stored k-permuted (position 8g+4h+j holds
+ * k = 8g+2j+h, the order the MFMA operands consume 16-byte chunks in); consumers are K1 and K1s only.
+ * out_f16 (may be NULL): [n_maps, rows_cap, C_pad] IEEE half copy of the same unit rows (round-to-nearest), natural k
+ * order - the operand of the screening pass of oryon_match_screened. */
 int oryon_gather_normalise_f32(const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride,
-                               const int32_t *count, int rows_cap, int C_pad, float *out, void *stream);
+                               const int32_t *count, int rows_cap, int C_pad, float *out, void *out_f16, void *stream);
 
 /* K1  cosine nearest neighbour: for every anchor row the query row minimising 0.5*(1 - a^.q^).
  *     Replaces pdist(...,'inv_norm_cosine') + amin + argmin + (min_dist < th) (utils/pcd.py:202-205)
@@ -89,6 +93,18 @@ size_t oryon_match_workspace_bytes(int B, int cap_a);
 int oryon_match_f32(const float *a_hat, const float *q_hat, int B, int C, int cap_a, int cap_q,
                     const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist, int32_t *argmin,
                     uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream);
+
+/* K1s same contract as oryon_match_f32 for every anchor row that can reach the threshold, computed as an fp16-MFMA
+ *     screening pass (v_mfma_f32_32x32x16_f16 on the IEEE-half copies written by oryon_gather_normalise_f32) followed by
+ *     an exact fp32 re-scoring of the surviving candidates with K1's canonical fmaf chain.  A proven error bound on the
+ *     screening scores (csrc/match16.hip) guarantees that every exact minimiser is a candidate, so on rows with
+ *     valid == 1 `min_dist` / `argmin` are bit-identical to oryon_match_f32, and `valid` is identical on every row.
+ *     Rows that provably cannot reach the threshold get valid = 0, argmin = 0 and the screening estimate as min_dist.
+ * C (padded) must be 128 or 256, cap_a a multiple of 256; a_f16 / q_f16 are the half copies [B, cap, C]. */
+size_t oryon_match_screened_workspace_bytes(int B, int cap_a);
+int oryon_match_screened(const float *a_hat, const float *q_hat, const void *a_f16, const void *q_f16, int B, int C,
+                         int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
+                         int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream);
 
 /* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).
  *     Replaces utils/pcd.py:205-214: keep rows with valid, need more than one, sample exactly max_corrs

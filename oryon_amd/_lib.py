@@ -34,9 +34,11 @@ _PROTOS = {
     "oryon_mask_from_logits": (c_int, [_P, c_int64, c_float, _P, _P]),
     "oryon_mask_resize_nearest": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "oryon_roi_subsample": (c_int, [_P, _P, c_int, c_int, c_int, c_uint64, _P, _P]),
-    "oryon_gather_normalise_f32": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P]),
+    "oryon_gather_normalise_f32": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P, _P]),
     "oryon_match_workspace_bytes": (c_size_t, [c_int, c_int]),
     "oryon_match_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "oryon_match_screened_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "oryon_match_screened": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "oryon_select_corrs": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_uint64, _P, _P,
                                    _P, _P, _P, _P, _P]),
     "oryon_lift_pairs": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,

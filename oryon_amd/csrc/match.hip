@@ -22,10 +22,9 @@
 // through that XCD's L2.
 #include <stdlib.h>
 #include "common.h"
+#include "match_common.h"
 
 namespace oryon {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MT = ORYON_MATCH_TILE;  // 128 queries x 128 anchors per workgroup step
 constexpr int BK = 32;                // k-tile
@@ -33,13 +32,6 @@ constexpr int LD = BK + 1;            // padded LDS row: ds_read_b32 of a 32-row
 constexpr int MATCH_THREADS = 256;
 constexpr int MAX_SPLIT = 16;
 constexpr int TILE_FLOATS = MT * LD;
-
-__device__ __forceinline__ void lex_min(float &d, int &i, float od, int oi)
-{
-    const bool take = (od < d) || (od == d && oi < i);
-    d = take ? od : d;
-    i = take ? oi : i;
-}
 
 __global__ __launch_bounds__(MATCH_THREADS, 2) void match_f32_kernel(
     const float *__restrict__ a_hat, const float *__restrict__ q_hat, int B, int Cp, int cap_a, int cap_q,
@@ -217,7 +209,8 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_f32_regb_kernel(
     const float *__restrict__ a_hat, const float *__restrict__ q_hat, int B, int cap_a, int cap_q,
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, float thr, int T, int S,
     float *__restrict__ min_dist, int32_t *__restrict__ argmin, uint8_t *__restrict__ valid,
-    float *__restrict__ ws_dist, int32_t *__restrict__ ws_idx)
+    float *__restrict__ ws_dist, int32_t *__restrict__ ws_idx, const int32_t *__restrict__ panel_flag,
+    const uint8_t *__restrict__ row_flag)
 {
     constexpr int RB = CP * 4;                          // source row bytes
     constexpr int ROWS = CP >= 128 ? 64 : 8192 / CP;    // query rows per LDS tile
@@ -241,6 +234,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_f32_regb_kernel(
     const int na = n_a[p], nq = n_q[p];
     const int a0 = panel * MT;
     if (a0 >= na) return;
+    if (panel_flag && !panel_flag[(size_t)p * T + panel]) return;   // flagged-recompute mode: untouched panels exit
     const int nqt = (nq + ROWS - 1) / ROWS;
     const int qt_per = (nqt + S - 1) / S;
     const int qt_begin = split * qt_per;
@@ -391,7 +385,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_f32_regb_kernel(
         lex_min(best, bidx, od, oi);
     }
     const int a = a0 + wave * 32 + l31;
-    if (hi == 0 && a < na) {
+    if (hi == 0 && a < na && (!row_flag || row_flag[(size_t)p * cap_a + a])) {
         if (S == 1) {
             const size_t o = (size_t)p * cap_a + a;
             min_dist[o] = best;
@@ -434,6 +428,24 @@ static int pick_split(int B, int T)
     return S;
 }
 
+int match_f32_flagged(const float *a_hat, const float *q_hat, int B, int C, int cap_a, int cap_q, const int32_t *n_a,
+                      const int32_t *n_q, float threshold, float *min_dist, int32_t *argmin, uint8_t *valid,
+                      const int32_t *panel_flag, const uint8_t *row_flag, void *stream)
+{
+    const int T = cap_a / MT;
+    const int groups = ((B + 7) / 8) * 8 * T;      // S = 1: one unit per pair
+    hipStream_t st = as_stream(stream);
+#define LAUNCH_FLAGGED(CPV)                                                                                               \
+    hipLaunchKernelGGL((match_f32_regb_kernel<CPV>), dim3(groups), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, cap_a, cap_q, \
+                       n_a, n_q, threshold, T, 1, min_dist, argmin, valid, nullptr, nullptr, panel_flag, row_flag)
+    if (C == 128) LAUNCH_FLAGGED(128);
+    else if (C == 256) LAUNCH_FLAGGED(256);
+    else { set_error("match_f32_flagged: unsupported C_pad %d", C); return ORYON_ERR_INVALID_ARG; }
+#undef LAUNCH_FLAGGED
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
 }  // namespace oryon
 
 using namespace oryon;
@@ -470,13 +482,13 @@ extern "C" int oryon_match_f32(const float *a_hat, const float *q_hat, int B, in
     hipStream_t st = as_stream(stream);
 #define LAUNCH_REGB(CPV)                                                                                                  \
     hipLaunchKernelGGL((match_f32_regb_kernel<CPV>), dim3(groups_regb), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, cap_a, cap_q, \
-                       n_a, n_q, threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx)
+                       n_a, n_q, threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx, nullptr, nullptr)
     if (C == 32) LAUNCH_REGB(32);
     else if (C == 64) LAUNCH_REGB(64);
     else if (C == 128) LAUNCH_REGB(128);
     else if (C == 256) {
         static const int var = getenv("ORYON_MATCH_VARIANT") ? atoi(getenv("ORYON_MATCH_VARIANT")) : 0;
-#define LAUNCH_VAR(V) hipLaunchKernelGGL((match_f32_regb_kernel<256, V>), dim3(groups_regb), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, cap_a, cap_q, n_a, n_q, threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx)
+#define LAUNCH_VAR(V) hipLaunchKernelGGL((match_f32_regb_kernel<256, V>), dim3(groups_regb), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, cap_a, cap_q, n_a, n_q, threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx, nullptr, nullptr)
         switch (var) {
             case 1: LAUNCH_VAR(1); break; case 2: LAUNCH_VAR(2); break; case 3: LAUNCH_VAR(3); break; case 4: LAUNCH_VAR(4); break;
             case 5: LAUNCH_VAR(5); break; case 6: LAUNCH_VAR(6); break; case 7: LAUNCH_VAR(7); break; default: LAUNCH_REGB(256);

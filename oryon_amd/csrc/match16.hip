@@ -1,0 +1,339 @@
+// K1s: cosine nearest neighbour with an fp16-MFMA SCREENING pass and an exact fp32 re-scoring pass.
+//
+// Same contract as K1 (utils/pcd.py:202-205: dist = 0.5*(1-cos), row amin/argmin, < threshold) for every
+// anchor row that can possibly be valid, at a fraction of the fp32-MFMA cost:
+//
+//   pass 0  s16_ij = a16_i . q16_j on v_mfma_f32_32x32x16_f16 (IEEE-half copies of the unit rows, fp32 accumulate);
+//           per anchor only max_j s16_ij is kept.
+//   pass 1  the same products again; every j with s16_ij >= max_i - MARGIN is appended to anchor i's candidate list.
+//           Rows with max_i < (1 - 2*threshold) - DELTA can never pass the threshold: no candidates, valid = 0.
+//   pass 2  candidates are re-scored with the canonical fp32 fmaf chain of K1 (bit-exact vs the oracle) and the first
+//           index of the smallest distance wins.  Lists that overflow (duplicate-heavy inputs) flag their anchor panel,
+//           which is then recomputed by the exact fp32 kernel (match_f32_regb_kernel) - still no host round trip.
+//
+// Why this is exact.  For unit rows |a16.q16 - a.q| <= DELTA with
+//   DELTA = (2^-10 + 2^-22) * sum|a_k q_k|   (two half roundings per product, sum|a_k q_k| <= |a||q| = 1)
+//         + 2 * C * 2^-24                     (fp32 accumulation of the MFMA and of the canonical chain)  ~= 1.01e-3  (C <= 256).
+// If j* minimises the exact distance then a.q_j* >= max_j a.q_j - 2^-23 (dist is a monotone rounding of the dot), hence
+// s16_ij* >= max_j s16_ij - 2*DELTA - 2^-23: every exact minimiser - including every tied one - is in the list, and pass 2
+// returns exactly what the full fp32 scan returns.  MARGIN = 2.2e-3 > 2*DELTA + 2^-23.
+#include <hip/hip_fp16.h>
+#include "common.h"
+#include "match_common.h"
+
+namespace oryon {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr float SCREEN_DELTA = 1.05e-3f;
+constexpr float SCREEN_MARGIN = 2.2e-3f;
+constexpr int SCREEN_CAP = 64;          // candidate slots per anchor
+constexpr int MT16 = 256;               // anchors per workgroup (4 waves x 2 blocks of 32)
+
+template <int CP, int MODE>
+__global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
+    const __half *__restrict__ a16, const __half *__restrict__ q16, int B, int cap_a, int cap_q,
+    const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, int T, int S, float valid_cut,
+    float *__restrict__ ws_max /*[B,S,cap_a]*/, int32_t *__restrict__ cnt /*[B,cap_a]*/, int32_t *__restrict__ cand)
+{
+    constexpr int RB = CP * 2;                   // row bytes
+    constexpr int ROWS = 32768 / RB;             // query rows per 32 KB LDS tile (64 at C=256)
+    constexpr int NQB = ROWS / 32;               // query blocks per tile
+    constexpr int NAB = 2;                       // anchor blocks per wave
+    constexpr int NKS = CP / 16;                 // MFMA k-steps
+    constexpr int TILE_BYTES = 32768;
+    constexpr int NI = 8;
+    constexpr int LPR = RB / 256;                // 256-byte lines per row
+    static_assert(NQB * NKS == 32 && LPR >= 1, "tile geometry");
+    __shared__ __attribute__((aligned(256))) char smem[2 * TILE_BYTES];
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = (slot / T) * 8 + xcd;
+    if (unit >= B * S) return;
+    const int panel = slot % T;
+    const int p = unit / S, split = unit % S;
+    const int na = n_a[p], nq = n_q[p];
+    const int a0 = panel * MT16;
+    if (a0 >= na) return;
+    const int nqt = (nq + ROWS - 1) / ROWS;
+    const int qt_per = (nqt + S - 1) / S;
+    const int qt_begin = split * qt_per;
+    const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const char *qp = reinterpret_cast<const char *>(q16 + (size_t)p * cap_q * CP);
+
+    // stationary B operand: anchors a0 + wave*64 + ab*32 + l31, k-step s -> halves 16s + 8hi .. +7
+    half8 breg[NAB][NKS];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const __half *arow = a16 + ((size_t)p * cap_a + a0 + wave * 64 + ab * 32 + l31) * CP + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) breg[ab][s] = *reinterpret_cast<const half8 *>(arow + 16 * s);
+    }
+
+    unsigned dma_off[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        const int row = line / LPR;
+        const int cc = sl ^ (row & 15);
+        dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue = [&](int qt, int buf) {
+        const char *qb = qp + (size_t)qt * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+    const unsigned rd_base = (unsigned)(l31 * RB);
+    const unsigned rd_key = (unsigned)(hi ^ (l31 & 15));
+    auto rd = [&](int s, int qb, unsigned tile) -> half8 {
+        unsigned key = rd_key;
+        asm volatile("" : "+v"(key));
+        const unsigned off = rd_base + ((key ^ (2u * (s & 7))) << 4) + (unsigned)(qb * 32 * RB + (s >> 3) * 256) + tile;
+        return *reinterpret_cast<const half8 *>(smem + off);
+    };
+
+    f32x16 acc[NQB][NAB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qb][ab][r] = 0.0f;
+
+    float runmax[NAB], thr[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        runmax[ab] = -INFINITY;
+        thr[ab] = INFINITY;
+        if (MODE == 1) {
+            const int a = a0 + wave * 64 + ab * 32 + l31;
+            float m = -INFINITY;
+            for (int s = 0; s < S; ++s) m = fmaxf(m, ws_max[((size_t)p * S + s) * cap_a + a]);
+            thr[ab] = (a < na && m >= valid_cut) ? m - SCREEN_MARGIN : INFINITY;
+        }
+    }
+
+    if (qt_end > qt_begin) issue(qt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int buf = 0;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        if (qt + 1 < qt_end) issue(qt + 1, buf ^ 1);
+        const unsigned tile = buf * TILE_BYTES;
+        half8 ring[2][NQB];
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) ring[0][qb] = rd(0, qb, tile);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            if (s + 1 < NKS) {
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) ring[(s + 1) & 1][qb] = rd(s + 1, qb, tile);
+            }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab)
+                    acc[qb][ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[s & 1][qb], breg[ab][s], acc[qb][ab], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: lane owns anchor column (ab, l31); rows of the C/D block are queries
+        const int qlane = qt * ROWS + 4 * hi;
+        const bool full = (qt + 1) * ROWS <= nq;
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[qb][ab][r];
+                    if (!full) {
+                        const int q = qlane + qb * 32 + (r & 3) + 8 * (r >> 2);
+                        v = (q < nq) ? v : -INFINITY;
+                        acc[qb][ab][r] = v;
+                    }
+                    m = fmaxf(m, v);
+                }
+            if (MODE == 0) {
+                runmax[ab] = fmaxf(runmax[ab], m);
+            } else if (__any(m >= thr[ab])) {
+                const size_t arow = (size_t)p * cap_a + a0 + wave * 64 + ab * 32 + l31;
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (acc[qb][ab][r] >= thr[ab]) {
+                            const int sl = atomicAdd(&cnt[arow], 1);
+                            if (sl < SCREEN_CAP) cand[arow * SCREEN_CAP + sl] = qlane + qb * 32 + (r & 3) + 8 * (r >> 2);
+                        }
+            }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[qb][ab][r] = 0.0f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab) {
+            const float m = fmaxf(runmax[ab], __shfl_xor(runmax[ab], 32));
+            const int a = a0 + wave * 64 + ab * 32 + l31;
+            if (hi == 0) ws_max[((size_t)p * S + split) * cap_a + a] = m;
+        }
+    }
+}
+
+// pass 2: one wave per anchor row, one candidate per lane; canonical fp32 chain on the k-permuted fp32 rows.
+__global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restrict__ a_hat, const float *__restrict__ q_hat,
+                                                             int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
+                                                             const int32_t *__restrict__ n_q, int S, float thr, float valid_cut,
+                                                             const float *__restrict__ ws_max, const int32_t *__restrict__ cnt,
+                                                             const int32_t *__restrict__ cand, float *__restrict__ min_dist,
+                                                             int32_t *__restrict__ argmin, uint8_t *__restrict__ valid,
+                                                             uint8_t *__restrict__ row_flag, int32_t *__restrict__ panel_flag)
+{
+    const int p = blockIdx.y;
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (a >= n_a[p]) return;
+    const size_t arow = (size_t)p * cap_a + a;
+    float m16 = -INFINITY;
+    for (int s = 0; s < S; ++s) m16 = fmaxf(m16, ws_max[((size_t)p * S + s) * cap_a + a]);
+    if (!(m16 >= valid_cut)) {          // cannot reach the threshold: report the screening estimate, valid = 0
+        if (lane == 0) {
+            min_dist[arow] = __fmaf_rn(-0.5f, m16, 0.5f);
+            argmin[arow] = 0;
+            valid[arow] = 0;
+        }
+        return;
+    }
+    const int c = cnt[arow];
+    if (c > SCREEN_CAP) {               // list overflow: the exact fp32 kernel recomputes this anchor's panel
+        if (lane == 0) {
+            row_flag[arow] = 1;
+            panel_flag[(size_t)p * (cap_a / ORYON_MATCH_TILE) + a / ORYON_MATCH_TILE] = 1;
+        }
+        return;
+    }
+    float d = INFINITY;
+    int j = 0x7fffffff;
+    if (lane < c) {
+        j = cand[arow * SCREEN_CAP + lane];
+        const float *ar = a_hat + arow * Cp;
+        const float *qr = q_hat + ((size_t)p * cap_q + j) * Cp;
+        float dot = 0.0f;
+        for (int g = 0; g < Cp; g += 8) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(ar + g), a1 = *reinterpret_cast<const float4 *>(ar + g + 4);
+            const float4 q0 = *reinterpret_cast<const float4 *>(qr + g), q1 = *reinterpret_cast<const float4 *>(qr + g + 4);
+            // positions 0..3 hold k = 8g+0,2,4,6 and 4..7 hold k = 8g+1,3,5,7: accumulate in natural k order
+            dot = __fmaf_rn(a0.x, q0.x, dot); dot = __fmaf_rn(a1.x, q1.x, dot);
+            dot = __fmaf_rn(a0.y, q0.y, dot); dot = __fmaf_rn(a1.y, q1.y, dot);
+            dot = __fmaf_rn(a0.z, q0.z, dot); dot = __fmaf_rn(a1.z, q1.z, dot);
+            dot = __fmaf_rn(a0.w, q0.w, dot); dot = __fmaf_rn(a1.w, q1.w, dot);
+        }
+        d = __fmaf_rn(-0.5f, dot, 0.5f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(d, off);
+        const int oj = __shfl_xor(j, off);
+        lex_min(d, j, od, oj);
+    }
+    if (lane == 0) {
+        min_dist[arow] = d;
+        argmin[arow] = j;
+        valid[arow] = (d < thr) ? 1 : 0;
+    }
+}
+
+static int pick_split16(int B, int T)
+{
+    int S = (8192 + B * T - 1) / (B * T);
+    if (S < 1) S = 1;
+    if (S > 16) S = 16;
+    return S;
+}
+
+struct ScreenWs {
+    float *ws_max;
+    int32_t *cnt, *cand, *panel_flag;
+    uint8_t *row_flag;
+    size_t bytes, zero_off, zero_bytes;
+};
+
+static ScreenWs carve_screen(void *base, int B, int cap_a, int S)
+{
+    ScreenWs w;
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) / 256 * 256; return o; };
+    const size_t o_max = take((size_t)B * S * cap_a * sizeof(float));
+    const size_t o_cand = take((size_t)B * cap_a * SCREEN_CAP * sizeof(int32_t));
+    w.zero_off = off;
+    const size_t o_cnt = take((size_t)B * cap_a * sizeof(int32_t));
+    const size_t o_rf = take((size_t)B * cap_a);
+    const size_t o_pf = take((size_t)B * (cap_a / ORYON_MATCH_TILE) * sizeof(int32_t));
+    w.zero_bytes = off - w.zero_off;
+    w.bytes = off;
+    w.ws_max = base ? reinterpret_cast<float *>(p + o_max) : nullptr;
+    w.cand = base ? reinterpret_cast<int32_t *>(p + o_cand) : nullptr;
+    w.cnt = base ? reinterpret_cast<int32_t *>(p + o_cnt) : nullptr;
+    w.row_flag = base ? reinterpret_cast<uint8_t *>(p + o_rf) : nullptr;
+    w.panel_flag = base ? reinterpret_cast<int32_t *>(p + o_pf) : nullptr;
+    return w;
+}
+
+}  // namespace oryon
+
+using namespace oryon;
+
+extern "C" size_t oryon_match_screened_workspace_bytes(int B, int cap_a)
+{
+    if (B <= 0 || cap_a <= 0 || cap_a % MT16) return 0;
+    return carve_screen(nullptr, B, cap_a, pick_split16(B, cap_a / MT16)).bytes;
+}
+
+extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, const void *a_f16, const void *q_f16, int B, int C,
+                                    int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
+                                    int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream)
+{
+    ORYON_CHECK_ARG(a_hat && q_hat && a_f16 && q_f16 && n_a && n_q && min_dist && argmin && valid);
+    ORYON_CHECK_ARG(B >= 0 && (C == 128 || C == 256) && cap_a > 0 && cap_a % MT16 == 0 && cap_q > 0 && cap_q % 256 == 0);
+    ORYON_CHECK_ARG(threshold > 0.0f && threshold <= 0.5f);
+    if (B == 0) return ORYON_OK;
+    const int T = cap_a / MT16;
+    const int S = pick_split16(B, T);
+    ScreenWs w = carve_screen(workspace, B, cap_a, S);
+    if (!workspace || workspace_bytes < w.bytes) {
+        set_error("oryon_match_screened: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+        return ORYON_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    ORYON_CHECK_HIP(hipMemsetAsync(static_cast<char *>(workspace) + w.zero_off, 0, w.zero_bytes, st));
+    // rows whose best fp16 score is below this can never satisfy 0.5*(1-dot) < threshold
+    const float valid_cut = (1.0f - 2.0f * threshold) - SCREEN_DELTA - 1e-6f;
+    const int groups = ((B * S + 7) / 8) * 8 * T;
+    const __half *a16 = static_cast<const __half *>(a_f16), *q16 = static_cast<const __half *>(q_f16);
+#define LAUNCH16(CPV, MODEV)                                                                                              \
+    hipLaunchKernelGGL((match_f16_screen_kernel<CPV, MODEV>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, \
+                       n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand)
+    if (C == 256) { LAUNCH16(256, 0); LAUNCH16(256, 1); } else { LAUNCH16(128, 0); LAUNCH16(128, 1); }
+#undef LAUNCH16
+    ORYON_CHECK_LAUNCH();
+    hipLaunchKernelGGL(match_rescore_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a, n_q, S,
+                       threshold, valid_cut, w.ws_max, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
+    ORYON_CHECK_LAUNCH();
+    // exact recomputation of the (rare) panels whose candidate lists overflowed; exits immediately elsewhere
+    return match_f32_flagged(a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag,
+                             w.row_flag, stream);
+}

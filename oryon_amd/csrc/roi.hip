@@ -2,6 +2,7 @@
 // Replaces utils/pcd.py:184-193, losses.py:58-59, pipeline.py:408-411 of the reference (see include/oryon_hip.h).
 // All of this is HBM-bound integer/gather work: coalesced row-major scans, wave ballots for the ordered
 // compaction, an LDS transpose so the [N,C] descriptor rows are written in 128-byte runs.
+#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace oryon {
@@ -139,7 +140,8 @@ constexpr int GN_KT = 32;
 __global__ __launch_bounds__(GN_ROWS) void gather_normalise_kernel(const float *__restrict__ feat, int C, int HW,
                                                                     const int32_t *__restrict__ roi, int roi_stride,
                                                                     const int32_t *__restrict__ count, int rows_cap,
-                                                                    int Cp, float *__restrict__ out)
+                                                                    int Cp, float *__restrict__ out,
+                                                                    __half *__restrict__ out16)
 {
     __shared__ float tile[GN_ROWS * (GN_KT + 1)];
     const int m = blockIdx.y;
@@ -179,6 +181,19 @@ __global__ __launch_bounds__(GN_ROWS) void gather_normalise_kernel(const float *
             v.z = tile[r * (GN_KT + 1) + kb + 4];
             v.w = tile[r * (GN_KT + 1) + kb + 6];
             *reinterpret_cast<float4 *>(o + (size_t)r * Cp + k0 + c4 * 4) = v;
+        }
+        if (out16) {
+            // fp16 copy of the same unit rows in NATURAL k order (operand of the screening pass K1s): 8 halves per store
+            __half *o16 = out16 + ((size_t)m * rows_cap + row0) * Cp;
+#pragma unroll
+            for (int i = 0; i < (GN_ROWS * GN_KT / 8) / GN_ROWS; ++i) {
+                const int fidx = t + GN_ROWS * i;
+                const int r = fidx / (GN_KT / 8), c8 = fidx % (GN_KT / 8);
+                union { __half h[8]; uint4 u; } pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk.h[e] = __float2half_rn(tile[r * (GN_KT + 1) + c8 * 8 + e]);
+                *reinterpret_cast<uint4 *>(o16 + (size_t)r * Cp + k0 + c8 * 8) = pk.u;
+            }
         }
         __syncthreads();
     }
@@ -231,14 +246,15 @@ extern "C" int oryon_roi_subsample(int32_t *roi, int32_t *count, int n_maps, int
 }
 
 extern "C" int oryon_gather_normalise_f32(const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride,
-                                          const int32_t *count, int rows_cap, int C_pad, float *out, void *stream)
+                                          const int32_t *count, int rows_cap, int C_pad, float *out, void *out_f16,
+                                          void *stream)
 {
     ORYON_CHECK_ARG(feat && roi && count && out && n_maps >= 0 && C > 0 && HW > 0 && roi_stride > 0);
     ORYON_CHECK_ARG(C_pad >= C && C_pad % GN_KT == 0);
     ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % GN_ROWS == 0);
     if (n_maps == 0) return ORYON_OK;
     hipLaunchKernelGGL(gather_normalise_kernel, dim3(rows_cap / GN_ROWS, n_maps), dim3(GN_ROWS), 0, as_stream(stream), feat,
-                       C, HW, roi, roi_stride, count, rows_cap, C_pad, out);
+                       C, HW, roi, roi_stride, count, rows_cap, C_pad, out, static_cast<__half *>(out_f16));
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

@@ -62,17 +62,20 @@ def roi_subsample_(roi: torch.Tensor, count: torch.Tensor, max_keep: int, seed: 
                                     ptr(map_key), stream_ptr(roi.device)), "oryon_roi_subsample")
 
 
-def gather_normalise(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int) -> torch.Tensor:
-    """feat [n_maps,C,H,W] fp32, roi [n_maps, stride] -> [n_maps, rows_cap, C_pad] unit rows (rows_cap % 256 == 0)."""
+def gather_normalise(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: Optional[int] = None,
+                     want_f16: bool = False):
+    """feat [n_maps,C,H,W] fp32, roi [n_maps, stride] -> [n_maps, rows_cap, C_pad] unit rows (rows_cap % 256 == 0);
+    with want_f16 also the IEEE-half copy used by the screening pass (returns (f32, f16))."""
     _lib.require_gpu(feat.device)
     assert feat.dtype == torch.float32 and feat.is_contiguous()
     n_maps, C = feat.shape[0], feat.shape[1]
     HW = feat.shape[2] * feat.shape[3]
-    Cp = round_up(C, K_PAD)
+    Cp = int(c_pad) if c_pad else round_up(C, K_PAD)
     out = torch.empty((n_maps, rows_cap, Cp), dtype=torch.float32, device=feat.device)
+    out16 = torch.empty((n_maps, rows_cap, Cp), dtype=torch.float16, device=feat.device) if want_f16 else None
     check(lib().oryon_gather_normalise_f32(ptr(feat), n_maps, C, HW, ptr(roi), roi.shape[1], ptr(count), rows_cap, Cp,
-                                           ptr(out), stream_ptr(feat.device)), "oryon_gather_normalise_f32")
-    return out
+                                           ptr(out), ptr(out16), stream_ptr(feat.device)), "oryon_gather_normalise_f32")
+    return (out, out16) if want_f16 else out
 
 
 def unpermute_k(x: torch.Tensor) -> torch.Tensor:
@@ -100,6 +103,23 @@ def match(a_hat: torch.Tensor, q_hat: torch.Tensor, n_a: torch.Tensor, n_q: torc
     ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
     check(lib().oryon_match_f32(ptr(a_hat), ptr(q_hat), B, Cp, cap_a, cap_q, ptr(n_a), ptr(n_q), float(threshold),
                                 ptr(min_dist), ptr(argmin), ptr(valid), ptr(ws), wsb, stream_ptr(dev)), "oryon_match_f32")
+    return min_dist, argmin, valid
+
+
+def match_screened(a_hat, q_hat, a16, q16, n_a, n_q, threshold: float):
+    """fp16-screened, fp32-exact matcher (K1s).  Same outputs as `match` on every row that can be valid."""
+    dev = _lib.require_gpu(a_hat.device)
+    B, cap_a, Cp = a_hat.shape
+    cap_q = q_hat.shape[1]
+    assert a16.dtype == torch.float16 and q16.dtype == torch.float16 and a16.shape == a_hat.shape and q16.shape == q_hat.shape
+    min_dist = torch.empty((B, cap_a), dtype=torch.float32, device=dev)
+    argmin = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
+    valid = torch.empty((B, cap_a), dtype=torch.uint8, device=dev)
+    wsb = lib().oryon_match_screened_workspace_bytes(B, cap_a)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+    check(lib().oryon_match_screened(ptr(a_hat), ptr(q_hat), ptr(a16), ptr(q16), B, Cp, cap_a, cap_q, ptr(n_a), ptr(n_q),
+                                     float(threshold), ptr(min_dist), ptr(argmin), ptr(valid), ptr(ws), wsb, stream_ptr(dev)),
+          "oryon_match_screened")
     return min_dist, argmin, valid
 
 

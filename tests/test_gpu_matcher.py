@@ -171,3 +171,64 @@ def test_batched_split_and_full_size_properties():
     # the generator plants a true match for most anchor pixels (some are overwritten by a later writer or
     # leave the query image): the matcher must find the bulk of them
     assert float(va[0, :n1].float().mean()) > 0.6
+
+
+def _screen_vs_exact(feat_a, feat_q, mask_a, mask_q, C_pad, thr=0.25, subsample=None):
+    from oryon_amd import ops
+    roi_a, na = ops.roi_compact(mask_a)
+    roi_q, nq = ops.roi_compact(mask_q)
+    if subsample:
+        ops.roi_subsample_(roi_a, na, subsample, seed=3)
+    cap_a = ops.round_up(int(na.max()), 256)
+    cap_q = ops.round_up(int(nq.max()), 256)
+    a_hat, a16 = ops.gather_normalise(feat_a, roi_a, na, cap_a, c_pad=C_pad, want_f16=True)
+    q_hat, q16 = ops.gather_normalise(feat_q, roi_q, nq, cap_q, c_pad=C_pad, want_f16=True)
+    md0, am0, va0 = ops.match(a_hat, q_hat, na, nq, thr)
+    md1, am1, va1 = ops.match_screened(a_hat, q_hat, a16, q16, na, nq, thr)
+    for b in range(feat_a.shape[0]):
+        n = int(na[b])
+        v0, v1 = va0[b, :n].bool(), va1[b, :n].bool()
+        assert torch.equal(v0, v1), "valid set differs"
+        assert torch.equal(am0[b, :n][v0], am1[b, :n][v0]), "argmin differs on valid rows"
+        assert torch.equal(md0[b, :n][v0].view(torch.int32), md1[b, :n][v0].view(torch.int32)), "min_dist differs on valid rows"
+        # rows the screen could not rule out are exact as well; ruled-out rows report an estimate >= threshold
+        exact_rows = md1[b, :n] == md0[b, :n]
+        assert bool((exact_rows | (md1[b, :n] >= thr - 2e-3)).all())
+    return va0, na
+
+
+def test_screened_matcher_equals_exact_synthetic():
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    for C, H in ((256, 64), (128, 56), (200, 48)):          # C=200 pads to 256
+        pairs = [make_pair(i, H, H, C, device=dev) for i in range(3)]
+        st = lambda k: torch.stack([p[k] for p in pairs])
+        fq = st("feat_q")
+        fq[2] = torch.randn_like(fq[2])                      # pair 2: nothing matches -> all rows ruled out by the screen
+        va, na = _screen_vs_exact(st("feat_a"), fq, st("mask_a"), st("mask_q"), 256 if C > 128 else 128)
+        assert int(va[2, : int(na[2])].sum()) == 0 and int(va[0, : int(na[0])].sum()) > 100
+
+
+def test_screened_matcher_duplicates_and_overflow():
+    """Query maps full of exact duplicates (ties) and near-duplicates: candidate lists overflow for some anchors and the
+    exact fp32 recomputation of their panels must kick in; first-index tie-breaking must survive."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(5)
+    C, H = 256, 40
+    base = torch.randn(C, 200, generator=g, device=dev)
+    idx = torch.randint(0, 200, (H * H,), generator=g, device=dev)
+    fq = base[:, idx].reshape(1, C, H, H).contiguous()        # only 200 distinct query descriptors -> ~8 exact copies each
+    fa = (base[:, idx.flip(0)] + 0.02 * torch.randn(C, H * H, generator=g, device=dev)).reshape(1, C, H, H).contiguous()
+    crowd = fq[0, :, 0, 0].clone()
+    fq[0, :, :4, :] = crowd[:, None, None]                    # one descriptor repeated 160 times (> 64 candidates)
+    fa[0, :, 0, :8] = crowd[:, None] + 0.001                  # anchors that match that crowd
+    ones = torch.ones((1, H, H), dtype=torch.int32, device=dev)
+    va, na = _screen_vs_exact(fa, fq, ones, ones, 256)
+    assert int(va[0, : int(na[0])].sum()) > 1000
+
+
+def test_screened_matcher_full_size_pair():
+    from oryon_amd.synth import make_pair
+    p = make_pair(1, 224, 224, 256, device="cuda")
+    va, na = _screen_vs_exact(p["feat_a"][None], p["feat_q"][None], p["mask_a"][None], p["mask_q"][None], 256, subsample=5000)
+    assert int(na) == 5000 and float(va[0, :5000].float().mean()) > 0.6
