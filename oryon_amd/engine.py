@@ -32,6 +32,9 @@ class MatchPoseConfig:
     n_corrs: int = 500             # test.n_corrs (= dataset.max_corrs)
     src_sampling: Optional[int] = 5000   # test.src_sampling
     seed: int = 1                  # seed (pipeline.py:296-299)
+    # "screened": fp16-MFMA screening + exact fp32 re-scoring (K1s; identical valid set / argmin / min_dist on valid rows,
+    # used when 64 < C <= 256);  "exact": full fp32-MFMA scan (K1) for every row
+    match_mode: str = "screened"
 
 
 class MatchPoseEngine:
@@ -60,9 +63,15 @@ class MatchPoseEngine:
         else:
             cap_a = ops.round_up(FH * FW, ops.ROW_PAD)
         cap_q = ops.round_up(FH * FW, ops.ROW_PAD)
-        a_hat = ops.gather_normalise(feat_a, roi_a, n_a, cap_a)
-        q_hat = ops.gather_normalise(feat_q, roi_q, n_q, cap_q)
-        min_dist, argmin, valid = ops.match(a_hat, q_hat, n_a, n_q, cfg.dist_th)
+        if cfg.match_mode == "screened" and 64 < C <= 256:
+            c_pad = 128 if C <= 128 else 256
+            a_hat, a16 = ops.gather_normalise(feat_a, roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
+            q_hat, q16 = ops.gather_normalise(feat_q, roi_q, n_q, cap_q, c_pad=c_pad, want_f16=True)
+            min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)
+        else:
+            a_hat = ops.gather_normalise(feat_a, roi_a, n_a, cap_a)
+            q_hat = ops.gather_normalise(feat_q, roi_q, n_q, cap_q)
+            min_dist, argmin, valid = ops.match(a_hat, q_hat, n_a, n_q, cfg.dist_th)
         corrs, n_valid, n_sel, status = ops.select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, FW, cfg.n_corrs, cfg.seed,
                                                          pair_key, corr_rows=self.n_cap)
         cam_a = cam_a.reshape(B, 9).to(torch.float32).contiguous()

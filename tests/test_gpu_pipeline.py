@@ -110,3 +110,25 @@ def test_predicted_mask_path():
     assert float(res["iou_a"].min()) == 1.0
     out = pl.test_step_batched(batch)
     assert out["status"].cpu().tolist() == [0, 0]
+
+
+def test_engine_screened_equals_exact_bit_for_bit():
+    """The fp16-screened matcher must leave every downstream result untouched: same correspondences, same poses."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    H, C = 64, 160                       # pads to 256 channels
+    pairs = [make_pair(i, H, H, C, device=dev) for i in range(20, 24)]
+    st = lambda k: torch.stack([p[k] for p in pairs])
+    solver = _solver()
+    outs = []
+    for mode in ("exact", "screened"):
+        eng = MatchPoseEngine(solver, MatchPoseConfig(match_mode=mode))
+        outs.append(eng.run(st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"),
+                            st("camera").to(dev), st("camera").to(dev), keep=True))
+    a, b = outs
+    assert torch.equal(a["status"], b["status"]) and a["status"].tolist() == [0, 0, 0, 0]
+    assert torch.equal(a["n_valid"], b["n_valid"])
+    assert torch.equal(a["corrs"], b["corrs"])
+    assert torch.equal(a["pcd_a"], b["pcd_a"]) and torch.equal(a["pcd_q"], b["pcd_q"])
+    assert torch.equal(a["pose"], b["pose"])
