@@ -18,6 +18,7 @@
 // s16_ij* >= max_j s16_ij - 2*DELTA - 2^-23: every exact minimiser - including every tied one - is in the list, and pass 2
 // returns exactly what the full fp32 scan returns.  MARGIN = 2.2e-3 > 2*DELTA + 2^-23.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 #include "common.h"
 #include "match_common.h"
 
@@ -30,7 +31,20 @@ constexpr float SCREEN_MARGIN = 2.2e-3f;
 constexpr int SCREEN_CAP = 64;          // candidate slots per anchor
 constexpr int MT16 = 256;               // anchors per workgroup (4 waves x 2 blocks of 32)
 
-template <int CP, int MODE>
+// Out-of-line candidate append (pass 1 slow path, taken by a few % of the tiles): keeping it out of the kernel body
+// keeps the hot loop's register allocation identical to pass 0.  vals: this lane's NV scores of one anchor column.
+template <int NV>
+__device__ __noinline__ void emit_candidates(const float *vals, float thr, int qlane, size_t arow, int32_t *cnt, int32_t *cand)
+{
+    for (int e = 0; e < NV; ++e)
+        if (vals[e] >= thr) {
+            const int r = e & 15, qb = e >> 4;
+            const int sl = atomicAdd(&cnt[arow], 1);
+            if (sl < SCREEN_CAP) cand[arow * SCREEN_CAP + sl] = qlane + qb * 32 + (r & 3) + 8 * (r >> 2);
+        }
+}
+
+template <int CP, int MODE, int VAR = 0>   // VAR != 0: timing ablations only (ORYON_MATCH16_VARIANT)
 __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
     const __half *__restrict__ a16, const __half *__restrict__ q16, int B, int cap_a, int cap_q,
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, int T, int S, float valid_cut,
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
 
     int buf = 0;
     for (int qt = qt_begin; qt < qt_end; ++qt) {
-        if (qt + 1 < qt_end) issue(qt + 1, buf ^ 1);
+        if (!(VAR & 2) && qt + 1 < qt_end) issue(qt + 1, buf ^ 1);
         const unsigned tile = buf * TILE_BYTES;
         half8 ring[2][NQB];
 #pragma unroll
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
         for (int s = 0; s < NKS; ++s) {
             if (s + 1 < NKS) {
 #pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) ring[(s + 1) & 1][qb] = rd(s + 1, qb, tile);
+                for (int qb = 0; qb < NQB; ++qb) ring[(s + 1) & 1][qb] = (VAR & 4) ? ring[s & 1][qb] : rd(s + 1, qb, tile);
             }
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb)
@@ -143,6 +157,17 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
                 for (int ab = 0; ab < NAB; ++ab)
                     acc[qb][ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[s & 1][qb], breg[ab][s], acc[qb][ab], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (VAR & 1) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[qb][ab][r]));
+            if (qt == qt_end - 1) runmax[0] = acc[0][0][0];
+            if (!(VAR & 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); buf ^= 1; }
+            continue;
         }
         // epilogue: lane owns anchor column (ab, l31); rows of the C/D block are queries
         const int qlane = qt * ROWS + 4 * hi;
@@ -165,24 +190,23 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
             if (MODE == 0) {
                 runmax[ab] = fmaxf(runmax[ab], m);
             } else if (__any(m >= thr[ab])) {
-                const size_t arow = (size_t)p * cap_a + a0 + wave * 64 + ab * 32 + l31;
+                float vals[NQB * 16];
 #pragma unroll
                 for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (acc[qb][ab][r] >= thr[ab]) {
-                            const int sl = atomicAdd(&cnt[arow], 1);
-                            if (sl < SCREEN_CAP) cand[arow * SCREEN_CAP + sl] = qlane + qb * 32 + (r & 3) + 8 * (r >> 2);
-                        }
+                    for (int r = 0; r < 16; ++r) vals[qb * 16 + r] = acc[qb][ab][r];
+                emit_candidates<NQB * 16>(vals, thr[ab], qlane, (size_t)p * cap_a + a0 + wave * 64 + ab * 32 + l31, cnt, cand);
             }
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[qb][ab][r] = 0.0f;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        buf ^= 1;
+        if (!(VAR & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
     }
     if (MODE == 0) {
 #pragma unroll
@@ -194,7 +218,8 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
     }
 }
 
-// pass 2: one wave per anchor row, one candidate per lane; canonical fp32 chain on the k-permuted fp32 rows.
+// pass 2: 16 lanes per anchor row (4 rows per wave), candidates strided over the 16 lanes; canonical fp32 chain on the
+// k-permuted fp32 rows.
 __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restrict__ a_hat, const float *__restrict__ q_hat,
                                                              int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
                                                              const int32_t *__restrict__ n_q, int S, float thr, float valid_cut,
@@ -204,52 +229,50 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
                                                              uint8_t *__restrict__ row_flag, int32_t *__restrict__ panel_flag)
 {
     const int p = blockIdx.y;
-    const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (a >= n_a[p]) return;
-    const size_t arow = (size_t)p * cap_a + a;
+    const int a = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const bool live = a < n_a[p];
+    const size_t arow = (size_t)p * cap_a + (live ? a : 0);
     float m16 = -INFINITY;
-    for (int s = 0; s < S; ++s) m16 = fmaxf(m16, ws_max[((size_t)p * S + s) * cap_a + a]);
-    if (!(m16 >= valid_cut)) {          // cannot reach the threshold: report the screening estimate, valid = 0
-        if (lane == 0) {
-            min_dist[arow] = __fmaf_rn(-0.5f, m16, 0.5f);
-            argmin[arow] = 0;
-            valid[arow] = 0;
-        }
-        return;
-    }
-    const int c = cnt[arow];
-    if (c > SCREEN_CAP) {               // list overflow: the exact fp32 kernel recomputes this anchor's panel
-        if (lane == 0) {
-            row_flag[arow] = 1;
-            panel_flag[(size_t)p * (cap_a / ORYON_MATCH_TILE) + a / ORYON_MATCH_TILE] = 1;
-        }
-        return;
-    }
+    if (live)
+        for (int s = 0; s < S; ++s) m16 = fmaxf(m16, ws_max[((size_t)p * S + s) * cap_a + a]);
+    const bool possible = live && (m16 >= valid_cut);
+    const int c = possible ? cnt[arow] : 0;
+    const bool overflow = c > SCREEN_CAP;
     float d = INFINITY;
     int j = 0x7fffffff;
-    if (lane < c) {
-        j = cand[arow * SCREEN_CAP + lane];
+    if (!overflow) {
         const float *ar = a_hat + arow * Cp;
-        const float *qr = q_hat + ((size_t)p * cap_q + j) * Cp;
-        float dot = 0.0f;
-        for (int g = 0; g < Cp; g += 8) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(ar + g), a1 = *reinterpret_cast<const float4 *>(ar + g + 4);
-            const float4 q0 = *reinterpret_cast<const float4 *>(qr + g), q1 = *reinterpret_cast<const float4 *>(qr + g + 4);
-            // positions 0..3 hold k = 8g+0,2,4,6 and 4..7 hold k = 8g+1,3,5,7: accumulate in natural k order
-            dot = __fmaf_rn(a0.x, q0.x, dot); dot = __fmaf_rn(a1.x, q1.x, dot);
-            dot = __fmaf_rn(a0.y, q0.y, dot); dot = __fmaf_rn(a1.y, q1.y, dot);
-            dot = __fmaf_rn(a0.z, q0.z, dot); dot = __fmaf_rn(a1.z, q1.z, dot);
-            dot = __fmaf_rn(a0.w, q0.w, dot); dot = __fmaf_rn(a1.w, q1.w, dot);
+        for (int ci = sub; ci < c; ci += 16) {
+            const int jj = cand[arow * SCREEN_CAP + ci];
+            const float *qr = q_hat + ((size_t)p * cap_q + jj) * Cp;
+            float dot = 0.0f;
+            for (int g = 0; g < Cp; g += 8) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(ar + g), a1 = *reinterpret_cast<const float4 *>(ar + g + 4);
+                const float4 q0 = *reinterpret_cast<const float4 *>(qr + g), q1 = *reinterpret_cast<const float4 *>(qr + g + 4);
+                // positions 0..3 hold k = 8g+0,2,4,6 and 4..7 hold k = 8g+1,3,5,7: accumulate in natural k order
+                dot = __fmaf_rn(a0.x, q0.x, dot); dot = __fmaf_rn(a1.x, q1.x, dot);
+                dot = __fmaf_rn(a0.y, q0.y, dot); dot = __fmaf_rn(a1.y, q1.y, dot);
+                dot = __fmaf_rn(a0.z, q0.z, dot); dot = __fmaf_rn(a1.z, q1.z, dot);
+                dot = __fmaf_rn(a0.w, q0.w, dot); dot = __fmaf_rn(a1.w, q1.w, dot);
+            }
+            lex_min(d, j, __fmaf_rn(-0.5f, dot, 0.5f), jj);
         }
-        d = __fmaf_rn(-0.5f, dot, 0.5f);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 8; off > 0; off >>= 1) {
         const float od = __shfl_xor(d, off);
         const int oj = __shfl_xor(j, off);
         lex_min(d, j, od, oj);
     }
-    if (lane == 0) {
+    if (!live || sub != 0) return;
+    if (!possible) {                    // cannot reach the threshold: report the screening estimate, valid = 0
+        min_dist[arow] = __fmaf_rn(-0.5f, m16, 0.5f);
+        argmin[arow] = 0;
+        valid[arow] = 0;
+    } else if (overflow) {              // list overflow: the exact fp32 kernel recomputes this anchor's panel
+        row_flag[arow] = 1;
+        panel_flag[(size_t)p * (cap_a / ORYON_MATCH_TILE) + a / ORYON_MATCH_TILE] = 1;
+    } else {
         min_dist[arow] = d;
         argmin[arow] = j;
         valid[arow] = (d < thr) ? 1 : 0;
@@ -327,10 +350,17 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
 #define LAUNCH16(CPV, MODEV)                                                                                              \
     hipLaunchKernelGGL((match_f16_screen_kernel<CPV, MODEV>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, \
                        n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand)
-    if (C == 256) { LAUNCH16(256, 0); LAUNCH16(256, 1); } else { LAUNCH16(128, 0); LAUNCH16(128, 1); }
+    static const int var16 = getenv("ORYON_MATCH16_VARIANT") ? atoi(getenv("ORYON_MATCH16_VARIANT")) : 0;
+#define LAUNCH16V(V) hipLaunchKernelGGL((match_f16_screen_kernel<256, 0, V>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand)
+    if (C == 256 && var16) {
+        switch (var16) { case 1: LAUNCH16V(1); break; case 2: LAUNCH16V(2); break; case 3: LAUNCH16V(3); break; case 4: LAUNCH16V(4); break;
+                         case 5: LAUNCH16V(5); break; case 6: LAUNCH16V(6); break; default: LAUNCH16V(7); break; }
+        LAUNCH16(256, 1);
+    } else if (C == 256) { LAUNCH16(256, 0); LAUNCH16(256, 1); } else { LAUNCH16(128, 0); LAUNCH16(128, 1); }
+#undef LAUNCH16V
 #undef LAUNCH16
     ORYON_CHECK_LAUNCH();
-    hipLaunchKernelGGL(match_rescore_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a, n_q, S,
+    hipLaunchKernelGGL(match_rescore_kernel, dim3(cap_a / 16, B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a, n_q, S,
                        threshold, valid_cut, w.ws_max, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
     ORYON_CHECK_LAUNCH();
     // exact recomputation of the (rare) panels whose candidate lists overflowed; exits immediately elsewhere
