@@ -435,3 +435,31 @@ def analytic_pointdsc_params(num_layers: int, C: int, sigma_d: float = 0.10, see
             val = 0.05 * u                         # biases / BN beta
         P[name] = torch.tensor(val.reshape(shape), dtype=torch.float32)
     return P
+
+
+# ----------------------------------------------------------------------------------------------
+# closed-form parameters / inputs for the backbone goldens (fusion, decoder): no blobs committed
+# ----------------------------------------------------------------------------------------------
+def hashed_tensor(shape, tensor_id: int, seed: int = 0, scale: float = 1.0) -> torch.Tensor:
+    """Deterministic uniform(-scale, scale) tensor from the splitmix64 stream (tensor_id, element)."""
+    numel = int(np.prod(shape)) if len(shape) else 1
+    return torch.tensor((_splitmix_uniform(tensor_id, numel, seed) * scale).reshape(shape), dtype=torch.float32)
+
+
+def analytic_state_dict(reference_state: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Fill a state dict (names/shapes taken from `reference_state`) with closed-form values: matrices / conv kernels
+    get a 1/sqrt(fan_in) amplitude, norm scales sit around 1, biases are small, integer buffers are kept."""
+    out = {}
+    for t, (name, ref) in enumerate(reference_state.items()):
+        if not torch.is_floating_point(ref) or name.endswith("attn_mask"):
+            out[name] = ref.clone()
+            continue
+        shape = tuple(ref.shape)
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            out[name] = hashed_tensor(shape, t, seed, math.sqrt(3.0 / fan_in) * 1.4)
+        elif name.endswith("weight"):
+            out[name] = 1.0 + hashed_tensor(shape, t, seed, 0.1)
+        else:
+            out[name] = hashed_tensor(shape, t, seed, 0.05)
+    return out

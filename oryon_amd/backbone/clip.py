@@ -1,0 +1,172 @@
+"""CLIP ViT towers as used by the reference's CLIPEncoder (models/vlm.py:14-86), restated on plain PyTorch
+(PyTorch-ROCm GEMMs; the north_star keeps the backbone on the framework's BLAS path).
+
+The reference builds its towers with the third-party `clip` package (`clip.load("ViT-L/14@336px")`, vlm.py:19),
+which is not part of the reference tree; this module restates the published architecture with the SAME parameter
+names, so `clip_model.*` entries of a reference / CATSeg checkpoint load unchanged:
+
+    visual.conv1.weight, visual.class_embedding, visual.positional_embedding, visual.ln_pre.*, visual.ln_post.*,
+    visual.proj, visual.transformer.resblocks.{i}.{ln_1,ln_2}.*, .attn.{in_proj_weight,in_proj_bias,out_proj.*},
+    .mlp.{c_fc,c_proj}.*, token_embedding.weight, positional_embedding, transformer.resblocks.*, ln_final.*,
+    text_projection, logit_scale
+
+What the reference touches (vlm.py:43-86): patch tokens after ln_post WITHOUT visual.proj, reshaped to
+[B, width, 24, 24]; text: token + positional embedding -> causal transformer -> ln_final -> EOT token -> @ text_projection.
+Residual block: x + attn(ln_1 x), x + c_proj(QuickGELU(c_fc(ln_2 x))), QuickGELU(x) = x * sigmoid(1.702 x).
+Parity: no reference test or golden vector exists for these towers (third-party arithmetic): PARITY UNPINNED; the
+structure is cross-checked against the independent `transformers` CLIP implementation in tests/test_backbone.py.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+
+@dataclass
+class CLIPConfig:
+    image_size: int = 336
+    patch: int = 14
+    v_width: int = 1024
+    v_layers: int = 24
+    v_heads: int = 16
+    embed_dim: int = 768
+    ctx: int = 77
+    vocab: int = 49408
+    t_width: int = 768
+    t_layers: int = 12
+    t_heads: int = 12
+
+    @staticmethod
+    def vit_l14_336() -> "CLIPConfig":
+        return CLIPConfig()
+
+
+class _Attention(nn.Module):
+    """Packed-qkv multi-head attention with nn.MultiheadAttention's parameter names."""
+
+    def __init__(self, width: int, heads: int):
+        super().__init__()
+        self.heads = heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * width, width))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * width))
+        self.out_proj = nn.Linear(width, width)
+        nn.init.normal_(self.in_proj_weight, std=width ** -0.5)
+
+    def forward(self, x: Tensor, causal: bool) -> Tensor:            # x: [N, L, D]
+        N, L, D = x.shape
+        qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias).view(N, L, 3, self.heads, D // self.heads)
+        q, k, v = qkv.permute(2, 0, 3, 1, 4)                          # [N, H, L, d] each
+        o = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
+        return self.out_proj(o.transpose(1, 2).reshape(N, L, D))
+
+
+class _MLP(nn.Module):
+    def __init__(self, width: int):
+        super().__init__()
+        self.c_fc = nn.Linear(width, 4 * width)
+        self.c_proj = nn.Linear(4 * width, width)
+
+    def forward(self, x: Tensor) -> Tensor:
+        h = self.c_fc(x)
+        return self.c_proj(h * torch.sigmoid(1.702 * h))
+
+
+class _Block(nn.Module):
+    def __init__(self, width: int, heads: int, causal: bool):
+        super().__init__()
+        self.causal = causal
+        self.ln_1 = nn.LayerNorm(width)
+        self.attn = _Attention(width, heads)
+        self.ln_2 = nn.LayerNorm(width)
+        self.mlp = _MLP(width)
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = x + self.attn(self.ln_1(x), self.causal)
+        return x + self.mlp(self.ln_2(x))
+
+
+class _Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int, causal: bool):
+        super().__init__()
+        self.resblocks = nn.Sequential(*[_Block(width, heads, causal) for _ in range(layers)])
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.resblocks(x)
+
+
+class _Visual(nn.Module):
+    def __init__(self, cfg: CLIPConfig):
+        super().__init__()
+        w = cfg.v_width
+        grid = cfg.image_size // cfg.patch
+        self.conv1 = nn.Conv2d(3, w, kernel_size=cfg.patch, stride=cfg.patch, bias=False)
+        self.class_embedding = nn.Parameter(w ** -0.5 * torch.randn(w))
+        self.positional_embedding = nn.Parameter(w ** -0.5 * torch.randn(grid * grid + 1, w))
+        self.ln_pre = nn.LayerNorm(w)
+        self.transformer = _Transformer(w, cfg.v_layers, cfg.v_heads, causal=False)
+        self.ln_post = nn.LayerNorm(w)
+        self.proj = nn.Parameter(w ** -0.5 * torch.randn(w, cfg.embed_dim))   # not applied on Oryon's path
+
+
+class CLIP(nn.Module):
+    def __init__(self, cfg: Optional[CLIPConfig] = None):
+        super().__init__()
+        self.cfg = cfg or CLIPConfig.vit_l14_336()
+        c = self.cfg
+        self.visual = _Visual(c)
+        self.transformer = _Transformer(c.t_width, c.t_layers, c.t_heads, causal=True)
+        self.token_embedding = nn.Embedding(c.vocab, c.t_width)
+        self.positional_embedding = nn.Parameter(0.01 * torch.randn(c.ctx, c.t_width))
+        self.ln_final = nn.LayerNorm(c.t_width)
+        self.text_projection = nn.Parameter(c.t_width ** -0.5 * torch.randn(c.t_width, c.embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    # vlm.py:45-59 (after the pre-processing transform)
+    def patch_tokens(self, clip_rgb: Tensor) -> Tensor:
+        v = self.visual
+        x = v.conv1(clip_rgb)                                         # [B, width, g, g]
+        B, W, g, _ = x.shape
+        x = x.flatten(2).transpose(1, 2)                              # [B, g*g, width]
+        cls = v.class_embedding.to(x.dtype).expand(B, 1, W)
+        x = torch.cat([cls, x], dim=1) + v.positional_embedding.to(x.dtype)
+        x = v.transformer(v.ln_pre(x))
+        toks = v.ln_post(x[:, 1:, :])
+        return toks.transpose(1, 2).reshape(B, W, g, g)
+
+    # vlm.py:74-83
+    def text_features(self, tokens: Tensor) -> Tensor:               # tokens [M, ctx] int64 -> [M, embed_dim]
+        x = self.token_embedding(tokens).to(self.dtype) + self.positional_embedding.to(self.dtype)
+        x = self.ln_final(self.transformer(x))
+        eot = tokens.argmax(dim=-1)
+        return x[torch.arange(x.shape[0], device=x.device), eot] @ self.text_projection
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess(image: Tensor, size: int) -> Tensor:
+    """Resize(size, bicubic) -> CenterCrop(size) -> Normalize(CLIP mean/std) on a float batch in [0,1]
+    (the three transforms vlm.py:20-21 keeps from clip's pipeline; torchvision tensor path = F.interpolate bicubic,
+    align_corners=False, no antialias - irrelevant when up-sampling 224 -> 336)."""
+    B, C, H, W = image.shape
+    if H <= W:
+        nh, nw = size, int(size * W / H)
+    else:
+        nh, nw = int(size * H / W), size
+    x = F.interpolate(image, size=(nh, nw), mode="bicubic", align_corners=False) if (nh, nw) != (H, W) else image
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    x = x[:, :, top:top + size, left:left + size]
+    mean = torch.tensor(CLIP_MEAN, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+    return (x - mean) / std

@@ -1,0 +1,175 @@
+"""`Oryon` - the per-pixel descriptor / mask network of the reference (net.py:25-167) on PyTorch-ROCm.
+
+Same constructor arguments (`args.model.image_encoder.*` of configs/config.yaml), same `forward(xs)` keys
+(`xs['anchor']['rgb']`, `xs['query']['rgb']`, `xs['prompt']`; returns featmap_a/q [B,32,192,192] and mask_a/q
+[B,1,192,192] logits), same `get_trainable_parameters`, `train` / `eval` behaviour (CLIP and Swin stay frozen in eval
+mode, net.py:78-89) and the same state-dict prefixes (`vlm.clip_model.*`, `guidance_backbone.*`, `fusion.*`, `decoder.*`)
+so reference checkpoints load unchanged; `load_catseg_checkpoint` applies the key remap of net.py:104-133.
+
+The towers are GEMM/conv/attention work and stay on the framework's BLAS path by design (BASELINE.json north_star);
+what is new here is only the prompt-embedding cache: the 80-template text pass (≈1 TFLOP per call) is
+a pure function of the prompt strings / token ids and is recomputed by the reference for every batch (net.py:147).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .backbone.clip import CLIP, CLIPConfig, clip_preprocess
+from .backbone.fusion import ImageTextFusion, StandardDecoder
+from .backbone.swin import SwinGuidance, guidance_embeds
+
+
+def default_model_args(**over) -> SimpleNamespace:
+    ie = SimpleNamespace(img_size=[192, 192], out_channels=32, extra_upsampling=True, vlm="clip", use_decoder_guidance=True,
+                         use_cost_guidance=True, decoder_type="standard")
+    for k, v in over.items():
+        setattr(ie, k, v)
+    return SimpleNamespace(model=SimpleNamespace(use_catseg_ckpt=False, image_encoder=ie))
+
+
+def _weights_init_kaiming(m: nn.Module) -> None:
+    """Initialisation the reference applies to fusion / decoder when no CATSeg checkpoint is used (net.py:16-22,137-139)."""
+    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Conv1d)):
+        nn.init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+    elif isinstance(m, (nn.BatchNorm2d, nn.LayerNorm)):
+        nn.init.normal_(m.weight.data, 1.0, 0.02)
+        nn.init.constant_(m.bias.data, 0.0)
+
+
+class CLIPEncoder(nn.Module):
+    """models/vlm.py:14-99: frozen CLIP, fp32, always in eval mode."""
+
+    def __init__(self, device: str, clip_cfg: Optional[CLIPConfig] = None, bpe_path: Optional[str] = None):
+        super().__init__()
+        self.clip_model = CLIP(clip_cfg).to(device).to(torch.float32).eval()
+        self.device = device
+        self.feature_size = self.clip_model.cfg.embed_dim
+        self._bpe_path = bpe_path
+        self._tokenizer = None
+        self._prompt_cache: Dict[tuple, Tensor] = {}
+        for p in self.clip_model.parameters():
+            p.requires_grad = False
+
+    def train(self, mode=True):
+        self.training = False
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            from .backbone.tokenizer import SimpleTokenizer
+            if self._bpe_path is None:
+                raise RuntimeError("string prompts need the CLIP BPE vocabulary (pretrained_models/bpe_simple_vocab_16e6.txt.gz); "
+                                   "pass bpe_path= or feed token ids through xs['prompt_tokens']")
+            self._tokenizer = SimpleTokenizer(self._bpe_path)
+        return self._tokenizer
+
+    def encode_image(self, image: Tensor) -> Tensor:
+        return self.clip_model.patch_tokens(clip_preprocess(image, self.clip_model.cfg.image_size))
+
+    def encode_tokens(self, tokens: Tensor) -> Tensor:
+        """tokens [B, T, L] int64 -> [B, T, embed]; identical prompt sets are served from the cache."""
+        B, T, L = tokens.shape
+        out = []
+        for b in range(B):
+            key = tuple(tokens[b].reshape(-1).tolist())
+            if key not in self._prompt_cache:
+                with torch.no_grad():
+                    self._prompt_cache[key] = self.clip_model.text_features(tokens[b].to(self.device))
+            out.append(self._prompt_cache[key])
+        return torch.stack(out)
+
+    def encode_prompt(self, prompts: List[List[str]]) -> Tensor:
+        """models/vlm.py:63-86: the first entry (bare object name) is dropped, the 80 templates are encoded."""
+        toks = torch.stack([self.tokenizer(p[1:]) for p in prompts])
+        return self.encode_tokens(toks)
+
+    def forward(self, image: Tensor, prompts):
+        return self.encode_image(image), self.encode_prompt(prompts)
+
+
+class Oryon(nn.Module):
+    def __init__(self, args, device: str, clip_cfg: Optional[CLIPConfig] = None, bpe_path: Optional[str] = None):
+        super().__init__()
+        self.args = args.model
+        self.device = device
+        ie = self.args.image_encoder
+        if ie.vlm != "clip":
+            raise RuntimeError(f"VLM {ie.vlm} not implemented.")
+        if ie.decoder_type != "standard":
+            raise RuntimeError(f"Decoder type {ie.decoder_type} not supported.")
+        self.vlm = CLIPEncoder(device, clip_cfg, bpe_path)
+        self.guidance_backbone = SwinGuidance().to(device).eval()
+        for p in self.guidance_backbone.parameters():
+            p.requires_grad = False
+        c = self.vlm.clip_model.cfg
+        self.fusion = ImageTextFusion(device, use_fusion_guidance=ie.use_cost_guidance, text_guidance_dim=c.embed_dim,
+                                      clip_width=c.v_width, in_feature_resolution=(c.image_size // c.patch,) * 2)
+        self.decoder = StandardDecoder(device, ie.extra_upsampling, ie.use_decoder_guidance, input_dim=128, decoder_dims=[64, 32])
+        self.fusion.clip_conv.apply(_weights_init_kaiming)                               # net.py:100
+        if getattr(self.args, "use_catseg_ckpt", False):
+            self.load_catseg_checkpoint("pretrained_models/catseg.pth")                  # net.py:102-134
+        else:
+            self.fusion.apply(_weights_init_kaiming)                                     # net.py:137-139
+            self.decoder.apply(_weights_init_kaiming)
+
+    def get_trainable_parameters(self) -> list:
+        return list(self.fusion.parameters()) + list(self.decoder.parameters())
+
+    def train(self, mode=True):
+        self.training = mode
+        self.vlm.train(mode)
+        self.fusion.train(mode)
+        self.decoder.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def get_guidance_embeds(self, img: Tensor) -> List[Tensor]:
+        return guidance_embeds(self.guidance_backbone, img.clone())
+
+    def forward(self, xs: dict) -> Dict[str, Tensor]:
+        rgb_a = xs["anchor"]["rgb"].to(self.device)
+        rgb_q = xs["query"]["rgb"].to(self.device)
+        visual_a = self.vlm.encode_image(rgb_a)
+        visual_q = self.vlm.encode_image(rgb_q)
+        if "prompt_tokens" in xs:
+            prompt_emb = self.vlm.encode_tokens(xs["prompt_tokens"])
+        else:
+            prompt_emb = self.vlm.encode_prompt(xs["prompt"])
+        guid_a = self.get_guidance_embeds(rgb_a)
+        guid_q = self.get_guidance_embeds(rgb_q)
+        prompt_emb = prompt_emb.unsqueeze(1)
+        feats_a = self.fusion(visual_a, prompt_emb, guid_a)
+        feats_q = self.fusion(visual_q, prompt_emb, guid_q)
+        mask_a, featmap_a = self.decoder(feats_a, guid_a)
+        mask_q, featmap_q = self.decoder(feats_q, guid_q)
+        assert list(featmap_a.shape[2:]) == list(self.args.image_encoder.img_size)
+        return {"featmap_a": featmap_a, "featmap_q": featmap_q, "mask_a": mask_a, "mask_q": mask_q}
+
+    def load_catseg_checkpoint(self, path: str) -> None:
+        """CATSeg -> Oryon key remap (net.py:104-133): predictor.transformer.* -> fusion.*, decoder*/head* moved under
+        `decoder.`, the fine-tuned CLIP under `vlm.clip_model.`; loaded non-strictly (fusion.clip_conv is new in Oryon)."""
+        state = torch.load(path, map_location=self.device)
+        state = state.get("model", state)
+        remapped = {}
+        for k, v in state.items():
+            if k.startswith("sem_seg_head.predictor.transformer."):
+                nk = "fusion." + k[len("sem_seg_head.predictor.transformer."):]
+                if nk.startswith("fusion.decoder"):
+                    nk = "decoder.decoder" + nk[len("fusion.decoder"):]
+                elif nk.startswith("fusion.head"):
+                    nk = "decoder.head" + nk[len("fusion.head"):]
+                remapped[nk] = v
+            elif k.startswith("sem_seg_head.predictor.clip_model."):
+                remapped["vlm.clip_model." + k[len("sem_seg_head.predictor.clip_model."):]] = v
+        self.load_state_dict(remapped, strict=False)

@@ -312,8 +312,54 @@ def gen_end_to_end():
          pcd_a=pcd_a, pcd_q=pcd_q, pose=pose, pose_gt=p["pose"], anchor_pose=anchor_pose, pred_q=pred_q)
 
 
+# ---------------------------------------------------------------------------------------------- G5
+def gen_backbone():
+    """Reference ImageTextFusion (models/fusion.py:533-625) and StandardDecoder (models/decoder.py:44-108) on closed-form
+    weights and inputs.  fusion.py imports timm.models.layers {Mlp, DropPath, to_2tuple, to_ntuple}: timm is not installed,
+    so a shim with the published semantics (fc1 -> GELU -> fc2; identity drop-path) stands in - the goldens therefore pin
+    everything in fusion.py except timm's Mlp itself."""
+    import torch.nn as nn
+    from oracle.oryon_oracle import analytic_state_dict, hashed_tensor
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+            super().__init__()
+            self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    layers = types.ModuleType("timm.models.layers")
+    layers.Mlp, layers.DropPath = Mlp, nn.Identity
+    layers.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+    layers.to_ntuple = lambda n: (lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x,) * n)
+    for name in ("timm", "timm.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["timm.models.layers"] = layers
+    from models.fusion import ImageTextFusion          # reference
+    from models.decoder import StandardDecoder         # reference
+
+    fusion = ImageTextFusion("cpu").eval()
+    fusion.load_state_dict(analytic_state_dict(fusion.state_dict(), seed=3), strict=True)
+    decoder = StandardDecoder("cpu", True, True, input_dim=128, decoder_dims=[64, 32]).eval()
+    decoder.load_state_dict(analytic_state_dict(decoder.state_dict(), seed=4), strict=True)
+    B = 2
+    img = hashed_tensor((B, 1024, 24, 24), 100, 0, 1.0)
+    text = hashed_tensor((B, 1, 80, 768), 101, 0, 1.0)
+    guid = [hashed_tensor((B, 512, 24, 24), 102, 0, 1.0), hashed_tensor((B, 256, 48, 48), 103, 0, 1.0),
+            hashed_tensor((B, 128, 96, 96), 104, 0, 1.0)]
+    with torch.no_grad():
+        feats = fusion(img, text, guid)
+        mask, featmap = decoder(feats, guid)
+    save("g5_backbone", fusion_out=feats, mask=mask[:, :, ::2, ::2], featmap_sub=featmap[:, :, ::4, ::4],
+         featmap_sum=featmap.double().sum(dim=(2, 3)), featmap_abs_sum=featmap.double().abs().sum(dim=(2, 3)),
+         fusion_keys=np.array(list(fusion.state_dict().keys())), decoder_keys=np.array(list(decoder.state_dict().keys())))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e"]
+    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone"]
     if "matcher" in which:
         gen_matcher()
     if "lift" in which:
@@ -324,3 +370,5 @@ if __name__ == "__main__":
         gen_pointdsc()
     if "e2e" in which:
         gen_end_to_end()
+    if "backbone" in which:
+        gen_backbone()
