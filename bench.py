@@ -128,6 +128,90 @@ def cpu_baseline(H, C, budget_rows=512):
     }
 
 
+def bench_full(a, rank, world, dev):
+    """Stage set 'full': Oryon.forward (random-init, reference architecture and shapes) + predicted masks + match + lift +
+    PointDSC for B pairs per GPU.  Reported under its own metric label; configs[1] (descriptors given) stays the headline."""
+    from oryon_amd.net import Oryon, default_model_args
+    B, H = a.batch, 224
+    torch.manual_seed(4321 + rank)
+    model = Oryon(default_model_args(), dev).eval()
+    gen = torch.Generator(device=dev).manual_seed(99 + rank)
+    rgb_a = torch.rand((B, 3, H, H), generator=gen, device=dev)
+    rgb_q = torch.rand((B, 3, H, H), generator=gen, device=dev)
+    toks = torch.randint(1, 49000, (1, 80, 77), generator=torch.Generator().manual_seed(7))
+    toks[..., 12] = 49407
+    toks[..., 13:] = 0
+    toks = toks.expand(B, 80, 77).contiguous()
+    geo = [make_pair(rank * B + i, H, H, 1, device=dev) for i in range(B)]
+    depth_a = torch.stack([g["depth_a"] for g in geo])
+    depth_q = torch.stack([g["depth_q"] for g in geo]).clamp_min(1.0)
+    cam = torch.stack([g["camera"] for g in geo]).to(dev)
+    engine = MatchPoseEngine(build_solver(dev), MatchPoseConfig(dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1,
+                                                                match_mode=a.match_mode))
+    key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
+    xs = {"anchor": {"rgb": rgb_a}, "query": {"rgb": rgb_q}, "prompt_tokens": toks}
+    amp = torch.autocast("cuda", dtype=torch.bfloat16) if a.backbone_dtype == "bf16" else torch.autocast("cuda", enabled=False)
+    total = B * world
+
+    def step():
+        with torch.no_grad(), amp:
+            out = model(xs)
+        fa, fq = out["featmap_a"].float().contiguous(), out["featmap_q"].float().contiguous()
+        ma = ops.mask_from_logits(out["mask_a"].float().squeeze(1), 0.5)
+        mq = ops.mask_from_logits(out["mask_q"].float().squeeze(1), 0.5)
+        res = engine.run(fa, fq, ma, mq, depth_a, depth_q, cam, cam, key)
+        return res, gather_poses(res["pose"], res["status"], total)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    bb_ms = 0.0
+    for _ in range(a.steps):
+        e0.record()
+        with torch.no_grad(), amp:
+            model(xs)
+        e1.record()
+        res, _ = step()
+        torch.cuda.synchronize()
+        bb_ms += e0.elapsed_time(e1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # the loop above runs the backbone twice per iteration (once timed alone): subtract the extra pass
+    el = torch.tensor([elapsed - bb_ms * 1e-3], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if rank == 0:
+        flops_backbone = B * 2 * 0.39e12          # ~0.39 TFLOP per ViT-L/14@336 image (SURVEY.md §3.2), 2 images per pair
+        rec = {
+            "metric": "image-pairs/sec end-to-end (feat+match+reg), stage set FULL at the reference's shapes (224x224 RGB -> C=32 @192x192)",
+            "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.backbone_dtype == "fp32" else "bf16 backbone GEMMs (autocast), f32 match+pose",
+            "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
+            "config": {"workload": f"Batch={B} synthetic 224x224 RGB-D pairs per GPU through CLIP ViT-L/14@336 + Swin-B(stages 1-2) + fusion + "
+                                   f"decoder (PyTorch-ROCm), then HIP match + lift + PointDSC 12x128",
+                       "stages": "full", "prompt_cache": "80-template text tower evaluated once (identical prompt set), as in eval of one object class",
+                       "pairs_per_gpu": B, "backbone_ms_per_step": bb_ms / a.steps, "pairs_ok": int((res["status"] == 0).sum())},
+            "roofline": {"bound": "mfma", "kernel": "backbone GEMMs (rocBLAS/hipBLASLt via PyTorch-ROCm)", "achieved": flops_backbone / (bb_ms / a.steps * 1e-3) / 1e12,
+                         "peak": PEAK_FP32_MFMA_TFLOPS if a.backbone_dtype == "fp32" else PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None, "traffic": None},
+        }
+        rec["roofline"]["frac"] = rec["roofline"]["achieved"] / rec["roofline"]["peak"]
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +221,11 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", choices=["match+pose", "full"], default="match+pose",
+                    help="match+pose: BASELINE configs[1], descriptor maps given (default, the headline line); full: random-init "
+                         "CLIP ViT-L/14@336 + Swin-B + fusion + decoder forward on 224x224 RGB (-> C=32 @192x192, the reference's own "
+                         "shapes), then match + pose - a separate stage set, never mixed into the headline")
+    ap.add_argument("--backbone-dtype", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--match-mode", choices=["screened", "exact"], default="screened",
                     help="screened: fp16-MFMA screening + exact fp32 re-scoring (K1s, identical results); exact: full fp32 scan (K1)")
     a = ap.parse_args()
@@ -147,6 +236,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, H, C = a.batch, a.size, a.channels
+    if a.stages == "full":
+        return bench_full(a, rank, world, dev)
     inputs = make_inputs(B, H, C, first=rank * B, dev=dev)
     engine = MatchPoseEngine(build_solver(dev), MatchPoseConfig(dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1,
                                                                 match_mode=a.match_mode))

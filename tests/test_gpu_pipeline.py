@@ -132,3 +132,30 @@ def test_engine_screened_equals_exact_bit_for_bit():
     assert torch.equal(a["corrs"], b["corrs"])
     assert torch.equal(a["pcd_a"], b["pcd_a"]) and torch.equal(a["pcd_q"], b["pcd_q"])
     assert torch.equal(a["pose"], b["pose"])
+
+
+def test_oryon_backbone_into_batched_pipeline_gpu():
+    """Rows a1-a5 on the GPU feeding the HIP path: Oryon.forward (shallow CLIP for speed) -> predicted masks -> match -> pose."""
+    from oryon_amd.backbone.clip import CLIPConfig
+    from oryon_amd.net import Oryon, default_model_args
+    from oryon_amd.pipeline import Pipeline, default_args
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    torch.manual_seed(0)
+    net = Oryon(default_model_args(), dev, clip_cfg=CLIPConfig(v_layers=2, t_layers=1)).eval()
+    B, H = 2, 224
+    geo = [make_pair(i, H, H, 1) for i in range(B)]
+    toks = torch.randint(1, 49000, (1, 80, 77)); toks[..., 9] = 49407; toks[..., 10:] = 0
+    batch = {"anchor": {"rgb": torch.rand(B, 3, H, H), "orig_depth": [g["depth_a"] for g in geo], "camera": torch.stack([g["camera"] for g in geo]),
+                        "pose": torch.eye(4).repeat(B, 1, 1), "instance_id": ["a0", "a1"]},
+             "query": {"rgb": torch.rand(B, 3, H, H), "orig_depth": [g["depth_q"].clamp_min(1.0) for g in geo],
+                       "camera": torch.stack([g["camera"] for g in geo]), "instance_id": ["q0", "q1"]},
+             "prompt_tokens": toks.expand(B, 80, 77).contiguous(), "instance_id": ["p0", "p1"]}
+    with torch.no_grad():
+        out = net(batch)
+    assert tuple(out["featmap_a"].shape) == (B, 32, 192, 192) and out["featmap_a"].device.type == "cuda"
+    pl = Pipeline(default_args(**{"test.mask": "predicted"}), model=net, pointdsc_solver=_solver())
+    with torch.no_grad():
+        res = pl.test_step_batched(batch)
+    assert tuple(res["pose"].shape) == (B, 4, 4) and torch.isfinite(res["pose"]).all()
+    assert set(res["status"].cpu().tolist()) <= {0, 1, 2}
