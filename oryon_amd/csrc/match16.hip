@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
                 }
             if (MODE == 0) {
                 runmax[ab] = fmaxf(runmax[ab], m);
-            } else if (__any(m >= thr[ab])) {
+            } else if (!(VAR & 8) && __any(m >= thr[ab])) {
                 float vals[NQB * 16];
 #pragma unroll
                 for (int qb = 0; qb < NQB; ++qb)
@@ -352,7 +352,10 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
                        n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand)
     static const int var16 = getenv("ORYON_MATCH16_VARIANT") ? atoi(getenv("ORYON_MATCH16_VARIANT")) : 0;
 #define LAUNCH16V(V) hipLaunchKernelGGL((match_f16_screen_kernel<256, 0, V>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand)
-    if (C == 256 && var16) {
+    if (C == 256 && var16 == 8) {
+        LAUNCH16(256, 0);
+        hipLaunchKernelGGL((match_f16_screen_kernel<256, 1, 8>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand);
+    } else if (C == 256 && var16) {
         switch (var16) { case 1: LAUNCH16V(1); break; case 2: LAUNCH16V(2); break; case 3: LAUNCH16V(3); break; case 4: LAUNCH16V(4); break;
                          case 5: LAUNCH16V(5); break; case 6: LAUNCH16V(6); break; default: LAUNCH16V(7); break; }
         LAUNCH16(256, 1);
