@@ -199,6 +199,90 @@ __global__ __launch_bounds__(GN_ROWS) void gather_normalise_kernel(const float *
     }
 }
 
+// Second-generation gather + normalise (C_pad <= 512): a workgroup owns 64 ROI rows and keeps their raw channel
+// values in LDS ([k][row], 65-float rows), so the channel-planar map is read from HBM exactly once:
+//   phase 1  all 4 waves load (wave w takes channels k = w mod 4; lane = row -> 256-byte coalesced reads per channel)
+//   phase 2  wave 0 runs the canonical k-ordered fmaf chain per row out of LDS (bit-exact vs the oracle) -> norms
+//   phase 3  all waves divide and write: fp32 rows k-permuted in 16-byte chunks, fp16 rows in natural order, 128-byte
+//            runs per row.
+constexpr int G2_ROWS = 64;
+constexpr int G2_LD = 65;
+__global__ __launch_bounds__(256) void gather_normalise_v2_kernel(const float *__restrict__ feat, int C, int HW,
+                                                                   const int32_t *__restrict__ roi, int roi_stride,
+                                                                   const int32_t *__restrict__ count, int rows_cap, int Cp,
+                                                                   float *__restrict__ out, __half *__restrict__ out16)
+{
+    extern __shared__ float raw[];             // [Cp][G2_LD] raw values, then sd[64] norms
+    float *sd = raw + (size_t)Cp * G2_LD;
+    const int m = blockIdx.y;
+    const int n = count[m];
+    const int row0 = blockIdx.x * G2_ROWS;
+    // zero-fill contract: rows [n, round_up(n, 256)) must be written as zeros
+    const int n_fill = (n + 255) / 256 * 256;
+    if (row0 >= n_fill) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *f = feat + (size_t)m * C * HW;
+    const int my_row = row0 + lane;
+    const bool live = my_row < n;
+    const int pix = live ? roi[(size_t)m * roi_stride + my_row] : 0;
+    // 16 independent loads in flight per lane before anything is consumed
+    for (int kb = wave; kb < Cp; kb += 64) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = kb + 4 * u;
+            v[u] = (live && k < C) ? f[(size_t)k * HW + pix] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = kb + 4 * u;
+            if (k < Cp) raw[k * G2_LD + lane] = v[u];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float n2 = 0.0f;
+        for (int k0 = 0; k0 < C; k0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (k0 + u < C) ? raw[(k0 + u) * G2_LD + lane] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (k0 + u < C) n2 = __fmaf_rn(v[u], v[u], n2);
+        }
+        float d = __fsqrt_rn(n2);
+        sd[lane] = d < 1e-8f ? 1e-8f : d;
+    }
+    __syncthreads();
+    float *o = out + ((size_t)m * rows_cap + row0) * Cp;
+    // fp32, k-permuted: lane -> (row_sub 0..7, chunk c4 0..7) of a 32-wide k group; 8 rows x 128 bytes per instruction
+    for (int rg = wave; rg < G2_ROWS / 8; rg += 4) {
+        const int r = rg * 8 + (lane >> 3), c4 = lane & 7;
+        const float d = sd[r];
+        const int kb = 8 * (c4 >> 1) + (c4 & 1);
+        for (int k0 = 0; k0 < Cp; k0 += 32) {
+            float4 v;
+            v.x = __fdiv_rn(raw[(k0 + kb + 0) * G2_LD + r], d);
+            v.y = __fdiv_rn(raw[(k0 + kb + 2) * G2_LD + r], d);
+            v.z = __fdiv_rn(raw[(k0 + kb + 4) * G2_LD + r], d);
+            v.w = __fdiv_rn(raw[(k0 + kb + 6) * G2_LD + r], d);
+            *reinterpret_cast<float4 *>(o + (size_t)r * Cp + k0 + c4 * 4) = v;
+        }
+    }
+    if (out16) {
+        __half *o16 = out16 + ((size_t)m * rows_cap + row0) * Cp;
+        // fp16, natural order: lane -> (row_sub 0..15, chunk c8 0..3) of a 32-wide k group
+        const int r = wave * 16 + (lane >> 2), c8 = lane & 3;
+        const float d = sd[r];
+        for (int k0 = 0; k0 < Cp; k0 += 32) {
+            union { __half h[8]; uint4 u; } pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk.h[e] = __float2half_rn(__fdiv_rn(raw[(k0 + c8 * 8 + e) * G2_LD + r], d));
+            *reinterpret_cast<uint4 *>(o16 + (size_t)r * Cp + k0 + c8 * 8) = pk.u;
+        }
+    }
+}
+
 }  // namespace oryon
 
 using namespace oryon;
@@ -253,8 +337,20 @@ extern "C" int oryon_gather_normalise_f32(const float *feat, int n_maps, int C, 
     ORYON_CHECK_ARG(C_pad >= C && C_pad % GN_KT == 0);
     ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % GN_ROWS == 0);
     if (n_maps == 0) return ORYON_OK;
-    hipLaunchKernelGGL(gather_normalise_kernel, dim3(rows_cap / GN_ROWS, n_maps), dim3(GN_ROWS), 0, as_stream(stream), feat,
-                       C, HW, roi, roi_stride, count, rows_cap, C_pad, out, static_cast<__half *>(out_f16));
+    if (C_pad <= 512) {
+        const size_t sh = ((size_t)C_pad * G2_LD + 64) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_v2_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gather_normalise_v2_kernel, dim3(rows_cap / G2_ROWS, n_maps), dim3(256), sh, as_stream(stream), feat, C, HW,
+                           roi, roi_stride, count, rows_cap, C_pad, out, static_cast<__half *>(out_f16));
+    } else {
+        hipLaunchKernelGGL(gather_normalise_kernel, dim3(rows_cap / GN_ROWS, n_maps), dim3(GN_ROWS), 0, as_stream(stream), feat,
+                           C, HW, roi, roi_stride, count, rows_cap, C_pad, out, static_cast<__half *>(out_f16));
+    }
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }
