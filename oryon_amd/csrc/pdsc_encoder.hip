@@ -91,16 +91,29 @@ __global__ __launch_bounds__(256) void pdsc_linear_kernel(const float *__restric
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
     for (int k0 = 0; k0 < K; k0 += LIN_BK) {
-        __syncthreads();
+        // all 24 global loads of this k-tile are in flight before the first LDS store
+        constexpr int NX = (LIN_ROWS * LIN_BK) / 256, NW = (LIN_COLS * LIN_BK) / 256;
+        float xv[NX], wv[NW];
 #pragma unroll
-        for (int i = 0; i < (LIN_ROWS * LIN_BK) / 256; ++i) {
+        for (int i = 0; i < NX; ++i) {
             const int e = t + 256 * i, row = e >> 5, kk = e & 31;
-            Xs[row * LIN_LD + kk] = (k0 + kk < K) ? x[(size_t)row * ldx + k0 + kk] : 0.0f;
+            xv[i] = (k0 + kk < K) ? x[(size_t)row * ldx + k0 + kk] : 0.0f;
         }
 #pragma unroll
-        for (int i = 0; i < (LIN_COLS * LIN_BK) / 256; ++i) {
+        for (int i = 0; i < NW; ++i) {
             const int e = t + 256 * i, col = e >> 5, kk = e & 31;
-            Ws[col * LIN_LD + kk] = (n0 + col < N && k0 + kk < K) ? W[(size_t)(n0 + col) * K + k0 + kk] : 0.0f;
+            wv[i] = (n0 + col < N && k0 + kk < K) ? W[(size_t)(n0 + col) * K + k0 + kk] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = t + 256 * i;
+            Xs[(e >> 5) * LIN_LD + (e & 31)] = xv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = t + 256 * i;
+            Ws[(e >> 5) * LIN_LD + (e & 31)] = wv[i];
         }
         __syncthreads();
         const float *xa = Xs + (wm * 32 + l31) * LIN_LD + hi;
@@ -176,13 +189,25 @@ __global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__rest
 
     for (int j0 = 0; j0 < n; j0 += ATT_KT) {
         __syncthreads();
-        // stage K, V rows j0..j0+63 (k-contiguous rows, coalesced along channels) and the keys' coordinates
-        for (int e = t; e < ATT_KT * C; e += 256) {
-            const int row = e / C, c = e % C;
-            const float *rp = base + (size_t)(j0 + row) * 3 * C;
-            const bool in = j0 + row < n_cap;
-            Ks[row * LD + c] = in ? rp[C + c] : 0.0f;
-            Vs[row * LD + c] = in ? rp[2 * C + c] : 0.0f;
+        // stage K, V rows j0..j0+63 (16-byte loads, all in flight before the first LDS store) and the keys' coordinates
+        {
+            constexpr int F4_PER_ROW = C / 4, F4_TOTAL = ATT_KT * F4_PER_ROW, PER_THREAD = F4_TOTAL / 256;
+            float4 kv[PER_THREAD], vv[PER_THREAD];
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                const int e = t + 256 * i, row = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
+                const bool in = j0 + row < n_cap;
+                const float *rp = base + (size_t)(in ? j0 + row : 0) * 3 * C;
+                kv[i] = in ? *reinterpret_cast<const float4 *>(rp + C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                vv[i] = in ? *reinterpret_cast<const float4 *>(rp + 2 * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                const int e = t + 256 * i, row = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
+                float *kd = Ks + row * LD + 4 * c4, *vd = Vs + row * LD + 4 * c4;
+                kd[0] = kv[i].x; kd[1] = kv[i].y; kd[2] = kv[i].z; kd[3] = kv[i].w;
+                vd[0] = vv[i].x; vd[1] = vv[i].y; vd[2] = vv[i].z; vd[3] = vv[i].w;
+            }
         }
         for (int e = t; e < ATT_KT * 3; e += 256) {
             const int row = e / 3, d = e % 3;
