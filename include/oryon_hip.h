@@ -41,6 +41,10 @@ extern "C" {
 
 const char *oryon_version(void);
 const char *oryon_last_error(void);
+/* Measurement hook used by bench.py: the two hipEvent_t handles (created by the caller) are recorded on the launch
+ * stream immediately before / after the DOMINANT kernel launch of the next oryon_match_f32 / oryon_match_screened call
+ * made by this thread (match_f32_regb_kernel, resp. the match_f16_screen_kernel screening pass), then forgotten. */
+int oryon_profile_events(void *start_event, void *stop_event);
 /* ORYON_OK iff device `device` exists and is gfx950. */
 int oryon_device_check(int device);
 

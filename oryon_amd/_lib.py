@@ -30,6 +30,7 @@ _PROTOS = {
     "oryon_version": (c_char_p, []),
     "oryon_last_error": (c_char_p, []),
     "oryon_device_check": (c_int, [c_int]),
+    "oryon_profile_events": (c_int, [_P, _P]),
     "oryon_roi_compact": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "oryon_mask_from_logits": (c_int, [_P, c_int64, c_float, _P, _P]),
     "oryon_mask_resize_nearest": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),

@@ -9,6 +9,9 @@
 namespace oryon {
 
 void set_error(const char *fmt, ...);
+// measurement hook (oryon_profile_events): HIP events recorded around the dominant kernel launch of the next matcher call
+void profile_begin(hipStream_t st);
+void profile_end(hipStream_t st);
 
 #define ORYON_CHECK_ARG(cond)                                                           \
     do {                                                                                \

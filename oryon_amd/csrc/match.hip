@@ -483,6 +483,7 @@ extern "C" int oryon_match_f32(const float *a_hat, const float *q_hat, int B, in
 #define LAUNCH_REGB(CPV)                                                                                                  \
     hipLaunchKernelGGL((match_f32_regb_kernel<CPV>), dim3(groups_regb), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, cap_a, cap_q, \
                        n_a, n_q, threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx, nullptr, nullptr)
+    profile_begin(st);
     if (C == 32) LAUNCH_REGB(32);
     else if (C == 64) LAUNCH_REGB(64);
     else if (C == 128) LAUNCH_REGB(128);
@@ -499,6 +500,7 @@ extern "C" int oryon_match_f32(const float *a_hat, const float *q_hat, int B, in
         hipLaunchKernelGGL(match_f32_kernel, dim3(groups), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q,
                            threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx);
 #undef LAUNCH_REGB
+    profile_end(st);
     ORYON_CHECK_LAUNCH();
     if (S > 1) {
         hipLaunchKernelGGL(match_merge_kernel, dim3(cap_a / 256 + 1, B), dim3(256), 0, as_stream(stream), ws_dist, ws_idx, B,

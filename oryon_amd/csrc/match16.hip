@@ -48,7 +48,8 @@ template <int CP, int MODE, int VAR = 0>   // VAR != 0: timing ablations only (O
 __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
     const __half *__restrict__ a16, const __half *__restrict__ q16, int B, int cap_a, int cap_q,
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, int T, int S, float valid_cut,
-    float *__restrict__ ws_max /*[B,S,cap_a]*/, int32_t *__restrict__ cnt /*[B,cap_a]*/, int32_t *__restrict__ cand)
+    float *__restrict__ ws_max /*[B,S_thr|S,cap_a]*/, int32_t *__restrict__ cnt /*[B,cap_a]*/, int32_t *__restrict__ cand,
+    int S_thr, const int32_t *__restrict__ row_map, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
 {
     constexpr int RB = CP * 2;                   // row bytes
     constexpr int ROWS = 32768 / RB;             // query rows per 32 KB LDS tile (64 at C=256)
@@ -121,15 +122,18 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qb][ab][r] = 0.0f;
 
-    float runmax[NAB], thr[NAB];
+    float runmax[NAB], thr[NAB], run2[NAB];
+    int runidx[NAB];
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
         runmax[ab] = -INFINITY;
+        run2[ab] = -INFINITY;
+        runidx[ab] = 0;
         thr[ab] = INFINITY;
         if (MODE == 1) {
             const int a = a0 + wave * 64 + ab * 32 + l31;
             float m = -INFINITY;
-            for (int s = 0; s < S; ++s) m = fmaxf(m, ws_max[((size_t)p * S + s) * cap_a + a]);
+            for (int s = 0; s < S_thr; ++s) m = fmaxf(m, ws_max[((size_t)p * S_thr + s) * cap_a + a]);
             thr[ab] = (a < na && m >= valid_cut) ? m - SCREEN_MARGIN : INFINITY;
         }
     }
@@ -189,13 +193,29 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
                 }
             if (MODE == 0) {
                 runmax[ab] = fmaxf(runmax[ab], m);
+            } else if (MODE == 2) {
+                // per (tile, query block) SLICE maxima only: running (m1, slice id of m1, m2 = best slice maximum other than
+                // m1's slice).  16 rows of one lane half form a slice; what happens INSIDE the winning slice is resolved by
+                // match_decide_kernel, which re-scores just those 16 rows.
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) {
+                    float x = acc[qb][ab][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) x = fmaxf(x, acc[qb][ab][r]);
+                    const bool improved = x > runmax[ab];
+                    run2[ab] = fmaxf(fminf(runmax[ab], x), run2[ab]);
+                    runmax[ab] = fmaxf(runmax[ab], x);
+                    runidx[ab] = improved ? ((qt * NQB + qb) * 2 + hi) : runidx[ab];
+                }
             } else if (!(VAR & 8) && __any(m >= thr[ab])) {
                 float vals[NQB * 16];
 #pragma unroll
                 for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) vals[qb * 16 + r] = acc[qb][ab][r];
-                emit_candidates<NQB * 16>(vals, thr[ab], qlane, (size_t)p * cap_a + a0 + wave * 64 + ab * 32 + l31, cnt, cand);
+                const int acol = a0 + wave * 64 + ab * 32 + l31;
+                const int aout = (row_map && acol < na) ? row_map[(size_t)p * cap_a + acol] : acol;
+                emit_candidates<NQB * 16>(vals, thr[ab], qlane, (size_t)p * cap_a + aout, cnt, cand);
             }
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb)
@@ -216,6 +236,108 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
             if (hi == 0) ws_max[((size_t)p * S + split) * cap_a + a] = m;
         }
     }
+    if (MODE == 2) {
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab) {
+            const float om1 = __shfl_xor(runmax[ab], 32), om2 = __shfl_xor(run2[ab], 32);
+            const int oi1 = __shfl_xor(runidx[ab], 32);
+            const float m1 = fmaxf(runmax[ab], om1);
+            const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
+            const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
+            const int a = a0 + wave * 64 + ab * 32 + l31;
+            if (hi == 0) {
+                const size_t o = ((size_t)p * S + split) * cap_a + a;
+                ws_max[o] = m1;
+                ws_i1[o] = i1;
+                ws_m2[o] = m2;
+            }
+        }
+    }
+}
+
+// Single-pass strategy, step 2 (one wave per anchor): merge the per-split (m1, slice of m1, m2) triples and decide
+//   m1 < valid_cut        -> can never be valid                                        (no candidates)
+//   m1 - m2 > MARGIN      -> every index within MARGIN of m1 lies in m1's 16-row slice: those 16 rows are re-scored here
+//                            from the fp16 rows (fp32 accumulate) and the ones within MARGIN (+ recomputation slack) become
+//                            the candidates
+//   otherwise             -> ambiguous: appended to the pair's list; a second, compacted screening pass collects every
+//                            index within MARGIN for these anchors only.
+template <int ROWS_TILE>
+__global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restrict__ a16, const __half *__restrict__ q16, int Cp,
+                                                            int cap_a, int cap_q, const int32_t *__restrict__ n_a,
+                                                            const int32_t *__restrict__ n_q, int S, float valid_cut,
+                                                            const float *__restrict__ ws_m1, const int32_t *__restrict__ ws_i1,
+                                                            const float *__restrict__ ws_m2, float *__restrict__ m_final,
+                                                            int32_t *__restrict__ cnt, int32_t *__restrict__ cand,
+                                                            int32_t *__restrict__ n_amb, int32_t *__restrict__ amb_idx)
+{
+    constexpr int NQB = ROWS_TILE / 32;
+    const int p = blockIdx.y, a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (a >= n_a[p]) return;
+    const size_t arow = (size_t)p * cap_a + a;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int sid = 0;
+    for (int s = 0; s < S; ++s) {
+        const size_t o = ((size_t)p * S + s) * cap_a + a;
+        const float x1 = ws_m1[o], x2 = ws_m2[o];
+        m2 = fmaxf(fminf(m1, x1), fmaxf(m2, x2));
+        if (x1 > m1) { m1 = x1; sid = ws_i1[o]; }
+    }
+    if (lane == 0) m_final[arow] = m1;
+    if (!(m1 >= valid_cut)) return;
+    if (!(m1 - m2 > SCREEN_MARGIN)) {
+        if (lane == 0) {
+            const int sl = atomicAdd(&n_amb[p], 1);
+            amb_idx[(size_t)p * cap_a + sl] = a;
+        }
+        return;
+    }
+    // slice sid = (tile*NQB + qb)*2 + half: rows tile*ROWS + qb*32 + (r&3) + 8*(r>>2) + 4*half, r = 0..15
+    const int half = sid & 1, qb = (sid >> 1) % NQB, tile = (sid >> 1) / NQB;
+    const int r = lane >> 2, seg = lane & 3;                   // 4 lanes per row, each a quarter of K
+    const int q = tile * ROWS_TILE + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int nq = n_q[p];
+    float sdot = 0.0f;
+    if (q < nq) {
+        const uint4 *ar = reinterpret_cast<const uint4 *>(a16 + arow * Cp) + seg * (Cp / 32);
+        const uint4 *qr = reinterpret_cast<const uint4 *>(q16 + ((size_t)p * cap_q + q) * Cp) + seg * (Cp / 32);
+        for (int i0 = 0; i0 < Cp / 32; i0 += 4) {
+            uint4 av[4], qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = ar[i0 + u]; qv[u] = qr[i0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const __half2 *ah = reinterpret_cast<const __half2 *>(&av[u]), *qh = reinterpret_cast<const __half2 *>(&qv[u]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 x = __half22float2(ah[e]), y = __half22float2(qh[e]);
+                    sdot = fmaf(x.x, y.x, sdot);
+                    sdot = fmaf(x.y, y.y, sdot);
+                }
+            }
+        }
+    }
+    sdot += __shfl_xor(sdot, 1);
+    sdot += __shfl_xor(sdot, 2);
+    const bool hit = (seg == 0) && (q < nq) && (sdot >= m1 - SCREEN_MARGIN - 4e-5f);
+    const unsigned long long b = __ballot(hit);
+    if (hit) cand[arow * SCREEN_CAP + __popcll(b & ((1ull << lane) - 1ull))] = q;
+    if (lane == 0) cnt[arow] = __popcll(b);
+}
+
+// gather the fp16 rows (and thresholds) of the ambiguous anchors into a dense panel layout for the second pass
+__global__ __launch_bounds__(256) void match_compact_kernel(const __half *__restrict__ a16, int Cp, int cap_a,
+                                                             const int32_t *__restrict__ n_amb, const int32_t *__restrict__ amb_idx,
+                                                             const float *__restrict__ m_final, __half *__restrict__ a16c,
+                                                             float *__restrict__ amb_max)
+{
+    const int p = blockIdx.y, sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sl >= n_amb[p]) return;
+    const int a = amb_idx[(size_t)p * cap_a + sl];
+    const uint4 *src = reinterpret_cast<const uint4 *>(a16 + ((size_t)p * cap_a + a) * Cp);
+    uint4 *dst = reinterpret_cast<uint4 *>(a16c + ((size_t)p * cap_a + sl) * Cp);
+    for (int i = lane; i < Cp / 8; i += 64) dst[i] = src[i];
+    if (lane == 0) amb_max[(size_t)p * cap_a + sl] = m_final[(size_t)p * cap_a + a];
 }
 
 // pass 2: 16 lanes per anchor row (4 rows per wave), candidates strided over the 16 lanes; canonical fp32 chain on the
@@ -223,7 +345,8 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
 __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restrict__ a_hat, const float *__restrict__ q_hat,
                                                              int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
                                                              const int32_t *__restrict__ n_q, int S, float thr, float valid_cut,
-                                                             const float *__restrict__ ws_max, const int32_t *__restrict__ cnt,
+                                                             const float *__restrict__ ws_max, const float *__restrict__ m_final,
+                                                             const int32_t *__restrict__ cnt,
                                                              const int32_t *__restrict__ cand, float *__restrict__ min_dist,
                                                              int32_t *__restrict__ argmin, uint8_t *__restrict__ valid,
                                                              uint8_t *__restrict__ row_flag, int32_t *__restrict__ panel_flag)
@@ -233,8 +356,11 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
     const bool live = a < n_a[p];
     const size_t arow = (size_t)p * cap_a + (live ? a : 0);
     float m16 = -INFINITY;
-    if (live)
-        for (int s = 0; s < S; ++s) m16 = fmaxf(m16, ws_max[((size_t)p * S + s) * cap_a + a]);
+    if (live) {
+        if (m_final) m16 = m_final[arow];
+        else
+            for (int s = 0; s < S; ++s) m16 = fmaxf(m16, ws_max[((size_t)p * S + s) * cap_a + a]);
+    }
     const bool possible = live && (m16 >= valid_cut);
     const int c = possible ? cnt[arow] : 0;
     const bool overflow = c > SCREEN_CAP;
@@ -288,8 +414,9 @@ static int pick_split16(int B, int T)
 }
 
 struct ScreenWs {
-    float *ws_max;
-    int32_t *cnt, *cand, *panel_flag;
+    float *ws_max, *ws_m2, *m_final, *amb_max;
+    int32_t *ws_i1, *cnt, *cand, *panel_flag, *n_amb, *amb_idx;
+    __half *a16c;
     uint8_t *row_flag;
     size_t bytes, zero_off, zero_bytes;
 };
@@ -301,13 +428,27 @@ static ScreenWs carve_screen(void *base, int B, int cap_a, int S)
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) / 256 * 256; return o; };
     const size_t o_max = take((size_t)B * S * cap_a * sizeof(float));
+    const size_t o_m2 = take((size_t)B * S * cap_a * sizeof(float));
+    const size_t o_i1 = take((size_t)B * S * cap_a * sizeof(int32_t));
+    const size_t o_mf = take((size_t)B * cap_a * sizeof(float));
+    const size_t o_am = take((size_t)B * cap_a * sizeof(float));
+    const size_t o_ai = take((size_t)B * cap_a * sizeof(int32_t));
+    const size_t o_a16 = take((size_t)B * cap_a * 256 * sizeof(__half));
     const size_t o_cand = take((size_t)B * cap_a * SCREEN_CAP * sizeof(int32_t));
     w.zero_off = off;
     const size_t o_cnt = take((size_t)B * cap_a * sizeof(int32_t));
     const size_t o_rf = take((size_t)B * cap_a);
     const size_t o_pf = take((size_t)B * (cap_a / ORYON_MATCH_TILE) * sizeof(int32_t));
+    const size_t o_na = take((size_t)B * sizeof(int32_t));
     w.zero_bytes = off - w.zero_off;
     w.bytes = off;
+    w.ws_m2 = base ? reinterpret_cast<float *>(p + o_m2) : nullptr;
+    w.ws_i1 = base ? reinterpret_cast<int32_t *>(p + o_i1) : nullptr;
+    w.m_final = base ? reinterpret_cast<float *>(p + o_mf) : nullptr;
+    w.amb_max = base ? reinterpret_cast<float *>(p + o_am) : nullptr;
+    w.amb_idx = base ? reinterpret_cast<int32_t *>(p + o_ai) : nullptr;
+    w.a16c = base ? reinterpret_cast<__half *>(p + o_a16) : nullptr;
+    w.n_amb = base ? reinterpret_cast<int32_t *>(p + o_na) : nullptr;
     w.ws_max = base ? reinterpret_cast<float *>(p + o_max) : nullptr;
     w.cand = base ? reinterpret_cast<int32_t *>(p + o_cand) : nullptr;
     w.cnt = base ? reinterpret_cast<int32_t *>(p + o_cnt) : nullptr;
@@ -349,22 +490,47 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
     const __half *a16 = static_cast<const __half *>(a_f16), *q16 = static_cast<const __half *>(q_f16);
 #define LAUNCH16(CPV, MODEV)                                                                                              \
     hipLaunchKernelGGL((match_f16_screen_kernel<CPV, MODEV>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, \
-                       n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand)
+                       n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand, S, nullptr, w.ws_i1, w.ws_m2)
+#define LAUNCH16_AMB(CPV)                                                                                                 \
+    hipLaunchKernelGGL((match_f16_screen_kernel<CPV, 1>), dim3(groups), dim3(256), 0, st, w.a16c, q16, B, cap_a, cap_q,       \
+                       w.n_amb, n_q, T, S, valid_cut, w.amb_max, w.cnt, w.cand, 1, w.amb_idx, nullptr, nullptr)
     static const int var16 = getenv("ORYON_MATCH16_VARIANT") ? atoi(getenv("ORYON_MATCH16_VARIANT")) : 0;
-#define LAUNCH16V(V) hipLaunchKernelGGL((match_f16_screen_kernel<256, 0, V>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand)
-    if (C == 256 && var16 == 8) {
-        LAUNCH16(256, 0);
-        hipLaunchKernelGGL((match_f16_screen_kernel<256, 1, 8>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand);
-    } else if (C == 256 && var16) {
-        switch (var16) { case 1: LAUNCH16V(1); break; case 2: LAUNCH16V(2); break; case 3: LAUNCH16V(3); break; case 4: LAUNCH16V(4); break;
-                         case 5: LAUNCH16V(5); break; case 6: LAUNCH16V(6); break; default: LAUNCH16V(7); break; }
-        LAUNCH16(256, 1);
-    } else if (C == 256) { LAUNCH16(256, 0); LAUNCH16(256, 1); } else { LAUNCH16(128, 0); LAUNCH16(128, 1); }
+    static const bool two_pass = getenv("ORYON_SCREEN_TWOPASS") != nullptr;
+    const float *m_final = nullptr;
+    if (two_pass || var16) {
+#define LAUNCH16V(V) hipLaunchKernelGGL((match_f16_screen_kernel<256, 0, V>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand, S, nullptr, w.ws_i1, w.ws_m2)
+        if (C == 256 && var16 == 8) {
+            LAUNCH16(256, 0);
+            hipLaunchKernelGGL((match_f16_screen_kernel<256, 1, 8>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand, S, nullptr, w.ws_i1, w.ws_m2);
+        } else if (C == 256 && var16) {
+            switch (var16) { case 1: LAUNCH16V(1); break; case 2: LAUNCH16V(2); break; case 3: LAUNCH16V(3); break; case 4: LAUNCH16V(4); break;
+                             case 5: LAUNCH16V(5); break; case 6: LAUNCH16V(6); break; default: LAUNCH16V(7); break; }
+            LAUNCH16(256, 1);
+        } else if (C == 256) { LAUNCH16(256, 0); LAUNCH16(256, 1); } else { LAUNCH16(128, 0); LAUNCH16(128, 1); }
 #undef LAUNCH16V
+    } else {
+        // single screening pass keeping (max, argmax, second max) per anchor; anchors whose runner-up is within MARGIN of the
+        // maximum (duplicates, smooth descriptor fields) go through a second, compacted candidate pass
+        profile_begin(st);
+        if (C == 256) LAUNCH16(256, 2); else LAUNCH16(128, 2);
+        profile_end(st);
+        ORYON_CHECK_LAUNCH();
+        if (C == 256)
+            hipLaunchKernelGGL((match_decide_kernel<64>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
+                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx);
+        else
+            hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
+                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx);
+        hipLaunchKernelGGL(match_compact_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a16, C, cap_a, w.n_amb, w.amb_idx, w.m_final,
+                           w.a16c, w.amb_max);
+        if (C == 256) LAUNCH16_AMB(256); else LAUNCH16_AMB(128);
+        m_final = w.m_final;
+    }
 #undef LAUNCH16
+#undef LAUNCH16_AMB
     ORYON_CHECK_LAUNCH();
     hipLaunchKernelGGL(match_rescore_kernel, dim3(cap_a / 16, B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a, n_q, S,
-                       threshold, valid_cut, w.ws_max, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
+                       threshold, valid_cut, w.ws_max, m_final, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
     ORYON_CHECK_LAUNCH();
     // exact recomputation of the (rare) panels whose candidate lists overflowed; exits immediately elsewhere
     return match_f32_flagged(a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag,

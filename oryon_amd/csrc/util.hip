@@ -13,6 +13,23 @@ void set_error(const char *fmt, ...)
 }
 }  // namespace oryon
 
+namespace oryon {
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void profile_begin(hipStream_t st) { if (g_ev_start) (void)hipEventRecord(g_ev_start, st); }
+void profile_end(hipStream_t st)
+{
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
+    g_ev_start = g_ev_stop = nullptr;
+}
+}  // namespace oryon
+
+extern "C" int oryon_profile_events(void *start_event, void *stop_event)
+{
+    oryon::g_ev_start = static_cast<hipEvent_t>(start_event);
+    oryon::g_ev_stop = static_cast<hipEvent_t>(stop_event);
+    return ORYON_OK;
+}
+
 extern "C" const char *oryon_version(void) { return "oryon_hip 0.1 (gfx950)"; }
 extern "C" const char *oryon_last_error(void) { return oryon::g_err; }
 
