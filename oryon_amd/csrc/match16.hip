@@ -173,24 +173,19 @@ __global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
             if (!(VAR & 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); buf ^= 1; }
             continue;
         }
-        // epilogue: lane owns anchor column (ab, l31); rows of the C/D block are queries
+        // epilogue: lane owns anchor column (ab, l31); rows of the C/D block are queries.
+        // Rows >= n_q of the last tile need no masking: K0 zero-fills them, so they score exactly 0, which can neither
+        // reach valid_cut (> 0 for thresholds < 0.5) nor a candidate threshold; pass 2 ignores indices >= n_q anyway.
         const int qlane = qt * ROWS + 4 * hi;
-        const bool full = (qt + 1) * ROWS <= nq;
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab) {
             float m = -INFINITY;
+            if (MODE != 2) {
 #pragma unroll
-            for (int qb = 0; qb < NQB; ++qb)
+                for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[qb][ab][r];
-                    if (!full) {
-                        const int q = qlane + qb * 32 + (r & 3) + 8 * (r >> 2);
-                        v = (q < nq) ? v : -INFINITY;
-                        acc[qb][ab][r] = v;
-                    }
-                    m = fmaxf(m, v);
-                }
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[qb][ab][r]);
+            }
             if (MODE == 0) {
                 runmax[ab] = fmaxf(runmax[ab], m);
             } else if (MODE == 2) {
@@ -368,8 +363,10 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
     int j = 0x7fffffff;
     if (!overflow) {
         const float *ar = a_hat + arow * Cp;
+        const int nq_p = n_q[p];
         for (int ci = sub; ci < c; ci += 16) {
             const int jj = cand[arow * SCREEN_CAP + ci];
+            if (jj >= nq_p) continue;                     // zero-padded query rows can never be the answer
             const float *qr = q_hat + ((size_t)p * cap_q + jj) * Cp;
             float dot = 0.0f;
             for (int g = 0; g < Cp; g += 8) {
