@@ -38,10 +38,25 @@ class MatchPoseConfig:
 
 
 class MatchPoseEngine:
-    def __init__(self, solver: PointDSC, cfg: Optional[MatchPoseConfig] = None):
+    def __init__(self, solver: PointDSC, cfg: Optional[MatchPoseConfig] = None, overlap_registration: bool = False):
+        """overlap_registration: run the registration stage (K3-K10: many small, latency-bound launches) on a second HIP
+        stream so that it overlaps with the matching stage of the NEXT batch submitted by the caller; `run` then returns
+        immediately after queueing and `finish(out)` makes the caller's stream wait for the poses."""
         self.solver = solver
         self.cfg = cfg or MatchPoseConfig()
         self.n_cap = ops.round_up(self.cfg.n_corrs, 128)
+        self.overlap = overlap_registration
+        self._reg_stream = None
+
+    def finish(self, out: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """Order the caller's current stream after the registration of `out` (no-op without overlap)."""
+        ev = out.pop("_done", None)
+        if ev is not None:
+            cur = torch.cuda.current_stream(out["pose"].device)
+            cur.wait_event(ev)
+            for k in ("pose", "status"):
+                out[k].record_stream(cur)
+        return out
 
     @torch.no_grad()
     def run(self, feat_a: Tensor, feat_q: Tensor, mask_a: Tensor, mask_q: Tensor, depth_a: Tensor, depth_q: Tensor,
@@ -77,8 +92,24 @@ class MatchPoseEngine:
         cam_a = cam_a.reshape(B, 9).to(torch.float32).contiguous()
         cam_q = cam_q.reshape(B, 9).to(torch.float32).contiguous()
         pcd_a, pcd_q, n_lift = ops.lift_pairs(corrs, n_sel, (FH, FW), depth_a, depth_q, cam_a, cam_q, status)
-        pose, _, status_out = self.solver.register(pcd_a, pcd_q, n_lift, status)
+        if self.overlap:
+            if self._reg_stream is None:
+                self._reg_stream = torch.cuda.Stream(device=dev)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._reg_stream):
+                self._reg_stream.wait_event(ready)
+                for t_ in (pcd_a, pcd_q, n_lift, status):
+                    t_.record_stream(self._reg_stream)
+                pose, _, status_out = self.solver.register(pcd_a, pcd_q, n_lift, status)
+                done = torch.cuda.Event()
+                done.record(self._reg_stream)
+        else:
+            pose, _, status_out = self.solver.register(pcd_a, pcd_q, n_lift, status)
+            done = None
         out = dict(pose=pose, status=status_out, n_valid=n_valid, n_lifted=n_lift)
+        if done is not None:
+            out["_done"] = done
         if keep:
             out.update(roi_a=roi_a, roi_q=roi_q, n_a=n_a, n_q=n_q, min_dist=min_dist, argmin=argmin, valid=valid, corrs=corrs,
                        pcd_a=pcd_a, pcd_q=pcd_q)

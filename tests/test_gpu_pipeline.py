@@ -159,3 +159,27 @@ def test_oryon_backbone_into_batched_pipeline_gpu():
         res = pl.test_step_batched(batch)
     assert tuple(res["pose"].shape) == (B, 4, 4) and torch.isfinite(res["pose"]).all()
     assert set(res["status"].cpu().tolist()) <= {0, 1, 2}
+
+
+def test_engine_overlap_stream_gives_identical_results():
+    """Registration on a second HIP stream (pipelined submission) must not change any result."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    H, C = 48, 32
+    pairs = [make_pair(i, H, H, C, device=dev) for i in range(30, 36)]
+    st = lambda k, sl: torch.stack([p[k] for p in pairs[sl]])
+    solver = _solver()
+    args = lambda sl: (st("feat_a", sl), st("feat_q", sl), st("mask_a", sl), st("mask_q", sl), st("depth_a", sl), st("depth_q", sl),
+                       st("camera", sl).to(dev), st("camera", sl).to(dev))
+    ref = MatchPoseEngine(solver, MatchPoseConfig())
+    r0 = ref.run(*args(slice(0, 3)), torch.arange(0, 3, device=dev))
+    r1 = ref.run(*args(slice(3, 6)), torch.arange(3, 6, device=dev))
+    eng = MatchPoseEngine(solver, MatchPoseConfig(), overlap_registration=True)
+    o0 = eng.run(*args(slice(0, 3)), torch.arange(0, 3, device=dev))
+    o1 = eng.run(*args(slice(3, 6)), torch.arange(3, 6, device=dev))      # queued before o0 is collected
+    eng.finish(o0)
+    eng.finish(o1)
+    torch.cuda.synchronize()
+    assert torch.equal(o0["pose"], r0["pose"]) and torch.equal(o1["pose"], r1["pose"])
+    assert torch.equal(o0["status"], r0["status"]) and torch.equal(o1["status"], r1["status"])
