@@ -55,11 +55,11 @@ class PrecomputedFeatures:
 
 
 def mask_iou(gt: Tensor, pred: Tensor) -> Tensor:
-    """Per-sample IoU of binary masks [B,H,W] (utils/metrics.py:18-40)."""
-    g, p = gt > 0, pred > 0
+    """Per-sample IoU of binary masks [B,H,W]: |and| / |or|; an empty union gives NaN, as in utils/metrics.py:18-40."""
+    g, p = gt != 0, pred != 0
     inter = (g & p).flatten(1).sum(1).float()
     union = (g | p).flatten(1).sum(1).float()
-    return torch.where(union > 0, inter / union.clamp_min(1), torch.zeros_like(union))
+    return inter / union
 
 
 class Pipeline:

@@ -358,8 +358,33 @@ def gen_backbone():
          fusion_keys=np.array(list(fusion.state_dict().keys())), decoder_keys=np.array(list(decoder.state_dict().keys())))
 
 
+# ---------------------------------------------------------------------------------------------- G7
+def gen_metrics():
+    from utils.metrics import compute_add, compute_adds, compute_RT_distances, mask_iou      # reference
+    g = torch.Generator().manual_seed(71)
+    pcd = (torch.rand(800, 3, generator=g).numpy() - 0.5) * 0.2
+    n = 6
+    pred, gt = np.tile(np.eye(4), (n, 1, 1)), np.tile(np.eye(4), (n, 1, 1))
+    for i in range(n):
+        gt[i, :3, :3] = _rand_rot(g).numpy()
+        gt[i, :3, 3] = torch.randn(3, generator=g).numpy() * 0.3 + np.array([0, 0, 0.8])
+        dR = _rand_rot(g).numpy()
+        ang = 0.02 * (i + 1)
+        pred[i, :3, :3] = gt[i, :3, :3] @ (np.eye(3) * (1 - ang) + dR * ang)     # not exactly orthonormal: exercises the det normalisation
+        pred[i, :3, 3] = gt[i, :3, 3] + 0.004 * (i + 1)
+    add = np.array([compute_add(pcd, pred[i], gt[i]) for i in range(n)])
+    adds = np.array([compute_adds(pcd, pred[i], gt[i]) for i in range(n)])
+    theta, shift = compute_RT_distances(pred, gt)
+    m1 = (torch.rand(3, 20, 20, generator=g) > 0.5)
+    m2 = (torch.rand(3, 20, 20, generator=g) > 0.5)
+    m2[2] = 0
+    m1[2] = 0
+    iou = mask_iou(m1.float(), m2.float())
+    save("g7_metrics", pcd=pcd, pred=pred, gt=gt, add=add, adds=adds, theta=theta, shift=shift, mask1=m1, mask2=m2, iou=iou)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone"]
+    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone", "metrics"]
     if "matcher" in which:
         gen_matcher()
     if "lift" in which:
@@ -372,3 +397,5 @@ if __name__ == "__main__":
         gen_end_to_end()
     if "backbone" in which:
         gen_backbone()
+    if "metrics" in which:
+        gen_metrics()
