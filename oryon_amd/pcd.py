@@ -29,7 +29,7 @@ def torch_sample_select(t: Tensor, n: int) -> Tensor:
 
 
 def match_presample(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor, threshold: float,
-                    subsample_source: Optional[int] = None):
+                    subsample_source: Optional[int] = None, half_descriptors: bool = False):
     """Deterministic half of the matcher (utils/pcd.py:184-205) on the GPU.
 
     Returns dict(roi1 [N1,2] i64 (y,x), roi2 [N2,2] i64, min_dist [N1] f32, argmin [N1] i64, valid [N1] bool).
@@ -37,6 +37,11 @@ def match_presample(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor
     dev = require_gpu(feats1.device)
     W = feats1.shape[2]
     W2 = feats2.shape[2]
+    if half_descriptors:
+        # K1': the reference's corrs_device='cuda' branch rounds the descriptors to float16 first (utils/pcd.py:195-197); the
+        # cosine itself is then evaluated exactly in fp32 on the rounded values (the reference's half arithmetic agrees with
+        # this to ~4e-4 in distance, see tests/golden/g1_matcher_half.npz)
+        feats1, feats2 = feats1.to(torch.float16), feats2.to(torch.float16)
     f1 = feats1.to(torch.float32).contiguous()[None]
     f2 = feats2.to(torch.float32).contiguous()[None]
     roi1_lin, c1 = ops.roi_compact(mask1.to(dev))
@@ -67,10 +72,11 @@ def nn_correspondences(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Ten
                        subsample_source: Optional[int], corrs_device: str = "cuda") -> Optional[Tensor]:
     """Matches between two [D,H,W] feature maps restricted to mask==1; int64 [max_corrs,4] rows
     (y1,x1,y2,x2) on feats1.device, or None when at most one anchor pixel finds a match under the
-    threshold (utils/pcd.py:177-216).  `corrs_device` is accepted for signature compatibility; the
-    contraction always runs in fp32 on the GPU (the reference's 'cpu' numerics)."""
+    threshold (utils/pcd.py:177-216).  The contraction always runs on the GPU and the two
+    host RNG draws are always made on the CPU generator.  corrs_device='cuda' selects the reference's fp16-descriptor
+    branch (descriptors rounded to float16, utils/pcd.py:195-197); anything else its fp32 branch."""
     orig_device = feats1.device
-    pre = match_presample(feats1, feats2, mask1, mask2, threshold, subsample_source)
+    pre = match_presample(feats1, feats2, mask1, mask2, threshold, subsample_source, half_descriptors=(corrs_device == "cuda"))
     valid_corr = torch.nonzero(pre["valid"]).squeeze(1)
     if valid_corr.shape[0] > 1:
         roi2 = pre["roi2"][pre["argmin"]]

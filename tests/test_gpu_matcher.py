@@ -18,7 +18,21 @@ def load(name):
 
 
 def names(prefix):
-    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, prefix + "*.npz")))
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, prefix + "*.npz")) if "matcher_half" not in p)
+
+
+def test_half_descriptor_branch_vs_reference():
+    """K1': the reference's corrs_device='cuda' branch (float16 descriptors).  Bar: same argmin wherever the reference's own
+    half-precision top-2 gap is resolvable (> 4e-3), distances within 1e-3."""
+    from oryon_amd import pcd
+    g = load("g1_matcher_half.npz")
+    dev = "cuda"
+    pre = pcd.match_presample(torch.from_numpy(g["feats1"]).to(dev), torch.from_numpy(g["feats2"]).to(dev),
+                              torch.from_numpy(g["mask1"]).to(dev), torch.from_numpy(g["mask2"]).to(dev), 0.25, half_descriptors=True)
+    md, am = pre["min_dist"].cpu().numpy(), pre["argmin"].cpu().numpy()
+    np.testing.assert_allclose(md, g["min_dist"], atol=1e-3)
+    clear = g["gap"] > 4e-3
+    assert clear.mean() > 0.8 and np.array_equal(am[clear], g["argmin"][clear])
 
 
 def _gpu_presample(g):

@@ -120,7 +120,28 @@ def matcher_case(tag, C, H, W, seed, mask_kind, threshold=0.25, ties=False, zero
     save(f"g1_matcher_{tag}", **out)
 
 
+def matcher_half_case():
+    """The reference's corrs_device='cuda' branch (descriptors cast to float16, utils/pcd.py:195-197), executed on CPU half tensors."""
+    g = torch.Generator().manual_seed(77)
+    C, H, W = 32, 24, 24
+    f1 = torch.randn(C, H, W, generator=g)
+    f2 = torch.randn(C, H, W, generator=g)
+    perm = torch.randperm(H * W, generator=g)
+    n = (H * W) // 2
+    f2.view(C, -1)[:, perm[:n]] = f1.view(C, -1)[:, perm[n:2 * n]] + 0.15 * torch.randn(C, n, generator=g)
+    m1 = (torch.rand(H, W, generator=g) > 0.3).to(torch.int32)
+    m2 = (torch.rand(H, W, generator=g) > 0.2).to(torch.int32)
+    roi1, roi2 = torch.nonzero(m1 == 1), torch.nonzero(m2 == 1)
+    a = f1[:, roi1[:, 0], roi1[:, 1]].T.to(torch.float16)
+    b = f2[:, roi2[:, 0], roi2[:, 1]].T.to(torch.float16)
+    dist = pdist(a, b, "inv_norm_cosine")
+    top2 = torch.topk(dist.float(), 2, dim=1, largest=False)[0]
+    save("g1_matcher_half", feats1=f1, feats2=f2, mask1=m1, mask2=m2, threshold=np.float32(0.25),
+         min_dist=torch.amin(dist, dim=1).float(), argmin=torch.argmin(dist, dim=1), gap=top2[:, 1] - top2[:, 0])
+
+
 def gen_matcher():
+    matcher_half_case()
     matcher_case("c32_24", 32, 24, 24, 11, "boxes")
     matcher_case("c256_16", 256, 16, 16, 12, "ones")
     matcher_case("c32_48", 32, 48, 48, 13, "random")
