@@ -284,7 +284,7 @@ def main():
     if a.warmup:
         run_steps(a.warmup)
     barrier()
-    screened = a.match_mode == "screened" and 64 < C <= 256
+    screened = a.match_mode == "screened" and 64 < C <= 512
     with MatchTimer("match_screened" if screened else "match") as mt:
         t0 = time.perf_counter()
         out, pose, status = run_steps(a.steps)
@@ -309,10 +309,13 @@ def main():
     trans_err = (mine[:, :3, 3] - gt[:, :3, 3]).abs().amax(dim=1)[st_local]
 
     if rank == 0:
+        cp = 32 if C <= 32 else 64 if C <= 64 else 128 if C <= 128 else 256 if C <= 256 else (C + 31) // 32 * 32
         if screened:
-            kernel, peak = "match_f16_screen_kernel<256,2> (fp16-MFMA screening pass of K1s)", PEAK_F16_MFMA_TFLOPS
+            kernel, peak = f"match_f16_screen_kernel<{max(cp, 128)},2> (fp16-MFMA screening pass of K1s)", PEAK_F16_MFMA_TFLOPS
+        elif cp <= 256:
+            kernel, peak = f"match_f32_regb_kernel<{cp}>", PEAK_FP32_MFMA_TFLOPS
         else:
-            kernel, peak = "match_f32_regb_kernel<256>", PEAK_FP32_MFMA_TFLOPS
+            kernel, peak = "match_f32_kernel (LDS-staged, wide descriptors)", PEAK_FP32_MFMA_TFLOPS
         launch_ms = match_ms
         achieved = flops / (launch_ms * 1e-3) / 1e12
         rec = {
@@ -320,7 +323,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"cfg2: Batch={B} synthetic {H}x{H} pairs per GPU, C={C} fp32 descriptors given (HIP matcher + lift + "
+                "workload": f"{'cfg2' if (H, C) == (224, 256) else 'cfg4 geometry' if (H, C) == (384, 512) else 'custom'}: Batch={B} synthetic {H}x{H} pairs per GPU, C={C} fp32 descriptors given (HIP matcher + lift + "
                             f"PointDSC 12x128), N1<=5000, n_corrs=500",
                 "stages": "match+lift+registration (descriptor maps resident in HBM; backbone not in the timed region)",
                 "match_mode": a.match_mode + (" (fp16-MFMA screening, exact fp32 re-scoring: outputs identical to the fp32 scan)" if screened else ""),

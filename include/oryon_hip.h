@@ -104,8 +104,8 @@ int oryon_match_f32(const float *a_hat, const float *q_hat, int B, int C, int ca
  *     screening scores (csrc/match16.hip) guarantees that every exact minimiser is a candidate, so on rows with
  *     valid == 1 `min_dist` / `argmin` are bit-identical to oryon_match_f32, and `valid` is identical on every row.
  *     Rows that provably cannot reach the threshold get valid = 0, argmin = 0 and the screening estimate as min_dist.
- * C (padded) must be 128 or 256, cap_a a multiple of 256; a_f16 / q_f16 are the half copies [B, cap, C]. */
-size_t oryon_match_screened_workspace_bytes(int B, int cap_a);
+ * C (padded) must be 128, 256 or 512, cap_a a multiple of 256; a_f16 / q_f16 are the half copies [B, cap, C]. */
+size_t oryon_match_screened_workspace_bytes(int B, int C, int cap_a);
 int oryon_match_screened(const float *a_hat, const float *q_hat, const void *a_f16, const void *q_f16, int B, int C,
                          int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
                          int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream);

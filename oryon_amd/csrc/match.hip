@@ -37,7 +37,8 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_f32_kernel(
     const float *__restrict__ a_hat, const float *__restrict__ q_hat, int B, int Cp, int cap_a, int cap_q,
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, float thr, int T, int S,
     float *__restrict__ min_dist, int32_t *__restrict__ argmin, uint8_t *__restrict__ valid,
-    float *__restrict__ ws_dist, int32_t *__restrict__ ws_idx)
+    float *__restrict__ ws_dist, int32_t *__restrict__ ws_idx, const int32_t *__restrict__ panel_flag,
+    const uint8_t *__restrict__ row_flag)
 {
     __shared__ float smem[4 * TILE_FLOATS];  // [buf][Q|A][128][33]
 
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_f32_kernel(
     const int na = n_a[p], nq = n_q[p];
     const int a0 = panel * MT;
     if (a0 >= na) return;
+    if (panel_flag && !panel_flag[(size_t)p * T + panel]) return;   // K1s fallback mode: only the flagged panels are recomputed
 
     const int nqt = (nq + MT - 1) / MT;
     const int qt_per = (nqt + S - 1) / S;
@@ -175,9 +177,11 @@ __global__ __launch_bounds__(MATCH_THREADS, 2) void match_f32_kernel(
         lex_min(d, i, sd[MT + t], si[MT + t]);
         if (S == 1) {
             const size_t o = (size_t)p * cap_a + a0 + t;
-            min_dist[o] = d;
-            argmin[o] = (i == 0x7fffffff) ? 0 : i;
-            valid[o] = (d < thr) ? 1 : 0;
+            if (!row_flag || row_flag[o]) {
+                min_dist[o] = d;
+                argmin[o] = (i == 0x7fffffff) ? 0 : i;
+                valid[o] = (d < thr) ? 1 : 0;
+            }
         } else {
             const size_t o = ((size_t)p * S + split) * cap_a + a0 + t;
             ws_dist[o] = d;
@@ -440,7 +444,9 @@ int match_f32_flagged(const float *a_hat, const float *q_hat, int B, int C, int 
                        n_a, n_q, threshold, T, 1, min_dist, argmin, valid, nullptr, nullptr, panel_flag, row_flag)
     if (C == 128) LAUNCH_FLAGGED(128);
     else if (C == 256) LAUNCH_FLAGGED(256);
-    else { set_error("match_f32_flagged: unsupported C_pad %d", C); return ORYON_ERR_INVALID_ARG; }
+    else   // wide descriptors: the LDS-staged kernel, one unit per pair
+        hipLaunchKernelGGL(match_f32_kernel, dim3(groups), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q,
+                           threshold, T, 1, min_dist, argmin, valid, nullptr, nullptr, panel_flag, row_flag);
 #undef LAUNCH_FLAGGED
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
@@ -498,7 +504,7 @@ extern "C" int oryon_match_f32(const float *a_hat, const float *q_hat, int B, in
     }
     else   // wide descriptors (e.g. C = 512): operands do not fit the register file, stage both through LDS
         hipLaunchKernelGGL(match_f32_kernel, dim3(groups), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q,
-                           threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx);
+                           threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx, nullptr, nullptr);
 #undef LAUNCH_REGB
     profile_end(st);
     ORYON_CHECK_LAUNCH();

@@ -13,10 +13,13 @@
 //
 // Why this is exact.  For unit rows |a16.q16 - a.q| <= DELTA with
 //   DELTA = (2^-10 + 2^-22) * sum|a_k q_k|   (two half roundings per product, sum|a_k q_k| <= |a||q| = 1)
-//         + 2 * C * 2^-24                     (fp32 accumulation of the MFMA and of the canonical chain)  ~= 1.01e-3  (C <= 256).
+//         + 2 * C * 2^-24                     (fp32 accumulation of the MFMA and of the canonical chain)  ~= 1.04e-3  (C <= 512).
 // If j* minimises the exact distance then a.q_j* >= max_j a.q_j - 2^-23 (dist is a monotone rounding of the dot), hence
 // s16_ij* >= max_j s16_ij - 2*DELTA - 2^-23: every exact minimiser - including every tied one - is in the list, and pass 2
 // returns exactly what the full fp32 scan returns.  MARGIN = 2.2e-3 > 2*DELTA + 2^-23.
+// Subnormal half inputs (|x| < 2^-14, common in unit rows of 256+ channels) are honoured by v_mfma_f32_32x32x16_f16 on gfx950
+// (tools/probe_mfma_f16_denorm.hip, measured), and K0's float->half conversion keeps them, so they round with an absolute
+// error <= 2^-25 each: <= 2 * 2^-25 * sqrt(C) ~= 1.3e-6 in the dot product, inside the slack of SCREEN_DELTA.
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 #include "common.h"
@@ -30,6 +33,7 @@ constexpr float SCREEN_DELTA = 1.05e-3f;
 constexpr float SCREEN_MARGIN = 2.2e-3f;
 constexpr int SCREEN_CAP = 64;          // candidate slots per anchor
 constexpr int MT16 = 256;               // anchors per workgroup (4 waves x 2 blocks of 32)
+constexpr int screen_tile_bytes(int CP) { return CP == 512 ? 65536 : 32768; }
 
 // Out-of-line candidate append (pass 1 slow path, taken by a few % of the tiles): keeping it out of the kernel body
 // keeps the hot loop's register allocation identical to pass 0.  vals: this lane's NV scores of one anchor column.
@@ -45,22 +49,29 @@ __device__ __noinline__ void emit_candidates(const float *vals, float thr, int q
 }
 
 template <int CP, int MODE, int VAR = 0>   // VAR != 0: timing ablations only (ORYON_MATCH16_VARIANT)
-__global__ __launch_bounds__(256, 2) void match_f16_screen_kernel(
+__global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_f16_screen_kernel(
     const __half *__restrict__ a16, const __half *__restrict__ q16, int B, int cap_a, int cap_q,
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, int T, int S, float valid_cut,
     float *__restrict__ ws_max /*[B,S_thr|S,cap_a]*/, int32_t *__restrict__ cnt /*[B,cap_a]*/, int32_t *__restrict__ cand,
     int S_thr, const int32_t *__restrict__ row_map, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
 {
     constexpr int RB = CP * 2;                   // row bytes
-    constexpr int ROWS = 32768 / RB;             // query rows per 32 KB LDS tile (64 at C=256)
+    constexpr int TILE_BYTES = screen_tile_bytes(CP);   // 32 KB; 64 KB at C=512 (one workgroup per CU, 512 registers per lane)
+    constexpr int ROWS = TILE_BYTES / RB;        // query rows per LDS tile (64 at C=256 and C=512)
     constexpr int NQB = ROWS / 32;               // query blocks per tile
     constexpr int NAB = 2;                       // anchor blocks per wave
     constexpr int NKS = CP / 16;                 // MFMA k-steps
-    constexpr int TILE_BYTES = 32768;
-    constexpr int NI = 8;
+    constexpr int NI = TILE_BYTES / 4096;        // 1 KB DMA instructions per wave and tile
     constexpr int LPR = RB / 256;                // 256-byte lines per row
-    static_assert(NQB * NKS == 32 && LPR >= 1, "tile geometry");
-    __shared__ __attribute__((aligned(256))) char smem[2 * TILE_BYTES];
+    static_assert(NQB * NKS * 1024 == TILE_BYTES && NQB >= 1 && LPR >= 1, "tile geometry");
+    char *smem;
+    if constexpr (2 * TILE_BYTES > 65536) {      // beyond the static LDS limit: dynamic, sized by the launcher
+        extern __shared__ __attribute__((aligned(256))) char smem_dyn[];
+        smem = smem_dyn;
+    } else {
+        __shared__ __attribute__((aligned(256))) char smem_st[2 * TILE_BYTES];
+        smem = smem_st;
+    }
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int unit = (slot / T) * 8 + xcd;
@@ -418,7 +429,7 @@ struct ScreenWs {
     size_t bytes, zero_off, zero_bytes;
 };
 
-static ScreenWs carve_screen(void *base, int B, int cap_a, int S)
+static ScreenWs carve_screen(void *base, int B, int C, int cap_a, int S)
 {
     ScreenWs w;
     char *p = static_cast<char *>(base);
@@ -430,7 +441,7 @@ static ScreenWs carve_screen(void *base, int B, int cap_a, int S)
     const size_t o_mf = take((size_t)B * cap_a * sizeof(float));
     const size_t o_am = take((size_t)B * cap_a * sizeof(float));
     const size_t o_ai = take((size_t)B * cap_a * sizeof(int32_t));
-    const size_t o_a16 = take((size_t)B * cap_a * 256 * sizeof(__half));
+    const size_t o_a16 = take((size_t)B * cap_a * C * sizeof(__half));
     const size_t o_cand = take((size_t)B * cap_a * SCREEN_CAP * sizeof(int32_t));
     w.zero_off = off;
     const size_t o_cnt = take((size_t)B * cap_a * sizeof(int32_t));
@@ -458,23 +469,44 @@ static ScreenWs carve_screen(void *base, int B, int cap_a, int S)
 
 using namespace oryon;
 
-extern "C" size_t oryon_match_screened_workspace_bytes(int B, int cap_a)
+extern "C" size_t oryon_match_screened_workspace_bytes(int B, int C, int cap_a)
 {
-    if (B <= 0 || cap_a <= 0 || cap_a % MT16) return 0;
-    return carve_screen(nullptr, B, cap_a, pick_split16(B, cap_a / MT16)).bytes;
+    if (B <= 0 || C <= 0 || cap_a <= 0 || cap_a % MT16) return 0;
+    return carve_screen(nullptr, B, C, cap_a, pick_split16(B, cap_a / MT16)).bytes;
 }
+
+namespace {
+// one launcher per descriptor width; C = 512 needs 2 x 64 KB of dynamic LDS (opt-in above 64 KB)
+template <int CP, int MODE>
+void launch_screen(int groups, hipStream_t st, const __half *a16, const __half *q16, int B, int cap_a, int cap_q, const int32_t *n_a,
+                   const int32_t *n_q, int T, int S, float valid_cut, float *ws_max, int32_t *cnt, int32_t *cand, int S_thr,
+                   const int32_t *row_map, int32_t *ws_i1, float *ws_m2)
+{
+    constexpr size_t dyn = 2 * screen_tile_bytes(CP) > 65536 ? 2 * screen_tile_bytes(CP) : 0;
+    if (dyn) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_f16_screen_kernel<CP, MODE, 0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((match_f16_screen_kernel<CP, MODE, 0>), dim3(groups), dim3(256), dyn, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T,
+                       S, valid_cut, ws_max, cnt, cand, S_thr, row_map, ws_i1, ws_m2);
+}
+}  // namespace
 
 extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, const void *a_f16, const void *q_f16, int B, int C,
                                     int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
                                     int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream)
 {
     ORYON_CHECK_ARG(a_hat && q_hat && a_f16 && q_f16 && n_a && n_q && min_dist && argmin && valid);
-    ORYON_CHECK_ARG(B >= 0 && (C == 128 || C == 256) && cap_a > 0 && cap_a % MT16 == 0 && cap_q > 0 && cap_q % 256 == 0);
+    ORYON_CHECK_ARG(B >= 0 && (C == 128 || C == 256 || C == 512) && cap_a > 0 && cap_a % MT16 == 0 && cap_q > 0 && cap_q % 256 == 0);
     ORYON_CHECK_ARG(threshold > 0.0f && threshold <= 0.5f);
     if (B == 0) return ORYON_OK;
     const int T = cap_a / MT16;
     const int S = pick_split16(B, T);
-    ScreenWs w = carve_screen(workspace, B, cap_a, S);
+    ScreenWs w = carve_screen(workspace, B, C, cap_a, S);
     if (!workspace || workspace_bytes < w.bytes) {
         set_error("oryon_match_screened: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
         return ORYON_ERR_WORKSPACE;
@@ -486,11 +518,11 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
     const int groups = ((B * S + 7) / 8) * 8 * T;
     const __half *a16 = static_cast<const __half *>(a_f16), *q16 = static_cast<const __half *>(q_f16);
 #define LAUNCH16(CPV, MODEV)                                                                                              \
-    hipLaunchKernelGGL((match_f16_screen_kernel<CPV, MODEV>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, \
-                       n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand, S, nullptr, w.ws_i1, w.ws_m2)
+    launch_screen<CPV, MODEV>(groups, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand, S, nullptr,   \
+                              w.ws_i1, w.ws_m2)
 #define LAUNCH16_AMB(CPV)                                                                                                 \
-    hipLaunchKernelGGL((match_f16_screen_kernel<CPV, 1>), dim3(groups), dim3(256), 0, st, w.a16c, q16, B, cap_a, cap_q,       \
-                       w.n_amb, n_q, T, S, valid_cut, w.amb_max, w.cnt, w.cand, 1, w.amb_idx, nullptr, nullptr)
+    launch_screen<CPV, 1>(groups, st, w.a16c, q16, B, cap_a, cap_q, w.n_amb, n_q, T, S, valid_cut, w.amb_max, w.cnt, w.cand, 1,        \
+                          w.amb_idx, nullptr, nullptr)
     static const int var16 = getenv("ORYON_MATCH16_VARIANT") ? atoi(getenv("ORYON_MATCH16_VARIANT")) : 0;
     static const bool two_pass = getenv("ORYON_SCREEN_TWOPASS") != nullptr;
     const float *m_final = nullptr;
@@ -503,16 +535,18 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
             switch (var16) { case 1: LAUNCH16V(1); break; case 2: LAUNCH16V(2); break; case 3: LAUNCH16V(3); break; case 4: LAUNCH16V(4); break;
                              case 5: LAUNCH16V(5); break; case 6: LAUNCH16V(6); break; default: LAUNCH16V(7); break; }
             LAUNCH16(256, 1);
-        } else if (C == 256) { LAUNCH16(256, 0); LAUNCH16(256, 1); } else { LAUNCH16(128, 0); LAUNCH16(128, 1); }
+        } else if (C == 256) { LAUNCH16(256, 0); LAUNCH16(256, 1); }
+        else if (C == 512) { LAUNCH16(512, 0); LAUNCH16(512, 1); }
+        else { LAUNCH16(128, 0); LAUNCH16(128, 1); }
 #undef LAUNCH16V
     } else {
         // single screening pass keeping (max, argmax, second max) per anchor; anchors whose runner-up is within MARGIN of the
         // maximum (duplicates, smooth descriptor fields) go through a second, compacted candidate pass
         profile_begin(st);
-        if (C == 256) LAUNCH16(256, 2); else LAUNCH16(128, 2);
+        if (C == 256) LAUNCH16(256, 2); else if (C == 512) LAUNCH16(512, 2); else LAUNCH16(128, 2);
         profile_end(st);
         ORYON_CHECK_LAUNCH();
-        if (C == 256)
+        if (C >= 256)
             hipLaunchKernelGGL((match_decide_kernel<64>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
                                valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx);
         else
@@ -520,7 +554,7 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
                                valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx);
         hipLaunchKernelGGL(match_compact_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a16, C, cap_a, w.n_amb, w.amb_idx, w.m_final,
                            w.a16c, w.amb_max);
-        if (C == 256) LAUNCH16_AMB(256); else LAUNCH16_AMB(128);
+        if (C == 256) LAUNCH16_AMB(256); else if (C == 512) LAUNCH16_AMB(512); else LAUNCH16_AMB(128);
         m_final = w.m_final;
     }
 #undef LAUNCH16

@@ -78,8 +78,8 @@ class MatchPoseEngine:
         else:
             cap_a = ops.round_up(FH * FW, ops.ROW_PAD)
         cap_q = ops.round_up(FH * FW, ops.ROW_PAD)
-        if cfg.match_mode == "screened" and 64 < C <= 256:
-            c_pad = 128 if C <= 128 else 256
+        if cfg.match_mode == "screened" and 64 < C <= 512:
+            c_pad = 128 if C <= 128 else (256 if C <= 256 else 512)
             a_hat, a16 = ops.gather_normalise(feat_a, roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
             q_hat, q16 = ops.gather_normalise(feat_q, roi_q, n_q, cap_q, c_pad=c_pad, want_f16=True)
             min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)

@@ -115,7 +115,7 @@ def match_screened(a_hat, q_hat, a16, q16, n_a, n_q, threshold: float):
     min_dist = torch.empty((B, cap_a), dtype=torch.float32, device=dev)
     argmin = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
     valid = torch.empty((B, cap_a), dtype=torch.uint8, device=dev)
-    wsb = lib().oryon_match_screened_workspace_bytes(B, cap_a)
+    wsb = lib().oryon_match_screened_workspace_bytes(B, Cp, cap_a)
     ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
     check(lib().oryon_match_screened(ptr(a_hat), ptr(q_hat), ptr(a16), ptr(q16), B, Cp, cap_a, cap_q, ptr(n_a), ptr(n_q),
                                      float(threshold), ptr(min_dist), ptr(argmin), ptr(valid), ptr(ws), wsb, stream_ptr(dev)),

@@ -214,21 +214,22 @@ def _screen_vs_exact(feat_a, feat_q, mask_a, mask_q, C_pad, thr=0.25, subsample=
 def test_screened_matcher_equals_exact_synthetic():
     from oryon_amd.synth import make_pair
     dev = "cuda"
-    for C, H in ((256, 64), (128, 56), (200, 48)):          # C=200 pads to 256
+    for C, H in ((256, 64), (128, 56), (200, 48), (512, 40), (400, 36)):   # C=200 pads to 256, C=400 to 512
         pairs = [make_pair(i, H, H, C, device=dev) for i in range(3)]
         st = lambda k: torch.stack([p[k] for p in pairs])
         fq = st("feat_q")
         fq[2] = torch.randn_like(fq[2])                      # pair 2: nothing matches -> all rows ruled out by the screen
-        va, na = _screen_vs_exact(st("feat_a"), fq, st("mask_a"), st("mask_q"), 256 if C > 128 else 128)
+        va, na = _screen_vs_exact(st("feat_a"), fq, st("mask_a"), st("mask_q"), 128 if C <= 128 else (256 if C <= 256 else 512))
         assert int(va[2, : int(na[2])].sum()) == 0 and int(va[0, : int(na[0])].sum()) > 100
 
 
-def test_screened_matcher_duplicates_and_overflow():
+@pytest.mark.parametrize("C", [256, 512])
+def test_screened_matcher_duplicates_and_overflow(C):
     """Query maps full of exact duplicates (ties) and near-duplicates: candidate lists overflow for some anchors and the
     exact fp32 recomputation of their panels must kick in; first-index tie-breaking must survive."""
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(5)
-    C, H = 256, 40
+    H = 40
     base = torch.randn(C, 200, generator=g, device=dev)
     idx = torch.randint(0, 200, (H * H,), generator=g, device=dev)
     fq = base[:, idx].reshape(1, C, H, H).contiguous()        # only 200 distinct query descriptors -> ~8 exact copies each
@@ -237,12 +238,13 @@ def test_screened_matcher_duplicates_and_overflow():
     fq[0, :, :4, :] = crowd[:, None, None]                    # one descriptor repeated 160 times (> 64 candidates)
     fa[0, :, 0, :8] = crowd[:, None] + 0.001                  # anchors that match that crowd
     ones = torch.ones((1, H, H), dtype=torch.int32, device=dev)
-    va, na = _screen_vs_exact(fa, fq, ones, ones, 256)
+    va, na = _screen_vs_exact(fa, fq, ones, ones, C)
     assert int(va[0, : int(na[0])].sum()) > 1000
 
 
-def test_screened_matcher_full_size_pair():
+@pytest.mark.parametrize("H,C", [(224, 256), (384, 512)])          # BASELINE cfg2 and cfg4 pair sizes
+def test_screened_matcher_full_size_pair(H, C):
     from oryon_amd.synth import make_pair
-    p = make_pair(1, 224, 224, 256, device="cuda")
-    va, na = _screen_vs_exact(p["feat_a"][None], p["feat_q"][None], p["mask_a"][None], p["mask_q"][None], 256, subsample=5000)
+    p = make_pair(1, H, H, C, device="cuda")
+    va, na = _screen_vs_exact(p["feat_a"][None], p["feat_q"][None], p["mask_a"][None], p["mask_q"][None], C, subsample=5000)
     assert int(na) == 5000 and float(va[0, :5000].float().mean()) > 0.6

@@ -112,12 +112,12 @@ def test_predicted_mask_path():
     assert out["status"].cpu().tolist() == [0, 0]
 
 
-def test_engine_screened_equals_exact_bit_for_bit():
+@pytest.mark.parametrize("H,C", [(64, 160), (48, 512)])         # 160 pads to 256 channels; 512 = BASELINE cfg4 width
+def test_engine_screened_equals_exact_bit_for_bit(H, C):
     """The fp16-screened matcher must leave every downstream result untouched: same correspondences, same poses."""
     from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
     from oryon_amd.synth import make_pair
     dev = "cuda"
-    H, C = 64, 160                       # pads to 256 channels
     pairs = [make_pair(i, H, H, C, device=dev) for i in range(20, 24)]
     st = lambda k: torch.stack([p[k] for p in pairs])
     solver = _solver()
@@ -183,3 +183,19 @@ def test_engine_overlap_stream_gives_identical_results():
     torch.cuda.synchronize()
     assert torch.equal(o0["pose"], r0["pose"]) and torch.equal(o1["pose"], r1["pose"])
     assert torch.equal(o0["status"], r0["status"]) and torch.equal(o1["status"], r1["status"])
+
+
+def test_cfg4_sized_pair_recovers_ground_truth():
+    """BASELINE cfg4 geometry (384x384 maps, C=512) for one rank's worth of two pairs: the pose must match the generator's."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    pairs = [make_pair(i, 384, 384, 512, device=dev) for i in (40, 41)]
+    st = lambda k: torch.stack([p[k] for p in pairs])
+    eng = MatchPoseEngine(_solver(), MatchPoseConfig())
+    out = eng.run(st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"),
+                  st("camera").to(dev), st("camera").to(dev))
+    assert out["status"].tolist() == [0, 0]
+    for b in range(2):
+        T, gt = out["pose"][b].cpu().numpy(), pairs[b]["pose"].cpu().numpy()
+        assert np.abs(T[:3, :3] - gt[:3, :3]).max() < 1e-2 and np.abs(T[:3, 3] - gt[:3, 3]).max() < 5e-3
