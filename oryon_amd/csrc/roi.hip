@@ -3,6 +3,7 @@
 // All of this is HBM-bound integer/gather work: coalesced row-major scans, wave ballots for the ordered
 // compaction, an LDS transpose so the [N,C] descriptor rows are written in 128-byte runs.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace oryon {
@@ -199,56 +200,66 @@ __global__ __launch_bounds__(GN_ROWS) void gather_normalise_kernel(const float *
     }
 }
 
-// Second-generation gather + normalise (C_pad <= 512): a workgroup owns 64 ROI rows and keeps their raw channel
-// values in LDS ([k][row], 65-float rows), so the channel-planar map is read from HBM exactly once:
-//   phase 1  all 4 waves load (wave w takes channels k = w mod 4; lane = row -> 256-byte coalesced reads per channel)
-//   phase 2  wave 0 runs the canonical k-ordered fmaf chain per row out of LDS (bit-exact vs the oracle) -> norms
-//   phase 3  all waves divide and write: fp32 rows k-permuted in 16-byte chunks, fp16 rows in natural order, 128-byte
-//            runs per row.
-constexpr int G2_ROWS = 64;
-constexpr int G2_LD = 65;
+// Second-generation gather + normalise (C_pad <= 512).  A workgroup owns ROWS ROI rows of one map and keeps their raw channel
+// values in LDS ([k][row], one float of padding per k), so the channel-planar map is read from HBM exactly once:
+//   load    all 4 waves, lane = row: every channel is one 128/256-byte run (each in its own DRAM page - this phase runs at
+//           ~3.7 TB/s on its own and bounds the kernel), NL loads in flight per lane
+//   norm    wave 0 runs the canonical k-ordered fmaf chain per row out of LDS (bit-exact vs the oracle)
+//   store   all waves divide and write FULL 128-byte lines: fp32 rows k-permuted in 16-byte chunks, fp16 rows in natural
+//           order (64-byte partial-line stores cost 3x per byte on this memory system, measured)
+// Phases of different workgroups overlap on a CU (4 workgroups at C_pad = 256); a register-staged software pipeline inside a
+// persistent workgroup (next tile's loads in flight under norm + stores) measured only 5-7 % faster on the same GPU and was
+// not kept.
+constexpr int G2_ROWS = 64;        // zero-fill granularity of the row capacity (callers pad caps to 256)
+template <int NL, int ROWS>        // NL: channel loads in flight per lane; ROWS: ROI rows per workgroup (32 or 64)
 __global__ __launch_bounds__(256) void gather_normalise_v2_kernel(const float *__restrict__ feat, int C, int HW,
                                                                    const int32_t *__restrict__ roi, int roi_stride,
                                                                    const int32_t *__restrict__ count, int rows_cap, int Cp,
                                                                    float *__restrict__ out, __half *__restrict__ out16)
 {
-    extern __shared__ float raw[];             // [Cp][G2_LD] raw values, then sd[64] norms
-    float *sd = raw + (size_t)Cp * G2_LD;
+    constexpr int LD = ROWS + 1;
+    constexpr int CPW = 64 / ROWS;             // channels one wave instruction covers (1 or 2)
+    constexpr int KSTEP = 4 * CPW;             // channel stride between a lane's consecutive values
+    constexpr int NRG = ROWS / 8;              // 8-row groups; waves beyond NRG split the k range instead
+    constexpr int KSPLIT = NRG >= 4 ? 1 : 4 / NRG;
+    extern __shared__ float raw[];             // [Cp][LD] raw values, then sd[ROWS] norms
+    float *sd = raw + (size_t)Cp * LD;
     const int m = blockIdx.y;
     const int n = count[m];
-    const int row0 = blockIdx.x * G2_ROWS;
+    const int row0 = blockIdx.x * ROWS;
     // zero-fill contract: rows [n, round_up(n, 256)) must be written as zeros
     const int n_fill = (n + 255) / 256 * 256;
     if (row0 >= n_fill) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float *f = feat + (size_t)m * C * HW;
-    const int my_row = row0 + lane;
+    const int lrow = lane & (ROWS - 1);
+    const int kfirst = wave * CPW + lane / ROWS;
+    const int my_row = row0 + lrow;
     const bool live = my_row < n;
     const int pix = live ? roi[(size_t)m * roi_stride + my_row] : 0;
-    // 16 independent loads in flight per lane before anything is consumed
-    for (int kb = wave; kb < Cp; kb += 64) {
-        float v[16];
+    for (int kb = kfirst; kb < Cp; kb += KSTEP * NL) {
+        float v[NL];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int k = kb + 4 * u;
+        for (int u = 0; u < NL; ++u) {
+            const int k = kb + KSTEP * u;
             v[u] = (live && k < C) ? f[(size_t)k * HW + pix] : 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int k = kb + 4 * u;
-            if (k < Cp) raw[k * G2_LD + lane] = v[u];
+        for (int u = 0; u < NL; ++u) {
+            const int k = kb + KSTEP * u;
+            if (k < Cp) raw[k * LD + lrow] = v[u];
         }
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && lane < ROWS) {
         float n2 = 0.0f;
         for (int k0 = 0; k0 < C; k0 += 16) {
-            float v[16];
+            float x[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = (k0 + u < C) ? raw[(k0 + u) * G2_LD + lane] : 0.0f;
+            for (int u = 0; u < 16; ++u) x[u] = (k0 + u < C) ? raw[(k0 + u) * LD + lane] : 0.0f;
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                if (k0 + u < C) n2 = __fmaf_rn(v[u], v[u], n2);
+                if (k0 + u < C) n2 = __fmaf_rn(x[u], x[u], n2);
         }
         float d = __fsqrt_rn(n2);
         sd[lane] = d < 1e-8f ? 1e-8f : d;
@@ -256,29 +267,45 @@ __global__ __launch_bounds__(256) void gather_normalise_v2_kernel(const float *_
     __syncthreads();
     float *o = out + ((size_t)m * rows_cap + row0) * Cp;
     // fp32, k-permuted: lane -> (row_sub 0..7, chunk c4 0..7) of a 32-wide k group; 8 rows x 128 bytes per instruction
-    for (int rg = wave; rg < G2_ROWS / 8; rg += 4) {
+    for (int rg = wave % NRG; rg < NRG; rg += 4) {
         const int r = rg * 8 + (lane >> 3), c4 = lane & 7;
         const float d = sd[r];
         const int kb = 8 * (c4 >> 1) + (c4 & 1);
-        for (int k0 = 0; k0 < Cp; k0 += 32) {
-            float4 v;
-            v.x = __fdiv_rn(raw[(k0 + kb + 0) * G2_LD + r], d);
-            v.y = __fdiv_rn(raw[(k0 + kb + 2) * G2_LD + r], d);
-            v.z = __fdiv_rn(raw[(k0 + kb + 4) * G2_LD + r], d);
-            v.w = __fdiv_rn(raw[(k0 + kb + 6) * G2_LD + r], d);
-            *reinterpret_cast<float4 *>(o + (size_t)r * Cp + k0 + c4 * 4) = v;
+        for (int k0 = 32 * (wave / NRG); k0 < Cp; k0 += 32 * KSPLIT) {
+            float4 q;
+            q.x = __fdiv_rn(raw[(k0 + kb + 0) * LD + r], d);
+            q.y = __fdiv_rn(raw[(k0 + kb + 2) * LD + r], d);
+            q.z = __fdiv_rn(raw[(k0 + kb + 4) * LD + r], d);
+            q.w = __fdiv_rn(raw[(k0 + kb + 6) * LD + r], d);
+            *reinterpret_cast<float4 *>(o + (size_t)r * Cp + k0 + c4 * 4) = q;
         }
     }
     if (out16) {
         __half *o16 = out16 + ((size_t)m * rows_cap + row0) * Cp;
-        // fp16, natural order: lane -> (row_sub 0..15, chunk c8 0..3) of a 32-wide k group
-        const int r = wave * 16 + (lane >> 2), c8 = lane & 3;
-        const float d = sd[r];
-        for (int k0 = 0; k0 < Cp; k0 += 32) {
-            union { __half h[8]; uint4 u; } pk;
+        if (Cp >= 64) {
+            // fp16, natural order: lane -> (row_sub 0..7, chunk c8 0..7) of a 64-wide k group
+            for (int rg = wave % NRG; rg < NRG; rg += 4) {
+                const int r = rg * 8 + (lane >> 3), c8 = lane & 7;
+                const float d = sd[r];
+                for (int k0 = 64 * (wave / NRG); k0 < Cp; k0 += 64 * KSPLIT) {
+                    if (k0 + c8 * 8 >= Cp) continue;
+                    union { __half h[8]; uint4 u; } pk;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pk.h[e] = __float2half_rn(__fdiv_rn(raw[(k0 + c8 * 8 + e) * G2_LD + r], d));
-            *reinterpret_cast<uint4 *>(o16 + (size_t)r * Cp + k0 + c8 * 8) = pk.u;
+                    for (int e = 0; e < 8; ++e) pk.h[e] = __float2half_rn(__fdiv_rn(raw[(k0 + c8 * 8 + e) * LD + r], d));
+                    *reinterpret_cast<uint4 *>(o16 + (size_t)r * Cp + k0 + c8 * 8) = pk.u;
+                }
+            }
+        } else {
+            // 64-byte rows are adjacent in memory: lane -> (row_sub 0..15, chunk c8 0..3), one contiguous 1 KB run
+            constexpr int NRG16 = ROWS / 16;
+            const int r = (wave % NRG16) * 16 + (lane >> 2), c8 = lane & 3;
+            const float d = sd[r];
+            if (wave < NRG16) {
+                union { __half h[8]; uint4 u; } pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk.h[e] = __float2half_rn(__fdiv_rn(raw[(c8 * 8 + e) * LD + r], d));
+                *reinterpret_cast<uint4 *>(o16 + (size_t)r * Cp + c8 * 8) = pk.u;
+            }
         }
     }
 }
@@ -338,15 +365,22 @@ extern "C" int oryon_gather_normalise_f32(const float *feat, int n_maps, int C, 
     ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % GN_ROWS == 0);
     if (n_maps == 0) return ORYON_OK;
     if (C_pad <= 512) {
-        const size_t sh = ((size_t)C_pad * G2_LD + 64) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_v2_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(gather_normalise_v2_kernel, dim3(rows_cap / G2_ROWS, n_maps), dim3(256), sh, as_stream(stream), feat, C, HW,
-                           roi, roi_stride, count, rows_cap, C_pad, out, static_cast<__half *>(out_f16));
+        static const int rows_env = getenv("ORYON_GATHER_ROWS") ? atoi(getenv("ORYON_GATHER_ROWS")) : 0;
+        const int rows = rows_env ? rows_env : 32;
+        const size_t sh = ((size_t)C_pad * (rows + 1) + 64) * sizeof(float);
+#define LAUNCH_G2(NLV, RV)                                                                                                 \
+    do {                                                                                                                   \
+        static bool attr_set = false;                                                                                      \
+        if (!attr_set) {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_v2_kernel<NLV, RV>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+            attr_set = true;                                                                                               \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((gather_normalise_v2_kernel<NLV, RV>), dim3(rows_cap / RV, n_maps), dim3(256), sh, as_stream(stream), feat, \
+                           C, HW, roi, roi_stride, count, rows_cap, C_pad, out, static_cast<__half *>(out_f16));          \
+    } while (0)
+        if (rows == 64) LAUNCH_G2(16, 64); else LAUNCH_G2(16, 32);
+#undef LAUNCH_G2
     } else {
         hipLaunchKernelGGL(gather_normalise_kernel, dim3(rows_cap / GN_ROWS, n_maps), dim3(GN_ROWS), 0, as_stream(stream), feat,
                            C, HW, roi, roi_stride, count, rows_cap, C_pad, out, static_cast<__half *>(out_f16));
