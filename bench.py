@@ -155,6 +155,10 @@ def bench_full(a, rank, world, dev):
     key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
     xs = {"anchor": {"rgb": rgb_a}, "query": {"rgb": rgb_q}, "prompt_tokens": toks}
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if a.backbone_dtype == "bf16" else torch.autocast("cuda", enabled=False)
+    if a.backbone_dtype == "bf16w":
+        # frozen towers converted once: no per-call weight casts, LayerNorm / softmax / activations on bf16 tensors
+        model = model.to(torch.bfloat16)
+        xs["anchor"]["rgb"], xs["query"]["rgb"] = rgb_a.to(torch.bfloat16), rgb_q.to(torch.bfloat16)
     total = B * world
 
     def step():
@@ -199,7 +203,8 @@ def bench_full(a, rank, world, dev):
             "metric": "image-pairs/sec end-to-end (feat+match+reg), stage set FULL at the reference's shapes (224x224 RGB -> C=32 @192x192)",
             "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.backbone_dtype == "fp32" else "bf16 backbone GEMMs (autocast), f32 match+pose",
+            "dtype": {"fp32": "f32", "bf16": "bf16 backbone GEMMs (autocast), f32 match+pose",
+                      "bf16w": "bf16 backbone (weights + activations), f32 match+pose"}[a.backbone_dtype],
             "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
             "config": {"workload": f"Batch={B} synthetic 224x224 RGB-D pairs per GPU through CLIP ViT-L/14@336 + Swin-B(stages 1-2) + fusion + "
                                    f"decoder (PyTorch-ROCm), then HIP match + lift + PointDSC 12x128",
@@ -229,7 +234,8 @@ def main():
                     help="match+pose: BASELINE configs[1], descriptor maps given (default, the headline line); full: random-init "
                          "CLIP ViT-L/14@336 + Swin-B + fusion + decoder forward on 224x224 RGB (-> C=32 @192x192, the reference's own "
                          "shapes), then match + pose - a separate stage set, never mixed into the headline")
-    ap.add_argument("--backbone-dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--backbone-dtype", choices=["fp32", "bf16", "bf16w"], default="fp32",
+                    help="fp32 | bf16 (autocast over fp32 weights) | bf16w (weights converted to bf16 once)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not overlap the registration of step k with the matching of step k+1 (second HIP stream)")
     ap.add_argument("--match-mode", choices=["screened", "exact"], default="screened",

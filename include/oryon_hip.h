@@ -48,6 +48,11 @@ int oryon_profile_events(void *start_event, void *stop_event);
 /* ORYON_OK iff device `device` exists and is gfx950. */
 int oryon_device_check(int device);
 
+/* B1  QuickGELU of the CLIP residual blocks, y = x * sigmoid(1.702 x)  (third-party clip model.py, loaded at
+ *     models/vlm.py:19), fused into one pass for bf16 activations: x, y [n] bf16 (16-byte aligned, may alias).
+ *     Arithmetic in fp32, one rounding.  The fp32 backbone path keeps torch's own ops. */
+int oryon_quick_gelu_bf16(const void *x, void *y, int64_t n, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K0  mask -> ROI.   Replaces torch.nonzero(mask == 1) (utils/pcd.py:184-185) and the validity test
  *     count_nonzero(mask == 1) > 0 (pipeline.py:391-393).

@@ -74,6 +74,9 @@ class _MLP(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         h = self.c_fc(x)
+        if h.is_cuda and h.dtype == torch.bfloat16 and not torch.is_grad_enabled():
+            from .. import ops                      # fused QuickGELU (B1): one pass instead of three bandwidth-bound ones
+            return self.c_proj(ops.quick_gelu_bf16(h))
         return self.c_proj(h * torch.sigmoid(1.702 * h))
 
 

@@ -40,9 +40,9 @@ class _WindowAttention(nn.Module):
         self.register_buffer("relative_position_index", _relative_index(window))
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
-    def _shift_mask(self, Hp: int, Wp: int, device) -> Tensor:
+    def _shift_mask(self, Hp: int, Wp: int, device, dtype) -> Tensor:
         w, s = self.window, self.shift
-        region = torch.zeros((Hp, Wp), device=device)
+        region = torch.zeros((Hp, Wp), device=device, dtype=torch.float32)
         bands = ((0, Hp - w), (Hp - w, Hp - s), (Hp - s, Hp))
         bands_w = ((0, Wp - w), (Wp - w, Wp - s), (Wp - s, Wp))
         label = 0
@@ -52,7 +52,7 @@ class _WindowAttention(nn.Module):
                 label += 1
         region = region.view(Hp // w, w, Wp // w, w).permute(0, 2, 1, 3).reshape(-1, w * w)   # [nW, N]
         diff = region[:, None, :] - region[:, :, None]
-        return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))   # [nW, N, N]
+        return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff)).to(dtype)   # [nW, N, N]
 
     def forward(self, x: Tensor) -> Tensor:                               # x: [B, H, W, C]
         B, H, W, C = x.shape
@@ -70,7 +70,7 @@ class _WindowAttention(nn.Module):
         bias = self.relative_position_bias_table[self.relative_position_index].view(w * w, w * w, nh).permute(2, 0, 1)
         attn = attn + bias[None]
         if s > 0:
-            m = self._shift_mask(Hp, Wp, x.device)
+            m = self._shift_mask(Hp, Wp, x.device, attn.dtype)
             attn = (attn.view(B, nW, nh, w * w, w * w) + m[None, :, None]).view(B * nW, nh, w * w, w * w)
         out = (torch.softmax(attn, dim=-1) @ v).transpose(1, 2).reshape(B * nW, w * w, C)
         out = self.proj(out)

@@ -20,6 +20,16 @@ def round_up(x: int, m: int) -> int:
     return ((int(x) + m - 1) // m) * m
 
 
+def quick_gelu_bf16(x: torch.Tensor) -> torch.Tensor:
+    """x * sigmoid(1.702 x) on a bf16 CUDA tensor in one pass (B1); used by the CLIP residual blocks at inference."""
+    _lib.require_gpu(x.device)
+    assert x.dtype == torch.bfloat16
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib().oryon_quick_gelu_bf16(ptr(x), ptr(y), x.numel(), stream_ptr(x.device)), "oryon_quick_gelu_bf16")
+    return y
+
+
 def roi_compact(mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """mask [n_maps, H, W] (or [H,W]) int32 -> (roi [n_maps, HW] int32 linear indices, count [n_maps] int32)."""
     if mask.dim() == 2:

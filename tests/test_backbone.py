@@ -175,6 +175,11 @@ def test_oryon_forward_contract_tiny_clip():
     assert all(torch.isfinite(v).all() for v in out.values())
     assert len(net.vlm._prompt_cache) == 1                       # identical prompt sets are encoded once
     assert torch.equal(out["featmap_a"], out2["featmap_a"])
+    # the joint anchor+query batch of the inference path must equal the two separate passes the reference makes (net.py:145-160)
+    with torch.no_grad():
+        solo = net({"anchor": {"rgb": xs["query"]["rgb"][:1]}, "query": {"rgb": xs["anchor"]["rgb"]}, "prompt_tokens": xs["prompt_tokens"][:1]})
+    torch.testing.assert_close(solo["featmap_a"][0], out["featmap_q"][0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(solo["mask_q"][1], out["mask_a"][1], rtol=1e-4, atol=1e-5)
     net.train()
     assert net.fusion.training and not net.vlm.training          # CLIP never leaves eval mode (net.py:78-89, vlm.py:30-34)
     with pytest.raises(RuntimeError):

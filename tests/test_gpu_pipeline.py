@@ -199,3 +199,16 @@ def test_cfg4_sized_pair_recovers_ground_truth():
     for b in range(2):
         T, gt = out["pose"][b].cpu().numpy(), pairs[b]["pose"].cpu().numpy()
         assert np.abs(T[:3, :3] - gt[:3, :3]).max() < 1e-2 and np.abs(T[:3, 3] - gt[:3, 3]).max() < 5e-3
+
+
+def test_quick_gelu_bf16_fused():
+    from oryon_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n in (8 * 1000, 8 * 1000 + 5, 3):
+        x = (4.0 * torch.randn(n, generator=g, device="cuda")).to(torch.bfloat16)
+        y = ops.quick_gelu_bf16(x)
+        xf = x.float()
+        ref = (xf * torch.sigmoid(1.702 * xf)).to(torch.bfloat16)           # fp32 arithmetic, one rounding
+        diff = (y.float() - ref.float()).abs()
+        assert float((diff / ref.float().abs().clamp_min(1e-3)).max()) < 1e-2     # at most one bf16 ulp (fast exp)
+        assert float((y.float() - ref.float()).abs().mean()) < 1e-4
