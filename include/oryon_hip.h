@@ -48,6 +48,15 @@ int oryon_profile_events(void *start_event, void *stop_event);
 /* ORYON_OK iff device `device` exists and is gfx950. */
 int oryon_device_check(int device);
 
+/* K-1 batched image pre-processing in front of the network: what the reference does per sample on dataloader workers
+ *     (utils/data/common.py:49 `rgb.transpose(2,0,1)/255.`, utils/augmentations.py:137-139 resize to dataset.img_size,
+ *     datasets.py:204 `.to(float32)`).  Resampling = torch upsample_bilinear2d, align_corners=False.
+ * rgb_hwc [n,HI,WI,3] uint8 -> out [n,3,HO,WO] fp32 (fp64 arithmetic, one rounding, like the reference's float64 tensor).
+ * in [n,HI,WI] fp32 -> out [n,HO,WO] fp32 (fp32 arithmetic; round_output != 0 rounds half-to-even as torchvision does
+ * for integer images such as the depth map). */
+int oryon_rgb_resize_bilinear(const uint8_t *rgb_hwc, int n, int HI, int WI, int HO, int WO, float *out, void *stream);
+int oryon_resize_bilinear_f32(const float *in, int n, int HI, int WI, int HO, int WO, int round_output, float *out, void *stream);
+
 /* B1  QuickGELU of the CLIP residual blocks, y = x * sigmoid(1.702 x)  (third-party clip model.py, loaded at
  *     models/vlm.py:19), fused into one pass for bf16 activations: x, y [n] bf16 (16-byte aligned, may alias).
  *     Arithmetic in fp32, one rounding.  The fp32 backbone path keeps torch's own ops. */

@@ -463,3 +463,71 @@ def analytic_state_dict(reference_state: Dict[str, torch.Tensor], seed: int = 0)
         else:
             out[name] = hashed_tensor(shape, t, seed, 0.05)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# data path in front of the network: preprocess_item -> resize -> collate, reference form on the CPU
+# ----------------------------------------------------------------------------------------------
+def tv_resize(img: torch.Tensor, size, mode: str) -> torch.Tensor:
+    """torchvision 0.13 `transforms.functional.resize` on a tensor [C,H,W] (functional_tensor.py::resize; the package is
+    third-party and absent here): integer / non-float inputs are cast to float32, resampled with torch `interpolate`
+    (bilinear: align_corners=False, no antialias; nearest: legacy rule), then rounded and cast back."""
+    out_dtype = img.dtype
+    need_cast = out_dtype not in (torch.float32, torch.float64)
+    x = img.to(torch.float32) if need_cast else img
+    x = F.interpolate(x[None], size=list(size), mode=mode, align_corners=False if mode == "bilinear" else None)[0]
+    if need_cast:
+        if out_dtype in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64):
+            x = torch.round(x)
+        x = x.to(out_dtype)
+    return x
+
+
+def preprocess_item(item: dict) -> dict:
+    """utils/data/common.py:41-75, pixel arithmetic included (rgb -> CHW float64 in [0,1])."""
+    item = dict(item)
+    item["metadata"] = dict(item["metadata"])
+    item["rgb"] = torch.tensor(np.asarray(item["rgb"]).transpose(2, 0, 1) / 255.0)
+    item["hw_size"] = tuple(np.asarray(item["mask"]).shape)
+    item["mask"] = torch.tensor(np.asarray(item["mask"]))
+    item["depth"] = torch.tensor(np.asarray(item["depth"]))
+    item["orig_rgb"] = item["rgb"].clone()
+    item["orig_depth"] = item["depth"].clone()
+    item["eval_depth"] = item["depth"].clone()
+    item["metadata"]["poses"] = [torch.tensor(np.asarray(v)) for v in item["metadata"]["poses"]]
+    mask = torch.where(item["mask"] == item["metadata"]["mask_ids"][0], 1, 0)
+    item["mask"] = mask
+    ys, xs = np.nonzero(mask.numpy() == 1)
+    y1, x1, y2, x2 = (int(ys.min()), int(xs.min()), int(ys.max()), int(xs.max())) if ys.size else (0, 0, 2, 2)
+    item["metadata"]["boxes"] = torch.tensor([y1, x1, y2 - y1, x2 - x1])
+    return item
+
+
+def resize_item(item: dict, coords: torch.Tensor, size) -> Tuple[dict, torch.Tensor]:
+    """utils/augmentations.py:133-149."""
+    H, W = item["mask"].shape
+    item["rgb"] = tv_resize(item["rgb"], size, "bilinear")
+    item["mask"] = tv_resize(item["mask"][None], size, "nearest")[0]
+    item["depth"] = tv_resize(item["depth"][None], size, "bilinear")[0]
+    y1, x1, h, w = item["metadata"]["boxes"]
+    item["metadata"]["boxes"] = torch.tensor([y1 * (size[0] / float(H)), x1 * (size[1] / float(W)), h * (size[0] / float(H)),
+                                              w * (size[1] / float(W))])
+    c = coords.clone().to(torch.float32)
+    c[:, 0] *= torch.tensor(size[0], dtype=torch.float32) / torch.tensor(H, dtype=torch.float32)
+    c[:, 1] *= torch.tensor(size[1], dtype=torch.float32) / torch.tensor(W, dtype=torch.float32)
+    return item, c
+
+
+def collate_side(items) -> dict:
+    """One side of CollateWrapper.__call__ (datasets.py:202-228)."""
+    return {
+        "rgb": torch.stack([it["rgb"].squeeze() for it in items]).to(torch.float32),
+        "mask": torch.stack([it["mask"].squeeze() for it in items]).to(torch.uint8),
+        "depth": torch.stack([it["depth"].squeeze() for it in items]).to(torch.float32),
+        "orig_depth": [it["orig_depth"].squeeze() for it in items],
+        "camera": torch.stack([torch.as_tensor(it["camera"]).squeeze() for it in items]),
+        "pose": torch.stack([it["metadata"]["poses"][0].squeeze() for it in items]),
+        "box": torch.stack([torch.as_tensor(it["metadata"]["boxes"]).squeeze() for it in items]),
+        "sizes": torch.stack([torch.as_tensor(it["hw_size"]) for it in items]),
+        "instance_id": [it["instance_id"] for it in items],
+    }

@@ -1,0 +1,99 @@
+// K-1: image pre-processing in front of the network - what the reference does per sample on dataloader
+// workers (utils/data/common.py:41-75 preprocess_item, utils/augmentations.py:129-149 resize, datasets.py:138-245 collate),
+// batched on the device:
+//   rgb    uint8 [n,HI,WI,3] (as PIL hands it over)  ->  /255., CHW, bilinear to [n,3,HO,WO] fp32
+//   depth  fp32 [n,HI,WI]                            ->  bilinear (optionally rounded half-to-even, as torchvision does for
+//                                                        integer images) [n,HO,WO] fp32
+// Resampling rule = torch's upsample_bilinear2d with align_corners=False (what torchvision's tensor resize calls):
+//   src = scale*(dst+0.5)-0.5 clamped at 0, i0 = floor(src), i1 = i0 + (i0 < in-1), l1 = src-i0, l0 = 1-l1,
+//   out = l0h*(l0w*a + l1w*b) + l1h*(l0w*c + l1w*d).
+// The reference's rgb is a float64 tensor at this point (numpy `/ 255.`), resized in float64 and cast to fp32 by the collate
+// (datasets.py:204): the rgb kernel therefore computes in fp64 and rounds once.  HBM-bound: 3*HI*WI bytes in (only the
+// touched texels), 12*HO*WO bytes out per image.
+#include "common.h"
+
+namespace oryon {
+
+template <typename T>
+struct Tap { int i0, i1; T l0, l1; };
+
+template <typename T>
+__device__ __forceinline__ Tap<T> make_tap(int dst, T scale, int in_size)
+{
+    T src = scale * ((T)dst + (T)0.5) - (T)0.5;
+    src = src < (T)0 ? (T)0 : src;
+    Tap<T> t;
+    t.i0 = (int)src;
+    if (t.i0 > in_size - 1) t.i0 = in_size - 1;
+    t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+    t.l1 = src - (T)t.i0;
+    t.l0 = (T)1 - t.l1;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void rgb_resize_bilinear_kernel(const uint8_t *__restrict__ in, int HI, int WI, int HO, int WO,
+                                                                   float *__restrict__ out)
+{
+    const int m = blockIdx.y;
+    const double sy = (double)HI / (double)HO, sx = (double)WI / (double)WO;
+    const uint8_t *img = in + (size_t)m * HI * WI * 3;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HO * WO; p += gridDim.x * blockDim.x) {
+        const int y = p / WO, x = p % WO;
+        const Tap<double> ty = make_tap<double>(y, sy, HI), tx = make_tap<double>(x, sx, WI);
+        const uint8_t *r0 = img + ((size_t)ty.i0 * WI) * 3, *r1 = img + ((size_t)ty.i1 * WI) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double a = r0[tx.i0 * 3 + c] / 255.0, b = r0[tx.i1 * 3 + c] / 255.0;
+            const double cc = r1[tx.i0 * 3 + c] / 255.0, d = r1[tx.i1 * 3 + c] / 255.0;
+            const double v = ty.l0 * (tx.l0 * a + tx.l1 * b) + ty.l1 * (tx.l0 * cc + tx.l1 * d);
+            out[((size_t)m * 3 + c) * HO * WO + p] = (float)v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_f32_kernel(const float *__restrict__ in, int HI, int WI, int HO, int WO,
+                                                                   int round_output, float *__restrict__ out)
+{
+    const int m = blockIdx.y;
+    const float sy = (float)HI / (float)HO, sx = (float)WI / (float)WO;
+    const float *img = in + (size_t)m * HI * WI;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HO * WO; p += gridDim.x * blockDim.x) {
+        const int y = p / WO, x = p % WO;
+        const Tap<float> ty = make_tap<float>(y, sy, HI), tx = make_tap<float>(x, sx, WI);
+        const float a = img[(size_t)ty.i0 * WI + tx.i0], b = img[(size_t)ty.i0 * WI + tx.i1];
+        const float c = img[(size_t)ty.i1 * WI + tx.i0], d = img[(size_t)ty.i1 * WI + tx.i1];
+        // evaluation order of torch's CPU kernel (`out = t0*w0; out += t1*w1` per dimension, rows outermost).  A given torch build
+        // may still differ in the last ulp, which flips round-half ties of integer depth maps: <= 1 mm on < 1 % of the
+        // pixels against the CPU golden (tests/test_data_path.py); this resized depth is not read by the hot path
+        const float top = __fmaf_rn(b, tx.l1, __fmul_rn(a, tx.l0));
+        const float bot = __fmaf_rn(d, tx.l1, __fmul_rn(c, tx.l0));
+        float v = __fmaf_rn(bot, ty.l1, __fmul_rn(top, ty.l0));
+        if (round_output) v = rintf(v);
+        out[(size_t)m * HO * WO + p] = v;
+    }
+}
+
+}  // namespace oryon
+
+using namespace oryon;
+
+extern "C" int oryon_rgb_resize_bilinear(const uint8_t *rgb_hwc, int n, int HI, int WI, int HO, int WO, float *out, void *stream)
+{
+    ORYON_CHECK_ARG(rgb_hwc && out && n >= 0 && HI > 0 && WI > 0 && HO > 0 && WO > 0);
+    if (n == 0) return ORYON_OK;
+    const int bx = ceil_div(HO * WO, 256) < 256 ? ceil_div(HO * WO, 256) : 256;
+    hipLaunchKernelGGL(rgb_resize_bilinear_kernel, dim3(bx, n), dim3(256), 0, as_stream(stream), rgb_hwc, HI, WI, HO, WO, out);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_resize_bilinear_f32(const float *in, int n, int HI, int WI, int HO, int WO, int round_output, float *out,
+                                         void *stream)
+{
+    ORYON_CHECK_ARG(in && out && n >= 0 && HI > 0 && WI > 0 && HO > 0 && WO > 0);
+    if (n == 0) return ORYON_OK;
+    const int bx = ceil_div(HO * WO, 256) < 256 ? ceil_div(HO * WO, 256) : 256;
+    hipLaunchKernelGGL(resize_bilinear_f32_kernel, dim3(bx, n), dim3(256), 0, as_stream(stream), in, HI, WI, HO, WO, round_output, out);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}

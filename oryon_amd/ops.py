@@ -30,6 +30,29 @@ def quick_gelu_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def rgb_resize_bilinear(rgb_hwc: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
+    """uint8 [n,HI,WI,3] -> fp32 [n,3,HO,WO] in [0,1] (K-1: /255., CHW, bilinear align_corners=False, fp64 arithmetic)."""
+    _lib.require_gpu(rgb_hwc.device)
+    assert rgb_hwc.dtype == torch.uint8 and rgb_hwc.dim() == 4 and rgb_hwc.shape[3] == 3
+    rgb_hwc = rgb_hwc.contiguous()
+    n, HI, WI = rgb_hwc.shape[:3]
+    out = torch.empty((n, 3, int(out_hw[0]), int(out_hw[1])), dtype=torch.float32, device=rgb_hwc.device)
+    check(lib().oryon_rgb_resize_bilinear(ptr(rgb_hwc), n, HI, WI, int(out_hw[0]), int(out_hw[1]), ptr(out), stream_ptr(rgb_hwc.device)),
+          "oryon_rgb_resize_bilinear")
+    return out
+
+
+def resize_bilinear(x: torch.Tensor, out_hw: Tuple[int, int], round_output: bool = False) -> torch.Tensor:
+    """fp32 [n,HI,WI] -> fp32 [n,HO,WO], torch bilinear (align_corners=False); round_output mimics torchvision on integer images."""
+    _lib.require_gpu(x.device)
+    x = x.to(torch.float32).contiguous()
+    n, HI, WI = x.shape
+    out = torch.empty((n, int(out_hw[0]), int(out_hw[1])), dtype=torch.float32, device=x.device)
+    check(lib().oryon_resize_bilinear_f32(ptr(x), n, HI, WI, int(out_hw[0]), int(out_hw[1]), int(round_output), ptr(out),
+                                          stream_ptr(x.device)), "oryon_resize_bilinear_f32")
+    return out
+
+
 def roi_compact(mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """mask [n_maps, H, W] (or [H,W]) int32 -> (roi [n_maps, HW] int32 linear indices, count [n_maps] int32)."""
     if mask.dim() == 2:

@@ -404,8 +404,62 @@ def gen_metrics():
     save("g7_metrics", pcd=pcd, pred=pred, gt=gt, add=add, adds=adds, theta=theta, shift=shift, mask1=m1, mask2=m2, iou=iou)
 
 
+def gen_data():
+    """G8: raw samples -> utils/data/common.preprocess_item -> utils/augmentations.resize -> datasets.CollateWrapper, all
+    REFERENCE code.  The modules import with permissive stubs for packages that are imported but never called on this path
+    (plyfile, open3d, vispy, ...).  torchvision is absent too, and its `functional.resize` IS called by augmentations.resize:
+    it is replaced by oracle.tv_resize, a restatement of torchvision 0.13's tensor resize on torch `interpolate` - so this
+    golden pins the reference's own arithmetic (mask selection, box, sizes, scaling of boxes / correspondences, collate
+    layout and dtypes) and torch's resampling, not torchvision's wrapper."""
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return type(k, (), {})
+    for name in ("plyfile", "open3d", "trimesh", "vispy", "matplotlib", "matplotlib.pyplot", "omegaconf.dictconfig", "torchvision",
+                 "torchvision.transforms", "torchvision.transforms.functional"):
+        sys.modules[name] = _Any(name)
+    sys.modules["omegaconf.dictconfig"].DictConfig = dict
+    from oracle.oryon_oracle import tv_resize
+
+    class _Mode:
+        BILINEAR, NEAREST = "bilinear", "nearest"
+    tvf = sys.modules["torchvision.transforms.functional"]
+    tvf.InterpolationMode = _Mode
+    tvf.resize = lambda img, size, interpolation: tv_resize(img, size, interpolation)
+    sys.modules["torchvision.transforms"].Compose = lambda l: l
+    sys.modules["torchvision.transforms"].functional = tvf
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    from utils.data import common  # noqa: E402  (reference)
+    import utils.augmentations as aug  # noqa: E402  (reference)
+    import datasets as ref_datasets  # noqa: E402  (reference)
+    from oryon_amd.data import make_raw_item
+    H, W, size, corr_n = 96, 128, (56, 56), 8
+    g = torch.Generator().manual_seed(11)
+    data, corrs_in = [], []
+    for i in range(2):
+        raw_a, raw_q = make_raw_item(2 * i, H, W), make_raw_item(2 * i + 1, H, W)
+        item_a, item_q = common.preprocess_item(raw_a), common.preprocess_item(raw_q)
+        corrs = torch.stack([torch.randint(0, H, (20,), generator=g), torch.randint(0, W, (20,), generator=g),
+                             torch.randint(0, H, (20,), generator=g), torch.randint(0, W, (20,), generator=g)], dim=1)
+        corrs_in.append(corrs.clone())
+        item_a, item_q, res_corrs = aug.resize(size)((item_a, item_q, corrs))
+        pose = np.eye(4) * (i + 1)
+        data.append((item_a, item_q, ["mug"] + ["a photo of a mug"] * 2, res_corrs[:corr_n], res_corrs, pose, "mug", f"pair{i}", True))
+    batch = ref_datasets.CollateWrapper(corr_n)(data)
+    out = {"size": np.asarray(size), "hw": np.asarray((H, W)), "corr_n": corr_n, "corrs_in": torch.stack(corrs_in)}
+    for side in ("anchor", "query"):
+        for k in ("rgb", "mask", "depth", "camera", "pose", "box", "sizes"):
+            out[f"{side}_{k}"] = batch[side][k]
+        out[f"{side}_orig_depth"] = torch.stack(batch[side]["orig_depth"])
+    out["corrs"], out["valid"], out["pose"] = batch["corrs"], batch["valid"], batch["pose"]
+    save("g8_data", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone", "metrics"]
+    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone", "metrics", "data"]
+    if "data" in which:
+        gen_data()
     if "matcher" in which:
         gen_matcher()
     if "lift" in which:
