@@ -236,6 +236,7 @@ def main():
                          "shapes), then match + pose - a separate stage set, never mixed into the headline")
     ap.add_argument("--backbone-dtype", choices=["fp32", "bf16", "bf16w"], default="fp32",
                     help="fp32 | bf16 (autocast over fp32 weights) | bf16w (weights converted to bf16 once)")
+    ap.add_argument("--overlap-gather", action="store_true", help="K0 gather of step k+1 on its own stream under the screening of step k")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not overlap the registration of step k with the matching of step k+1 (second HIP stream)")
     ap.add_argument("--match-mode", choices=["screened", "exact"], default="screened",
@@ -252,13 +253,14 @@ def main():
         return bench_full(a, rank, world, dev)
     inputs = make_inputs(B, H, C, first=rank * B, dev=dev)
     engine = MatchPoseEngine(build_solver(dev), MatchPoseConfig(dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1,
-                                                                match_mode=a.match_mode), overlap_registration=not a.no_overlap)
+                                                                match_mode=a.match_mode), overlap_registration=not a.no_overlap,
+                             overlap_gather=a.overlap_gather and not a.no_overlap)
     key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
     total = B * world
 
     def submit(keep=False):
         return engine.run(inputs["feat_a"], inputs["feat_q"], inputs["mask_a"], inputs["mask_q"], inputs["depth_a"],
-                          inputs["depth_q"], inputs["cam"], inputs["cam"], key, keep=keep)
+                          inputs["depth_q"], inputs["cam"], inputs["cam"], key, keep=keep, inputs_resident=True)
 
     def collect(out):
         engine.finish(out)

@@ -1,5 +1,6 @@
 // Internal structures shared by the PointDSC translation units.
 #pragma once
+#include <stdlib.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,6 +31,9 @@ struct PdscWorkspace {
     float *feat1;     // [B,n_cap,C]
     float *qkv;       // [B,n_cap,3C]
     float *msg;       // [B,n_cap,C]
+    float *att_o;     // [att_splits,B,n_cap,C]   key-split attention partials (att_splits > 1 only)
+    float *att_ml;    // [att_splits,B,n_cap,2]   running max, exp-sum
+    int att_splits;
     float *h1, *h2;   // [B,n_cap,max(C/2,32)]
     float *feat_n;    // [B,n_cap,C]
     float *conf;      // [B,n_cap]
@@ -44,6 +48,18 @@ struct PdscWorkspace {
     float *T0;        // [B,16]
     int S_cap, k;
 };
+
+// key splits of the attention launch: aim at >= 2 workgroups per CU (512), never more splits than 64-key tiles
+inline int pdsc_attention_splits(int B, int n_cap)
+{
+    static const int forced = getenv("ORYON_PDSC_ATT_SPLITS") ? atoi(getenv("ORYON_PDSC_ATT_SPLITS")) : 0;
+    const int blocks = B * (n_cap / 128);
+    int ks = forced ? forced : (512 + blocks - 1) / blocks;
+    const int tiles = n_cap / 64;
+    if (ks > 4) ks = 4;
+    if (ks > tiles) ks = tiles;
+    return ks < 1 ? 1 : ks;
+}
 
 inline int pdsc_seed_cap(const oryon_pointdsc_config_t &cfg, int n_cap)
 {

@@ -144,23 +144,31 @@ __global__ __launch_bounds__(256) void pdsc_linear_kernel(const float *__restric
 // ------------------------------------------------------------------------------------------------
 // Flash-style SC-modulated attention.  One workgroup = 128 queries (4 waves x 32), key tiles of 64.
 // QKV: [B, n_cap, 3C] (q | k | v), coords: src,tgt [B, n_cap, 3];  msg: [B, n_cap, C].
+// Key split (flash-decoding): with B pairs x n_cap/128 query blocks alone a launch has one 4-wave workgroup per CU and the
+// staging / softmax / MFMA phases of that single wave per SIMD run back to back.  blockIdx.y = split s of KS takes every
+// KS-th share of the key tiles and writes un-normalised partials (O_s, m_s, l_s); independent workgroups then interleave
+// their phases on a CU, and `pdsc_attention_merge_kernel` combines the partials (exact softmax algebra, fp32).
 constexpr int ATT_Q = 128, ATT_KT = 64;
 
 template <int C>
-__global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__restrict__ QKV, const float *__restrict__ src,
+__global__ __launch_bounds__(256, 2) void pdsc_attention_kernel(const float *__restrict__ QKV, const float *__restrict__ src,
                                                               const float *__restrict__ tgt,
                                                               const int32_t *__restrict__ n_rows, int n_cap,
-                                                              float inv_sigma2, float inv_sqrt_c, float *__restrict__ msg)
+                                                              float inv_sigma2, float inv_sqrt_c, float *__restrict__ msg,
+                                                              int KS, float *__restrict__ part_o, float *__restrict__ part_ml)
 {
     constexpr int LD = C + 1;
     constexpr int CB = C / 32;
     __shared__ float Ks[ATT_KT * LD];
     __shared__ float Vs[ATT_KT * LD];
     __shared__ float Cs[ATT_KT * 6];
-    const int b = blockIdx.y;
+    const int b = blockIdx.z, split = blockIdx.y;
     const int n = n_rows[b];
     const int q0 = blockIdx.x * ATT_Q;
     if (q0 >= n) return;
+    const int n_tiles = (n + ATT_KT - 1) / ATT_KT, per = (n_tiles + KS - 1) / KS;
+    const int j_begin = split * per * ATT_KT;
+    const int j_end = ((split + 1) * per * ATT_KT < n) ? (split + 1) * per * ATT_KT : n;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int qrow = q0 + wave * 32 + l31;  // this lane's query (< n_cap always)
     const float *base = QKV + (size_t)b * n_cap * 3 * C;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__rest
         for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
-    for (int j0 = 0; j0 < n; j0 += ATT_KT) {
+    for (int j0 = j_begin; j0 < j_end; j0 += ATT_KT) {
         __syncthreads();
         // stage K, V rows j0..j0+63 (16-byte loads, all in flight before the first LDS store) and the keys' coordinates
         {
@@ -220,12 +228,17 @@ __global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__rest
         // S^T = K Q^T : rows = keys (two blocks of 32), columns = this wave's 32 queries
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
-            const float *ka = Ks + (kb * 32 + l31) * LD + hi;
+        {
+            // the two key blocks alternate: back-to-back MFMAs never depend on each other
+            const float *ka0 = Ks + l31 * LD + hi, *ka1 = Ks + (32 + l31) * LD + hi;
 #pragma unroll
-            for (int ks = 0; ks < C / 2; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * ks], qreg[ks], s[kb], 0, 0, 0);
+            for (int ks = 0; ks < C / 2; ++ks) {
+                s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka0[2 * ks], qreg[ks], s[0], 0, 0, 0);
+                s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka1[2 * ks], qreg[ks], s[1], 0, 0, 0);
+            }
         }
         // logits = SC * (q.k) / sqrt(C);  running max
         float m_tile = -INFINITY;
@@ -276,7 +289,23 @@ __global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__rest
                 for (int cb = 0; cb < CB; ++cb) acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[cb * 32], p, acc_o[cb], 0, 0, 0);
             }
     }
-    const float inv_l = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    const float l_all = l_run + __shfl_xor(l_run, 32);
+    if (KS > 1) {
+        // partials: O un-normalised (empty key ranges leave O = 0, m = -inf, l = 0 and drop out of the merge)
+        const size_t prow = ((size_t)split * gridDim.z + b) * n_cap + qrow;
+        float *po = part_o + prow * C;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = acc_o[cb][4 * g + 0]; v.y = acc_o[cb][4 * g + 1]; v.z = acc_o[cb][4 * g + 2]; v.w = acc_o[cb][4 * g + 3];
+                *reinterpret_cast<float4 *>(po + cb * 32 + 8 * g + 4 * hi) = v;
+            }
+        if (hi == 0) { part_ml[prow * 2] = m_run; part_ml[prow * 2 + 1] = l_all; }
+        return;
+    }
+    const float inv_l = 1.0f / l_all;
     float *mo = msg + ((size_t)b * n_cap + qrow) * C;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -289,6 +318,35 @@ __global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__rest
             v.w = acc_o[cb][4 * g + 3] * inv_l;
             *reinterpret_cast<float4 *>(mo + cb * 32 + 8 * g + 4 * hi) = v;
         }
+}
+
+// Combine the key-split partials: msg = sum_s e^{m_s - m} O_s / sum_s e^{m_s - m} l_s,  m = max_s m_s.
+__global__ __launch_bounds__(256) void pdsc_attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
+                                                                    const int32_t *__restrict__ n_rows, int n_cap, int C, int KS,
+                                                                    int B, float *__restrict__ msg)
+{
+    const int b = blockIdx.y;
+    const int n_live = (n_rows[b] + ATT_Q - 1) / ATT_Q * ATT_Q;          // rows the attention kernel produced
+    const int c4n = C / 4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_live * c4n; e += gridDim.x * blockDim.x) {
+        const int row = e / c4n, c4 = e % c4n;
+        float m = -INFINITY;
+        for (int s = 0; s < KS; ++s) m = fmaxf(m, part_ml[(((size_t)s * B + b) * n_cap + row) * 2]);
+        float L = 0.0f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < KS; ++s) {
+            const size_t prow = ((size_t)s * B + b) * n_cap + row;
+            const float ms = part_ml[prow * 2];
+            if (ms == -INFINITY) continue;
+            const float w = __expf(ms - m);
+            L += w * part_ml[prow * 2 + 1];
+            const float4 v = *reinterpret_cast<const float4 *>(part_o + prow * C + 4 * c4);
+            o.x += w * v.x; o.y += w * v.y; o.z += w * v.z; o.w += w * v.w;
+        }
+        const float inv = 1.0f / L;
+        o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+        *reinterpret_cast<float4 *>(msg + ((size_t)b * n_cap + row) * C + 4 * c4) = o;
+    }
 }
 
 // F.normalize(feat, p=2, dim=-1) (PointDSC.py:156): one wave per row.
@@ -353,13 +411,17 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         // q | k | v projections as one GEMM with N = 3C
         rc = launch_linear(false, false, ws.feat1, C, fb, L.w_qkv, L.b_qkv, nullptr, 0, 0, ws.qkv, 3 * C, qb, C, 3 * C, B, n_cap, n_rows, st);
         if (rc) return rc;
-        dim3 ag(n_cap / ATT_Q, B);
+        const int KS = ws.att_splits;
+        dim3 ag(n_cap / ATT_Q, KS, B);
         if (C == 128)
-            hipLaunchKernelGGL((pdsc_attention_kernel<128>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg);
+            hipLaunchKernelGGL((pdsc_attention_kernel<128>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         else if (C == 64)
-            hipLaunchKernelGGL((pdsc_attention_kernel<64>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg);
+            hipLaunchKernelGGL((pdsc_attention_kernel<64>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         else
-            hipLaunchKernelGGL((pdsc_attention_kernel<32>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg);
+            hipLaunchKernelGGL((pdsc_attention_kernel<32>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
+        if (KS > 1)
+            hipLaunchKernelGGL(pdsc_attention_merge_kernel, dim3((n_cap * (C / 4) + 255) / 256, B), dim3(256), 0, st, ws.att_o, ws.att_ml,
+                               n_rows, n_cap, C, KS, B, ws.msg);
         if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
         // fc_message: C -> C/2 -> C/2 -> C, residual onto the PointCN output
         rc = launch_linear(true, false, ws.msg, C, fb, L.w_m1, L.b_m1, nullptr, 0, 0, ws.h1, H, hb, C, H, B, n_cap, n_rows, st);

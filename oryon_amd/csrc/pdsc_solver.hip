@@ -77,35 +77,66 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
     if (s >= n_seeds[b]) return;
     const int n = n_rows[b];
     const int k = k_cfg < n - 1 ? k_cfg : n - 1;
-    float *dist = sm;                       // [n_cap]
-    float *fs = dist + n_cap;               // [C] seed feature
+    int P = 256;                            // sort size: power of two >= n
+    while (P < n) P <<= 1;
+    float *dist = sm;                       // [P] sort keys
+    int *order = reinterpret_cast<int *>(dist + P);           // [P] row indices, sorted along with the keys
+    float *fs = reinterpret_cast<float *>(order + P);          // [C] seed feature
     float *kf = fs + C;                     // [KNN_MAX_K][C+1]
     float *kc = kf + KNN_MAX_K * (C + 1);   // [KNN_MAX_K][6]
     int *kidx = reinterpret_cast<int *>(kc + KNN_MAX_K * 6);  // [KNN_MAX_K]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x;
     const int seed_row = seeds[(size_t)b * S_cap + s];
     const float *F = feat_n + (size_t)b * n_cap * C;
     for (int c = t; c < C; c += 256) fs[c] = F[(size_t)seed_row * C + c];
     __syncthreads();
-    // 2 - 2 f_seed.f_j : one wave per row, lanes over channels
-    for (int j = wave; j < n; j += 4) {
-        float acc = 0.0f;
-        for (int c = lane; c < C; c += 64) acc = fmaf(fs[c], F[(size_t)j * C + c], acc);
+    // 2 - 2 f_seed.f_j : one thread per row (16-byte loads, all of a row's loads independent), k-ordered fmaf chain
+    for (int j = t; j < P; j += 256) {
+        float d = INFINITY;
+        if (j < n) {
+            const float4 *row = reinterpret_cast<const float4 *>(F + (size_t)j * C);
+            float acc = 0.0f;
+            for (int c4 = 0; c4 < C / 4; c4 += 8) {
+                float4 v[8];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (lane == 0) dist[j] = 2.0f - 2.0f * acc;
+                for (int u = 0; u < 8; ++u) v[u] = (c4 + u < C / 4) ? row[c4 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (c4 + u < C / 4) {
+                        const float *f4 = fs + 4 * (c4 + u);
+                        acc = fmaf(f4[0], v[u].x, acc);
+                        acc = fmaf(f4[1], v[u].y, acc);
+                        acc = fmaf(f4[2], v[u].z, acc);
+                        acc = fmaf(f4[3], v[u].w, acc);
+                    }
+                }
+            }
+            d = 2.0f - 2.0f * acc;
+        }
+        dist[j] = d;
+        order[j] = j;
     }
     __syncthreads();
-    // ascending rank (ties by index); rank 0 is dropped, ranks 1..k are the neighbours (common.py:68)
-    for (int j = t; j < n; j += 256) {
-        const float d = dist[j];
-        int rank = 0;
-        for (int m = 0; m < n; ++m) {
-            const float dm = dist[m];
-            rank += (dm < d || (dm == d && m < j)) ? 1 : 0;
+    // ascending bitonic sort of (distance, row index): ties resolve to the smaller index; rank 0 is dropped, ranks 1..k are the
+    // neighbours (common.py:68)
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = t; e < P / 2; e += 256) {
+                const int lo = 2 * e - (e & (stride - 1));          // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const float dl = dist[lo], dh = dist[hi];
+                const int il = order[lo], ih = order[hi];
+                const bool lo_gt = (dl > dh) || (dl == dh && il > ih);
+                if (lo_gt == up) {
+                    dist[lo] = dh; dist[hi] = dl;
+                    order[lo] = ih; order[hi] = il;
+                }
+            }
+            __syncthreads();
         }
-        if (rank >= 1 && rank <= k) kidx[rank - 1] = j;
     }
+    if (t < k) kidx[t] = order[t + 1];
     __syncthreads();
     for (int e = t; e < k * C; e += 256) {
         const int a = e / C, c = e % C;
@@ -119,24 +150,29 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
     if (t < k) knn_out[((size_t)b * S_cap + s) * k_cfg + t] = kidx[t];
     __syncthreads();
     float *Mo = M_out + ((size_t)b * S_cap + s) * k_cfg * k_cfg;
-    for (int e = t; e < k * k; e += 256) {
-        const int a = e / k, c2 = e % k;
-        float v = 0.0f;
-        if (a != c2) {
-            float dot = 0.0f;
-            const float *fa = kf + a * (C + 1), *fb = kf + c2 * (C + 1);
-            for (int c = 0; c < C; ++c) dot = fmaf(fa[c], fb[c], dot);
-            float fm = 1.0f - (1.0f - dot) * inv_sigma2;
-            fm = fm > 0.0f ? fm : 0.0f;
-            const float *pa = kc + a * 6, *pb = kc + c2 * 6;
-            const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
-            const float ex = pa[3] - pb[3], ey = pa[4] - pb[4], ez = pa[5] - pb[5];
-            const float df = __fsqrt_rn(dx * dx + dy * dy + dz * dz) - __fsqrt_rn(ex * ex + ey * ey + ez * ez);
-            float smv = 1.0f - df * df * inv_sigma_d2;
-            smv = smv > 0.0f ? smv : 0.0f;
-            v = fm * smv;
-        }
+    // the matrix is symmetric: one thread per unordered pair (a < c2), both entries written; the diagonal is zero
+    for (int e = t; e < k; e += 256) Mo[e * k_cfg + e] = 0.0f;
+    const int n_pairs = k * (k - 1) / 2;
+    for (int e = t; e < n_pairs; e += 256) {
+        // e -> (a, c2), a < c2, row-major over the strict upper triangle
+        int a = (int)((2.0f * k - 1.0f - __fsqrt_rn((2.0f * k - 1.0f) * (2.0f * k - 1.0f) - 8.0f * (float)e)) * 0.5f);
+        while (a > 0 && a * (2 * k - a - 1) / 2 > e) --a;
+        while ((a + 1) * (2 * k - a - 2) / 2 <= e) ++a;
+        const int c2 = a + 1 + (e - a * (2 * k - a - 1) / 2);
+        float dot = 0.0f;
+        const float *fa = kf + a * (C + 1), *fb = kf + c2 * (C + 1);
+        for (int c = 0; c < C; ++c) dot = fmaf(fa[c], fb[c], dot);
+        float fm = 1.0f - (1.0f - dot) * inv_sigma2;
+        fm = fm > 0.0f ? fm : 0.0f;
+        const float *pa = kc + a * 6, *pb = kc + c2 * 6;
+        const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+        const float ex = pa[3] - pb[3], ey = pa[4] - pb[4], ez = pa[5] - pb[5];
+        const float df = __fsqrt_rn(dx * dx + dy * dy + dz * dz) - __fsqrt_rn(ex * ex + ey * ey + ez * ez);
+        float smv = 1.0f - df * df * inv_sigma_d2;
+        smv = smv > 0.0f ? smv : 0.0f;
+        const float v = fm * smv;
         Mo[a * k_cfg + c2] = v;
+        Mo[c2 * k_cfg + a] = v;
     }
 }
 
@@ -359,7 +395,9 @@ int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float
                         float *fitness, int32_t *best, float *T_best, uint8_t *labels, hipStream_t st)
 {
     const int C = M.cfg.num_channels, k = M.cfg.k, S_cap = ws.S_cap;
-    const size_t sh1 = ((size_t)n_cap + C + (size_t)KNN_MAX_K * (C + 1) + KNN_MAX_K * 6 + KNN_MAX_K) * sizeof(float);
+    size_t P = 256;
+    while (P < (size_t)n_cap) P <<= 1;
+    const size_t sh1 = (2 * P + C + (size_t)KNN_MAX_K * (C + 1) + KNN_MAX_K * 6 + KNN_MAX_K) * sizeof(float);
     hipLaunchKernelGGL(pdsc_knn_matrix_kernel, dim3(S_cap, B), dim3(256), sh1, st, feat_n, src, tgt, n_rows, n_cap, C, seeds,
                        n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat);
     if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;

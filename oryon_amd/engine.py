@@ -38,15 +38,20 @@ class MatchPoseConfig:
 
 
 class MatchPoseEngine:
-    def __init__(self, solver: PointDSC, cfg: Optional[MatchPoseConfig] = None, overlap_registration: bool = False):
+    def __init__(self, solver: PointDSC, cfg: Optional[MatchPoseConfig] = None, overlap_registration: bool = False,
+                 overlap_gather: bool = False):
         """overlap_registration: run the registration stage (K3-K10: many small, latency-bound launches) on a second HIP
         stream so that it overlaps with the matching stage of the NEXT batch submitted by the caller; `run` then returns
-        immediately after queueing and `finish(out)` makes the caller's stream wait for the poses."""
+        immediately after queueing and `finish(out)` makes the caller's stream wait for the poses.
+        overlap_gather: additionally run K0 (ROI + gather/normalise: HBM-bound) on its own stream, so that the gather of
+        the next batch overlaps the MFMA-bound screening of the current one."""
         self.solver = solver
         self.cfg = cfg or MatchPoseConfig()
         self.n_cap = ops.round_up(self.cfg.n_corrs, 128)
         self.overlap = overlap_registration
+        self.overlap_gather = overlap_gather
         self._reg_stream = None
+        self._gather_stream = None
 
     def finish(self, out: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Order the caller's current stream after the registration of `out` (no-op without overlap)."""
@@ -60,14 +65,30 @@ class MatchPoseEngine:
 
     @torch.no_grad()
     def run(self, feat_a: Tensor, feat_q: Tensor, mask_a: Tensor, mask_q: Tensor, depth_a: Tensor, depth_q: Tensor,
-            cam_a: Tensor, cam_q: Tensor, pair_key: Optional[Tensor] = None, keep: bool = False) -> Dict[str, Tensor]:
+            cam_a: Tensor, cam_q: Tensor, pair_key: Optional[Tensor] = None, keep: bool = False,
+            inputs_event: Optional["torch.cuda.Event"] = None, inputs_resident: bool = False) -> Dict[str, Tensor]:
         """feat_* [B,C,FH,FW] fp32, mask_* [B,FH,FW] int (==1 selects), depth_* [B,H,W] fp32 mm, cam_* [B,3,3] or [B,9].
-        Returns pose [B,4,4] fp32 (identity on failure), status [B] int32, n_valid [B], n_lifted [B]."""
+        Returns pose [B,4,4] fp32 (identity on failure), status [B] int32, n_valid [B], n_lifted [B].
+        With overlap_gather the gather stream starts after `inputs_event` (the producer's event), or immediately when
+        `inputs_resident` says the inputs were complete before this call; by default it waits for everything queued on the
+        caller's stream so far (always correct, but then it cannot overlap the previous batch's matching)."""
         dev = _lib.require_gpu(feat_a.device)
         cfg = self.cfg
         B, C, FH, FW = feat_a.shape
         if pair_key is None:
             pair_key = torch.arange(B, dtype=torch.int64, device=dev)
+        main = torch.cuda.current_stream(dev)
+        screened = cfg.match_mode == "screened" and 64 < C <= 512
+        if self.overlap_gather:
+            if self._gather_stream is None:
+                self._gather_stream = torch.cuda.Stream(device=dev)
+            if inputs_event is None and not inputs_resident:
+                inputs_event = torch.cuda.Event()
+                inputs_event.record(main)
+            gctx = torch.cuda.stream(self._gather_stream)
+            gctx.__enter__()
+            if inputs_event is not None:
+                self._gather_stream.wait_event(inputs_event)
         masks = torch.cat((mask_a.reshape(B, FH, FW), mask_q.reshape(B, FH, FW)), dim=0)
         roi, cnt = ops.roi_compact(masks)
         roi_a, roi_q = roi[:B], roi[B:]
@@ -78,14 +99,25 @@ class MatchPoseEngine:
         else:
             cap_a = ops.round_up(FH * FW, ops.ROW_PAD)
         cap_q = ops.round_up(FH * FW, ops.ROW_PAD)
-        if cfg.match_mode == "screened" and 64 < C <= 512:
+        a16 = q16 = None
+        if screened:
             c_pad = 128 if C <= 128 else (256 if C <= 256 else 512)
             a_hat, a16 = ops.gather_normalise(feat_a, roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
             q_hat, q16 = ops.gather_normalise(feat_q, roi_q, n_q, cap_q, c_pad=c_pad, want_f16=True)
-            min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)
         else:
             a_hat = ops.gather_normalise(feat_a, roi_a, n_a, cap_a)
             q_hat = ops.gather_normalise(feat_q, roi_q, n_q, cap_q)
+        if self.overlap_gather:
+            gathered = torch.cuda.Event()
+            gathered.record(self._gather_stream)
+            gctx.__exit__(None, None, None)
+            main.wait_event(gathered)
+            for t_ in (roi, cnt, a_hat, q_hat, a16, q16):
+                if t_ is not None:
+                    t_.record_stream(main)
+        if screened:
+            min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)
+        else:
             min_dist, argmin, valid = ops.match(a_hat, q_hat, n_a, n_q, cfg.dist_th)
         corrs, n_valid, n_sel, status = ops.select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, FW, cfg.n_corrs, cfg.seed,
                                                          pair_key, corr_rows=self.n_cap)
