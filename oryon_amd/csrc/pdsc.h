@@ -31,6 +31,7 @@ struct PdscWorkspace {
     float *feat1;     // [B,n_cap,C]
     float *qkv;       // [B,n_cap,3C]
     float *msg;       // [B,n_cap,C]
+    float *sc;        // [B,n_cap/32,n_cap/64,8,64,4] spatial-consistency tiles in attention-register layout
     float *att_o;     // [att_splits,B,n_cap,C]   key-split attention partials (att_splits > 1 only)
     float *att_ml;    // [att_splits,B,n_cap,2]   running max, exp-sum
     int att_splits;
@@ -54,7 +55,7 @@ inline int pdsc_attention_splits(int B, int n_cap)
 {
     static const int forced = getenv("ORYON_PDSC_ATT_SPLITS") ? atoi(getenv("ORYON_PDSC_ATT_SPLITS")) : 0;
     const int blocks = B * (n_cap / 128);
-    int ks = forced ? forced : (512 + blocks - 1) / blocks;
+    int ks = forced ? forced : (256 + blocks - 1) / blocks;     // one workgroup per CU is enough once tile t+1 is prefetched
     const int tiles = n_cap / 64;
     if (ks > 4) ks = 4;
     if (ks > tiles) ks = tiles;

@@ -142,26 +142,67 @@ __global__ __launch_bounds__(256) void pdsc_linear_kernel(const float *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Flash-style SC-modulated attention.  One workgroup = 128 queries (4 waves x 32), key tiles of 64.
-// QKV: [B, n_cap, 3C] (q | k | v), coords: src,tgt [B, n_cap, 3];  msg: [B, n_cap, C].
-// Key split (flash-decoding): with B pairs x n_cap/128 query blocks alone a launch has one 4-wave workgroup per CU and the
-// staging / softmax / MFMA phases of that single wave per SIMD run back to back.  blockIdx.y = split s of KS takes every
-// KS-th share of the key tiles and writes un-normalised partials (O_s, m_s, l_s); independent workgroups then interleave
-// their phases on a CU, and `pdsc_attention_merge_kernel` combines the partials (exact softmax algebra, fp32).
+// Spatial-consistency matrix (PointDSC.py:150-153), computed ONCE per registration and reused by all layers (as the reference
+// does): SC_qk = clamp(1 - (|s_q - s_k| - |t_q - t_k|)^2 / sigma_d^2, 0).  Stored in the register layout of the attention
+// kernel so that a lane fetches its 32 values of a (32-query, 64-key) tile with 8 coalesced 16-byte loads:
+//   sc[b][q_block32][key_tile64][v4 = kb*4 + r/4][lane][r%4],  key = kb*32 + crow(r, lane/32), query = lane%32.
+// Keys >= n hold -1 (masked).
 constexpr int ATT_Q = 128, ATT_KT = 64;
+__global__ __launch_bounds__(256) void pdsc_sc_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                       const int32_t *__restrict__ n_rows, int n_cap, float inv_sigma2,
+                                                       float *__restrict__ sc)
+{
+    const int b = blockIdx.z, kt = blockIdx.y;
+    const int n = n_rows[b];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int qb = blockIdx.x * 4 + wave;
+    if (qb * 32 >= n || kt * ATT_KT >= n) return;
+    const float *sp = src + (size_t)b * n_cap * 3, *tp = tgt + (size_t)b * n_cap * 3;
+    const int q = qb * 32 + l31;
+    float sq[3], tq[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { sq[d] = sp[(size_t)q * 3 + d]; tq[d] = tp[(size_t)q * 3 + d]; }
+    float4 *out = reinterpret_cast<float4 *>(sc) + ((((size_t)b * (n_cap / 32) + qb) * (n_cap / ATT_KT) + kt) * 8) * 64 + lane;
+#pragma unroll
+    for (int v4 = 0; v4 < 8; ++v4) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = (v4 & 3) * 4 + e, kb = v4 >> 2;
+            const int k = kt * ATT_KT + kb * 32 + crow(r, hi);
+            float v = -1.0f;
+            if (k < n) {
+                const float dx = sq[0] - sp[(size_t)k * 3], dy = sq[1] - sp[(size_t)k * 3 + 1], dz = sq[2] - sp[(size_t)k * 3 + 2];
+                const float ex = tq[0] - tp[(size_t)k * 3], ey = tq[1] - tp[(size_t)k * 3 + 1], ez = tq[2] - tp[(size_t)k * 3 + 2];
+                const float ds = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+                const float dt = __fsqrt_rn(ex * ex + ey * ey + ez * ez);
+                const float df = ds - dt;
+                v = 1.0f - df * df * inv_sigma2;
+                v = v > 0.0f ? v : 0.0f;
+            }
+            o[e] = v;
+        }
+        out[(size_t)v4 * 64] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
 
+// Flash-style SC-modulated attention.  One workgroup = 128 queries (4 waves x 32), key tiles of 64.
+// QKV: [B, n_cap, 3C] (q | k | v), sc: pdsc_sc_kernel's tiles;  msg: [B, n_cap, C].
+// The K/V rows and the SC values of tile t+1 are fetched into registers while tile t is computed (the phases of a wave run
+// back to back - measured: MFMA 43 %, softmax VALU 25 %, staging 16 % of the un-prefetched kernel, nothing overlapping).
+// Key split (flash-decoding), used for small batches: blockIdx.y = split s of KS takes a share of the key tiles and writes
+// un-normalised partials (O_s, m_s, l_s) that `pdsc_attention_merge_kernel` combines (exact softmax algebra, fp32).
 template <int C>
-__global__ __launch_bounds__(256, 2) void pdsc_attention_kernel(const float *__restrict__ QKV, const float *__restrict__ src,
-                                                              const float *__restrict__ tgt,
+__global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__restrict__ QKV, const float *__restrict__ sc,
                                                               const int32_t *__restrict__ n_rows, int n_cap,
-                                                              float inv_sigma2, float inv_sqrt_c, float *__restrict__ msg,
+                                                              float inv_sqrt_c, float *__restrict__ msg,
                                                               int KS, float *__restrict__ part_o, float *__restrict__ part_ml)
 {
     constexpr int LD = C + 1;
     constexpr int CB = C / 32;
+    constexpr int F4_PER_ROW = C / 4, PER_THREAD = ATT_KT * F4_PER_ROW / 256;
     __shared__ float Ks[ATT_KT * LD];
     __shared__ float Vs[ATT_KT * LD];
-    __shared__ float Cs[ATT_KT * 6];
     const int b = blockIdx.z, split = blockIdx.y;
     const int n = n_rows[b];
     const int q0 = blockIdx.x * ATT_Q;
@@ -172,7 +213,32 @@ __global__ __launch_bounds__(256, 2) void pdsc_attention_kernel(const float *__r
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int qrow = q0 + wave * 32 + l31;  // this lane's query (< n_cap always)
     const float *base = QKV + (size_t)b * n_cap * 3 * C;
-    const float *sp = src + (size_t)b * n_cap * 3, *tp = tgt + (size_t)b * n_cap * 3;
+    const float4 *sc_q = reinterpret_cast<const float4 *>(sc) + (((size_t)b * (n_cap / 32) + (q0 / 32 + wave)) * (n_cap / ATT_KT)) * 8 * 64 + lane;
+    const bool q_live = q0 + wave * 32 < n;         // query blocks past n have no SC tiles (their rows are never consumed)
+
+    float4 kv[PER_THREAD], vv[PER_THREAD], scv[8];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int e = t + 256 * i, row = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
+            const bool in = j0 + row < n_cap;
+            const float *rp = base + (size_t)(in ? j0 + row : 0) * 3 * C;
+            kv[i] = in ? *reinterpret_cast<const float4 *>(rp + C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vv[i] = in ? *reinterpret_cast<const float4 *>(rp + 2 * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 *sp = sc_q + (size_t)(j0 / ATT_KT) * 8 * 64;
+#pragma unroll
+        for (int v4 = 0; v4 < 8; ++v4) scv[v4] = q_live ? sp[(size_t)v4 * 64] : make_float4(-1.f, -1.f, -1.f, -1.f);
+    };
+    auto land = [&]() {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int e = t + 256 * i, row = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
+            float *kd = Ks + row * LD + 4 * c4, *vd = Vs + row * LD + 4 * c4;
+            kd[0] = kv[i].x; kd[1] = kv[i].y; kd[2] = kv[i].z; kd[3] = kv[i].w;
+            vd[0] = vv[i].x; vd[1] = vv[i].y; vd[2] = vv[i].z; vd[3] = vv[i].w;
+        }
+    };
 
     // Q^T as B operand: lane (query l31, half hi) holds Q[query][2ks + hi]
     float qreg[C / 2];
@@ -184,10 +250,6 @@ __global__ __launch_bounds__(256, 2) void pdsc_attention_kernel(const float *__r
             qreg[ks] = hi ? v.y : v.x;
         }
     }
-    float sq[3], tq[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { sq[d] = sp[(size_t)qrow * 3 + d]; tq[d] = tp[(size_t)qrow * 3 + d]; }
-
     f32x16 acc_o[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -195,44 +257,24 @@ __global__ __launch_bounds__(256, 2) void pdsc_attention_kernel(const float *__r
         for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
+    if (j_begin < j_end) fetch(j_begin);
     for (int j0 = j_begin; j0 < j_end; j0 += ATT_KT) {
-        __syncthreads();
-        // stage K, V rows j0..j0+63 (16-byte loads, all in flight before the first LDS store) and the keys' coordinates
-        {
-            constexpr int F4_PER_ROW = C / 4, F4_TOTAL = ATT_KT * F4_PER_ROW, PER_THREAD = F4_TOTAL / 256;
-            float4 kv[PER_THREAD], vv[PER_THREAD];
+        __syncthreads();                       // everyone is done reading the previous tile
+        land();
+        float4 sct[8];
 #pragma unroll
-            for (int i = 0; i < PER_THREAD; ++i) {
-                const int e = t + 256 * i, row = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
-                const bool in = j0 + row < n_cap;
-                const float *rp = base + (size_t)(in ? j0 + row : 0) * 3 * C;
-                kv[i] = in ? *reinterpret_cast<const float4 *>(rp + C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                vv[i] = in ? *reinterpret_cast<const float4 *>(rp + 2 * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < PER_THREAD; ++i) {
-                const int e = t + 256 * i, row = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
-                float *kd = Ks + row * LD + 4 * c4, *vd = Vs + row * LD + 4 * c4;
-                kd[0] = kv[i].x; kd[1] = kv[i].y; kd[2] = kv[i].z; kd[3] = kv[i].w;
-                vd[0] = vv[i].x; vd[1] = vv[i].y; vd[2] = vv[i].z; vd[3] = vv[i].w;
-            }
-        }
-        for (int e = t; e < ATT_KT * 3; e += 256) {
-            const int row = e / 3, d = e % 3;
-            const bool in = j0 + row < n_cap;
-            Cs[row * 6 + d] = in ? sp[(size_t)(j0 + row) * 3 + d] : 0.0f;
-            Cs[row * 6 + 3 + d] = in ? tp[(size_t)(j0 + row) * 3 + d] : 0.0f;
-        }
+        for (int v4 = 0; v4 < 8; ++v4) sct[v4] = scv[v4];
         __syncthreads();
+        if (j0 + ATT_KT < j_end) fetch(j0 + ATT_KT);      // in flight during this tile's MFMAs and softmax
 
-        // S^T = K Q^T : rows = keys (two blocks of 32), columns = this wave's 32 queries
+        // S^T = K Q^T : rows = keys (two blocks of 32, alternating so that back-to-back MFMAs are independent),
+        // columns = this wave's 32 queries
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
         {
-            // the two key blocks alternate: back-to-back MFMAs never depend on each other
             const float *ka0 = Ks + l31 * LD + hi, *ka1 = Ks + (32 + l31) * LD + hi;
 #pragma unroll
             for (int ks = 0; ks < C / 2; ++ks) {
@@ -246,22 +288,15 @@ __global__ __launch_bounds__(256, 2) void pdsc_attention_kernel(const float *__r
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kk = kb * 32 + crow(r, hi);
-                const float *kc = Cs + kk * 6;
-                const float dx = sq[0] - kc[0], dy = sq[1] - kc[1], dz = sq[2] - kc[2];
-                const float ex = tq[0] - kc[3], ey = tq[1] - kc[4], ez = tq[2] - kc[5];
-                const float ds = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
-                const float dt = __fsqrt_rn(ex * ex + ey * ey + ez * ez);
-                const float df = ds - dt;
-                float sc = 1.0f - df * df * inv_sigma2;
-                sc = sc > 0.0f ? sc : 0.0f;
-                float v = sc * (s[kb][r] * inv_sqrt_c);
-                v = (j0 + kk < n) ? v : -INFINITY;
+                const float4 q4 = sct[kb * 4 + (r >> 2)];
+                const float scq = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+                float v = scq * (s[kb][r] * inv_sqrt_c);
+                v = (scq >= 0.0f) ? v : -INFINITY;
                 s[kb][r] = v;
                 m_tile = fmaxf(m_tile, v);
             }
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
-        const float m_new = fmaxf(m_run, m_tile);        // finite: key j0 < n is always live
+        const float m_new = fmaxf(m_run, m_tile);        // finite for live queries: key j0 < n is always live
         const float alpha = __expf(m_run - m_new);       // exp(-inf) = 0 on the first tile
         float l_tile = 0.0f;
 #pragma unroll
@@ -403,6 +438,8 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
     if (rc) return rc;
     const float inv_sigma2 = 1.0f / (M.sigma_d * M.sigma_d);
     const float inv_sqrt_c = 1.0f / sqrtf((float)C);
+    // spatial-consistency tiles, shared by all layers
+    hipLaunchKernelGGL(pdsc_sc_kernel, dim3(n_cap / 128, n_cap / ATT_KT, B), dim3(256), 0, st, src, tgt, n_rows, n_cap, inv_sigma2, ws.sc);
     for (int l = 0; l < M.cfg.num_layers; ++l) {
         const PdscLayer &L = M.layers[l];
         // PointCN: conv + BN + ReLU (BN folded)
@@ -414,11 +451,11 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         const int KS = ws.att_splits;
         dim3 ag(n_cap / ATT_Q, KS, B);
         if (C == 128)
-            hipLaunchKernelGGL((pdsc_attention_kernel<128>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
+            hipLaunchKernelGGL((pdsc_attention_kernel<128>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         else if (C == 64)
-            hipLaunchKernelGGL((pdsc_attention_kernel<64>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
+            hipLaunchKernelGGL((pdsc_attention_kernel<64>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         else
-            hipLaunchKernelGGL((pdsc_attention_kernel<32>), ag, dim3(256), 0, st, ws.qkv, src, tgt, n_rows, n_cap, inv_sigma2, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
+            hipLaunchKernelGGL((pdsc_attention_kernel<32>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         if (KS > 1)
             hipLaunchKernelGGL(pdsc_attention_merge_kernel, dim3((n_cap * (C / 4) + 255) / 256, B), dim3(256), 0, st, ws.att_o, ws.att_ml,
                                n_rows, n_cap, C, KS, B, ws.msg);
