@@ -346,8 +346,10 @@ __global__ __launch_bounds__(256) void match_compact_kernel(const __half *__rest
     if (lane == 0) amb_max[(size_t)p * cap_a + sl] = m_final[(size_t)p * cap_a + a];
 }
 
-// pass 2: 16 lanes per anchor row (4 rows per wave), candidates strided over the 16 lanes; canonical fp32 chain on the
-// k-permuted fp32 rows.
+// pass 2: L lanes per anchor row, candidates strided over them; canonical fp32 chain on the k-permuted fp32 rows.  Almost
+// every anchor has ONE candidate and the chain is a serial 256-step fmaf per (anchor, candidate): few lanes per anchor keep
+// more lanes of a wave busy.
+template <int L>
 __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restrict__ a_hat, const float *__restrict__ q_hat,
                                                              int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
                                                              const int32_t *__restrict__ n_q, int S, float thr, float valid_cut,
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
                                                              uint8_t *__restrict__ row_flag, int32_t *__restrict__ panel_flag)
 {
     const int p = blockIdx.y;
-    const int a = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int a = blockIdx.x * (256 / L) + (threadIdx.x / L), sub = threadIdx.x % L;
     const bool live = a < n_a[p];
     const size_t arow = (size_t)p * cap_a + (live ? a : 0);
     float m16 = -INFINITY;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
     if (!overflow) {
         const float *ar = a_hat + arow * Cp;
         const int nq_p = n_q[p];
-        for (int ci = sub; ci < c; ci += 16) {
+        for (int ci = sub; ci < c; ci += L) {
             const int jj = cand[arow * SCREEN_CAP + ci];
             if (jj >= nq_p) continue;                     // zero-padded query rows can never be the answer
             const float *qr = q_hat + ((size_t)p * cap_q + jj) * Cp;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
         }
     }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
+    for (int off = L / 2; off > 0; off >>= 1) {
         const float od = __shfl_xor(d, off);
         const int oj = __shfl_xor(j, off);
         lex_min(d, j, od, oj);
@@ -560,8 +562,13 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
 #undef LAUNCH16
 #undef LAUNCH16_AMB
     ORYON_CHECK_LAUNCH();
-    hipLaunchKernelGGL(match_rescore_kernel, dim3(cap_a / 16, B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a, n_q, S,
-                       threshold, valid_cut, w.ws_max, m_final, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
+    static const int rl = getenv("ORYON_RESCORE_LANES") ? atoi(getenv("ORYON_RESCORE_LANES")) : 4;
+#define LAUNCH_RESCORE(LV)                                                                                                 \
+    hipLaunchKernelGGL((match_rescore_kernel<LV>), dim3(cap_a / (256 / LV), B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a,  \
+                       n_q, S, threshold, valid_cut, w.ws_max, m_final, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag,          \
+                       w.panel_flag)
+    if (rl == 16) LAUNCH_RESCORE(16); else if (rl == 8) LAUNCH_RESCORE(8); else if (rl == 2) LAUNCH_RESCORE(2); else if (rl == 1) LAUNCH_RESCORE(1); else LAUNCH_RESCORE(4);
+#undef LAUNCH_RESCORE
     ORYON_CHECK_LAUNCH();
     // exact recomputation of the (rare) panels whose candidate lists overflowed; exits immediately elsewhere
     return match_f32_flagged(a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag,

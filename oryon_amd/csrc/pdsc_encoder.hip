@@ -12,6 +12,7 @@
 //     softmax is online.  It works on TRANSPOSED tiles, S^T = K Q^T and O^T = V^T P^T: in the 32x32 MFMA
 //     C/D layout a lane then owns ONE query column, so max / sum / rescale are lane-local, and the P
 //     registers feed the second MFMA directly as its B operand (no LDS round trip, no shuffles).
+#include <stdlib.h>
 #include "common.h"
 #include "pdsc.h"
 
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void pdsc_center_kernel(const float *__restric
 // Y[b, rows, :N] = act(X[b, rows, :K] W^T + bias) (+ R[b, rows, :N]);   W is [N, K] row-major.
 // Tile: 64 rows x 128 columns per workgroup, k-tiles of 32 staged in LDS (LD = 33: conflict-free
 // ds_read_b32 of a 32-row column); 4 waves as 2 (row halves) x 2 (column halves of 64 = two 32x32 blocks).
+// Measured and NOT kept: prefetching k-tile t+1 under tile t's MFMAs (+-0), 16-byte staging loads (-20 %: LDS store conflicts).
 constexpr int LIN_ROWS = 64, LIN_COLS = 128, LIN_BK = 32, LIN_LD = LIN_BK + 1;
 
 template <bool RELU, bool RESID>
@@ -198,11 +200,11 @@ __global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__rest
                                                               float inv_sqrt_c, float *__restrict__ msg,
                                                               int KS, float *__restrict__ part_o, float *__restrict__ part_ml)
 {
-    constexpr int LD = C + 1;
+    constexpr int LD = C + 4;                 // 16-byte aligned rows: staging lands with ds_write_b128
     constexpr int CB = C / 32;
     constexpr int F4_PER_ROW = C / 4, PER_THREAD = ATT_KT * F4_PER_ROW / 256;
-    __shared__ float Ks[ATT_KT * LD];
-    __shared__ float Vs[ATT_KT * LD];
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * LD];
     const int b = blockIdx.z, split = blockIdx.y;
     const int n = n_rows[b];
     const int q0 = blockIdx.x * ATT_Q;
@@ -234,9 +236,8 @@ __global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__rest
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int e = t + 256 * i, row = e / F4_PER_ROW, c4 = e % F4_PER_ROW;
-            float *kd = Ks + row * LD + 4 * c4, *vd = Vs + row * LD + 4 * c4;
-            kd[0] = kv[i].x; kd[1] = kv[i].y; kd[2] = kv[i].z; kd[3] = kv[i].w;
-            vd[0] = vv[i].x; vd[1] = vv[i].y; vd[2] = vv[i].z; vd[3] = vv[i].w;
+            *reinterpret_cast<float4 *>(Ks + row * LD + 4 * c4) = kv[i];
+            *reinterpret_cast<float4 *>(Vs + row * LD + 4 * c4) = vv[i];
         }
     };
 
