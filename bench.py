@@ -326,6 +326,14 @@ def main():
             kernel, peak = "match_f32_kernel (LDS-staged, wide descriptors)", PEAK_FP32_MFMA_TFLOPS
         launch_ms = match_ms
         achieved = flops / (launch_ms * 1e-3) / 1e12
+        # HBM bytes per launch cannot be counted from inside the process: taken from the committed rocprofv3 PMC passes of this
+        # exact workload (profiles/r01_pmc_counters.md), null for any other workload
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        if screened and (B, H, C) == (64, 224, 256) and os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_pmc_counters.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)"
         rec = {
             "metric": METRIC, "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -342,7 +350,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": flops, "avg_launch_ms": launch_ms,
                 "share_of_step": match_ms / (elapsed / a.steps * 1e3),
             },

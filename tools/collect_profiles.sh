@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence that profiles/ holds, on the GPU box:  bash tools/collect_profiles.sh <out_dir>
+#   1. kernel-trace of `python bench.py` (default workload)                     -> <out>/kernel_stats.md + the printed JSON line
+#   2. separate --pmc passes (no trace domains besides --kernel-trace), restricted to the heavy kernels -> <out>/pmc_counters.md
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=${1:-$R/gpurun_out/profiles}
+mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
+cd /tmp
+python $R/bench.py --no-cpu-baseline > "$OUT/bench_line.json" 2> /tmp/bench.err
+D=/tmp/prof_trace; rm -rf $D
+rocprofv3 --kernel-trace --stats -d $D -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/trace.log 2>&1
+python $R/tools/rocpd_summary.py $D/bench_results.db > "$OUT/kernel_stats.md"
+RX='screen_kernel|gather_normalise|pdsc_attention_kernel|match_decide|pdsc_linear'
+{
+  echo "# rocprofv3 PMC passes: bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap (2 engine passes, B=64), kernels /$RX/"
+  for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
+             "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+    P=/tmp/prof_pmc; rm -rf $P
+    rocprofv3 --pmc $SET --kernel-trace --kernel-include-regex "$RX" -d $P -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap > /tmp/pmc.log 2>&1
+    echo; echo "## pass: $SET"; echo
+    python $R/tools/rocpd_summary.py $P/p_results.db | sed -n '/## PMC counters/,$p' | tail -n +3
+  done
+} > "$OUT/pmc_counters.md"
+ls -la "$OUT"
