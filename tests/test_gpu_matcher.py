@@ -248,3 +248,35 @@ def test_screened_matcher_full_size_pair(H, C):
     p = make_pair(1, H, H, C, device="cuda")
     va, na = _screen_vs_exact(p["feat_a"][None], p["feat_q"][None], p["mask_a"][None], p["mask_q"][None], C, subsample=5000)
     assert int(na) == 5000 and float(va[0, :5000].float().mean()) > 0.6
+
+
+def test_screened_matcher_degenerate_rois():
+    """Screened path with empty / tiny ROIs inside a batch: empty anchor mask, empty query mask, 3-pixel query ROI, 1-pixel anchor ROI."""
+    from oryon_amd import ops
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    C, H = 256, 32
+    pairs = [make_pair(i, H, H, C, device=dev) for i in range(4)]
+    st = lambda k: torch.stack([p[k] for p in pairs])
+    fa, fq, ma, mq = st("feat_a"), st("feat_q"), st("mask_a").clone(), st("mask_q").clone()
+    ma[0] = 0                                   # pair 0: no anchor pixels
+    mq[1] = 0                                   # pair 1: no query pixels
+    mq[2] = 0
+    mq[2].view(-1)[[5, 77, 300]] = 1            # pair 2: three query pixels
+    ma[3] = 0
+    ma[3, H // 2, H // 2] = 1                   # pair 3: one anchor pixel
+    roi_a, na = ops.roi_compact(ma)
+    roi_q, nq = ops.roi_compact(mq)
+    assert na.tolist()[0] == 0 and nq.tolist()[1] == 0 and nq.tolist()[2] == 3 and na.tolist()[3] == 1
+    cap_a, cap_q = ops.round_up(int(na.max()), 256), ops.round_up(int(nq.max()), 256)
+    a_hat, a16 = ops.gather_normalise(fa, roi_a, na, cap_a, c_pad=256, want_f16=True)
+    q_hat, q16 = ops.gather_normalise(fq, roi_q, nq, cap_q, c_pad=256, want_f16=True)
+    md0, am0, va0 = ops.match(a_hat, q_hat, na, nq, 0.25)
+    md1, am1, va1 = ops.match_screened(a_hat, q_hat, a16, q16, na, nq, 0.25)
+    torch.cuda.synchronize()
+    for b in range(4):
+        n = int(na[b])
+        assert torch.equal(va0[b, :n], va1[b, :n])
+        v = va0[b, :n].bool()
+        assert torch.equal(am0[b, :n][v], am1[b, :n][v]) and torch.equal(md0[b, :n][v], md1[b, :n][v])
+    assert int(va1[1, : int(na[1])].sum()) == 0                 # nothing to match against
