@@ -31,6 +31,7 @@ from oryon_amd.synth import make_pair  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # same table, "Peak BF16/FP16 MFMA" dense
+PEAK_I8_MFMA_TOPS = 5000.0         # dense INT8 = 2x the 16-bit rate (same table: FP8 ~5 PF dense; i8 32x32x32 measured 4.4 POP/s)
 METRIC = "image-pairs/sec end-to-end (feat+match+reg) @224², C=256; ADD(-S) parity"
 
 
@@ -239,7 +240,7 @@ def main():
     ap.add_argument("--overlap-gather", action="store_true", help="K0 gather of step k+1 on its own stream under the screening of step k")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not overlap the registration of step k with the matching of step k+1 (second HIP stream)")
-    ap.add_argument("--match-mode", choices=["screened", "exact"], default="screened",
+    ap.add_argument("--match-mode", choices=["screened", "screened16", "exact"], default="screened",
                     help="screened: fp16-MFMA screening + exact fp32 re-scoring (K1s, identical results); exact: full fp32 scan (K1)")
     a = ap.parse_args()
 
@@ -292,8 +293,9 @@ def main():
     if a.warmup:
         run_steps(a.warmup)
     barrier()
-    screened = a.match_mode == "screened" and 64 < C <= 512
-    with MatchTimer("match_screened" if screened else "match") as mt:
+    screened = a.match_mode in ("screened", "screened16") and 64 < C <= 512
+    use_i8 = screened and a.match_mode == "screened" and C > 128
+    with MatchTimer("match_screened8" if use_i8 else "match_screened" if screened else "match") as mt:
         t0 = time.perf_counter()
         out, pose, status = run_steps(a.steps)
         barrier()
@@ -318,7 +320,9 @@ def main():
 
     if rank == 0:
         cp = 32 if C <= 32 else 64 if C <= 64 else 128 if C <= 128 else 256 if C <= 256 else (C + 31) // 32 * 32
-        if screened:
+        if use_i8:
+            kernel, peak = f"match_i8_screen_kernel<{cp}> (int8-MFMA pre-screen of K1s8)", PEAK_I8_MFMA_TOPS
+        elif screened:
             kernel, peak = f"match_f16_screen_kernel<{max(cp, 128)},2> (fp16-MFMA screening pass of K1s)", PEAK_F16_MFMA_TFLOPS
         elif cp <= 256:
             kernel, peak = f"match_f32_regb_kernel<{cp}>", PEAK_FP32_MFMA_TFLOPS
@@ -330,7 +334,7 @@ def main():
         # exact workload (profiles/r01_pmc_counters.md), null for any other workload
         traffic, traffic_src = None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if screened and (B, H, C) == (64, 224, 256) and os.path.exists(tpath):
+        if screened and not use_i8 and (B, H, C) == (64, 224, 256) and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_pmc_counters.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)"
@@ -342,7 +346,7 @@ def main():
                 "workload": f"{'cfg2' if (H, C) == (224, 256) else 'cfg4 geometry' if (H, C) == (384, 512) else 'custom'}: Batch={B} synthetic {H}x{H} pairs per GPU, C={C} fp32 descriptors given (HIP matcher + lift + "
                             f"PointDSC 12x128), N1<=5000, n_corrs=500",
                 "stages": "match+lift+registration (descriptor maps resident in HBM; backbone not in the timed region)",
-                "match_mode": a.match_mode + (" (fp16-MFMA screening, exact fp32 re-scoring: outputs identical to the fp32 scan)" if screened else ""),
+                "match_mode": a.match_mode + (" (int8-MFMA pre-screen, fp16-MFMA screening of the undecided anchors, exact fp32 re-scoring: outputs identical to the fp32 scan)" if use_i8 else " (fp16-MFMA screening, exact fp32 re-scoring: outputs identical to the fp32 scan)" if screened else ""),
                 "pairs_per_gpu": B, "global_pairs": total, "parallelism": f"pairs sharded over {world} GPU(s), all_gather of poses",
                 "pipelining": "none" if a.no_overlap else "registration of step k on a second HIP stream under the matching of step k+1",
                 "pairs_ok": int(ok.sum()), "max_rot_err_vs_gt": float(rot_err.max()) if rot_err.numel() else None,
@@ -350,7 +354,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "unit": "TOP/s (int8 MAC x2)" if use_i8 else "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": flops, "avg_launch_ms": launch_ms,
                 "share_of_step": match_ms / (elapsed / a.steps * 1e3),
             },

@@ -124,6 +124,22 @@ int oryon_match_screened(const float *a_hat, const float *q_hat, const void *a_f
                          int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
                          int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream);
 
+/* K1s8 the same contract again with an INT8 pre-screen (v_mfma_i32_32x32x32_i8: twice the fp16 matrix rate) in front of K1s:
+ *     oryon_gather_normalise_q8 additionally writes int8 rows q = rint(x^ * 2^E) with one exponent per 16-row slice of the
+ *     screening kernel's accumulator layout (slice_scale = 2^-E, eps_max = largest 2^-(E+1) of the map).  Anchors whose int8
+ *     maximum is decided within the proven int8 bound go straight to fp16 slice re-scoring + exact fp32 re-scoring; every other
+ *     anchor runs through the complete K1s pipeline on a compacted set.  Outputs are therefore identical to oryon_match_screened
+ *     (and to oryon_match_f32 on valid rows) for every input; only the run time depends on the data.  C_pad 256 or 512.
+ *     C_true = number of real channels (<= C_pad), used in the bound. */
+int oryon_gather_normalise_q8(const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride, const int32_t *count,
+                              int rows_cap, int C_pad, float *out, void *out_f16, int8_t *out_i8, float *slice_scale, float *eps_max,
+                              void *stream);
+size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a);
+int oryon_match_screened8(const float *a_hat, const float *q_hat, const void *a_f16, const void *q_f16, const int8_t *a_i8,
+                          const int8_t *q_i8, const float *a_scale, const float *q_scale, const float *q_eps_max, int B, int C_true,
+                          int C, int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
+                          int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream);
+
 /* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).
  *     Replaces utils/pcd.py:205-214: keep rows with valid, need more than one, sample exactly max_corrs
  *     (with replacement iff fewer are available).

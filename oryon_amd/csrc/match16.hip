@@ -275,8 +275,12 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
                                                             const float *__restrict__ ws_m1, const int32_t *__restrict__ ws_i1,
                                                             const float *__restrict__ ws_m2, float *__restrict__ m_final,
                                                             int32_t *__restrict__ cnt, int32_t *__restrict__ cand,
-                                                            int32_t *__restrict__ n_amb, int32_t *__restrict__ amb_idx)
+                                                            int32_t *__restrict__ n_amb, int32_t *__restrict__ amb_idx,
+                                                            const float *__restrict__ a_scale8, const float *__restrict__ eps_a8,
+                                                            const float *__restrict__ eps_q8, float cut0, float sqrt_c, float c_true)
 {
+    // a_scale8 != nullptr: the (m1, slice, m2) triples come from the INT8 screening pass (K1s8) in units of 2^-E_a per anchor
+    // slice; margin and validity cut then follow the per-anchor int8 bound DELTA8 (see the header of the int8 kernel).
     constexpr int NQB = ROWS_TILE / 32;
     const int p = blockIdx.y, a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (a >= n_a[p]) return;
@@ -289,9 +293,22 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
         m2 = fmaxf(fminf(m1, x1), fmaxf(m2, x2));
         if (x1 > m1) { m1 = x1; sid = ws_i1[o]; }
     }
+    float margin = SCREEN_MARGIN;
+    if (a_scale8) {
+        const float sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];   // 2^-E of the anchor's slice
+        m1 *= sa;                                             // exact: power of two
+        m2 *= sa;
+        const float ea = 0.5f * sa, eq = eps_q8[p];
+        (void)eps_a8;
+        // |s8 - a^.q^| <= ea*|q^|_1 + eq*|a^|_1 + C*ea*eq <= (ea + eq)*sqrt(C) + C*ea*eq   (+ fp32 accumulation slack of the exact scan)
+        const float delta = (ea + eq) * sqrt_c + c_true * ea * eq + 4e-5f;
+        margin = 2.0f * delta + 2e-7f;
+        valid_cut = cut0 - delta - 1e-6f;
+        if (!(delta < 0.2f)) { margin = INFINITY; valid_cut = -INFINITY; }     // degenerate scales: leave it to the fp16 pass
+    }
     if (lane == 0) m_final[arow] = m1;
     if (!(m1 >= valid_cut)) return;
-    if (!(m1 - m2 > SCREEN_MARGIN)) {
+    if (!(m1 - m2 > margin)) {
         if (lane == 0) {
             const int sl = atomicAdd(&n_amb[p], 1);
             amb_idx[(size_t)p * cap_a + sl] = a;
@@ -325,6 +342,16 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
     }
     sdot += __shfl_xor(sdot, 1);
     sdot += __shfl_xor(sdot, 2);
+    if (a_scale8) {
+        // every exact minimiser lies in this slice (int8 bound): from here on the fp16 argument applies within the slice, with
+        // the slice's fp16 maximum in the role of m1
+        float mx = (q < nq) ? sdot : -INFINITY;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        m1 = mx;
+        if (lane == 0) m_final[arow] = m1;
+        if (!(m1 >= cut0 - SCREEN_DELTA - 1e-6f)) { if (lane == 0) cnt[arow] = 0; return; }
+    }
     const bool hit = (seg == 0) && (q < nq) && (sdot >= m1 - SCREEN_MARGIN - 4e-5f);
     const unsigned long long b = __ballot(hit);
     if (hit) cand[arow * SCREEN_CAP + __popcll(b & ((1ull << lane) - 1ull))] = q;
@@ -413,6 +440,210 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
         argmin[arow] = j;
         valid[arow] = (d < thr) ? 1 : 0;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ K1s8: int8 pre-screen
+// The same single-pass (m1, slice, m2) screening as MODE 2 above on v_mfma_i32_32x32x32_i8 - twice the fp16 matrix rate on
+// gfx950 (3.4 POP/s sustained vs 1.7 PFLOP/s, tools/probe_mfma_rates.hip), half the operand bytes, 128 query rows per 32 KB
+// tile.  K0 writes q = rint(x^ * 2^E) with one exponent per 16-row slice, so inside a slice the integer maximum IS the score
+// maximum and the epilogue costs what the fp16 one costs: integer max tree, one convert, one multiply by the slice's 2^-E.
+// Accumulation is exact (|sum| <= 512 * 127^2 < 2^24).
+//
+// Bound: with ea = 2^-(E_a+1), eq = max over the pair's query slices of 2^-(E_q+1):
+//   |s8_ij - a^_i.q^_j| <= ea*|q^_j|_1 + eq*|a^_i|_1 + C*ea*eq <= (ea + eq)*sqrt(C) + C*ea*eq =: DELTA8_i   (unit rows: |x|_1 <= sqrt(C)).
+// match_decide_kernel then decides per anchor exactly as for fp16, with DELTA8_i in place of DELTA:
+//   m1 < (1-2thr) - DELTA8      -> cannot be valid
+//   m1 - m2 > 2*DELTA8          -> every exact minimiser lies in m1's slice: its 16 rows are re-scored in fp16, candidates -> exact
+//                                  fp32 re-scoring (unchanged)
+//   otherwise                   -> the anchor is handed to the fp16 screening (compacted set, complete K1s pipeline), so the int8
+//                                  stage can only ever lose time, never exactness.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr int screen8_tile_bytes(int CP) { return CP * 128; }     // 128 query rows per tile
+
+template <int CP>
+__global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_kernel(
+    const int8_t *__restrict__ a8, const int8_t *__restrict__ q8, const float *__restrict__ q_scale, int B, int cap_a, int cap_q,
+    const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max,
+    int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
+{
+    constexpr int RB = CP;                       // row bytes
+    constexpr int TILE_BYTES = screen8_tile_bytes(CP);
+    constexpr int ROWS = 128, NQB = 4, NAB = 2;
+    constexpr int NKS = CP / 32;                 // MFMA k-steps
+    constexpr int NI = TILE_BYTES / 4096;
+    constexpr int LPR = RB / 256;
+    static_assert(LPR >= 1, "rows are whole 256-byte lines");
+    char *smem;
+    if constexpr (2 * TILE_BYTES > 65536) {
+        extern __shared__ __attribute__((aligned(256))) char smem_dyn8[];
+        smem = smem_dyn8;
+    } else {
+        __shared__ __attribute__((aligned(256))) char smem_st8[2 * TILE_BYTES];
+        smem = smem_st8;
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = (slot / T) * 8 + xcd;
+    if (unit >= B * S) return;
+    const int panel = slot % T;
+    const int p = unit / S, split = unit % S;
+    const int na = n_a[p], nq = n_q[p];
+    const int a0 = panel * MT16;
+    if (a0 >= na) return;
+    const int nqt = (nq + ROWS - 1) / ROWS;
+    const int qt_per = (nqt + S - 1) / S;
+    const int qt_begin = split * qt_per;
+    const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const char *qp = reinterpret_cast<const char *>(q8) + (size_t)p * cap_q * RB;
+    const float2 *qs = reinterpret_cast<const float2 *>(q_scale + (size_t)p * (cap_q / 16));    // (h = 0, h = 1) per 32-row block
+
+    // stationary B operand: anchors a0 + wave*64 + ab*32 + l31, k-step s -> bytes 32s + 16hi .. +15
+    i32x4 breg[NAB][NKS];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const char *arow = reinterpret_cast<const char *>(a8) + ((size_t)p * cap_a + a0 + wave * 64 + ab * 32 + l31) * RB + 16 * hi;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) breg[ab][s] = *reinterpret_cast<const i32x4 *>(arow + 32 * s);
+    }
+    unsigned dma_off[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        const int row = line / LPR;
+        const int cc = sl ^ (row & 15);
+        dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue = [&](int qt, int buf) {
+        const char *qb = qp + (size_t)qt * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+    const unsigned rd_base = (unsigned)(l31 * RB);
+    const unsigned rd_key = (unsigned)(hi ^ (l31 & 15));
+    auto rd = [&](int s, int qb, unsigned tile) -> i32x4 {
+        unsigned key = rd_key;
+        asm volatile("" : "+v"(key));
+        const unsigned off = rd_base + ((key ^ (2u * (s & 7))) << 4) + (unsigned)(qb * 32 * RB + (s >> 3) * 256) + tile;
+        return *reinterpret_cast<const i32x4 *>(smem + off);
+    };
+
+    i32x16 acc[NQB][NAB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qb][ab][r] = 0;
+    float runmax[NAB], run2[NAB];
+    int runidx[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; run2[ab] = -INFINITY; runidx[ab] = 0; }
+
+    if (qt_end > qt_begin) issue(qt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        if (qt + 1 < qt_end) issue(qt + 1, buf ^ 1);
+        float2 sc2[NQB];
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) sc2[qb] = qs[qt * NQB + qb];
+        const unsigned tile = buf * TILE_BYTES;
+        i32x4 ring[2][NQB];
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) ring[0][qb] = rd(0, qb, tile);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            if (s + 1 < NKS) {
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) ring[(s + 1) & 1][qb] = rd(s + 1, qb, tile);
+            }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab)
+                    acc[qb][ab] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[s & 1][qb], breg[ab][s], acc[qb][ab], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: slice maxima.  Zero-padded rows score exactly 0 and cannot reach any cut (> 0).
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                int xi = acc[qb][ab][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) xi = max(xi, acc[qb][ab][r]);
+                const float x = (float)xi * (hi ? sc2[qb].y : sc2[qb].x);
+                const bool improved = x > runmax[ab];
+                run2[ab] = fmaxf(fminf(runmax[ab], x), run2[ab]);
+                runmax[ab] = fmaxf(runmax[ab], x);
+                runidx[ab] = improved ? ((qt * NQB + qb) * 2 + hi) : runidx[ab];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[qb][ab][r] = 0;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const float om1 = __shfl_xor(runmax[ab], 32), om2 = __shfl_xor(run2[ab], 32);
+        const int oi1 = __shfl_xor(runidx[ab], 32);
+        const float m1 = fmaxf(runmax[ab], om1);
+        const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
+        const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
+        const int a = a0 + wave * 64 + ab * 32 + l31;
+        if (hi == 0) {
+            const size_t o = ((size_t)p * S + split) * cap_a + a;
+            ws_max[o] = m1;
+            ws_i1[o] = i1;
+            ws_m2[o] = m2;
+        }
+    }
+}
+
+// gather the fp32 + fp16 rows of the anchors the int8 stage could not decide into dense panels for the fp16 pipeline
+__global__ __launch_bounds__(256) void match_compact8_kernel(const float *__restrict__ a_hat, const __half *__restrict__ a16, int Cp,
+                                                              int cap_a, const int32_t *__restrict__ n_amb,
+                                                              const int32_t *__restrict__ amb_idx, float *__restrict__ a_hat_c,
+                                                              __half *__restrict__ a16_c)
+{
+    const int p = blockIdx.y, sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n_fill = (n_amb[p] + 255) / 256 * 256;               // the fp16 kernels read whole 256-anchor panels: zero-fill the tail
+    if (sl >= n_fill) return;
+    uint4 *d32 = reinterpret_cast<uint4 *>(a_hat_c + ((size_t)p * cap_a + sl) * Cp);
+    uint4 *d16 = reinterpret_cast<uint4 *>(a16_c + ((size_t)p * cap_a + sl) * Cp);
+    if (sl >= n_amb[p]) {
+        for (int i = lane; i < Cp / 4; i += 64) d32[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < Cp / 8; i += 64) d16[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const int a = amb_idx[(size_t)p * cap_a + sl];
+    const uint4 *s32 = reinterpret_cast<const uint4 *>(a_hat + ((size_t)p * cap_a + a) * Cp);
+    const uint4 *s16 = reinterpret_cast<const uint4 *>(a16 + ((size_t)p * cap_a + a) * Cp);
+    for (int i = lane; i < Cp / 4; i += 64) d32[i] = s32[i];
+    for (int i = lane; i < Cp / 8; i += 64) d16[i] = s16[i];
+}
+
+__global__ __launch_bounds__(256) void match_scatter8_kernel(int cap_a, const int32_t *__restrict__ n_amb,
+                                                              const int32_t *__restrict__ amb_idx, const float *__restrict__ md_c,
+                                                              const int32_t *__restrict__ am_c, const uint8_t *__restrict__ va_c,
+                                                              float *__restrict__ min_dist, int32_t *__restrict__ argmin,
+                                                              uint8_t *__restrict__ valid)
+{
+    const int p = blockIdx.y, sl = blockIdx.x * 256 + threadIdx.x;
+    if (sl >= n_amb[p]) return;
+    const size_t src = (size_t)p * cap_a + sl, dst = (size_t)p * cap_a + amb_idx[src];
+    min_dist[dst] = md_c[src];
+    argmin[dst] = am_c[src];
+    valid[dst] = va_c[src];
 }
 
 static int pick_split16(int B, int T)
@@ -550,10 +781,10 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
         ORYON_CHECK_LAUNCH();
         if (C >= 256)
             hipLaunchKernelGGL((match_decide_kernel<64>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
-                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx);
+                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f);
         else
             hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
-                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx);
+                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f);
         hipLaunchKernelGGL(match_compact_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a16, C, cap_a, w.n_amb, w.amb_idx, w.m_final,
                            w.a16c, w.amb_max);
         if (C == 256) LAUNCH16_AMB(256); else if (C == 512) LAUNCH16_AMB(512); else LAUNCH16_AMB(128);
@@ -573,4 +804,113 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
     // exact recomputation of the (rare) panels whose candidate lists overflowed; exits immediately elsewhere
     return match_f32_flagged(a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag,
                              w.row_flag, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------ K1s8 entry points
+namespace {
+struct Screen8Ws {
+    ScreenWs top;
+    float *a_hat_c, *md_c;
+    int32_t *am_c;
+    uint8_t *va_c;
+    void *nested;
+    size_t nested_bytes, bytes;
+};
+
+Screen8Ws carve_screen8(void *base, int B, int C, int cap_a, int S)
+{
+    Screen8Ws w;
+    w.top = carve_screen(base, B, C, cap_a, S);
+    char *p = static_cast<char *>(base);
+    size_t off = (w.top.bytes + 255) / 256 * 256;
+    auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) / 256 * 256; return o; };
+    const size_t o_ah = take((size_t)B * cap_a * C * sizeof(float));
+    const size_t o_md = take((size_t)B * cap_a * sizeof(float));
+    const size_t o_am = take((size_t)B * cap_a * sizeof(int32_t));
+    const size_t o_va = take((size_t)B * cap_a);
+    w.nested_bytes = carve_screen(nullptr, B, C, cap_a, S).bytes;
+    const size_t o_ne = take(w.nested_bytes);
+    w.bytes = off;
+    w.a_hat_c = base ? reinterpret_cast<float *>(p + o_ah) : nullptr;
+    w.md_c = base ? reinterpret_cast<float *>(p + o_md) : nullptr;
+    w.am_c = base ? reinterpret_cast<int32_t *>(p + o_am) : nullptr;
+    w.va_c = base ? reinterpret_cast<uint8_t *>(p + o_va) : nullptr;
+    w.nested = base ? static_cast<void *>(p + o_ne) : nullptr;
+    return w;
+}
+
+template <int CP>
+void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *q8, const float *q_scale, int B, int cap_a, int cap_q,
+                    const int32_t *n_a, const int32_t *n_q, int T, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
+{
+    constexpr size_t dyn = 2 * screen8_tile_bytes(CP) > 65536 ? 2 * screen8_tile_bytes(CP) : 0;
+    if (dyn) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_i8_screen_kernel<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((match_i8_screen_kernel<CP>), dim3(groups), dim3(256), dyn, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S,
+                       ws_max, ws_i1, ws_m2);
+}
+}  // namespace
+
+extern "C" size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a)
+{
+    if (B <= 0 || C <= 0 || cap_a <= 0 || cap_a % MT16) return 0;
+    return carve_screen8(nullptr, B, C, cap_a, pick_split16(B, cap_a / MT16)).bytes;
+}
+
+extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, const void *a_f16, const void *q_f16, const int8_t *a_i8,
+                                     const int8_t *q_i8, const float *a_scale, const float *q_scale, const float *q_eps_max, int B,
+                                     int C_true, int C, int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold,
+                                     float *min_dist, int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes,
+                                     void *stream)
+{
+    ORYON_CHECK_ARG(a_hat && q_hat && a_f16 && q_f16 && a_i8 && q_i8 && a_scale && q_scale && q_eps_max && n_a && n_q);
+    ORYON_CHECK_ARG(min_dist && argmin && valid && B >= 0 && (C == 256 || C == 512) && C_true > 0 && C_true <= C);
+    ORYON_CHECK_ARG(cap_a > 0 && cap_a % MT16 == 0 && cap_q > 0 && cap_q % 256 == 0 && threshold > 0.0f && threshold <= 0.5f);
+    if (B == 0) return ORYON_OK;
+    const int T = cap_a / MT16;
+    const int S = pick_split16(B, T);
+    Screen8Ws w8 = carve_screen8(workspace, B, C, cap_a, S);
+    if (!workspace || workspace_bytes < w8.bytes) {
+        set_error("oryon_match_screened8: workspace too small (%zu < %zu)", workspace_bytes, w8.bytes);
+        return ORYON_ERR_WORKSPACE;
+    }
+    ScreenWs &w = w8.top;
+    hipStream_t st = as_stream(stream);
+    ORYON_CHECK_HIP(hipMemsetAsync(static_cast<char *>(workspace) + w.zero_off, 0, w.zero_bytes, st));
+    const float cut0 = 1.0f - 2.0f * threshold;
+    const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
+    const int groups = ((B * S + 7) / 8) * 8 * T;
+    const __half *a16 = static_cast<const __half *>(a_f16), *q16 = static_cast<const __half *>(q_f16);
+    profile_begin(st);
+    if (C == 256) launch_screen8<256>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
+    else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
+    profile_end(st);
+    ORYON_CHECK_LAUNCH();
+    hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S, valid_cut16,
+                       w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, a_scale, nullptr, q_eps_max, cut0,
+                       sqrtf((float)C_true), (float)C_true);
+    ORYON_CHECK_LAUNCH();
+    hipLaunchKernelGGL((match_rescore_kernel<4>), dim3(cap_a / 64, B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a, n_q, S,
+                       threshold, valid_cut16, w.ws_max, w.m_final, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
+    ORYON_CHECK_LAUNCH();
+    int rc = match_f32_flagged(a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag, w.row_flag,
+                               stream);
+    if (rc) return rc;
+    // anchors the int8 stage could not decide: complete fp16 pipeline on the compacted set, results scattered back
+    hipLaunchKernelGGL(match_compact8_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a_hat, a16, C, cap_a, w.n_amb, w.amb_idx, w8.a_hat_c,
+                       w.a16c);
+    ORYON_CHECK_LAUNCH();
+    rc = oryon_match_screened(w8.a_hat_c, q_hat, w.a16c, q_f16, B, C, cap_a, cap_q, w.n_amb, n_q, threshold, w8.md_c, w8.am_c, w8.va_c,
+                              w8.nested, w8.nested_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_scatter8_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, w.n_amb, w.amb_idx, w8.md_c, w8.am_c, w8.va_c,
+                       min_dist, argmin, valid);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
 }

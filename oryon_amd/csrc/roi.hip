@@ -310,6 +310,125 @@ __global__ __launch_bounds__(256) void gather_normalise_v2_kernel(const float *_
     }
 }
 
+// K0 with the int8 copies for K1s8 (C_pad 256 / 512, 32-row tiles): everything gather_normalise_v2_kernel<.,32> writes, plus
+//   out8   [n_maps, rows_cap, Cp] int8:  q = rint(x^ * 2^E), |q| <= 127, with ONE exponent E per 16-row slice of the screening
+//          kernel's accumulator layout (rows {0-3,8-11,16-19,24-27} + 4*h of each 32-row block, h = 0/1), so that the
+//          integer maximum over a slice is also its score maximum
+//   scale  [n_maps, rows_cap/16] fp32 = 2^-E per slice (slice id = (row / 32) * 2 + h)
+//   eps_max[n_maps] fp32 = max over the map's slices of 2^-(E+1), the per-element quantisation bound (atomic max on the bits)
+// x^ is the canonical fp32 value (fdiv), so |q * 2^-E - x^| <= 2^-(E+1) exactly as match16.hip's error analysis needs.
+template <int NL>
+__global__ __launch_bounds__(256) void gather_normalise_q8_kernel(const float *__restrict__ feat, int C, int HW,
+                                                                   const int32_t *__restrict__ roi, int roi_stride,
+                                                                   const int32_t *__restrict__ count, int rows_cap, int Cp,
+                                                                   float *__restrict__ out, __half *__restrict__ out16,
+                                                                   int8_t *__restrict__ out8, float *__restrict__ scale,
+                                                                   unsigned *__restrict__ eps_max)
+{
+    constexpr int ROWS = 32, LD = ROWS + 1, CPW = 2, KSTEP = 8;
+    extern __shared__ float raw[];             // [Cp][LD] raw values -> unit values, then sd[ROWS] norms, smax[2] slice maxima
+    float *sd = raw + (size_t)Cp * LD;
+    unsigned *smax = reinterpret_cast<unsigned *>(sd + ROWS);
+    const int m = blockIdx.y;
+    const int n = count[m];
+    const int row0 = blockIdx.x * ROWS;
+    const int n_fill = (n + 255) / 256 * 256;
+    if (row0 >= n_fill) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *f = feat + (size_t)m * C * HW;
+    const int lrow = lane & (ROWS - 1);
+    const int kfirst = wave * CPW + lane / ROWS;
+    const int my_row = row0 + lrow;
+    const bool live = my_row < n;
+    const int pix = live ? roi[(size_t)m * roi_stride + my_row] : 0;
+    if (t < 2) smax[t] = 0u;
+    for (int kb = kfirst; kb < Cp; kb += KSTEP * NL) {
+        float v[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int k = kb + KSTEP * u;
+            v[u] = (live && k < C) ? f[(size_t)k * HW + pix] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int k = kb + KSTEP * u;
+            if (k < Cp) raw[k * LD + lrow] = v[u];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < ROWS) {
+        float n2 = 0.0f;
+        for (int k0 = 0; k0 < C; k0 += 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = (k0 + u < C) ? raw[(k0 + u) * LD + lane] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (k0 + u < C) n2 = __fmaf_rn(x[u], x[u], n2);
+        }
+        float d = __fsqrt_rn(n2);
+        sd[lane] = d < 1e-8f ? 1e-8f : d;
+    }
+    __syncthreads();
+    float *o = out + ((size_t)m * rows_cap + row0) * Cp;
+    // fp32, k-permuted, and the unit value written back in place: lane -> (row_sub 0..7, chunk c4 0..7) of a 32-wide k group,
+    // wave = 8-row group.  The slice maximum of |x^| rides along.
+    {
+        const int r = wave * 8 + (lane >> 3), c4 = lane & 7;
+        const float d = sd[r];
+        const int kb = 8 * (c4 >> 1) + (c4 & 1);
+        float mx = 0.0f;
+        for (int k0 = 0; k0 < Cp; k0 += 32) {
+            float4 q;
+            q.x = __fdiv_rn(raw[(k0 + kb + 0) * LD + r], d);
+            q.y = __fdiv_rn(raw[(k0 + kb + 2) * LD + r], d);
+            q.z = __fdiv_rn(raw[(k0 + kb + 4) * LD + r], d);
+            q.w = __fdiv_rn(raw[(k0 + kb + 6) * LD + r], d);
+            raw[(k0 + kb + 0) * LD + r] = q.x;
+            raw[(k0 + kb + 2) * LD + r] = q.y;
+            raw[(k0 + kb + 4) * LD + r] = q.z;
+            raw[(k0 + kb + 6) * LD + r] = q.w;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+            *reinterpret_cast<float4 *>(o + (size_t)r * Cp + k0 + c4 * 4) = q;
+        }
+        atomicMax(&smax[(r >> 2) & 1], __float_as_uint(mx));        // non-negative floats order like their bit patterns
+    }
+    __syncthreads();
+    // slice exponents: 2^E * max|x^| <= 127
+    float sc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float mxs = __uint_as_float(smax[h]);
+        int E = mxs > 0.0f ? ilogbf(127.0f / mxs) : 30;
+        E = E > 30 ? 30 : (E < 0 ? 0 : E);
+        sc[h] = ldexpf(1.0f, E);
+        if (t == h) {
+            scale[(size_t)m * (rows_cap / 16) + (row0 / 32) * 2 + h] = ldexpf(1.0f, -E);
+            if (row0 < n) atomicMax(&eps_max[m], __float_as_uint(ldexpf(1.0f, -E - 1)));
+        }
+    }
+    {
+        // fp16, natural order: lane -> (row_sub 0..7, chunk c8 0..7) of a 64-wide k group: 8 rows x one 128-byte line
+        __half *o16 = out16 + ((size_t)m * rows_cap + row0) * Cp;
+        const int r = wave * 8 + (lane >> 3), c8 = lane & 7;
+        for (int k0 = 0; k0 < Cp; k0 += 64) {
+            union { __half h[8]; uint4 u; } pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk.h[e] = __float2half_rn(raw[(k0 + c8 * 8 + e) * LD + r]);
+            *reinterpret_cast<uint4 *>(o16 + (size_t)r * Cp + k0 + c8 * 8) = pk.u;
+        }
+        // int8, natural order: lane -> (row_sub 0..7, chunk c16 0..7) of a 128-wide k group: 8 rows x one 128-byte line
+        int8_t *o8 = out8 + ((size_t)m * rows_cap + row0) * Cp;
+        const float s8 = sc[(r >> 2) & 1];
+        for (int k0 = 0; k0 < Cp; k0 += 128) {
+            union { int8_t b[16]; uint4 u; } pk;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pk.b[e] = (int8_t)(int)rintf(raw[(k0 + c8 * 16 + e) * LD + r] * s8);
+            *reinterpret_cast<uint4 *>(o8 + (size_t)r * Cp + k0 + c8 * 16) = pk.u;
+        }
+    }
+}
+
 }  // namespace oryon
 
 using namespace oryon;
@@ -352,6 +471,28 @@ extern "C" int oryon_roi_subsample(int32_t *roi, int32_t *count, int n_maps, int
     if (n_maps == 0) return ORYON_OK;
     hipLaunchKernelGGL(roi_subsample_kernel, dim3(n_maps), dim3(SCAN_THREADS), 0, as_stream(stream), roi, count, roi_stride,
                        max_keep, seed, map_key);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_gather_normalise_q8(const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride,
+                                         const int32_t *count, int rows_cap, int C_pad, float *out, void *out_f16, int8_t *out_i8,
+                                         float *slice_scale, float *eps_max, void *stream)
+{
+    ORYON_CHECK_ARG(feat && roi && count && out && out_f16 && out_i8 && slice_scale && eps_max);
+    ORYON_CHECK_ARG(n_maps >= 0 && C > 0 && HW > 0 && roi_stride > 0 && C_pad >= C && (C_pad == 256 || C_pad == 512));
+    ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % 256 == 0);
+    if (n_maps == 0) return ORYON_OK;
+    hipStream_t st = as_stream(stream);
+    ORYON_CHECK_HIP(hipMemsetAsync(eps_max, 0, (size_t)n_maps * sizeof(float), st));
+    const size_t sh = ((size_t)C_pad * 33 + 32 + 8) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gather_normalise_q8_kernel<16>), dim3(rows_cap / 32, n_maps), dim3(256), sh, st, feat, C, HW, roi, roi_stride, count,
+                       rows_cap, C_pad, out, static_cast<__half *>(out_f16), out_i8, slice_scale, reinterpret_cast<unsigned *>(eps_max));
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

@@ -32,8 +32,10 @@ class MatchPoseConfig:
     n_corrs: int = 500             # test.n_corrs (= dataset.max_corrs)
     src_sampling: Optional[int] = 5000   # test.src_sampling
     seed: int = 1                  # seed (pipeline.py:296-299)
-    # "screened": fp16-MFMA screening + exact fp32 re-scoring (K1s; identical valid set / argmin / min_dist on valid rows,
-    # used when 64 < C <= 256);  "exact": full fp32-MFMA scan (K1) for every row
+    # "screened":   int8 pre-screen (K1s8, C_pad 256 / 512) -> fp16 screening (K1s) -> exact fp32 re-scoring; identical valid
+    #               set / argmin / min_dist on valid rows for every input, used when 64 < C <= 512
+    # "screened16": the same without the int8 stage
+    # "exact":      full fp32-MFMA scan (K1) for every row
     match_mode: str = "screened"
 
 
@@ -78,7 +80,8 @@ class MatchPoseEngine:
         if pair_key is None:
             pair_key = torch.arange(B, dtype=torch.int64, device=dev)
         main = torch.cuda.current_stream(dev)
-        screened = cfg.match_mode == "screened" and 64 < C <= 512
+        screened = cfg.match_mode in ("screened", "screened16") and 64 < C <= 512
+        use_i8 = screened and cfg.match_mode == "screened" and C > 128
         if self.overlap_gather:
             if self._gather_stream is None:
                 self._gather_stream = torch.cuda.Stream(device=dev)
@@ -99,8 +102,12 @@ class MatchPoseEngine:
         else:
             cap_a = ops.round_up(FH * FW, ops.ROW_PAD)
         cap_q = ops.round_up(FH * FW, ops.ROW_PAD)
-        a16 = q16 = None
-        if screened:
+        a16 = q16 = a8 = q8 = a_sc = q_sc = q_eps = None
+        if use_i8:
+            c_pad = 256 if C <= 256 else 512
+            a_hat, a16, a8, a_sc, _ = ops.gather_normalise_q8(feat_a, roi_a, n_a, cap_a, c_pad)
+            q_hat, q16, q8, q_sc, q_eps = ops.gather_normalise_q8(feat_q, roi_q, n_q, cap_q, c_pad)
+        elif screened:
             c_pad = 128 if C <= 128 else (256 if C <= 256 else 512)
             a_hat, a16 = ops.gather_normalise(feat_a, roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
             q_hat, q16 = ops.gather_normalise(feat_q, roi_q, n_q, cap_q, c_pad=c_pad, want_f16=True)
@@ -112,10 +119,12 @@ class MatchPoseEngine:
             gathered.record(self._gather_stream)
             gctx.__exit__(None, None, None)
             main.wait_event(gathered)
-            for t_ in (roi, cnt, a_hat, q_hat, a16, q16):
+            for t_ in (roi, cnt, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps):
                 if t_ is not None:
                     t_.record_stream(main)
-        if screened:
+        if use_i8:
+            min_dist, argmin, valid = ops.match_screened8(a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, n_a, n_q, cfg.dist_th, C)
+        elif screened:
             min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)
         else:
             min_dist, argmin, valid = ops.match(a_hat, q_hat, n_a, n_q, cfg.dist_th)

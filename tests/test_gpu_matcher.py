@@ -189,6 +189,8 @@ def test_batched_split_and_full_size_properties():
 
 def _screen_vs_exact(feat_a, feat_q, mask_a, mask_q, C_pad, thr=0.25, subsample=None):
     from oryon_amd import ops
+    if C_pad >= 256:
+        _screen8_vs_exact(feat_a, feat_q, mask_a, mask_q, C_pad, thr, subsample)
     roi_a, na = ops.roi_compact(mask_a)
     roi_q, nq = ops.roi_compact(mask_q)
     if subsample:
@@ -209,6 +211,42 @@ def _screen_vs_exact(feat_a, feat_q, mask_a, mask_q, C_pad, thr=0.25, subsample=
         exact_rows = md1[b, :n] == md0[b, :n]
         assert bool((exact_rows | (md1[b, :n] >= thr - 2e-3)).all())
     return va0, na
+
+
+def _screen8_vs_exact(feat_a, feat_q, mask_a, mask_q, C_pad, thr=0.25, subsample=None):
+    """K1s8 (int8 pre-screen) against the exact scan: same bars as K1s; the q8 gather must reproduce the fp32 / fp16 rows bit for bit."""
+    from oryon_amd import ops
+    roi_a, na = ops.roi_compact(mask_a)
+    roi_q, nq = ops.roi_compact(mask_q)
+    if subsample:
+        ops.roi_subsample_(roi_a, na, subsample, seed=3)
+    cap_a = ops.round_up(int(na.max()), 256)
+    cap_q = ops.round_up(int(nq.max()), 256)
+    C = feat_a.shape[1]
+    a_hat, a16, a8, a_sc, _ = ops.gather_normalise_q8(feat_a, roi_a, na, cap_a, C_pad)
+    q_hat, q16, q8, q_sc, q_eps = ops.gather_normalise_q8(feat_q, roi_q, nq, cap_q, C_pad)
+    r_hat, r16 = ops.gather_normalise(feat_q, roi_q, nq, cap_q, c_pad=C_pad, want_f16=True)
+    for b in range(feat_q.shape[0]):
+        nf = ops.round_up(int(nq[b]), 256)                      # rows past the zero-filled pad are never written
+        assert torch.equal(r_hat[b, :nf], q_hat[b, :nf]) and torch.equal(r16[b, :nf], q16[b, :nf])
+    # int8 rows: |q * 2^-E - x^| <= 2^-(E+1) with the slice's scale; |q| <= 127
+    for b in range(feat_q.shape[0]):
+        n = ops.round_up(int(nq[b]), 32)
+        rows = torch.arange(n, device=q8.device)
+        sl = (rows // 32) * 2 + ((rows // 4) % 2)
+        sc = q_sc[b][sl][:, None]
+        xk = ops.unpermute_k(q_hat[b, :n])
+        err = (q8[b, :n].float() * sc - xk).abs()
+        assert bool((err <= 0.5 * sc + 1e-12).all()) and int(q8[b, :n].abs().max()) <= 127
+        assert float(q_eps[b]) >= float(0.5 * q_sc[b][: max(1, (int(nq[b]) + 31) // 32 * 2)].max()) - 1e-12
+    md0, am0, va0 = ops.match(a_hat, q_hat, na, nq, thr)
+    md1, am1, va1 = ops.match_screened8(a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, na, nq, thr, C)
+    for b in range(feat_a.shape[0]):
+        n = int(na[b])
+        v0, v1 = va0[b, :n].bool(), va1[b, :n].bool()
+        assert torch.equal(v0, v1), "valid set differs (int8 path)"
+        assert torch.equal(am0[b, :n][v0], am1[b, :n][v0]), "argmin differs on valid rows (int8 path)"
+        assert torch.equal(md0[b, :n][v0].view(torch.int32), md1[b, :n][v0].view(torch.int32)), "min_dist differs on valid rows (int8 path)"
 
 
 def test_screened_matcher_equals_exact_synthetic():
