@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
                                                             int32_t *__restrict__ cnt, int32_t *__restrict__ cand,
                                                             int32_t *__restrict__ n_amb, int32_t *__restrict__ amb_idx,
                                                             const float *__restrict__ a_scale8, const float *__restrict__ eps_a8,
-                                                            const float *__restrict__ eps_q8, float cut0, float sqrt_c, float c_true)
+                                                            const float *__restrict__ eps_q8, float cut0, float sqrt_c, float c_true,
+                                                            const int8_t *__restrict__ a8, const int8_t *__restrict__ q8,
+                                                            const float *__restrict__ q_scale8)
 {
     // a_scale8 != nullptr: the (m1, slice, m2) triples come from the INT8 screening pass (K1s8) in units of 2^-E_a per anchor
     // slice; margin and validity cut then follow the per-anchor int8 bound DELTA8 (see the header of the int8 kernel).
@@ -293,9 +295,9 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
         m2 = fmaxf(fminf(m1, x1), fmaxf(m2, x2));
         if (x1 > m1) { m1 = x1; sid = ws_i1[o]; }
     }
-    float margin = SCREEN_MARGIN;
+    float margin = SCREEN_MARGIN, sa = 1.0f;
     if (a_scale8) {
-        const float sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];   // 2^-E of the anchor's slice
+        sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];   // 2^-E of the anchor's slice
         m1 *= sa;                                             // exact: power of two
         m2 *= sa;
         const float ea = 0.5f * sa, eq = eps_q8[p];
@@ -307,7 +309,10 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
         if (!(delta < 0.2f)) { margin = INFINITY; valid_cut = -INFINITY; }     // degenerate scales: leave it to the fp16 pass
     }
     if (lane == 0) m_final[arow] = m1;
-    if (!(m1 >= valid_cut)) return;
+    if (!(m1 >= valid_cut)) {
+        if (a_scale8 && lane == 0) cnt[arow] = -1;            // int8 mode: "cannot be valid" is carried by the count
+        return;
+    }
     if (!(m1 - m2 > margin)) {
         if (lane == 0) {
             const int sl = atomicAdd(&n_amb[p], 1);
@@ -320,6 +325,35 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
     const int r = lane >> 2, seg = lane & 3;                   // 4 lanes per row, each a quarter of K
     const int q = tile * ROWS_TILE + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
     const int nq = n_q[p];
+    if (a_scale8) {
+        // int8 mode: the slice is re-scored from the int8 rows (the very integers the screening pass accumulated, so the slice
+        // maximum reproduces m1 exactly); every row within the int8 margin of it goes to the exact fp32 re-scoring
+        int idot = 0;
+        if (q < nq) {
+            const uint4 *ar = reinterpret_cast<const uint4 *>(a8 + arow * Cp) + seg * (Cp / 64);
+            const uint4 *qr = reinterpret_cast<const uint4 *>(q8 + ((size_t)p * cap_q + q) * Cp) + seg * (Cp / 64);
+            for (int i0 = 0; i0 < Cp / 64; i0 += 4) {
+                uint4 av[4], qv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = ar[i0 + u]; qv[u] = qr[i0 + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    idot = __builtin_amdgcn_sdot4((int)av[u].x, (int)qv[u].x, idot, false);
+                    idot = __builtin_amdgcn_sdot4((int)av[u].y, (int)qv[u].y, idot, false);
+                    idot = __builtin_amdgcn_sdot4((int)av[u].z, (int)qv[u].z, idot, false);
+                    idot = __builtin_amdgcn_sdot4((int)av[u].w, (int)qv[u].w, idot, false);
+                }
+            }
+        }
+        idot += __shfl_xor(idot, 1);
+        idot += __shfl_xor(idot, 2);
+        const float s8 = (float)idot * q_scale8[(size_t)p * (cap_q / 16) + (sid >> 1) * 2 + half] * sa;
+        const bool hit8 = (seg == 0) && (q < nq) && (s8 >= m1 - margin);
+        const unsigned long long b8 = __ballot(hit8);
+        if (hit8) cand[arow * SCREEN_CAP + __popcll(b8 & ((1ull << lane) - 1ull))] = q;
+        if (lane == 0) cnt[arow] = __popcll(b8);
+        return;
+    }
     float sdot = 0.0f;
     if (q < nq) {
         const uint4 *ar = reinterpret_cast<const uint4 *>(a16 + arow * Cp) + seg * (Cp / 32);
@@ -342,16 +376,6 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
     }
     sdot += __shfl_xor(sdot, 1);
     sdot += __shfl_xor(sdot, 2);
-    if (a_scale8) {
-        // every exact minimiser lies in this slice (int8 bound): from here on the fp16 argument applies within the slice, with
-        // the slice's fp16 maximum in the role of m1
-        float mx = (q < nq) ? sdot : -INFINITY;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        m1 = mx;
-        if (lane == 0) m_final[arow] = m1;
-        if (!(m1 >= cut0 - SCREEN_DELTA - 1e-6f)) { if (lane == 0) cnt[arow] = 0; return; }
-    }
     const bool hit = (seg == 0) && (q < nq) && (sdot >= m1 - SCREEN_MARGIN - 4e-5f);
     const unsigned long long b = __ballot(hit);
     if (hit) cand[arow * SCREEN_CAP + __popcll(b & ((1ull << lane) - 1ull))] = q;
@@ -396,8 +420,9 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
         else
             for (int s = 0; s < S; ++s) m16 = fmaxf(m16, ws_max[((size_t)p * S + s) * cap_a + a]);
     }
-    const bool possible = live && (m16 >= valid_cut);
-    const int c = possible ? cnt[arow] : 0;
+    const int c_raw = live ? cnt[arow] : 0;
+    const bool possible = live && (m16 >= valid_cut) && c_raw >= 0;      // count -1: ruled out by the int8 stage
+    const int c = possible ? c_raw : 0;
     const bool overflow = c > SCREEN_CAP;
     float d = INFINITY;
     int j = 0x7fffffff;
@@ -781,10 +806,10 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
         ORYON_CHECK_LAUNCH();
         if (C >= 256)
             hipLaunchKernelGGL((match_decide_kernel<64>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
-                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f);
+                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr);
         else
             hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
-                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f);
+                               valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr);
         hipLaunchKernelGGL(match_compact_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a16, C, cap_a, w.n_amb, w.amb_idx, w.m_final,
                            w.a16c, w.amb_max);
         if (C == 256) LAUNCH16_AMB(256); else if (C == 512) LAUNCH16_AMB(512); else LAUNCH16_AMB(128);
@@ -894,10 +919,10 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
     ORYON_CHECK_LAUNCH();
     hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S, valid_cut16,
                        w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, a_scale, nullptr, q_eps_max, cut0,
-                       sqrtf((float)C_true), (float)C_true);
+                       sqrtf((float)C_true), (float)C_true, a_i8, q_i8, q_scale);
     ORYON_CHECK_LAUNCH();
     hipLaunchKernelGGL((match_rescore_kernel<4>), dim3(cap_a / 64, B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a, n_q, S,
-                       threshold, valid_cut16, w.ws_max, w.m_final, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
+                       threshold, -INFINITY, w.ws_max, w.m_final, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
     ORYON_CHECK_LAUNCH();
     int rc = match_f32_flagged(a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag, w.row_flag,
                                stream);
