@@ -130,13 +130,14 @@ int oryon_match_screened(const float *a_hat, const float *q_hat, const void *a_f
  *     maximum is decided within the proven int8 bound go straight to fp16 slice re-scoring + exact fp32 re-scoring; every other
  *     anchor runs through the complete K1s pipeline on a compacted set.  Outputs are therefore identical to oryon_match_screened
  *     (and to oryon_match_f32 on valid rows) for every input; only the run time depends on the data.  C_pad 256 or 512.
+ *     The fp16 operands of that second stage are derived from the fp32 rows inside the call, and only for pairs that need
+ *     them, so out_f16 of oryon_gather_normalise_q8 may be NULL on this path.
  *     C_true = number of real channels (<= C_pad), used in the bound. */
 int oryon_gather_normalise_q8(const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride, const int32_t *count,
                               int rows_cap, int C_pad, float *out, void *out_f16, int8_t *out_i8, float *slice_scale, float *eps_max,
                               void *stream);
-size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a);
-int oryon_match_screened8(const float *a_hat, const float *q_hat, const void *a_f16, const void *q_f16, const int8_t *a_i8,
-                          const int8_t *q_i8, const float *a_scale, const float *q_scale, const float *q_eps_max, int B, int C_true,
+size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a, int cap_q);
+int oryon_match_screened8(const float *a_hat, const float *q_hat, const int8_t *a_i8, const int8_t *q_i8, const float *a_scale, const float *q_scale, const float *q_eps_max, int B, int C_true,
                           int C, int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
                           int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -634,7 +634,34 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_kernel
     }
 }
 
-// gather the fp32 + fp16 rows of the anchors the int8 stage could not decide into dense panels for the fp16 pipeline
+// fp32 rows (k permuted inside groups of 8: position 8g+4h+j holds k = 8g+2j+h) -> fp16 rows in natural k order, the values K0's
+// fp16 output would hold.  One lane per group of 8.
+__device__ __forceinline__ uint4 half_group_from_permuted(const float4 lo, const float4 hi4)
+{
+    union { __half h[8]; uint4 u; } pk;
+    pk.h[0] = __float2half_rn(lo.x); pk.h[1] = __float2half_rn(hi4.x);
+    pk.h[2] = __float2half_rn(lo.y); pk.h[3] = __float2half_rn(hi4.y);
+    pk.h[4] = __float2half_rn(lo.z); pk.h[5] = __float2half_rn(hi4.z);
+    pk.h[6] = __float2half_rn(lo.w); pk.h[7] = __float2half_rn(hi4.w);
+    return pk.u;
+}
+
+// query-side fp16 copies for the fp16 pipeline, made only for pairs that have undecided anchors (flag-gated on the device)
+__global__ __launch_bounds__(256) void match_make_q16_kernel(const float *__restrict__ q_hat, int Cp, int cap_q,
+                                                              const int32_t *__restrict__ n_q, const int32_t *__restrict__ n_amb,
+                                                              __half *__restrict__ q16)
+{
+    const int p = blockIdx.y;
+    if (n_amb[p] == 0) return;
+    const int n_fill = (n_q[p] + 255) / 256 * 256;
+    const size_t groups = (size_t)n_fill * (Cp / 8);
+    const float4 *src = reinterpret_cast<const float4 *>(q_hat + (size_t)p * cap_q * Cp);
+    uint4 *dst = reinterpret_cast<uint4 *>(q16 + (size_t)p * cap_q * Cp);
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (size_t)gridDim.x * 256)
+        dst[g] = half_group_from_permuted(src[2 * g], src[2 * g + 1]);
+}
+
+// gather the rows of the anchors the int8 stage could not decide into dense panels for the fp16 pipeline (fp32 copy + fp16 copy)
 __global__ __launch_bounds__(256) void match_compact8_kernel(const float *__restrict__ a_hat, const __half *__restrict__ a16, int Cp,
                                                               int cap_a, const int32_t *__restrict__ n_amb,
                                                               const int32_t *__restrict__ amb_idx, float *__restrict__ a_hat_c,
@@ -652,9 +679,10 @@ __global__ __launch_bounds__(256) void match_compact8_kernel(const float *__rest
     }
     const int a = amb_idx[(size_t)p * cap_a + sl];
     const uint4 *s32 = reinterpret_cast<const uint4 *>(a_hat + ((size_t)p * cap_a + a) * Cp);
-    const uint4 *s16 = reinterpret_cast<const uint4 *>(a16 + ((size_t)p * cap_a + a) * Cp);
+    (void)a16;
     for (int i = lane; i < Cp / 4; i += 64) d32[i] = s32[i];
-    for (int i = lane; i < Cp / 8; i += 64) d16[i] = s16[i];
+    const float4 *f32 = reinterpret_cast<const float4 *>(s32);
+    for (int g = lane; g < Cp / 8; g += 64) d16[g] = half_group_from_permuted(f32[2 * g], f32[2 * g + 1]);
 }
 
 __global__ __launch_bounds__(256) void match_scatter8_kernel(int cap_a, const int32_t *__restrict__ n_amb,
@@ -836,6 +864,7 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
 namespace {
 struct Screen8Ws {
     ScreenWs top;
+    __half *q16;
     float *a_hat_c, *md_c;
     int32_t *am_c;
     uint8_t *va_c;
@@ -843,13 +872,14 @@ struct Screen8Ws {
     size_t nested_bytes, bytes;
 };
 
-Screen8Ws carve_screen8(void *base, int B, int C, int cap_a, int S)
+Screen8Ws carve_screen8(void *base, int B, int C, int cap_a, int cap_q, int S)
 {
     Screen8Ws w;
     w.top = carve_screen(base, B, C, cap_a, S);
     char *p = static_cast<char *>(base);
     size_t off = (w.top.bytes + 255) / 256 * 256;
     auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) / 256 * 256; return o; };
+    const size_t o_q16 = take((size_t)B * cap_q * C * sizeof(__half));
     const size_t o_ah = take((size_t)B * cap_a * C * sizeof(float));
     const size_t o_md = take((size_t)B * cap_a * sizeof(float));
     const size_t o_am = take((size_t)B * cap_a * sizeof(int32_t));
@@ -857,6 +887,7 @@ Screen8Ws carve_screen8(void *base, int B, int C, int cap_a, int S)
     w.nested_bytes = carve_screen(nullptr, B, C, cap_a, S).bytes;
     const size_t o_ne = take(w.nested_bytes);
     w.bytes = off;
+    w.q16 = base ? reinterpret_cast<__half *>(p + o_q16) : nullptr;
     w.a_hat_c = base ? reinterpret_cast<float *>(p + o_ah) : nullptr;
     w.md_c = base ? reinterpret_cast<float *>(p + o_md) : nullptr;
     w.am_c = base ? reinterpret_cast<int32_t *>(p + o_am) : nullptr;
@@ -882,25 +913,24 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
 }
 }  // namespace
 
-extern "C" size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a)
+extern "C" size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a, int cap_q)
 {
-    if (B <= 0 || C <= 0 || cap_a <= 0 || cap_a % MT16) return 0;
-    return carve_screen8(nullptr, B, C, cap_a, pick_split16(B, cap_a / MT16)).bytes;
+    if (B <= 0 || C <= 0 || cap_a <= 0 || cap_a % MT16 || cap_q <= 0) return 0;
+    return carve_screen8(nullptr, B, C, cap_a, cap_q, pick_split16(B, cap_a / MT16)).bytes;
 }
 
-extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, const void *a_f16, const void *q_f16, const int8_t *a_i8,
-                                     const int8_t *q_i8, const float *a_scale, const float *q_scale, const float *q_eps_max, int B,
+extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, const int8_t *a_i8, const int8_t *q_i8, const float *a_scale, const float *q_scale, const float *q_eps_max, int B,
                                      int C_true, int C, int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold,
                                      float *min_dist, int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes,
                                      void *stream)
 {
-    ORYON_CHECK_ARG(a_hat && q_hat && a_f16 && q_f16 && a_i8 && q_i8 && a_scale && q_scale && q_eps_max && n_a && n_q);
+    ORYON_CHECK_ARG(a_hat && q_hat && a_i8 && q_i8 && a_scale && q_scale && q_eps_max && n_a && n_q);
     ORYON_CHECK_ARG(min_dist && argmin && valid && B >= 0 && (C == 256 || C == 512) && C_true > 0 && C_true <= C);
     ORYON_CHECK_ARG(cap_a > 0 && cap_a % MT16 == 0 && cap_q > 0 && cap_q % 256 == 0 && threshold > 0.0f && threshold <= 0.5f);
     if (B == 0) return ORYON_OK;
     const int T = cap_a / MT16;
     const int S = pick_split16(B, T);
-    Screen8Ws w8 = carve_screen8(workspace, B, C, cap_a, S);
+    Screen8Ws w8 = carve_screen8(workspace, B, C, cap_a, cap_q, S);
     if (!workspace || workspace_bytes < w8.bytes) {
         set_error("oryon_match_screened8: workspace too small (%zu < %zu)", workspace_bytes, w8.bytes);
         return ORYON_ERR_WORKSPACE;
@@ -911,13 +941,13 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
     const float cut0 = 1.0f - 2.0f * threshold;
     const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    const __half *a16 = static_cast<const __half *>(a_f16), *q16 = static_cast<const __half *>(q_f16);
     profile_begin(st);
     if (C == 256) launch_screen8<256>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     profile_end(st);
     ORYON_CHECK_LAUNCH();
-    hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S, valid_cut16,
+    hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, static_cast<const __half *>(nullptr),
+                       static_cast<const __half *>(nullptr), C, cap_a, cap_q, n_a, n_q, S, valid_cut16,
                        w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, a_scale, nullptr, q_eps_max, cut0,
                        sqrtf((float)C_true), (float)C_true, a_i8, q_i8, q_scale);
     ORYON_CHECK_LAUNCH();
@@ -928,10 +958,12 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
                                stream);
     if (rc) return rc;
     // anchors the int8 stage could not decide: complete fp16 pipeline on the compacted set, results scattered back
-    hipLaunchKernelGGL(match_compact8_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a_hat, a16, C, cap_a, w.n_amb, w.amb_idx, w8.a_hat_c,
-                       w.a16c);
+    // (their fp16 operands are made here, and only for pairs that have such anchors: K0 does not write fp16 rows for this path)
+    hipLaunchKernelGGL(match_compact8_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a_hat, static_cast<const __half *>(nullptr), C, cap_a,
+                       w.n_amb, w.amb_idx, w8.a_hat_c, w.a16c);
+    hipLaunchKernelGGL(match_make_q16_kernel, dim3(512, B), dim3(256), 0, st, q_hat, C, cap_q, n_q, w.n_amb, w8.q16);
     ORYON_CHECK_LAUNCH();
-    rc = oryon_match_screened(w8.a_hat_c, q_hat, w.a16c, q_f16, B, C, cap_a, cap_q, w.n_amb, n_q, threshold, w8.md_c, w8.am_c, w8.va_c,
+    rc = oryon_match_screened(w8.a_hat_c, q_hat, w.a16c, w8.q16, B, C, cap_a, cap_q, w.n_amb, n_q, threshold, w8.md_c, w8.am_c, w8.va_c,
                               w8.nested, w8.nested_bytes, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(match_scatter8_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, w.n_amb, w.amb_idx, w8.md_c, w8.am_c, w8.va_c,

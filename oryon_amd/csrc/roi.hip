@@ -408,9 +408,10 @@ __global__ __launch_bounds__(256) void gather_normalise_q8_kernel(const float *_
         }
     }
     {
-        // fp16, natural order: lane -> (row_sub 0..7, chunk c8 0..7) of a 64-wide k group: 8 rows x one 128-byte line
+        // fp16 (optional), natural order: lane -> (row_sub 0..7, chunk c8 0..7) of a 64-wide k group: 8 rows x one 128-byte line
         __half *o16 = out16 + ((size_t)m * rows_cap + row0) * Cp;
         const int r = wave * 8 + (lane >> 3), c8 = lane & 7;
+        if (out16)
         for (int k0 = 0; k0 < Cp; k0 += 64) {
             union { __half h[8]; uint4 u; } pk;
 #pragma unroll
@@ -479,7 +480,7 @@ extern "C" int oryon_gather_normalise_q8(const float *feat, int n_maps, int C, i
                                          const int32_t *count, int rows_cap, int C_pad, float *out, void *out_f16, int8_t *out_i8,
                                          float *slice_scale, float *eps_max, void *stream)
 {
-    ORYON_CHECK_ARG(feat && roi && count && out && out_f16 && out_i8 && slice_scale && eps_max);
+    ORYON_CHECK_ARG(feat && roi && count && out && out_i8 && slice_scale && eps_max);      // out_f16 may be NULL
     ORYON_CHECK_ARG(n_maps >= 0 && C > 0 && HW > 0 && roi_stride > 0 && C_pad >= C && (C_pad == 256 || C_pad == 512));
     ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % 256 == 0);
     if (n_maps == 0) return ORYON_OK;

@@ -105,8 +105,8 @@ class MatchPoseEngine:
         a16 = q16 = a8 = q8 = a_sc = q_sc = q_eps = None
         if use_i8:
             c_pad = 256 if C <= 256 else 512
-            a_hat, a16, a8, a_sc, _ = ops.gather_normalise_q8(feat_a, roi_a, n_a, cap_a, c_pad)
-            q_hat, q16, q8, q_sc, q_eps = ops.gather_normalise_q8(feat_q, roi_q, n_q, cap_q, c_pad)
+            a_hat, _, a8, a_sc, _ = ops.gather_normalise_q8(feat_a, roi_a, n_a, cap_a, c_pad)
+            q_hat, _, q8, q_sc, q_eps = ops.gather_normalise_q8(feat_q, roi_q, n_q, cap_q, c_pad)
         elif screened:
             c_pad = 128 if C <= 128 else (256 if C <= 256 else 512)
             a_hat, a16 = ops.gather_normalise(feat_a, roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
@@ -123,7 +123,7 @@ class MatchPoseEngine:
                 if t_ is not None:
                     t_.record_stream(main)
         if use_i8:
-            min_dist, argmin, valid = ops.match_screened8(a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, n_a, n_q, cfg.dist_th, C)
+            min_dist, argmin, valid = ops.match_screened8(a_hat, q_hat, a8, q8, a_sc, q_sc, q_eps, n_a, n_q, cfg.dist_th, C)
         elif screened:
             min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)
         else:

@@ -156,14 +156,14 @@ def match_screened(a_hat, q_hat, a16, q16, n_a, n_q, threshold: float):
     return min_dist, argmin, valid
 
 
-def gather_normalise_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: int):
-    """K0 with int8 copies: -> (rows fp32 k-permuted, rows fp16, rows int8, slice_scale [n, rows_cap/16], eps_max [n])."""
+def gather_normalise_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: int, want_f16: bool = False):
+    """K0 with int8 copies: -> (rows fp32 k-permuted, rows fp16 | None, rows int8, slice_scale [n, rows_cap/16], eps_max [n])."""
     dev = _lib.require_gpu(feat.device)
     feat = feat.to(torch.float32).contiguous()
     n_maps, C, H, W = feat.shape
     assert c_pad in (256, 512) and C <= c_pad and rows_cap % ROW_PAD == 0
     out = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.float32, device=dev)
-    out16 = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.float16, device=dev)
+    out16 = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.float16, device=dev) if want_f16 else None
     out8 = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.int8, device=dev)
     scale = torch.ones((n_maps, rows_cap // 16), dtype=torch.float32, device=dev)
     eps = torch.empty((n_maps,), dtype=torch.float32, device=dev)
@@ -172,7 +172,7 @@ def gather_normalise_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tens
     return out, out16, out8, scale, eps
 
 
-def match_screened8(a_hat, q_hat, a16, q16, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, threshold: float, c_true: int):
+def match_screened8(a_hat, q_hat, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, threshold: float, c_true: int):
     """int8 pre-screen + fp16 screen + exact fp32 re-scoring (K1s8).  Same outputs as `match_screened`."""
     dev = _lib.require_gpu(a_hat.device)
     B, cap_a, Cp = a_hat.shape
@@ -180,9 +180,9 @@ def match_screened8(a_hat, q_hat, a16, q16, a8, q8, a_scale, q_scale, q_eps, n_a
     min_dist = torch.empty((B, cap_a), dtype=torch.float32, device=dev)
     argmin = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
     valid = torch.empty((B, cap_a), dtype=torch.uint8, device=dev)
-    wsb = lib().oryon_match_screened8_workspace_bytes(B, Cp, cap_a)
+    wsb = lib().oryon_match_screened8_workspace_bytes(B, Cp, cap_a, cap_q)
     ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
-    check(lib().oryon_match_screened8(ptr(a_hat), ptr(q_hat), ptr(a16), ptr(q16), ptr(a8), ptr(q8), ptr(a_scale), ptr(q_scale), ptr(q_eps),
+    check(lib().oryon_match_screened8(ptr(a_hat), ptr(q_hat), ptr(a8), ptr(q8), ptr(a_scale), ptr(q_scale), ptr(q_eps),
                                       B, int(c_true), Cp, cap_a, cap_q, ptr(n_a), ptr(n_q), float(threshold), ptr(min_dist), ptr(argmin),
                                       ptr(valid), ptr(ws), wsb, stream_ptr(dev)), "oryon_match_screened8")
     return min_dist, argmin, valid

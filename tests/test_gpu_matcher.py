@@ -223,8 +223,8 @@ def _screen8_vs_exact(feat_a, feat_q, mask_a, mask_q, C_pad, thr=0.25, subsample
     cap_a = ops.round_up(int(na.max()), 256)
     cap_q = ops.round_up(int(nq.max()), 256)
     C = feat_a.shape[1]
-    a_hat, a16, a8, a_sc, _ = ops.gather_normalise_q8(feat_a, roi_a, na, cap_a, C_pad)
-    q_hat, q16, q8, q_sc, q_eps = ops.gather_normalise_q8(feat_q, roi_q, nq, cap_q, C_pad)
+    a_hat, _, a8, a_sc, _ = ops.gather_normalise_q8(feat_a, roi_a, na, cap_a, C_pad)
+    q_hat, q16, q8, q_sc, q_eps = ops.gather_normalise_q8(feat_q, roi_q, nq, cap_q, C_pad, want_f16=True)
     r_hat, r16 = ops.gather_normalise(feat_q, roi_q, nq, cap_q, c_pad=C_pad, want_f16=True)
     for b in range(feat_q.shape[0]):
         nf = ops.round_up(int(nq[b]), 256)                      # rows past the zero-filled pad are never written
@@ -240,7 +240,7 @@ def _screen8_vs_exact(feat_a, feat_q, mask_a, mask_q, C_pad, thr=0.25, subsample
         assert bool((err <= 0.5 * sc + 1e-12).all()) and int(q8[b, :n].abs().max()) <= 127
         assert float(q_eps[b]) >= float(0.5 * q_sc[b][: max(1, (int(nq[b]) + 31) // 32 * 2)].max()) - 1e-12
     md0, am0, va0 = ops.match(a_hat, q_hat, na, nq, thr)
-    md1, am1, va1 = ops.match_screened8(a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, na, nq, thr, C)
+    md1, am1, va1 = ops.match_screened8(a_hat, q_hat, a8, q8, a_sc, q_sc, q_eps, na, nq, thr, C)
     for b in range(feat_a.shape[0]):
         n = int(na[b])
         v0, v1 = va0[b, :n].bool(), va1[b, :n].bool()
