@@ -356,6 +356,231 @@ __global__ __launch_bounds__(256) void pdsc_attention_kernel(const float *__rest
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same attention on the fp16 matrix pipe with error-compensated operands ("fp16x3"): every fp32 operand x is split as
+// x = hi + lo with hi = half(x), lo = half(x - hi) (22 significant bits together) and a product a.b is accumulated as
+// a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on v_mfma_f32_32x32x16_f16 (exact fp16 x fp16 products, fp32 accumulate).  The dropped
+// a_lo.b_lo term and the split residuals are ~2^-22 |a.b| - the order of the fp32 accumulation error itself - while three
+// fp16 MFMAs replace eight fp32 ones (16 k per 32 cycles vs 2 k per 64 cycles).  Range: operands must stay below 65504 in
+// magnitude (PointDSC activations are O(1..100)).  Layout notes:
+//   K tile   [key][channel] halves (hi and lo arrays): a lane's 8 consecutive channels are one ds_read_b128
+//   V tile   arranged so that the MFMA k-slot (lane half h, element e) of block (kb, t) IS the key the softmax registers hold:
+//            Vp[kb][t][h][channel][e] with key = kb*32 + 16t + 8(e>>2) + 4h + (e&3)  - again one ds_read_b128 per operand
+//   P        split in registers right after the softmax (B operand of the second product)
+typedef _Float16 xhalf8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_half(float x, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__restrict__ QKV, const float *__restrict__ sc,
+                                                                 const int32_t *__restrict__ n_rows, int n_cap,
+                                                                 float inv_sqrt_c, float *__restrict__ msg,
+                                                                 int KS, float *__restrict__ part_o, float *__restrict__ part_ml)
+{
+    constexpr int CB = C / 32;
+    constexpr int NS = C / 16;                    // k16 steps of the first product
+    constexpr int KLD = C + 8;                    // halves per K row (16-byte pad: rows 16 bytes apart in bank space)
+    constexpr int KF4 = ATT_KT * (C / 4) / 256;   // float4 of K per thread and tile
+    constexpr int VPT = ATT_KT * C / 256;         // V scalars per thread and tile
+    constexpr int VOCT = VPT / 8;                 // key octets per thread
+    static_assert(C % 32 == 0 && C <= 256 && VPT % 8 == 0 && 256 % C == 0, "tile geometry");
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[ATT_KT * KLD], Kl[ATT_KT * KLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[ATT_KT * C], Vl[ATT_KT * C];
+    const int b = blockIdx.z, split = blockIdx.y;
+    const int n = n_rows[b];
+    const int q0 = blockIdx.x * ATT_Q;
+    if (q0 >= n) return;
+    const int n_tiles = (n + ATT_KT - 1) / ATT_KT, per = (n_tiles + KS - 1) / KS;
+    const int j_begin = split * per * ATT_KT;
+    const int j_end = ((split + 1) * per * ATT_KT < n) ? (split + 1) * per * ATT_KT : n;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int qrow = q0 + wave * 32 + l31;
+    const float *base = QKV + (size_t)b * n_cap * 3 * C;
+    const float4 *sc_q = reinterpret_cast<const float4 *>(sc) + (((size_t)b * (n_cap / 32) + (q0 / 32 + wave)) * (n_cap / ATT_KT)) * 8 * 64 + lane;
+    const bool q_live = q0 + wave * 32 < n;
+
+    // staging registers of the NEXT tile: K as float4 (4 channels of a key), V as scalars (thread = one channel, 8 keys per octet)
+    float4 kv[KF4], scv[8];
+    float vv[VPT];
+    constexpr int GROUPS = 256 / C;               // thread groups along the key octets (2 at C = 128)
+    const int vch = t % C, vgrp = t / C;
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < KF4; ++i) {
+            const int e = t + 256 * i, row = e / (C / 4), c4 = e % (C / 4);
+            const bool in = j0 + row < n_cap;
+            kv[i] = in ? *reinterpret_cast<const float4 *>(base + (size_t)(j0 + row) * 3 * C + C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int o = 0; o < VOCT; ++o) {
+            const int oct = vgrp + GROUPS * o;     // octet index = (kb*2 + t2)*2 + h
+            const int kb = oct >> 2, t2 = (oct >> 1) & 1, h = oct & 1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = j0 + kb * 32 + 16 * t2 + 8 * (e >> 2) + 4 * h + (e & 3);
+                vv[o * 8 + e] = key < n_cap ? base[(size_t)key * 3 * C + 2 * C + vch] : 0.0f;
+            }
+        }
+        const float4 *sp = sc_q + (size_t)(j0 / ATT_KT) * 8 * 64;
+#pragma unroll
+        for (int v4 = 0; v4 < 8; ++v4) scv[v4] = q_live ? sp[(size_t)v4 * 64] : make_float4(-1.f, -1.f, -1.f, -1.f);
+    };
+    auto land = [&]() {
+#pragma unroll
+        for (int i = 0; i < KF4; ++i) {
+            const int e = t + 256 * i, row = e / (C / 4), c4 = e % (C / 4);
+            union { _Float16 h[4]; uint2 u; } ph, pl;
+            split_half(kv[i].x, ph.h[0], pl.h[0]); split_half(kv[i].y, ph.h[1], pl.h[1]);
+            split_half(kv[i].z, ph.h[2], pl.h[2]); split_half(kv[i].w, ph.h[3], pl.h[3]);
+            *reinterpret_cast<uint2 *>(Kh + row * KLD + 4 * c4) = ph.u;
+            *reinterpret_cast<uint2 *>(Kl + row * KLD + 4 * c4) = pl.u;
+        }
+#pragma unroll
+        for (int o = 0; o < VOCT; ++o) {
+            const int oct = vgrp + GROUPS * o;
+            union { _Float16 h[8]; uint4 u; } ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split_half(vv[o * 8 + e], ph.h[e], pl.h[e]);
+            *reinterpret_cast<uint4 *>(Vh + ((size_t)oct * C + vch) * 8) = ph.u;
+            *reinterpret_cast<uint4 *>(Vl + ((size_t)oct * C + vch) * 8) = pl.u;
+        }
+    };
+
+    // Q^T as B operand: lane (query l31, half hi), k16 step s -> channels 16s + 8hi .. +7, split once
+    xhalf8 qh[NS], ql[NS];
+    {
+        const float4 *qv = reinterpret_cast<const float4 *>(base + (size_t)qrow * 3 * C);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const float4 a = qv[4 * s_ + 2 * hi], c = qv[4 * s_ + 2 * hi + 1];
+            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h_, l_;
+                split_half(x[e], h_, l_);
+                qh[s_][e] = h_;
+                ql[s_][e] = l_;
+            }
+        }
+    }
+    f32x16 acc_o[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    if (j_begin < j_end) fetch(j_begin);
+    for (int j0 = j_begin; j0 < j_end; j0 += ATT_KT) {
+        __syncthreads();
+        land();
+        float4 sct[8];
+#pragma unroll
+        for (int v4 = 0; v4 < 8; ++v4) sct[v4] = scv[v4];
+        __syncthreads();
+        if (j0 + ATT_KT < j_end) fetch(j0 + ATT_KT);
+
+        // S^T = K Q^T, three fp16 products per k16 step and key block
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const xhalf8 ah = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+                const xhalf8 al = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s_], s[kb], 0, 0, 0);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s_], s[kb], 0, 0, 0);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s_], s[kb], 0, 0, 0);
+            }
+        }
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 q4 = sct[kb * 4 + (r >> 2)];
+                const float scq = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+                float v = scq * (s[kb][r] * inv_sqrt_c);
+                v = (scq >= 0.0f) ? v : -INFINITY;
+                s[kb][r] = v;
+                m_tile = fmaxf(m_tile, v);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = __expf(m_run - m_new);
+        float l_tile = 0.0f;
+        xhalf8 ph[2][2], pl[2][2];                  // [kb][t2]: keys crow(8*t2 + e, hi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = expf(s[kb][r] - m_new);
+                l_tile += p;
+                _Float16 h_, l_;
+                split_half(p, h_, l_);
+                ph[kb][r >> 3][r & 7] = h_;
+                pl[kb][r >> 3][r & 7] = l_;
+            }
+        l_run = l_run * alpha + l_tile;
+        m_run = m_new;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
+        // O^T += V^T P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int oct = (kb * 2 + t2) * 2 + hi;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const xhalf8 vh = *reinterpret_cast<const xhalf8 *>(Vh + ((size_t)oct * C + cb * 32 + l31) * 8);
+                    const xhalf8 vl = *reinterpret_cast<const xhalf8 *>(Vl + ((size_t)oct * C + cb * 32 + l31) * 8);
+                    acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kb][t2], acc_o[cb], 0, 0, 0);
+                    acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t2], acc_o[cb], 0, 0, 0);
+                    acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kb][t2], acc_o[cb], 0, 0, 0);
+                }
+            }
+    }
+    const float l_all = l_run + __shfl_xor(l_run, 32);
+    if (KS > 1) {
+        const size_t prow = ((size_t)split * gridDim.z + b) * n_cap + qrow;
+        float *po = part_o + prow * C;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                v.x = acc_o[cb][4 * g + 0]; v.y = acc_o[cb][4 * g + 1]; v.z = acc_o[cb][4 * g + 2]; v.w = acc_o[cb][4 * g + 3];
+                *reinterpret_cast<float4 *>(po + cb * 32 + 8 * g + 4 * hi) = v;
+            }
+        if (hi == 0) { part_ml[prow * 2] = m_run; part_ml[prow * 2 + 1] = l_all; }
+        return;
+    }
+    const float inv_l = 1.0f / l_all;
+    float *mo = msg + ((size_t)b * n_cap + qrow) * C;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = acc_o[cb][4 * g + 0] * inv_l;
+            v.y = acc_o[cb][4 * g + 1] * inv_l;
+            v.z = acc_o[cb][4 * g + 2] * inv_l;
+            v.w = acc_o[cb][4 * g + 3] * inv_l;
+            *reinterpret_cast<float4 *>(mo + cb * 32 + 8 * g + 4 * hi) = v;
+        }
+}
+
 // Combine the key-split partials: msg = sum_s e^{m_s - m} O_s / sum_s e^{m_s - m} l_s,  m = max_s m_s.
 __global__ __launch_bounds__(256) void pdsc_attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
                                                                     const int32_t *__restrict__ n_rows, int n_cap, int C, int KS,
@@ -451,7 +676,10 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         if (rc) return rc;
         const int KS = ws.att_splits;
         dim3 ag(n_cap / ATT_Q, KS, B);
-        if (C == 128)
+        static const bool x3 = getenv("ORYON_PDSC_FP32_MFMA") == nullptr;     // fp16x3 unless the pure-fp32 kernels are asked for
+        if (C == 128 && x3)
+            hipLaunchKernelGGL((pdsc_attention_x3_kernel<128>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
+        else if (C == 128)
             hipLaunchKernelGGL((pdsc_attention_kernel<128>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         else if (C == 64)
             hipLaunchKernelGGL((pdsc_attention_kernel<64>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
