@@ -581,6 +581,94 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
         }
 }
 
+// fp16x3 version of pdsc_linear_kernel (same tile, same epilogue) for K % 32 == 0: X and W tiles are split into hi/lo halves
+// while they are staged (8-byte loads, 4-byte LDS stores; rows 80 bytes apart: the ds_read_b128 of a 16-lane group is
+// conflict-free), 12 fp16 MFMAs per k-tile and wave instead of 32 fp32 ones.
+template <bool RELU, bool RESID>
+__global__ __launch_bounds__(256) void pdsc_linear_x3_kernel(const float *__restrict__ X, int ldx, size_t x_batch,
+                                                              const float *__restrict__ W, const float *__restrict__ bias,
+                                                              const float *__restrict__ R, int ldr, size_t r_batch,
+                                                              float *__restrict__ Y, int ldy, size_t y_batch, int K, int N,
+                                                              const int32_t *__restrict__ n_rows)
+{
+    constexpr int XLD = LIN_BK + 8;              // halves per LDS row
+    __shared__ __attribute__((aligned(16))) _Float16 Xh[LIN_ROWS * XLD], Xl[LIN_ROWS * XLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Wh[LIN_COLS * XLD], Wl[LIN_COLS * XLD];
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.x * LIN_ROWS, n0 = blockIdx.y * LIN_COLS;
+    if (n_rows && m0 >= n_rows[b]) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const float *x = X + (size_t)b * x_batch + (size_t)m0 * ldx;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    constexpr int NX = (LIN_ROWS * LIN_BK) / 512, NW = (LIN_COLS * LIN_BK) / 512;     // float2 per thread: 4 + 8
+    for (int k0 = 0; k0 < K; k0 += LIN_BK) {
+        float2 xv[NX], wv[NW];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = t + 256 * i, row = e >> 4, kk = (e & 15) * 2;
+            xv[i] = *reinterpret_cast<const float2 *>(x + (size_t)row * ldx + k0 + kk);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = t + 256 * i, col = e >> 4, kk = (e & 15) * 2;
+            wv[i] = (n0 + col < N) ? *reinterpret_cast<const float2 *>(W + (size_t)(n0 + col) * K + k0 + kk) : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = t + 256 * i, row = e >> 4, kk = (e & 15) * 2;
+            union { _Float16 h[2]; unsigned u; } ph, pl;
+            split_half(xv[i].x, ph.h[0], pl.h[0]);
+            split_half(xv[i].y, ph.h[1], pl.h[1]);
+            *reinterpret_cast<unsigned *>(Xh + row * XLD + kk) = ph.u;
+            *reinterpret_cast<unsigned *>(Xl + row * XLD + kk) = pl.u;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = t + 256 * i, col = e >> 4, kk = (e & 15) * 2;
+            union { _Float16 h[2]; unsigned u; } ph, pl;
+            split_half(wv[i].x, ph.h[0], pl.h[0]);
+            split_half(wv[i].y, ph.h[1], pl.h[1]);
+            *reinterpret_cast<unsigned *>(Wh + col * XLD + kk) = ph.u;
+            *reinterpret_cast<unsigned *>(Wl + col * XLD + kk) = pl.u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s_ = 0; s_ < LIN_BK / 16; ++s_) {
+            const int ko = 16 * s_ + 8 * hi;
+            const xhalf8 ah = *reinterpret_cast<const xhalf8 *>(Xh + (wm * 32 + l31) * XLD + ko);
+            const xhalf8 al = *reinterpret_cast<const xhalf8 *>(Xl + (wm * 32 + l31) * XLD + ko);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const xhalf8 bh = *reinterpret_cast<const xhalf8 *>(Wh + (wn * 64 + j * 32 + l31) * XLD + ko);
+                const xhalf8 bl = *reinterpret_cast<const xhalf8 *>(Wl + (wn * 64 + j * 32 + l31) * XLD + ko);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = n0 + wn * 64 + j * 32 + l31;
+        if (c >= N) continue;
+        const float bv = bias ? bias[c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + crow(r, hi);
+            float v = acc[j][r] + bv;
+            if (RELU) v = v > 0.0f ? v : 0.0f;
+            if (RESID) v += R[(size_t)b * r_batch + (size_t)row * ldr + c];
+            Y[(size_t)b * y_batch + (size_t)row * ldy + c] = v;
+        }
+    }
+}
+
 // Combine the key-split partials: msg = sum_s e^{m_s - m} O_s / sum_s e^{m_s - m} l_s,  m = max_s m_s.
 __global__ __launch_bounds__(256) void pdsc_attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
                                                                     const int32_t *__restrict__ n_rows, int n_cap, int C, int KS,
@@ -635,6 +723,14 @@ static int launch_linear(bool relu, bool resid, const float *X, int ldx, size_t 
                          const int32_t *n_rows, hipStream_t st)
 {
     dim3 grid(n_cap / LIN_ROWS, ceil_div(N, LIN_COLS), B), block(256);
+    static const bool x3 = getenv("ORYON_PDSC_FP32_MFMA") == nullptr;
+    if (x3 && K % LIN_BK == 0 && ldx % 2 == 0) {
+        if (relu && !resid) hipLaunchKernelGGL((pdsc_linear_x3_kernel<true, false>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
+        else if (!relu && resid) hipLaunchKernelGGL((pdsc_linear_x3_kernel<false, true>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
+        else if (!relu && !resid) hipLaunchKernelGGL((pdsc_linear_x3_kernel<false, false>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
+        else hipLaunchKernelGGL((pdsc_linear_x3_kernel<true, true>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
+        return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+    }
     if (relu && !resid)
         hipLaunchKernelGGL((pdsc_linear_kernel<true, false>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
     else if (!relu && resid)
