@@ -334,7 +334,7 @@ def main():
         # exact workload (profiles/r01_pmc_counters.md), null for any other workload
         traffic, traffic_src = None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if screened and not use_i8 and (B, H, C) == (64, 224, 256) and os.path.exists(tpath):
+        if use_i8 and (B, H, C) == (64, 224, 256) and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_pmc_counters.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)"
