@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_f16_screen_kerne
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
-    const unsigned rd_base = (unsigned)(l31 * RB);
-    const unsigned rd_key = (unsigned)(hi ^ (l31 & 15));
+    // swizzled operand addresses: 8 per-lane offsets in registers, the rest immediates / one add per tile (VALU and MFMA issue
+    // serialise on a SIMD: every VALU instruction taken out of the loop is MFMA time)
+    unsigned koff[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) koff[c] = (unsigned)(l31 * RB) + ((((unsigned)(hi ^ (l31 & 15))) ^ (2u * c)) << 4);
     auto rd = [&](int s, int qb, unsigned tile) -> half8 {
-        unsigned key = rd_key;
-        asm volatile("" : "+v"(key));
-        const unsigned off = rd_base + ((key ^ (2u * (s & 7))) << 4) + (unsigned)(qb * 32 * RB + (s >> 3) * 256) + tile;
-        return *reinterpret_cast<const half8 *>(smem + off);
+        return *reinterpret_cast<const half8 *>(smem + koff[s & 7] + tile + (unsigned)(qb * 32 * RB + (s >> 3) * 256));
     };
 
     f32x16 acc[NQB][NAB];
@@ -549,13 +549,14 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_kernel
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
-    const unsigned rd_base = (unsigned)(l31 * RB);
-    const unsigned rd_key = (unsigned)(hi ^ (l31 & 15));
+    // swizzled operand addresses: 8 per-lane offsets (one per 16-byte chunk pair of a 256-byte line) live in registers, everything
+    // else (query block, line, tile) is an immediate or one add per tile - VALU and MFMA issue serialise on a SIMD of this chip
+    // (tools/probe_mfma_valu_overlap.hip), so every VALU instruction taken out of the loop is MFMA time
+    unsigned koff[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) koff[c] = (unsigned)(l31 * RB) + ((((unsigned)(hi ^ (l31 & 15))) ^ (2u * c)) << 4);
     auto rd = [&](int s, int qb, unsigned tile) -> i32x4 {
-        unsigned key = rd_key;
-        asm volatile("" : "+v"(key));
-        const unsigned off = rd_base + ((key ^ (2u * (s & 7))) << 4) + (unsigned)(qb * 32 * RB + (s >> 3) * 256) + tile;
-        return *reinterpret_cast<const i32x4 *>(smem + off);
+        return *reinterpret_cast<const i32x4 *>(smem + koff[s & 7] + tile + (unsigned)(qb * 32 * RB + (s >> 3) * 256));
     };
 
     i32x16 acc[NQB][NAB];

@@ -39,6 +39,47 @@ __global__ __launch_bounds__(512) void probe(float *out, int n_mfma, int n_valu,
     if (r == 123.456f) out[0] = r;
 }
 
+// same-wave variant: every wave issues 4 independent MFMAs and NV independent VALU fmas per iteration
+template <int KIND, int NV>
+__global__ __launch_bounds__(256) void probe_same_wave(float *out, int n_iter)
+{
+    f32x16 acc[4];
+    for (int a = 0; a < 4; ++a) for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    float x = threadIdx.x * 1e-3f, y = 1.0f;
+    half8 hx, hy;
+    for (int i = 0; i < 8; ++i) { hx[i] = (_Float16)x; hy[i] = (_Float16)1; }
+    float v[16];
+    for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 1e-4f + i;
+    for (int it = 0; it < n_iter; ++it) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (KIND == 0) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[a], 0, 0, 0);
+            else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hy, acc[a], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NV / 4; ++i) v[(a * (NV / 4) + i) & 15] = __builtin_fmaf(v[(a * (NV / 4) + i) & 15], 1.0001f, 0.5f);
+        }
+    }
+    float r = 0.f;
+    for (int a = 0; a < 4; ++a) r += acc[a][0];
+    for (int i = 0; i < 16; ++i) r += v[i];
+    if (r == 123.456f) out[0] = r;
+}
+
+template <int KIND, int NV>
+static float run_same(int n_iter)
+{
+    float *d; (void)hipMalloc(&d, 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe_same_wave<KIND, NV>), dim3(256), dim3(256), 0, 0, d, n_iter);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((probe_same_wave<KIND, NV>), dim3(256), dim3(256), 0, 0, d, n_iter);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipFree(d);
+    return ms * 1e3f;
+}
+
 template <int KIND>
 static float run(int n_mfma, int n_valu, int mode)
 {
@@ -66,5 +107,9 @@ int main()
         printf("%s: mfma-only %.1f us, valu-only %.1f us, both (different waves, same SIMD) %.1f us -> %s\n",
                kind ? "f16 32x32x16" : "f32 32x32x2 ", tm, tv, tb, tb < 0.75f * (tm + tv) ? "OVERLAP" : "SERIALISED");
     }
+    printf("same wave, f16 32x32x16 (4 MFMAs = 128 cycles per iteration): +0 VALU %.1f us, +16 VALU %.1f us, +32 VALU %.1f us, +64 VALU %.1f us\n",
+           run_same<1, 0>(4096), run_same<1, 16>(4096), run_same<1, 32>(4096), run_same<1, 64>(4096));
+    printf("same wave, f32 32x32x2  (4 MFMAs = 256 cycles per iteration): +0 VALU %.1f us, +16 VALU %.1f us, +32 VALU %.1f us, +64 VALU %.1f us\n",
+           run_same<0, 0>(4096), run_same<0, 16>(4096), run_same<0, 32>(4096), run_same<0, 64>(4096));
     return 0;
 }
