@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = expf(s[kb][r] - m_new);
+                const float p = __expf(s[kb][r] - m_new);     // v_exp_f32 path: ~1e-6 relative, VALU issue is what bounds this kernel
                 l_tile += p;
                 _Float16 h_, l_;
                 split_half(p, h_, l_);
