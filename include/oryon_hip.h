@@ -139,7 +139,8 @@ int oryon_gather_normalise_q8(const float *feat, int n_maps, int C, int HW, cons
 size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a, int cap_q);
 int oryon_match_screened8(const float *a_hat, const float *q_hat, const int8_t *a_i8, const int8_t *q_i8, const float *a_scale, const float *q_scale, const float *q_eps_max, int B, int C_true,
                           int C, int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
-                          int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes, void *stream);
+                          int32_t *argmin, uint8_t *valid, int32_t *n_undecided /* [B] or NULL: anchors handed to the fp16 stage */,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).
  *     Replaces utils/pcd.py:205-214: keep rows with valid, need more than one, sample exactly max_corrs

@@ -45,7 +45,7 @@ _PROTOS = {
     "oryon_gather_normalise_q8": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "oryon_match_screened8_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oryon_match_screened8": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P,
-                                      _P, c_size_t, _P]),
+                                      _P, _P, c_size_t, _P]),
     "oryon_match_screened": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "oryon_select_corrs": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_uint64, _P, _P,
                                    _P, _P, _P, _P, _P]),

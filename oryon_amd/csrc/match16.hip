@@ -922,8 +922,8 @@ extern "C" size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a,
 
 extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, const int8_t *a_i8, const int8_t *q_i8, const float *a_scale, const float *q_scale, const float *q_eps_max, int B,
                                      int C_true, int C, int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold,
-                                     float *min_dist, int32_t *argmin, uint8_t *valid, void *workspace, size_t workspace_bytes,
-                                     void *stream)
+                                     float *min_dist, int32_t *argmin, uint8_t *valid, int32_t *n_undecided, void *workspace,
+                                     size_t workspace_bytes, void *stream)
 {
     ORYON_CHECK_ARG(a_hat && q_hat && a_i8 && q_i8 && a_scale && q_scale && q_eps_max && n_a && n_q);
     ORYON_CHECK_ARG(min_dist && argmin && valid && B >= 0 && (C == 256 || C == 512) && C_true > 0 && C_true <= C);
@@ -958,6 +958,7 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
     int rc = match_f32_flagged(a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag, w.row_flag,
                                stream);
     if (rc) return rc;
+    if (n_undecided) ORYON_CHECK_HIP(hipMemcpyAsync(n_undecided, w.n_amb, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     // anchors the int8 stage could not decide: complete fp16 pipeline on the compacted set, results scattered back
     // (their fp16 operands are made here, and only for pairs that have such anchors: K0 does not write fp16 rows for this path)
     hipLaunchKernelGGL(match_compact8_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a_hat, static_cast<const __half *>(nullptr), C, cap_a,

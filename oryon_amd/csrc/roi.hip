@@ -492,6 +492,18 @@ extern "C" int oryon_gather_normalise_q8(const float *feat, int n_maps, int C, i
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    static const int nl = getenv("ORYON_GATHER_NL") ? atoi(getenv("ORYON_GATHER_NL")) : 16;
+    if (nl == 32) {
+        static bool a32 = false;
+        if (!a32) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a32 = true; }
+        hipLaunchKernelGGL((gather_normalise_q8_kernel<32>), dim3(rows_cap / 32, n_maps), dim3(256), sh, st, feat, C, HW, roi, roi_stride, count,
+                           rows_cap, C_pad, out, static_cast<__half *>(out_f16), out_i8, slice_scale, reinterpret_cast<unsigned *>(eps_max));
+    } else if (nl == 8) {
+        static bool a8 = false;
+        if (!a8) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a8 = true; }
+        hipLaunchKernelGGL((gather_normalise_q8_kernel<8>), dim3(rows_cap / 32, n_maps), dim3(256), sh, st, feat, C, HW, roi, roi_stride, count,
+                           rows_cap, C_pad, out, static_cast<__half *>(out_f16), out_i8, slice_scale, reinterpret_cast<unsigned *>(eps_max));
+    } else
     hipLaunchKernelGGL((gather_normalise_q8_kernel<16>), dim3(rows_cap / 32, n_maps), dim3(256), sh, st, feat, C, HW, roi, roi_stride, count,
                        rows_cap, C_pad, out, static_cast<__half *>(out_f16), out_i8, slice_scale, reinterpret_cast<unsigned *>(eps_max));
     ORYON_CHECK_LAUNCH();

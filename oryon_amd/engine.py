@@ -54,6 +54,15 @@ class MatchPoseEngine:
         self.overlap_gather = overlap_gather
         self._reg_stream = None
         self._gather_stream = None
+        # adaptive use of the int8 pre-screen: the fraction of anchors it had to hand to the fp16 stage is read back
+        # asynchronously (pinned buffer + event, never a sync); above `i8_max_undecided` the next batches skip the int8 stage
+        # and it is tried again every `i8_retry_every` batches.  Exactness never depends on this - only the run time does.
+        self.i8_max_undecided = 0.25
+        self.i8_retry_every = 16
+        self._i8_pending = None        # (pinned [2] int64 tensor, event)
+        self._i8_host = None           # pinned buffer, allocated once
+        self._i8_frac = 0.0
+        self._i8_skipped = 0
 
     def finish(self, out: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Order the caller's current stream after the registration of `out` (no-op without overlap)."""
@@ -82,6 +91,17 @@ class MatchPoseEngine:
         main = torch.cuda.current_stream(dev)
         screened = cfg.match_mode in ("screened", "screened16") and 64 < C <= 512
         use_i8 = screened and cfg.match_mode == "screened" and C > 128
+        if use_i8:
+            if self._i8_pending is not None and self._i8_pending[1].query():
+                und, tot = self._i8_pending[0].tolist()
+                self._i8_frac = und / max(1, tot)
+                self._i8_pending = None
+            if self._i8_frac > self.i8_max_undecided:
+                self._i8_skipped += 1
+                if self._i8_skipped < self.i8_retry_every:
+                    use_i8 = False
+                else:
+                    self._i8_skipped, self._i8_frac = 0, 0.0
         if self.overlap_gather:
             if self._gather_stream is None:
                 self._gather_stream = torch.cuda.Stream(device=dev)
@@ -123,7 +143,17 @@ class MatchPoseEngine:
                 if t_ is not None:
                     t_.record_stream(main)
         if use_i8:
-            min_dist, argmin, valid = ops.match_screened8(a_hat, q_hat, a8, q8, a_sc, q_sc, q_eps, n_a, n_q, cfg.dist_th, C)
+            n_und = torch.empty((B,), dtype=torch.int32, device=dev)
+            min_dist, argmin, valid = ops.match_screened8(a_hat, q_hat, a8, q8, a_sc, q_sc, q_eps, n_a, n_q, cfg.dist_th, C, n_und)
+            if self._i8_pending is None:
+                stats = torch.stack((n_und.sum(dtype=torch.int64), n_a.sum(dtype=torch.int64)))
+                if self._i8_host is None:
+                    self._i8_host = torch.empty((2,), dtype=torch.int64, pin_memory=True)
+                host = self._i8_host
+                host.copy_(stats, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                self._i8_pending = (host, ev)
         elif screened:
             min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)
         else:

@@ -172,8 +172,9 @@ def gather_normalise_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tens
     return out, out16, out8, scale, eps
 
 
-def match_screened8(a_hat, q_hat, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, threshold: float, c_true: int):
-    """int8 pre-screen + fp16 screen + exact fp32 re-scoring (K1s8).  Same outputs as `match_screened`."""
+def match_screened8(a_hat, q_hat, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, threshold: float, c_true: int, n_undecided=None):
+    """int8 pre-screen + fp16 screen + exact fp32 re-scoring (K1s8).  Same outputs as `match_screened`.
+    n_undecided: optional int32 [B] tensor receiving the number of anchors the int8 stage handed to the fp16 stage."""
     dev = _lib.require_gpu(a_hat.device)
     B, cap_a, Cp = a_hat.shape
     cap_q = q_hat.shape[1]
@@ -184,7 +185,7 @@ def match_screened8(a_hat, q_hat, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, thr
     ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
     check(lib().oryon_match_screened8(ptr(a_hat), ptr(q_hat), ptr(a8), ptr(q8), ptr(a_scale), ptr(q_scale), ptr(q_eps),
                                       B, int(c_true), Cp, cap_a, cap_q, ptr(n_a), ptr(n_q), float(threshold), ptr(min_dist), ptr(argmin),
-                                      ptr(valid), ptr(ws), wsb, stream_ptr(dev)), "oryon_match_screened8")
+                                      ptr(valid), ptr(n_undecided), ptr(ws), wsb, stream_ptr(dev)), "oryon_match_screened8")
     return min_dist, argmin, valid
 
 

@@ -212,3 +212,28 @@ def test_quick_gelu_bf16_fused():
         diff = (y.float() - ref.float()).abs()
         assert float((diff / ref.float().abs().clamp_min(1e-3)).max()) < 1e-2     # at most one bf16 ulp (fast exp)
         assert float((y.float() - ref.float()).abs().mean()) < 1e-4
+
+
+def test_engine_int8_stage_backs_off_on_ambiguous_descriptors():
+    """Descriptor maps made of a few hundred distinct vectors (every anchor has many near-ties): the int8 pre-screen cannot decide
+    them, the engine notices (async read-back) and skips it for the following batches - results stay those of the exact matcher."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    H, C = 48, 256
+    pairs = [make_pair(i, H, H, C, device=dev) for i in range(30, 32)]
+    st = lambda k: torch.stack([p[k] for p in pairs])
+    g = torch.Generator(device=dev).manual_seed(9)
+    base = torch.randn(C, 150, generator=g, device=dev)
+    idx = torch.randint(0, 150, (2, H * H), generator=g, device=dev)
+    fq = torch.stack([base[:, idx[b]].reshape(C, H, H) for b in range(2)])
+    fa = fq + 0.01 * torch.randn(fq.shape, generator=g, device=dev)
+    solver = _solver()
+    ref = MatchPoseEngine(solver, MatchPoseConfig(match_mode="exact")).run(fa, fq, st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"),
+                                                                          st("camera").to(dev), st("camera").to(dev), keep=True)
+    eng = MatchPoseEngine(solver, MatchPoseConfig())
+    for it in range(4):
+        out = eng.run(fa, fq, st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"), st("camera").to(dev), st("camera").to(dev), keep=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out["corrs"], ref["corrs"]) and torch.equal(out["status"], ref["status"])
+    assert eng._i8_frac > eng.i8_max_undecided and eng._i8_skipped >= 1
