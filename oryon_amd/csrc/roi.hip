@@ -391,7 +391,11 @@ __global__ __launch_bounds__(256) void gather_normalise_q8_kernel(const float *_
             mx = fmaxf(fmaxf(mx, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
             *reinterpret_cast<float4 *>(o + (size_t)r * Cp + k0 + c4 * 4) = q;
         }
-        atomicMax(&smax[(r >> 2) & 1], __float_as_uint(mx));        // non-negative floats order like their bit patterns
+        // a wave covers rows 8w..8w+7: lanes 0-31 belong to slice h = 0, lanes 32-63 to h = 1 -> reduce inside each half, one
+        // LDS atomic per half-wave (non-negative floats order like their bit patterns)
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((lane & 31) == 0) atomicMax(&smax[lane >> 5], __float_as_uint(mx));
     }
     __syncthreads();
     // slice exponents: 2^E * max|x^| <= 127
