@@ -847,13 +847,9 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
 #undef LAUNCH16
 #undef LAUNCH16_AMB
     ORYON_CHECK_LAUNCH();
-    static const int rl = getenv("ORYON_RESCORE_LANES") ? atoi(getenv("ORYON_RESCORE_LANES")) : 4;
-#define LAUNCH_RESCORE(LV)                                                                                                 \
-    hipLaunchKernelGGL((match_rescore_kernel<LV>), dim3(cap_a / (256 / LV), B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a,  \
-                       n_q, S, threshold, valid_cut, w.ws_max, m_final, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag,          \
-                       w.panel_flag)
-    if (rl == 16) LAUNCH_RESCORE(16); else if (rl == 8) LAUNCH_RESCORE(8); else if (rl == 2) LAUNCH_RESCORE(2); else if (rl == 1) LAUNCH_RESCORE(1); else LAUNCH_RESCORE(4);
-#undef LAUNCH_RESCORE
+    // 4 lanes per anchor: 16 -> 394 us, 8 -> 230, 4 -> 184, 2 -> 175, 1 -> 200 us at cfg2 (almost every anchor has one candidate)
+    hipLaunchKernelGGL((match_rescore_kernel<4>), dim3(cap_a / 64, B), dim3(256), 0, st, a_hat, q_hat, C, cap_a, cap_q, n_a, n_q, S,
+                       threshold, valid_cut, w.ws_max, m_final, w.cnt, w.cand, min_dist, argmin, valid, w.row_flag, w.panel_flag);
     ORYON_CHECK_LAUNCH();
     // exact recomputation of the (rare) panels whose candidate lists overflowed; exits immediately elsewhere
     return match_f32_flagged(a_hat, q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag,

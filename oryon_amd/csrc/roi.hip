@@ -493,21 +493,9 @@ extern "C" int oryon_gather_normalise_q8(const float *feat, int n_maps, int C, i
     const size_t sh = ((size_t)C_pad * 33 + 32 + 8) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // 8 / 16 / 32 loads in flight measure the same
         attr_set = true;
     }
-    static const int nl = getenv("ORYON_GATHER_NL") ? atoi(getenv("ORYON_GATHER_NL")) : 16;
-    if (nl == 32) {
-        static bool a32 = false;
-        if (!a32) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a32 = true; }
-        hipLaunchKernelGGL((gather_normalise_q8_kernel<32>), dim3(rows_cap / 32, n_maps), dim3(256), sh, st, feat, C, HW, roi, roi_stride, count,
-                           rows_cap, C_pad, out, static_cast<__half *>(out_f16), out_i8, slice_scale, reinterpret_cast<unsigned *>(eps_max));
-    } else if (nl == 8) {
-        static bool a8 = false;
-        if (!a8) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a8 = true; }
-        hipLaunchKernelGGL((gather_normalise_q8_kernel<8>), dim3(rows_cap / 32, n_maps), dim3(256), sh, st, feat, C, HW, roi, roi_stride, count,
-                           rows_cap, C_pad, out, static_cast<__half *>(out_f16), out_i8, slice_scale, reinterpret_cast<unsigned *>(eps_max));
-    } else
     hipLaunchKernelGGL((gather_normalise_q8_kernel<16>), dim3(rows_cap / 32, n_maps), dim3(256), sh, st, feat, C, HW, roi, roi_stride, count,
                        rows_cap, C_pad, out, static_cast<__half *>(out_f16), out_i8, slice_scale, reinterpret_cast<unsigned *>(eps_max));
     ORYON_CHECK_LAUNCH();
