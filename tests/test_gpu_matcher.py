@@ -318,3 +318,20 @@ def test_screened_matcher_degenerate_rois():
         v = va0[b, :n].bool()
         assert torch.equal(am0[b, :n][v], am1[b, :n][v]) and torch.equal(md0[b, :n][v], md1[b, :n][v])
     assert int(va1[1, : int(na[1])].sum()) == 0                 # nothing to match against
+
+
+def test_screened8_peaky_descriptors_fall_back_exactly():
+    """A few one-hot-like descriptors make the int8 scales coarse (DELTA8 above its usable range for every anchor of that pair):
+    all anchors must then take the fp16 route and the outputs must still equal the exact scan."""
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    C, H = 256, 32
+    pairs = [make_pair(i, H, H, C, device=dev) for i in range(2)]
+    st = lambda k: torch.stack([p[k] for p in pairs])
+    fa, fq = st("feat_a").clone(), st("feat_q").clone()
+    fq[0, :, 3, 3] = 0.0
+    fq[0, 7, 3, 3] = 5.0                      # one-hot query pixel in pair 0
+    fa[1, :, H // 2, H // 2] = 0.0
+    fa[1, 11, H // 2, H // 2] = -2.0          # one-hot anchor pixel in pair 1
+    ones = torch.ones_like(st("mask_a"))
+    _screen8_vs_exact(fa, fq, ones, ones, 256)
