@@ -354,7 +354,8 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
-                "unit": "TOP/s (int8 MAC x2)" if use_i8 else "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "unit": "TFLOP/s", "op": "int8 multiply-accumulate, 2 ops each, i32 accumulate" if use_i8 else "floating-point fma, 2 flops each",
+                "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": flops, "avg_launch_ms": launch_ms,
                 "share_of_step": match_ms / (elapsed / a.steps * 1e3),
             },
