@@ -177,116 +177,136 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------------------------------------ K7b + K8 + K9
-// One workgroup per pair (16 waves, one wave per seed at a time): joint power iteration, weight
-// normalisation, weighted Kabsch per seed, fitness over all correspondences, first-argmax, labels.
-constexpr int HYP_THREADS = 1024, HYP_WAVES = HYP_THREADS / 64;
-__global__ __launch_bounds__(HYP_THREADS) void pdsc_hypotheses_kernel(
-    const float *__restrict__ src, const float *__restrict__ tgt, const int32_t *__restrict__ n_rows, int n_cap,
-    const int32_t *__restrict__ n_seeds, int S_cap, int k_cfg, int num_iterations, float inlier_thr,
-    const int32_t *__restrict__ knn, const float *__restrict__ Mmat, float *__restrict__ seed_T, float *__restrict__ fitness,
-    int32_t *__restrict__ best, float *__restrict__ T_best, uint8_t *__restrict__ labels)
+// Seed hypotheses in three small launches over (seed, pair) instead of one workgroup per pair:
+//   power    one wave per (seed, pair): the leading eigenvector iteration of the k x k compatibility matrix with the row of M
+//            in registers; ALL num_iterations iterates and their closeness flags are stored, because the reference stops every
+//            seed of a pair at the first iteration at which all of them are close (PointDSC.py:347-357, joint allclose)
+//   solve    one wave per (seed, pair): picks that joint iteration, normalises the weights, weighted Kabsch on the k neighbours,
+//            fitness over all n correspondences
+//   select   one workgroup per pair: first-argmax over the seeds, best transform, labels
+// Arithmetic per seed is unchanged from the single-workgroup version (seeds only interact through the stopping iteration).
+constexpr int HYP_MAX_IT = 16;
+__global__ __launch_bounds__(64) void pdsc_power_kernel(const int32_t *__restrict__ n_rows, const int32_t *__restrict__ n_seeds,
+                                                         int S_cap, int k_cfg, int num_iterations, const float *__restrict__ Mmat,
+                                                         float *__restrict__ v_hist /*[B,S_cap,it,64]*/,
+                                                         int32_t *__restrict__ close_hist /*[B,S_cap,it]*/)
 {
-    extern __shared__ float sm[];
-    float *v_cur = sm;                          // [S_cap][64]
-    float *v_last = v_cur + S_cap * KNN_MAX_K;  // [S_cap][64]
-    float *s_fit = v_last + S_cap * KNN_MAX_K;  // [S_cap]
-    int *s_flag = reinterpret_cast<int *>(s_fit + S_cap);  // [S_cap] closeness per seed
-    float *s_T = s_fit + 2 * S_cap;             // [S_cap][16] per-seed transforms
-    __shared__ int s_all_close;
+    const int b = blockIdx.y, s = blockIdx.x, lane = threadIdx.x;
+    if (s >= n_seeds[b]) return;
+    const int n = n_rows[b];
+    const int k = k_cfg < n - 1 ? k_cfg : n - 1;
+    __shared__ float v_sh[KNN_MAX_K];
+    float mrow[KNN_MAX_K];
+    const float *Ms = Mmat + ((size_t)b * S_cap + s) * k_cfg * k_cfg;
+#pragma unroll
+    for (int c = 0; c < KNN_MAX_K; ++c) mrow[c] = (lane < k && c < k) ? Ms[lane * k_cfg + c] : 0.0f;
+    float vl = 1.0f;
+    for (int it = 0; it < num_iterations; ++it) {
+        v_sh[lane] = vl;
+        __syncthreads();
+        float u = 0.0f;
+#pragma unroll
+        for (int c = 0; c < KNN_MAX_K; ++c)
+            if (c < k) u = fmaf(mrow[c], v_sh[c], u);
+        __syncthreads();
+        if (lane >= k) u = 0.0f;
+        float sq = u * u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+        const float vn = u / (__fsqrt_rn(sq) + 1e-6f);
+        const bool close = (lane >= k) || (fabsf(vn - vl) <= 1e-8f + 1e-5f * fabsf(vl));
+        const bool all = __all(close);
+        const size_t h = ((size_t)b * S_cap + s) * num_iterations + it;
+        v_hist[h * KNN_MAX_K + lane] = vn;
+        if (lane == 0) close_hist[h] = all ? 1 : 0;
+        vl = (lane < k) ? vn : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(64) void pdsc_seed_solve_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                              const int32_t *__restrict__ n_rows, int n_cap,
+                                                              const int32_t *__restrict__ n_seeds, int S_cap, int k_cfg,
+                                                              int num_iterations, float inlier_thr, const int32_t *__restrict__ knn,
+                                                              const float *__restrict__ v_hist, const int32_t *__restrict__ close_hist,
+                                                              float *__restrict__ seed_T, float *__restrict__ fitness)
+{
+    const int b = blockIdx.y, s = blockIdx.x, lane = threadIdx.x;
+    const int S = n_seeds[b];
+    if (s >= S) return;
+    const int n = n_rows[b];
+    const int k = k_cfg < n - 1 ? k_cfg : n - 1;
+    // joint stopping iteration: the first one at which every seed of the pair is close (else the last)
+    int stop = num_iterations - 1;
+    for (int it = 0; it < num_iterations; ++it) {
+        int ok = 1;
+        for (int q = lane; q < S; q += 64) ok &= close_hist[((size_t)b * S_cap + q) * num_iterations + it];
+        if (__all(ok)) { stop = it; break; }
+    }
+    const float *sp = src + (size_t)b * n_cap * 3, *tp = tgt + (size_t)b * n_cap * 3;
+    const float vv = lane < k ? v_hist[(((size_t)b * S_cap + s) * num_iterations + stop) * KNN_MAX_K + lane] : 0.0f;
+    float sum = vv;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    float w = vv / (sum + 1e-6f);
+    w = w < 0.0f ? 0.0f : w;
+    KabschAcc acc;
+    acc.clear();
+    if (lane < k) {
+        const int j = knn[((size_t)b * S_cap + s) * k_cfg + lane];
+        acc.add(sp[3 * j], sp[3 * j + 1], sp[3 * j + 2], tp[3 * j], tp[3 * j + 1], tp[3 * j + 2], w);
+    }
+    acc.wave_reduce();
+    float T[16];
+    acc.solve(T);
+    int cnt = 0;
+    for (int j = lane; j < n; j += 64) {
+        const float x = sp[3 * j], y = sp[3 * j + 1], z = sp[3 * j + 2];
+        const float dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - tp[3 * j];
+        const float dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - tp[3 * j + 1];
+        const float dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - tp[3 * j + 2];
+        cnt += (__fsqrt_rn(dx * dx + dy * dy + dz * dz) < inlier_thr) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) {
+        fitness[(size_t)b * S_cap + s] = (float)cnt / (float)n;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) seed_T[((size_t)b * S_cap + s) * 16 + i] = T[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void pdsc_seed_select_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                                const int32_t *__restrict__ n_rows, int n_cap,
+                                                                const int32_t *__restrict__ n_seeds, int S_cap, float inlier_thr,
+                                                                const float *__restrict__ seed_T, const float *__restrict__ fitness,
+                                                                int32_t *__restrict__ best, float *__restrict__ T_best,
+                                                                uint8_t *__restrict__ labels)
+{
     __shared__ int s_best;
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x, t = threadIdx.x;
     const int n = n_rows[b], S = n_seeds[b];
     if (S <= 0) {
         if (t == 0) best[b] = -1;
         return;
     }
-    const int k = k_cfg < n - 1 ? k_cfg : n - 1;
-    const float *sp = src + (size_t)b * n_cap * 3, *tp = tgt + (size_t)b * n_cap * 3;
-    for (int e = t; e < S * KNN_MAX_K; e += HYP_THREADS) { v_cur[e] = 1.0f; v_last[e] = 1.0f; }
-    __syncthreads();
-    // power iteration (PointDSC.py:347-357); the allclose test is over ALL seeds of the pair jointly
-    for (int it = 0; it < num_iterations; ++it) {
-        for (int s = wave; s < S; s += HYP_WAVES) {
-            const float *Ms = Mmat + ((size_t)b * S_cap + s) * k_cfg * k_cfg;
-            float u = 0.0f;
-            if (lane < k)
-                for (int c = 0; c < k; ++c) u = fmaf(Ms[lane * k_cfg + c], v_last[s * KNN_MAX_K + c], u);
-            float sq = (lane < k) ? u * u : 0.0f;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
-            const float vn = u / (__fsqrt_rn(sq) + 1e-6f);
-            const float vl = v_last[s * KNN_MAX_K + (lane < k ? lane : 0)];
-            const bool close = (lane >= k) || (fabsf(vn - vl) <= 1e-8f + 1e-5f * fabsf(vl));
-            const bool all = __all(close);
-            if (lane < k) v_cur[s * KNN_MAX_K + lane] = vn;
-            if (lane == 0) s_flag[s] = all ? 1 : 0;
-        }
-        __syncthreads();
-        if (t == 0) {
-            int ok = 1;
-            for (int s = 0; s < S; ++s) ok &= s_flag[s];
-            s_all_close = ok;
-        }
-        for (int e = t; e < S * KNN_MAX_K; e += HYP_THREADS) v_last[e] = v_cur[e];
-        __syncthreads();
-        if (s_all_close) break;
-    }
-    // per seed: normalise weights, weighted Kabsch on the k neighbours, fitness over all n correspondences
-    for (int s = wave; s < S; s += HYP_WAVES) {
-        const float vv = lane < k ? v_last[s * KNN_MAX_K + lane] : 0.0f;
-        float sum = vv;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-        float w = vv / (sum + 1e-6f);
-        w = w < 0.0f ? 0.0f : w;
-        KabschAcc acc;
-        acc.clear();
-        if (lane < k) {
-            const int j = knn[((size_t)b * S_cap + s) * k_cfg + lane];
-            acc.add(sp[3 * j], sp[3 * j + 1], sp[3 * j + 2], tp[3 * j], tp[3 * j + 1], tp[3 * j + 2], w);
-        }
-        acc.wave_reduce();
-        float T[16];
-        acc.solve(T);   // every lane solves the same 3x3 (keeps T in registers for the fitness pass)
-        int cnt = 0;
-        for (int j = lane; j < n; j += 64) {
-            const float x = sp[3 * j], y = sp[3 * j + 1], z = sp[3 * j + 2];
-            const float dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - tp[3 * j];
-            const float dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - tp[3 * j + 1];
-            const float dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - tp[3 * j + 2];
-            cnt += (__fsqrt_rn(dx * dx + dy * dy + dz * dz) < inlier_thr) ? 1 : 0;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-        if (lane == 0) {
-            const float f = (float)cnt / (float)n;
-            s_fit[s] = f;
-            fitness[(size_t)b * S_cap + s] = f;
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s_T[s * 16 + i] = T[i];
-                seed_T[((size_t)b * S_cap + s) * 16 + i] = T[i];
-            }
-        }
-    }
-    __syncthreads();
     if (t == 0) {
         int bi = 0;
-        float bf = s_fit[0];
-        for (int s = 1; s < S; ++s)
-            if (s_fit[s] > bf) { bf = s_fit[s]; bi = s; }   // first maximum, as torch.argmax
+        float bf = fitness[(size_t)b * S_cap];
+        for (int s = 1; s < S; ++s) {
+            const float f = fitness[(size_t)b * S_cap + s];
+            if (f > bf) { bf = f; bi = s; }                 // first maximum, as torch.argmax
+        }
         s_best = bi;
         best[b] = bi;
     }
     __syncthreads();
     float T[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) T[i] = s_T[s_best * 16 + i];
+    for (int i = 0; i < 16; ++i) T[i] = seed_T[((size_t)b * S_cap + s_best) * 16 + i];
     if (t < 16) T_best[(size_t)b * 16 + t] = T[t];
+    const float *sp = src + (size_t)b * n_cap * 3, *tp = tgt + (size_t)b * n_cap * 3;
     if (labels)
-        for (int j = t; j < n_cap; j += HYP_THREADS) {
+        for (int j = t; j < n_cap; j += 256) {
             uint8_t lab = 0;
             if (j < n) {
                 const float x = sp[3 * j], y = sp[3 * j + 1], z = sp[3 * j + 2];
@@ -401,9 +421,12 @@ int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float
     hipLaunchKernelGGL(pdsc_knn_matrix_kernel, dim3(S_cap, B), dim3(256), sh1, st, feat_n, src, tgt, n_rows, n_cap, C, seeds,
                        n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat);
     if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
-    const size_t sh2 = ((size_t)2 * S_cap * KNN_MAX_K + 2 * S_cap + 16 * S_cap) * sizeof(float);
-    hipLaunchKernelGGL(pdsc_hypotheses_kernel, dim3(B), dim3(HYP_THREADS), sh2, st, src, tgt, n_rows, n_cap, n_seeds, S_cap, k,
-                       M.cfg.num_iterations, M.cfg.inlier_threshold, ws.knn, ws.Mmat, seed_T, fitness, best, T_best, labels);
+    const int nit = M.cfg.num_iterations < HYP_MAX_IT ? M.cfg.num_iterations : HYP_MAX_IT;
+    hipLaunchKernelGGL(pdsc_power_kernel, dim3(S_cap, B), dim3(64), 0, st, n_rows, n_seeds, S_cap, k, nit, ws.Mmat, ws.v_hist, ws.close_hist);
+    hipLaunchKernelGGL(pdsc_seed_solve_kernel, dim3(S_cap, B), dim3(64), 0, st, src, tgt, n_rows, n_cap, n_seeds, S_cap, k, nit,
+                       M.cfg.inlier_threshold, ws.knn, ws.v_hist, ws.close_hist, seed_T, fitness);
+    hipLaunchKernelGGL(pdsc_seed_select_kernel, dim3(B), dim3(256), 0, st, src, tgt, n_rows, n_cap, n_seeds, S_cap, M.cfg.inlier_threshold,
+                       seed_T, fitness, best, T_best, labels);
     return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
 }
 

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(GN_ROWS) void gather_normalise_kernel(const float *
 // Phases of different workgroups overlap on a CU (4 workgroups at C_pad = 256); a register-staged software pipeline inside a
 // persistent workgroup (next tile's loads in flight under norm + stores) measured only 5-7 % faster on the same GPU and was
 // not kept.
-constexpr int G2_ROWS = 64;        // zero-fill granularity of the row capacity (callers pad caps to 256)
+// (callers pad row capacities to 256: the zero-fill granularity)
 template <int NL, int ROWS>        // NL: channel loads in flight per lane; ROWS: ROI rows per workgroup (32 or 64)
 __global__ __launch_bounds__(256) void gather_normalise_v2_kernel(const float *__restrict__ feat, int C, int HW,
                                                                    const int32_t *__restrict__ roi, int roi_stride,
