@@ -38,6 +38,7 @@ struct PdscWorkspace {
     float *h1, *h2;   // [B,n_cap,max(C/2,32)]
     float *feat_n;    // [B,n_cap,C]
     float *conf;      // [B,n_cap]
+    float *seed_key;  // [B,n_cap] NMS keys
     int32_t *seeds;   // [B,S_cap]
     int32_t *n_seeds; // [B]
     int32_t *knn;     // [B,S_cap,k]
@@ -73,7 +74,7 @@ void pdsc_launch_normalise(const float *feat, int C, int n_cap, int B, const int
 int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *src, const float *tgt, const int32_t *n_rows,
                      int B, int n_cap, hipStream_t st);
 int pdsc_run_seeds(const PdscModel &M, const float *src, const float *conf, const int32_t *n_rows, int B, int n_cap, int S_cap,
-                   int32_t *seeds, int32_t *n_seeds, hipStream_t st);
+                   int32_t *seeds, int32_t *n_seeds, float *key_scratch, hipStream_t st);
 int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float *src, const float *tgt, const float *feat_n,
                         const int32_t *n_rows, const int32_t *seeds, const int32_t *n_seeds, int B, int n_cap, float *seed_T,
                         float *fitness, int32_t *best, float *T_best, uint8_t *labels, hipStream_t st);

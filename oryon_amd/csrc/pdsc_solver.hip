@@ -18,45 +18,80 @@ namespace oryon {
 
 // ------------------------------------------------------------------------------------------------ K5
 // is_local_max_i = AND_j (score_i >= score_j  OR  |s_i - s_j| >= R);  seeds = first S of the descending
-// order of score * is_local_max.  One workgroup per pair; O(n^2) compares out of LDS.
-__global__ __launch_bounds__(512) void pdsc_seeds_kernel(const float *__restrict__ src, const float *__restrict__ conf,
-                                                          const int32_t *__restrict__ n_rows, int n_cap, int S_cap,
-                                                          float radius, float ratio, int32_t *__restrict__ seeds,
-                                                          int32_t *__restrict__ n_seeds)
+// order of score * is_local_max (ties by ascending index).
+//   pdsc_seed_keys_kernel  (n_cap/64 x B workgroups)  the O(n^2) NMS test: 4 lanes per row, each a quarter of the j range
+//   pdsc_seed_rank_kernel  (B workgroups)             bitonic sort of (key, index), first S indices
+__global__ __launch_bounds__(256) void pdsc_seed_keys_kernel(const float *__restrict__ src, const float *__restrict__ conf,
+                                                              const int32_t *__restrict__ n_rows, int n_cap, float radius,
+                                                              float *__restrict__ key)
 {
     extern __shared__ float sm[];
-    float *px = sm, *py = sm + n_cap, *pz = sm + 2 * n_cap, *sc = sm + 3 * n_cap, *key = sm + 4 * n_cap;
-    const int b = blockIdx.x, t = threadIdx.x;
+    float *px = sm, *py = sm + n_cap, *pz = sm + 2 * n_cap, *sc = sm + 3 * n_cap;
+    const int b = blockIdx.y, t = threadIdx.x;
     const int n = n_rows[b];
-    int S = (int)((double)n * (double)ratio);
-    S = S < S_cap ? S : S_cap;
-    for (int i = t; i < n; i += blockDim.x) {
+    if ((int)blockIdx.x * 64 >= n) return;
+    for (int i = t; i < n; i += 256) {
         px[i] = src[((size_t)b * n_cap + i) * 3 + 0];
         py[i] = src[((size_t)b * n_cap + i) * 3 + 1];
         pz[i] = src[((size_t)b * n_cap + i) * 3 + 2];
         sc[i] = conf[(size_t)b * n_cap + i];
     }
     __syncthreads();
-    for (int i = t; i < n; i += blockDim.x) {
-        const float x = px[i], y = py[i], z = pz[i], s = sc[i];
-        bool lm = true;
-        for (int j = 0; j < n; ++j) {
+    const int i = blockIdx.x * 64 + (t >> 2), part = t & 3;
+    bool lm = true;
+    float s = 0.0f;
+    if (i < n) {
+        const float x = px[i], y = py[i], z = pz[i];
+        s = sc[i];
+        const int per = (n + 3) / 4, j0 = part * per, j1 = (j0 + per < n) ? j0 + per : n;
+        for (int j = j0; j < j1; ++j) {
             const float dx = x - px[j], dy = y - py[j], dz = z - pz[j];
             const float d = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
             lm = lm && ((s >= sc[j]) || (d >= radius));
         }
-        key[i] = s * (lm ? 1.0f : 0.0f);
+    }
+    int ok = lm ? 1 : 0;
+    ok &= __shfl_xor(ok, 1);
+    ok &= __shfl_xor(ok, 2);
+    if (i < n && part == 0) key[(size_t)b * n_cap + i] = s * (ok ? 1.0f : 0.0f);
+}
+
+__global__ __launch_bounds__(256) void pdsc_seed_rank_kernel(const float *__restrict__ key_in, const int32_t *__restrict__ n_rows,
+                                                              int n_cap, int S_cap, float ratio, int32_t *__restrict__ seeds,
+                                                              int32_t *__restrict__ n_seeds)
+{
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int n = n_rows[b];
+    int S = (int)((double)n * (double)ratio);
+    S = S < S_cap ? S : S_cap;
+    int P = 256;
+    while (P < n) P <<= 1;
+    float *key = sm;                                   // [P]
+    int *order = reinterpret_cast<int *>(sm + P);       // [P]
+    for (int j = t; j < P; j += 256) {
+        key[j] = j < n ? key_in[(size_t)b * n_cap + j] : -INFINITY;
+        order[j] = j;
     }
     __syncthreads();
-    for (int i = t; i < n; i += blockDim.x) {
-        const float k = key[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const float kj = key[j];
-            rank += (kj > k || (kj == k && j < i)) ? 1 : 0;
+    // descending by key, ties by ascending index (what a stable descending sort gives)
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = t; e < P / 2; e += 256) {
+                const int lo = 2 * e - (e & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const float kl = key[lo], kh = key[hi];
+                const int il = order[lo], ih = order[hi];
+                const bool hi_first = (kh > kl) || (kh == kl && ih < il);      // hi belongs before lo
+                if (hi_first == up) {
+                    key[lo] = kh; key[hi] = kl;
+                    order[lo] = ih; order[hi] = il;
+                }
+            }
+            __syncthreads();
         }
-        if (rank < S) seeds[(size_t)b * S_cap + rank] = i;
     }
+    for (int r = t; r < S; r += 256) seeds[(size_t)b * S_cap + r] = order[r];
     if (t == 0) n_seeds[b] = S;
 }
 
@@ -402,11 +437,14 @@ __global__ __launch_bounds__(256) void pdsc_refine_kernel(const float *__restric
 
 // ------------------------------------------------------------------------------------------------ host side
 int pdsc_run_seeds(const PdscModel &M, const float *src, const float *conf, const int32_t *n_rows, int B, int n_cap, int S_cap,
-                   int32_t *seeds, int32_t *n_seeds, hipStream_t st)
+                   int32_t *seeds, int32_t *n_seeds, float *key_scratch /* [B,n_cap] */, hipStream_t st)
 {
-    const size_t sh = (size_t)5 * n_cap * sizeof(float);
-    hipLaunchKernelGGL(pdsc_seeds_kernel, dim3(B), dim3(512), sh, st, src, conf, n_rows, n_cap, S_cap, M.cfg.nms_radius,
-                       M.cfg.ratio, seeds, n_seeds);
+    size_t P = 256;
+    while (P < (size_t)n_cap) P <<= 1;
+    hipLaunchKernelGGL(pdsc_seed_keys_kernel, dim3(n_cap / 64, B), dim3(256), (size_t)4 * n_cap * sizeof(float), st, src, conf, n_rows, n_cap,
+                       M.cfg.nms_radius, key_scratch);
+    hipLaunchKernelGGL(pdsc_seed_rank_kernel, dim3(B), dim3(256), 2 * P * sizeof(float), st, key_scratch, n_rows, n_cap, S_cap, M.cfg.ratio,
+                       seeds, n_seeds);
     return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
 }
 

@@ -12,6 +12,8 @@ struct oryon_pointdsc {
     oryon_pointdsc_config_t cfg;
     std::map<std::string, std::vector<float>> host;   // raw tensors by reference name
     float *dev_blob = nullptr;
+    float *seed_scratch = nullptr;      // oryon_pointdsc_seeds (stage API, no workspace argument): grown on demand
+    size_t seed_scratch_floats = 0;
     PdscModel model;
     bool finalized = false;
 };
@@ -53,6 +55,7 @@ size_t carve(const oryon_pointdsc_config_t &cfg, int B, int n_cap, void *ws_ptr,
     w.h2 = c.take<float>(rows * Hh);
     w.feat_n = c.take<float>(rows * C);
     w.conf = c.take<float>(rows);
+    w.seed_key = c.take<float>(rows);
     w.seeds = c.take<int32_t>((size_t)B * S_cap);
     w.n_seeds = c.take<int32_t>(B);
     w.knn = c.take<int32_t>((size_t)B * S_cap * k);
@@ -135,6 +138,7 @@ extern "C" void oryon_pointdsc_destroy(oryon_pointdsc_t *h)
 {
     if (!h) return;
     if (h->dev_blob) (void)hipFree(h->dev_blob);
+    if (h->seed_scratch) (void)hipFree(h->seed_scratch);
     delete h;
 }
 
@@ -279,7 +283,7 @@ extern "C" int oryon_pointdsc_register(oryon_pointdsc_t *h, const float *src, co
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
     if ((rc = pdsc_run_encoder(h->model, ws, src, tgt, n, B, n_cap, st))) { set_error("pointdsc encoder launch failed"); return rc; }
-    if ((rc = pdsc_run_seeds(h->model, src, ws.conf, n, B, n_cap, ws.S_cap, ws.seeds, ws.n_seeds, st))) { set_error("pointdsc seeds launch failed"); return rc; }
+    if ((rc = pdsc_run_seeds(h->model, src, ws.conf, n, B, n_cap, ws.S_cap, ws.seeds, ws.n_seeds, ws.seed_key, st))) { set_error("pointdsc seeds launch failed"); return rc; }
     if ((rc = pdsc_run_hypotheses(h->model, ws, src, tgt, ws.feat_n, n, ws.seeds, ws.n_seeds, B, n_cap, ws.seed_T, ws.fitness,
                                   ws.best, ws.T0, labels, st))) { set_error("pointdsc hypotheses launch failed"); return rc; }
     if ((rc = pdsc_run_refine(h->model, src, tgt, n, B, n_cap, ws.T0, status_in, ws.n_seeds, T, status_out, st))) { set_error("pointdsc refine launch failed"); return rc; }
@@ -307,7 +311,15 @@ extern "C" int oryon_pointdsc_seeds(oryon_pointdsc_t *h, const float *src, const
 {
     PDSC_COMMON_CHECKS();
     ORYON_CHECK_ARG(src && confidence && n && seeds && n_seeds && S_cap >= pdsc_seed_cap(h->cfg, n_cap));
-    int rc = pdsc_run_seeds(h->model, src, confidence, n, B, n_cap, S_cap, seeds, n_seeds, as_stream(stream));
+    const size_t need = (size_t)B * n_cap;
+    if (need > h->seed_scratch_floats) {
+        if (h->seed_scratch) (void)hipFree(h->seed_scratch);
+        h->seed_scratch = nullptr;
+        h->seed_scratch_floats = 0;
+        ORYON_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&h->seed_scratch), need * sizeof(float)));
+        h->seed_scratch_floats = need;
+    }
+    int rc = pdsc_run_seeds(h->model, src, confidence, n, B, n_cap, S_cap, seeds, n_seeds, h->seed_scratch, as_stream(stream));
     if (rc) set_error("pointdsc seeds launch failed");
     return rc;
 }
