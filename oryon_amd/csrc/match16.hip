@@ -284,8 +284,12 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
     // a_scale8 != nullptr: the (m1, slice, m2) triples come from the INT8 screening pass (K1s8) in units of 2^-E_a per anchor
     // slice; margin and validity cut then follow the per-anchor int8 bound DELTA8 (see the header of the int8 kernel).
     constexpr int NQB = ROWS_TILE / 32;
-    const int p = blockIdx.y, a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (a >= n_a[p]) return;
+    // 16 anchors per wave: an empty launch (the fp16 stage behind K1s8 usually has nothing to do) costs 5 k workgroups, not 80 k
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
+    const int n_anchors = n_a[p];
+    const float valid_cut_in = valid_cut;
+    auto one_anchor = [&](const int a) {
+    float valid_cut = valid_cut_in;
     const size_t arow = (size_t)p * cap_a + a;
     float m1 = -INFINITY, m2 = -INFINITY;
     int sid = 0;
@@ -380,6 +384,12 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
     const unsigned long long b = __ballot(hit);
     if (hit) cand[arow * SCREEN_CAP + __popcll(b & ((1ull << lane) - 1ull))] = q;
     if (lane == 0) cnt[arow] = __popcll(b);
+    };
+    for (int g = 0; g < 16; ++g) {
+        const int a = (blockIdx.x * 16 + g) * 4 + (threadIdx.x >> 6);
+        if (a >= n_anchors) break;
+        one_anchor(a);
+    }
 }
 
 // gather the fp16 rows (and thresholds) of the ambiguous anchors into a dense panel layout for the second pass
@@ -388,13 +398,17 @@ __global__ __launch_bounds__(256) void match_compact_kernel(const __half *__rest
                                                              const float *__restrict__ m_final, __half *__restrict__ a16c,
                                                              float *__restrict__ amb_max)
 {
-    const int p = blockIdx.y, sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (sl >= n_amb[p]) return;
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
+    const int n_sl = n_amb[p];
+    for (int g = 0; g < 16; ++g) {
+    const int sl = (blockIdx.x * 16 + g) * 4 + (threadIdx.x >> 6);
+    if (sl >= n_sl) break;
     const int a = amb_idx[(size_t)p * cap_a + sl];
     const uint4 *src = reinterpret_cast<const uint4 *>(a16 + ((size_t)p * cap_a + a) * Cp);
     uint4 *dst = reinterpret_cast<uint4 *>(a16c + ((size_t)p * cap_a + sl) * Cp);
     for (int i = lane; i < Cp / 8; i += 64) dst[i] = src[i];
     if (lane == 0) amb_max[(size_t)p * cap_a + sl] = m_final[(size_t)p * cap_a + a];
+    }
 }
 
 // pass 2: L lanes per anchor row, candidates strided over them; canonical fp32 chain on the k-permuted fp32 rows.  Almost
@@ -668,15 +682,17 @@ __global__ __launch_bounds__(256) void match_compact8_kernel(const float *__rest
                                                               const int32_t *__restrict__ amb_idx, float *__restrict__ a_hat_c,
                                                               __half *__restrict__ a16_c)
 {
-    const int p = blockIdx.y, sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
     const int n_fill = (n_amb[p] + 255) / 256 * 256;               // the fp16 kernels read whole 256-anchor panels: zero-fill the tail
-    if (sl >= n_fill) return;
+    for (int g = 0; g < 16; ++g) {
+    const int sl = (blockIdx.x * 16 + g) * 4 + (threadIdx.x >> 6);
+    if (sl >= n_fill) break;
     uint4 *d32 = reinterpret_cast<uint4 *>(a_hat_c + ((size_t)p * cap_a + sl) * Cp);
     uint4 *d16 = reinterpret_cast<uint4 *>(a16_c + ((size_t)p * cap_a + sl) * Cp);
     if (sl >= n_amb[p]) {
         for (int i = lane; i < Cp / 4; i += 64) d32[i] = make_uint4(0, 0, 0, 0);
         for (int i = lane; i < Cp / 8; i += 64) d16[i] = make_uint4(0, 0, 0, 0);
-        return;
+        continue;
     }
     const int a = amb_idx[(size_t)p * cap_a + sl];
     const uint4 *s32 = reinterpret_cast<const uint4 *>(a_hat + ((size_t)p * cap_a + a) * Cp);
@@ -684,6 +700,7 @@ __global__ __launch_bounds__(256) void match_compact8_kernel(const float *__rest
     for (int i = lane; i < Cp / 4; i += 64) d32[i] = s32[i];
     const float4 *f32 = reinterpret_cast<const float4 *>(s32);
     for (int g = lane; g < Cp / 8; g += 64) d16[g] = half_group_from_permuted(f32[2 * g], f32[2 * g + 1]);
+    }
 }
 
 __global__ __launch_bounds__(256) void match_scatter8_kernel(int cap_a, const int32_t *__restrict__ n_amb,
@@ -834,12 +851,12 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
         profile_end(st);
         ORYON_CHECK_LAUNCH();
         if (C >= 256)
-            hipLaunchKernelGGL((match_decide_kernel<64>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
+            hipLaunchKernelGGL((match_decide_kernel<64>), dim3(cap_a / 64, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
                                valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr);
         else
-            hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
+            hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 64, B), dim3(256), 0, st, a16, q16, C, cap_a, cap_q, n_a, n_q, S,
                                valid_cut, w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr);
-        hipLaunchKernelGGL(match_compact_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a16, C, cap_a, w.n_amb, w.amb_idx, w.m_final,
+        hipLaunchKernelGGL(match_compact_kernel, dim3(cap_a / 64, B), dim3(256), 0, st, a16, C, cap_a, w.n_amb, w.amb_idx, w.m_final,
                            w.a16c, w.amb_max);
         if (C == 256) LAUNCH16_AMB(256); else if (C == 512) LAUNCH16_AMB(512); else LAUNCH16_AMB(128);
         m_final = w.m_final;
@@ -943,7 +960,7 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
     else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     profile_end(st);
     ORYON_CHECK_LAUNCH();
-    hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 4, B), dim3(256), 0, st, static_cast<const __half *>(nullptr),
+    hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 64, B), dim3(256), 0, st, static_cast<const __half *>(nullptr),
                        static_cast<const __half *>(nullptr), C, cap_a, cap_q, n_a, n_q, S, valid_cut16,
                        w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, a_scale, nullptr, q_eps_max, cut0,
                        sqrtf((float)C_true), (float)C_true, a_i8, q_i8, q_scale);
@@ -957,9 +974,9 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
     if (n_undecided) ORYON_CHECK_HIP(hipMemcpyAsync(n_undecided, w.n_amb, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     // anchors the int8 stage could not decide: complete fp16 pipeline on the compacted set, results scattered back
     // (their fp16 operands are made here, and only for pairs that have such anchors: K0 does not write fp16 rows for this path)
-    hipLaunchKernelGGL(match_compact8_kernel, dim3(cap_a / 4, B), dim3(256), 0, st, a_hat, static_cast<const __half *>(nullptr), C, cap_a,
+    hipLaunchKernelGGL(match_compact8_kernel, dim3(cap_a / 64, B), dim3(256), 0, st, a_hat, static_cast<const __half *>(nullptr), C, cap_a,
                        w.n_amb, w.amb_idx, w8.a_hat_c, w.a16c);
-    hipLaunchKernelGGL(match_make_q16_kernel, dim3(512, B), dim3(256), 0, st, q_hat, C, cap_q, n_q, w.n_amb, w8.q16);
+    hipLaunchKernelGGL(match_make_q16_kernel, dim3(64, B), dim3(256), 0, st, q_hat, C, cap_q, n_q, w.n_amb, w8.q16);
     ORYON_CHECK_LAUNCH();
     rc = oryon_match_screened(w8.a_hat_c, q_hat, w.a16c, w8.q16, B, C, cap_a, cap_q, w.n_amb, n_q, threshold, w8.md_c, w8.am_c, w8.va_c,
                               w8.nested, w8.nested_bytes, stream);
