@@ -44,6 +44,7 @@ struct PdscWorkspace {
     int32_t *knn;     // [B,S_cap,k]
     float *Mmat;      // [B,S_cap,k,k]
     float *seed_w;    // [B,S_cap,k]
+    float *seed_dist; // [B,S_cap,n_cap] feature distances seed -> every row
     float *v_hist;    // [B,S_cap,16,64] power-iteration iterates
     int32_t *close_hist;  // [B,S_cap,16] per-iteration closeness flags
     float *seed_T;    // [B,S_cap,16]

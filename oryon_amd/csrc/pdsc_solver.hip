@@ -99,13 +99,53 @@ __global__ __launch_bounds__(256) void pdsc_seed_rank_kernel(const float *__rest
 // One workgroup per (seed, pair): feature-space kNN of the seed row, then the k x k compatibility matrix
 //   M_ab = clamp(1 - (1 - f_a.f_b)/sigma^2, 0) * clamp(1 - (|s_a-s_b| - |t_a-t_b|)^2/sigma_d^2, 0),  M_aa = 0.
 constexpr int KNN_MAX_K = 64;
+// 2 - 2 f_seed.f_j for every (seed, row) of a pair, with the feature matrix read once per 64-row block instead of once per seed:
+// grid (n_cap/64, B), 4 lanes per row (each a quarter of the seeds), the row's C values in registers, seed features in LDS.
+// The dot product is the same k-ordered fmaf chain the per-seed kernel used.
+template <int C>
+__global__ __launch_bounds__(256) void pdsc_seed_dist_kernel(const float *__restrict__ feat_n, const int32_t *__restrict__ n_rows, int n_cap,
+                                                              const int32_t *__restrict__ seeds, const int32_t *__restrict__ n_seeds,
+                                                              int S_cap, float *__restrict__ dist /*[B,S_cap,n_cap]*/)
+{
+    extern __shared__ float fs[];           // [S][C]
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int n = n_rows[b], S = n_seeds[b];
+    if ((int)blockIdx.x * 64 >= n || S <= 0) return;
+    const float *F = feat_n + (size_t)b * n_cap * C;
+    for (int e = t; e < S * C; e += 256) fs[e] = F[(size_t)seeds[(size_t)b * S_cap + e / C] * C + e % C];
+    __syncthreads();
+    const int j = blockIdx.x * 64 + (t >> 2), part = t & 3;
+    if (j >= n) return;
+    float row[C];
+    const float4 *rp = reinterpret_cast<const float4 *>(F + (size_t)j * C);
+#pragma unroll
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+        const float4 v = rp[c4];
+        row[4 * c4] = v.x; row[4 * c4 + 1] = v.y; row[4 * c4 + 2] = v.z; row[4 * c4 + 3] = v.w;
+    }
+    for (int s = part; s < S; s += 4) {
+        const float4 *f4 = reinterpret_cast<const float4 *>(fs + s * C);
+        float acc = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const float4 f = f4[c4];
+            acc = fmaf(f.x, row[4 * c4], acc);
+            acc = fmaf(f.y, row[4 * c4 + 1], acc);
+            acc = fmaf(f.z, row[4 * c4 + 2], acc);
+            acc = fmaf(f.w, row[4 * c4 + 3], acc);
+        }
+        dist[((size_t)b * S_cap + s) * n_cap + j] = 2.0f - 2.0f * acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__restrict__ feat_n, const float *__restrict__ src,
                                                                const float *__restrict__ tgt,
                                                                const int32_t *__restrict__ n_rows, int n_cap, int C,
                                                                const int32_t *__restrict__ seeds,
                                                                const int32_t *__restrict__ n_seeds, int S_cap, int k_cfg,
                                                                float inv_sigma2, float inv_sigma_d2,
-                                                               int32_t *__restrict__ knn_out, float *__restrict__ M_out)
+                                                               int32_t *__restrict__ knn_out, float *__restrict__ M_out,
+                                                               const float *__restrict__ dist_pre /* [B,S_cap,n_cap] or NULL */)
 {
     extern __shared__ float sm[];
     const int b = blockIdx.y, s = blockIdx.x;
@@ -117,8 +157,8 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
     float *dist = sm;                       // [P] sort keys
     int *order = reinterpret_cast<int *>(dist + P);           // [P] row indices, sorted along with the keys
     float *fs = reinterpret_cast<float *>(order + P);          // [C] seed feature
-    float *kf = fs + C;                     // [KNN_MAX_K][C+1]
-    float *kc = kf + KNN_MAX_K * (C + 1);   // [KNN_MAX_K][6]
+    float *kf = fs + C;                     // [KNN_MAX_K][C+4]: 16-byte aligned rows for the b128 reads of the matrix phase
+    float *kc = kf + KNN_MAX_K * (C + 4);   // [KNN_MAX_K][6]
     int *kidx = reinterpret_cast<int *>(kc + KNN_MAX_K * 6);  // [KNN_MAX_K]
     const int t = threadIdx.x;
     const int seed_row = seeds[(size_t)b * S_cap + s];
@@ -128,7 +168,9 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
     // 2 - 2 f_seed.f_j : one thread per row (16-byte loads, all of a row's loads independent), k-ordered fmaf chain
     for (int j = t; j < P; j += 256) {
         float d = INFINITY;
-        if (j < n) {
+        if (j < n && dist_pre) {
+            d = dist_pre[((size_t)b * S_cap + s) * n_cap + j];
+        } else if (j < n) {
             const float4 *row = reinterpret_cast<const float4 *>(F + (size_t)j * C);
             float acc = 0.0f;
             for (int c4 = 0; c4 < C / 4; c4 += 8) {
@@ -175,7 +217,7 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
     __syncthreads();
     for (int e = t; e < k * C; e += 256) {
         const int a = e / C, c = e % C;
-        kf[a * (C + 1) + c] = F[(size_t)kidx[a] * C + c];
+        kf[a * (C + 4) + c] = F[(size_t)kidx[a] * C + c];
     }
     for (int e = t; e < k * 3; e += 256) {
         const int a = e / 3, d = e % 3;
@@ -195,8 +237,14 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
         while ((a + 1) * (2 * k - a - 2) / 2 <= e) ++a;
         const int c2 = a + 1 + (e - a * (2 * k - a - 1) / 2);
         float dot = 0.0f;
-        const float *fa = kf + a * (C + 1), *fb = kf + c2 * (C + 1);
-        for (int c = 0; c < C; ++c) dot = fmaf(fa[c], fb[c], dot);
+        const float4 *fa = reinterpret_cast<const float4 *>(kf + a * (C + 4)), *fb = reinterpret_cast<const float4 *>(kf + c2 * (C + 4));
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const float4 x = fa[c4], y = fb[c4];
+            dot = fmaf(x.x, y.x, dot);
+            dot = fmaf(x.y, y.y, dot);
+            dot = fmaf(x.z, y.z, dot);
+            dot = fmaf(x.w, y.w, dot);
+        }
         float fm = 1.0f - (1.0f - dot) * inv_sigma2;
         fm = fm > 0.0f ? fm : 0.0f;
         const float *pa = kc + a * 6, *pb = kc + c2 * 6;
@@ -455,9 +503,15 @@ int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float
     const int C = M.cfg.num_channels, k = M.cfg.k, S_cap = ws.S_cap;
     size_t P = 256;
     while (P < (size_t)n_cap) P <<= 1;
-    const size_t sh1 = (2 * P + C + (size_t)KNN_MAX_K * (C + 1) + KNN_MAX_K * 6 + KNN_MAX_K) * sizeof(float);
+    const size_t sh1 = (2 * P + C + (size_t)KNN_MAX_K * (C + 4) + KNN_MAX_K * 6 + KNN_MAX_K) * sizeof(float);
+    const float *dist_pre = nullptr;
+    if (C == 128 && (size_t)S_cap * 128 * sizeof(float) <= 64 * 1024) {
+        hipLaunchKernelGGL((pdsc_seed_dist_kernel<128>), dim3(n_cap / 64, B), dim3(256), (size_t)S_cap * 128 * sizeof(float), st, feat_n, n_rows,
+                           n_cap, seeds, n_seeds, S_cap, ws.seed_dist);
+        dist_pre = ws.seed_dist;
+    }
     hipLaunchKernelGGL(pdsc_knn_matrix_kernel, dim3(S_cap, B), dim3(256), sh1, st, feat_n, src, tgt, n_rows, n_cap, C, seeds,
-                       n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat);
+                       n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, dist_pre);
     if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
     const int nit = M.cfg.num_iterations < HYP_MAX_IT ? M.cfg.num_iterations : HYP_MAX_IT;
     hipLaunchKernelGGL(pdsc_power_kernel, dim3(S_cap, B), dim3(64), 0, st, n_rows, n_seeds, S_cap, k, nit, ws.Mmat, ws.v_hist, ws.close_hist);

@@ -61,6 +61,7 @@ size_t carve(const oryon_pointdsc_config_t &cfg, int B, int n_cap, void *ws_ptr,
     w.knn = c.take<int32_t>((size_t)B * S_cap * k);
     w.Mmat = c.take<float>((size_t)B * S_cap * k * k);
     w.seed_w = c.take<float>((size_t)B * S_cap * k);
+    w.seed_dist = c.take<float>((size_t)B * S_cap * n_cap);
     w.v_hist = c.take<float>((size_t)B * S_cap * 16 * 64);
     w.close_hist = c.take<int32_t>((size_t)B * S_cap * 16);
     w.seed_T = c.take<float>((size_t)B * S_cap * 16);
