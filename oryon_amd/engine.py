@@ -53,6 +53,7 @@ class MatchPoseEngine:
         self.overlap = overlap_registration
         self.overlap_gather = overlap_gather
         self._reg_stream = None
+        self.reg_streams = 2
         self._gather_stream = None
         # adaptive use of the int8 pre-screen: the fraction of anchors it had to hand to the fp16 stage is read back
         # asynchronously (pinned buffer + event, never a sync); above `i8_max_undecided` the next batches skip the int8 stage
@@ -164,17 +165,23 @@ class MatchPoseEngine:
         cam_q = cam_q.reshape(B, 9).to(torch.float32).contiguous()
         pcd_a, pcd_q, n_lift = ops.lift_pairs(corrs, n_sel, (FH, FW), depth_a, depth_q, cam_a, cam_q, status)
         if self.overlap:
+            # registrations of consecutive batches alternate between two streams (and two workspaces): their many small,
+            # low-occupancy launches then overlap each other as well as the next batch's matching
             if self._reg_stream is None:
-                self._reg_stream = torch.cuda.Stream(device=dev)
+                self._reg_stream = [torch.cuda.Stream(device=dev) for _ in range(self.reg_streams)]
+                self._reg_turn = 0
+            slot = self._reg_turn % len(self._reg_stream)
+            self._reg_turn += 1
+            rs = self._reg_stream[slot]
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._reg_stream):
-                self._reg_stream.wait_event(ready)
+            with torch.cuda.stream(rs):
+                rs.wait_event(ready)
                 for t_ in (pcd_a, pcd_q, n_lift, status):
-                    t_.record_stream(self._reg_stream)
-                pose, _, status_out = self.solver.register(pcd_a, pcd_q, n_lift, status)
+                    t_.record_stream(rs)
+                pose, _, status_out = self.solver.register(pcd_a, pcd_q, n_lift, status, ws_slot=slot)
                 done = torch.cuda.Event()
-                done.record(self._reg_stream)
+                done.record(rs)
         else:
             pose, _, status_out = self.solver.register(pcd_a, pcd_q, n_lift, status)
             done = None

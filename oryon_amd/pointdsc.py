@@ -128,20 +128,26 @@ class PointDSC(nn.Module):
         except Exception:
             pass
 
-    def _workspace(self, B: int, n_cap: int, dev) -> Tensor:
+    def _workspace(self, B: int, n_cap: int, dev, slot: int = 0) -> Tensor:
+        """One cached workspace per slot: registrations that may run concurrently (different HIP streams) use different slots."""
         need = lib().oryon_pointdsc_workspace_bytes(self._handle, B, n_cap)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-        return self._ws
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+            self._ws[slot] = ws
+        return ws
 
     # ---- batched registration (the product path) ----------------------------------------------
-    def register(self, src: Tensor, tgt: Tensor, n: Tensor, status: Optional[Tensor] = None, want_labels: bool = False):
+    def register(self, src: Tensor, tgt: Tensor, n: Tensor, status: Optional[Tensor] = None, want_labels: bool = False,
+                 ws_slot: int = 0):
         """src,tgt [B,n_cap,3] fp32 CUDA (metres, n_cap % 128 == 0), n [B] int32 -> (T [B,4,4], labels|None, status [B])."""
         dev = _lib.require_gpu(src.device)
         self._ensure_handle(dev)
         B, n_cap = src.shape[0], src.shape[1]
         assert n_cap % N_ALIGN == 0 and src.dtype == torch.float32 and tgt.shape == src.shape
-        ws = self._workspace(B, n_cap, dev)
+        ws = self._workspace(B, n_cap, dev, ws_slot)
         T = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
         labels = torch.empty((B, n_cap), dtype=torch.uint8, device=dev) if want_labels else None
         st_out = torch.empty((B,), dtype=torch.int32, device=dev)
