@@ -425,6 +425,9 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
                 vv[o * 8 + e] = key < n_cap ? base[(size_t)key * 3 * C + 2 * C + vch] : 0.0f;
             }
         }
+    };
+    // the SC values of a tile are fetched right after the softmax of the previous one has consumed them (no second copy live)
+    auto fetch_sc = [&](int j0) {
         const float4 *sp = sc_q + (size_t)(j0 / ATT_KT) * 8 * 64;
 #pragma unroll
         for (int v4 = 0; v4 < 8; ++v4) scv[v4] = q_live ? sp[(size_t)v4 * 64] : make_float4(-1.f, -1.f, -1.f, -1.f);
@@ -474,13 +477,10 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
         for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
-    if (j_begin < j_end) fetch(j_begin);
+    if (j_begin < j_end) { fetch(j_begin); fetch_sc(j_begin); }
     for (int j0 = j_begin; j0 < j_end; j0 += ATT_KT) {
         __syncthreads();
         land();
-        float4 sct[8];
-#pragma unroll
-        for (int v4 = 0; v4 < 8; ++v4) sct[v4] = scv[v4];
         __syncthreads();
         if (j0 + ATT_KT < j_end) fetch(j0 + ATT_KT);
 
@@ -506,13 +506,14 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float4 q4 = sct[kb * 4 + (r >> 2)];
+                const float4 q4 = scv[kb * 4 + (r >> 2)];
                 const float scq = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
                 float v = scq * (s[kb][r] * inv_sqrt_c);
                 v = (scq >= 0.0f) ? v : -INFINITY;
                 s[kb][r] = v;
                 m_tile = fmaxf(m_tile, v);
             }
+        if (j0 + ATT_KT < j_end) fetch_sc(j0 + ATT_KT);
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
         const float m_new = fmaxf(m_run, m_tile);
         const float alpha = __expf(m_run - m_new);
