@@ -237,3 +237,16 @@ def test_engine_int8_stage_backs_off_on_ambiguous_descriptors():
         torch.cuda.synchronize()
         assert torch.equal(out["corrs"], ref["corrs"]) and torch.equal(out["status"], ref["status"])
     assert eng._i8_frac > eng.i8_max_undecided and eng._i8_skipped >= 1
+
+
+def test_run_test_driver_batched_and_per_sample(tmp_path):
+    """run_test.py (the build's counterpart of the reference's test entry point) on synthetic pairs: both loops recover the ground
+    truth and write one CSV line per pair in the reference's format."""
+    import run_test
+    from oryon_amd.evaluation import read_pred_csv
+    for extra in ([], ["--per-sample"]):
+        out = str(tmp_path / ("pred" + "_".join(extra) + ".csv"))
+        s = run_test.main(["--pairs", "4", "--batch", "2", "--size", "64", "--channels", "32", "--out", out] + extra)
+        assert s["pairs"] == 4 and s["failures"] == 0 and s["rot_err_deg_max"] < 1.0 and s["trans_err_cm_max"] < 1.0
+        assert s["ADD_0.1d_accuracy"] == 1.0
+        assert len(read_pred_csv(out)) == 4
