@@ -57,6 +57,10 @@ int oryon_device_check(int device);
 int oryon_rgb_resize_bilinear(const uint8_t *rgb_hwc, int n, int HI, int WI, int HO, int WO, float *out, void *stream);
 int oryon_resize_bilinear_f32(const float *in, int n, int HI, int WI, int HO, int WO, int round_output, float *out, void *stream);
 
+/* K1' the reference's fp16 matcher branch (corrs_device='cuda', utils/pcd.py:195-197) casts the descriptors to float16 first:
+ *     out[i] = float(half(in[i])) (round to nearest even; may alias).  The exact matcher then runs on the rounded values. */
+int oryon_round_to_f16_f32(const float *in, float *out, int64_t n, void *stream);
+
 /* B1  QuickGELU of the CLIP residual blocks, y = x * sigmoid(1.702 x)  (third-party clip model.py, loaded at
  *     models/vlm.py:19), fused into one pass for bf16 activations: x, y [n] bf16 (16-byte aligned, may alias).
  *     Arithmetic in fp32, one rounding.  The fp32 backbone path keeps torch's own ops. */

@@ -73,9 +73,28 @@ __global__ __launch_bounds__(256) void resize_bilinear_f32_kernel(const float *_
     }
 }
 
+// K1' input rounding: the reference's corrs_device='cuda' branch casts the ROI descriptors to float16 before pdist
+// (utils/pcd.py:195-197); here the maps are rounded to the nearest half and kept as fp32 for the exact kernels.
+__global__ __launch_bounds__(256) void round_to_f16_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)(_Float16)in[i];
+}
+
 }  // namespace oryon
 
 using namespace oryon;
+
+extern "C" int oryon_round_to_f16_f32(const float *in, float *out, int64_t n, void *stream)
+{
+    ORYON_CHECK_ARG(in && out && n >= 0);
+    if (n == 0) return ORYON_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(round_to_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in, out, n);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
 
 extern "C" int oryon_rgb_resize_bilinear(const uint8_t *rgb_hwc, int n, int HI, int WI, int HO, int WO, float *out, void *stream)
 {

@@ -20,6 +20,15 @@ def round_up(x: int, m: int) -> int:
     return ((int(x) + m - 1) // m) * m
 
 
+def round_to_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 CUDA tensor rounded to the nearest float16 value, returned as fp32 (K1' input rounding)."""
+    _lib.require_gpu(x.device)
+    x = x.to(torch.float32).contiguous()
+    out = torch.empty_like(x)
+    check(lib().oryon_round_to_f16_f32(ptr(x), ptr(out), x.numel(), stream_ptr(x.device)), "oryon_round_to_f16_f32")
+    return out
+
+
 def quick_gelu_bf16(x: torch.Tensor) -> torch.Tensor:
     """x * sigmoid(1.702 x) on a bf16 CUDA tensor in one pass (B1); used by the CLIP residual blocks at inference."""
     _lib.require_gpu(x.device)

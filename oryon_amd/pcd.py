@@ -41,7 +41,7 @@ def match_presample(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor
         # K1': the reference's corrs_device='cuda' branch rounds the descriptors to float16 first (utils/pcd.py:195-197); the
         # cosine itself is then evaluated exactly in fp32 on the rounded values (the reference's half arithmetic agrees with
         # this to ~4e-4 in distance, see tests/golden/g1_matcher_half.npz)
-        feats1, feats2 = feats1.to(torch.float16), feats2.to(torch.float16)
+        feats1, feats2 = ops.round_to_f16(feats1.to(dev)), ops.round_to_f16(feats2.to(dev))
     f1 = feats1.to(torch.float32).contiguous()[None]
     f2 = feats2.to(torch.float32).contiguous()[None]
     roi1_lin, c1 = ops.roi_compact(mask1.to(dev))
