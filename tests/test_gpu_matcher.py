@@ -335,3 +335,36 @@ def test_screened8_peaky_descriptors_fall_back_exactly():
     fa[1, 11, H // 2, H // 2] = -2.0          # one-hot anchor pixel in pair 1
     ones = torch.ones_like(st("mask_a"))
     _screen8_vs_exact(fa, fq, ones, ones, 256)
+
+
+def test_screened_paths_randomised_stress():
+    """Seeded sweep over channel counts, map sizes, mask densities, thresholds and descriptor statistics (planted matches, pure noise,
+    smooth low-rank fields that make many anchors ambiguous): K1s8 and K1s must reproduce the exact scan on every case."""
+    dev = "cuda"
+    rng = np.random.default_rng(1234)
+    for case in range(16):
+        C = int(rng.choice([130, 192, 256, 300, 384, 512]))
+        H, W = int(rng.integers(20, 56)), int(rng.integers(20, 56))
+        B = int(rng.integers(1, 4))
+        thr = float(rng.choice([0.1, 0.25, 0.4, 0.5]))
+        g = torch.Generator(device=dev).manual_seed(1000 + case)
+        kind = case % 4
+        fq = torch.randn(B, C, H, W, generator=g, device=dev)
+        if kind == 0:                       # planted matches + noise
+            fa = fq.flip(-1) + 0.1 * torch.randn(B, C, H, W, generator=g, device=dev)
+        elif kind == 1:                     # unrelated maps: nothing under the threshold
+            fa = torch.randn(B, C, H, W, generator=g, device=dev)
+        elif kind == 2:                     # smooth low-rank field: neighbouring pixels nearly parallel
+            basis = torch.randn(B, C, 6, generator=g, device=dev)
+            yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, W, device=dev), indexing="ij")
+            coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy)])       # [6,H,W]
+            fq = torch.einsum("bck,khw->bchw", basis, coef) + 0.01 * torch.randn(B, C, H, W, generator=g, device=dev)
+            fa = fq + 0.005 * torch.randn(B, C, H, W, generator=g, device=dev)
+        else:                               # heavy-tailed descriptors (a few dominant channels)
+            fq = fq * torch.exp(2.0 * torch.randn(1, C, 1, 1, generator=g, device=dev))
+            fa = fq.roll(3, -1) + 0.05 * torch.randn(B, C, H, W, generator=g, device=dev)
+        dens_a, dens_q = float(rng.uniform(0.2, 1.0)), float(rng.uniform(0.2, 1.0))
+        ma = (torch.rand(B, H, W, generator=g, device=dev) < dens_a).int()
+        mq = (torch.rand(B, H, W, generator=g, device=dev) < dens_q).int()
+        c_pad = 256 if C <= 256 else 512
+        _screen_vs_exact(fa.contiguous(), fq.contiguous(), ma, mq, c_pad, thr=thr)
