@@ -66,6 +66,15 @@ int oryon_round_to_f16_f32(const float *in, float *out, int64_t n, void *stream)
  *     Arithmetic in fp32, one rounding.  The fp32 backbone path keeps torch's own ops. */
 int oryon_quick_gelu_bf16(const void *x, void *y, int64_t n, void *stream);
 
+/* B2  residual add + LayerNorm of the CLIP residual stream (clip model.py ResidualAttentionBlock.forward:
+ *     x = x + attention(ln_1(x)); x = x + mlp(ln_2(x)); torch.nn.LayerNorm semantics, biased variance), bf16 inference only:
+ *         s = bf16(x + delta)   -> x_out   (delta == NULL: s = x, x_out not written)
+ *         h = bf16((s - mean(s)) * rsqrt(var(s) + eps) * gamma + beta) -> h_out          statistics in fp32 over the rounded s
+ *     x, delta, x_out, h_out [rows, D] bf16, gamma / beta [D] bf16; D % 8 == 0, D <= 4096; 16-byte aligned; x_out may alias x
+ *     or delta, h_out must not alias an input. */
+int oryon_add_layernorm_bf16(const void *x, const void *delta, const void *gamma, const void *beta, int64_t rows, int D, float eps,
+                             void *x_out, void *h_out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K0  mask -> ROI.   Replaces torch.nonzero(mask == 1) (utils/pcd.py:184-185) and the validity test
  *     count_nonzero(mask == 1) > 0 (pipeline.py:391-393).

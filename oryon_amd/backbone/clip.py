@@ -47,6 +47,24 @@ class CLIPConfig:
         return CLIPConfig()
 
 
+class PatchEmbed(nn.Conv2d):
+    """Non-overlapping patch embedding (kernel == stride, no padding) with nn.Conv2d's parameters and state-dict names, computed as ONE
+    GEMM over the unfolded patches.  MIOpen runs such a convolution as a per-image im2col + small GEMM (2 x 64 launches per CLIP
+    forward, 7.8 ms per 64 images on MI355X); the unfold here is a single strided copy and the GEMM has N*g*g rows."""
+
+    def tokens(self, x: Tensor) -> Tensor:                           # [N, Cin, H, W] -> [N, H/p, W/p, Cout]
+        p = self.kernel_size[0]
+        assert self.kernel_size == self.stride and self.kernel_size[0] == self.kernel_size[1] and self.padding == (0, 0)
+        N, Cin, H, W = x.shape
+        gh, gw = H // p, W // p
+        cols = x[:, :, : gh * p, : gw * p].reshape(N, Cin, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(N * gh * gw, Cin * p * p)
+        out = F.linear(cols, self.weight.view(self.out_channels, -1), self.bias)
+        return out.view(N, gh, gw, self.out_channels)
+
+    def forward(self, x: Tensor) -> Tensor:                          # nn.Conv2d's layout, for callers that want NCHW
+        return self.tokens(x).permute(0, 3, 1, 2)
+
+
 class _Attention(nn.Module):
     """Packed-qkv multi-head attention with nn.MultiheadAttention's parameter names."""
 
@@ -93,6 +111,16 @@ class _Block(nn.Module):
         x = x + self.attn(self.ln_1(x), self.causal)
         return x + self.mlp(self.ln_2(x))
 
+    def forward_fused(self, x: Tensor, h: Tensor, next_ln: Optional[nn.LayerNorm]):
+        """Same block with the residual adds fused into the following LayerNorm (ops.add_layernorm_bf16): takes the stream x and
+        h = ln_1(x), returns the new stream and next_ln(new stream) (None for the last block)."""
+        from .. import ops
+        x, h = ops.add_layernorm_bf16(x, self.attn(h, self.causal), self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+        d = self.mlp(h)
+        if next_ln is None:
+            return x + d, None
+        return ops.add_layernorm_bf16(x, d, next_ln.weight, next_ln.bias, next_ln.eps)
+
 
 class _Transformer(nn.Module):
     def __init__(self, width: int, layers: int, heads: int, causal: bool):
@@ -100,6 +128,14 @@ class _Transformer(nn.Module):
         self.resblocks = nn.Sequential(*[_Block(width, heads, causal) for _ in range(layers)])
 
     def forward(self, x: Tensor) -> Tensor:
+        if x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.shape[-1] % 8 == 0:
+            from .. import ops                      # bf16 inference: residual add + LayerNorm in one pass (B2)
+            blocks = list(self.resblocks)
+            ln0 = blocks[0].ln_1
+            x, h = ops.add_layernorm_bf16(x, None, ln0.weight, ln0.bias, ln0.eps)
+            for i, blk in enumerate(blocks):
+                x, h = blk.forward_fused(x, h, blocks[i + 1].ln_1 if i + 1 < len(blocks) else None)
+            return x
         return self.resblocks(x)
 
 
@@ -108,7 +144,7 @@ class _Visual(nn.Module):
         super().__init__()
         w = cfg.v_width
         grid = cfg.image_size // cfg.patch
-        self.conv1 = nn.Conv2d(3, w, kernel_size=cfg.patch, stride=cfg.patch, bias=False)
+        self.conv1 = PatchEmbed(3, w, kernel_size=cfg.patch, stride=cfg.patch, bias=False)
         self.class_embedding = nn.Parameter(w ** -0.5 * torch.randn(w))
         self.positional_embedding = nn.Parameter(w ** -0.5 * torch.randn(grid * grid + 1, w))
         self.ln_pre = nn.LayerNorm(w)
@@ -137,9 +173,9 @@ class CLIP(nn.Module):
     # vlm.py:45-59 (after the pre-processing transform)
     def patch_tokens(self, clip_rgb: Tensor) -> Tensor:
         v = self.visual
-        x = v.conv1(clip_rgb)                                         # [B, width, g, g]
-        B, W, g, _ = x.shape
-        x = x.flatten(2).transpose(1, 2)                              # [B, g*g, width]
+        x = v.conv1.tokens(clip_rgb)                                  # [B, g, g, width]
+        B, g, _, W = x.shape
+        x = x.view(B, g * g, W)
         cls = v.class_embedding.to(x.dtype).expand(B, 1, W)
         x = torch.cat([cls, x], dim=1) + v.positional_embedding.to(x.dtype)
         x = v.transformer(v.ln_pre(x))

@@ -19,6 +19,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from .clip import PatchEmbed
+
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
@@ -90,15 +92,34 @@ class _SwinBlock(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(dim, 4 * dim), nn.GELU(), nn.Identity(), nn.Linear(4 * dim, dim), nn.Identity())
 
     def forward(self, x: Tensor) -> Tensor:
+        if _fast_ln(x):
+            from .. import ops                      # bf16 inference: LayerNorm / residual add + LayerNorm in one pass (B2)
+            h = ops.add_layernorm_bf16(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)[1]
+            x, h = ops.add_layernorm_bf16(x, self.attn(h), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return x + self.mlp(h)
         x = x + self.attn(self.norm1(x))
         return x + self.mlp(self.norm2(x))
+
+
+def _fast_ln(x: Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.shape[-1] % 8 == 0
+
+
+class _FastLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm whose bf16 CUDA inference path is the one-pass HIP kernel (torch's runs at ~1.3 TB/s on these row widths)."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        if _fast_ln(x) and self.weight.dtype == torch.bfloat16:
+            from .. import ops
+            return ops.add_layernorm_bf16(x, None, self.weight, self.bias, self.eps)[1]
+        return super().forward(x)
 
 
 class _PatchMerging(nn.Module):
     def __init__(self, dim: int):
         super().__init__()
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
-        self.norm = nn.LayerNorm(4 * dim)
+        self.norm = _FastLayerNorm(4 * dim)
 
     def forward(self, x: Tensor) -> Tensor:                               # [B, H, W, C] -> [B, H/2, W/2, 2C]
         H, W = x.shape[1], x.shape[2]
@@ -107,9 +128,9 @@ class _PatchMerging(nn.Module):
         return self.reduction(self.norm(x))
 
 
-class _ToNHWC(nn.Module):
-    def forward(self, x: Tensor) -> Tensor:
-        return x.permute(0, 2, 3, 1)
+class _PatchEmbedNHWC(PatchEmbed):
+    def forward(self, x: Tensor) -> Tensor:                               # [B, 3, H, W] -> [B, H/4, W/4, C]
+        return self.tokens(x)
 
 
 class SwinGuidance(nn.Module):
@@ -118,7 +139,7 @@ class SwinGuidance(nn.Module):
     def __init__(self, embed: int = 128, window: int = 7, heads=(4, 8)):
         super().__init__()
         self.features = nn.Sequential(
-            nn.Sequential(nn.Conv2d(3, embed, kernel_size=4, stride=4), _ToNHWC(), nn.LayerNorm(embed)),
+            nn.Sequential(_PatchEmbedNHWC(3, embed, kernel_size=4, stride=4), nn.Identity(), _FastLayerNorm(embed)),   # .1 was the NHWC permute
             nn.Sequential(_SwinBlock(embed, heads[0], window, 0), _SwinBlock(embed, heads[0], window, window // 2)),
             _PatchMerging(embed),
             nn.Sequential(_SwinBlock(2 * embed, heads[1], window, 0), _SwinBlock(2 * embed, heads[1], window, window // 2)),

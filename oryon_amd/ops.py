@@ -39,6 +39,27 @@ def quick_gelu_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def add_layernorm_bf16(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor, eps: float):
+    """(x + delta, LayerNorm(x + delta)) for bf16 CUDA tensors in one pass (B2); delta None -> (x, LayerNorm(x)).
+    Used by the CLIP residual blocks at inference."""
+    _lib.require_gpu(x.device)
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and bias.dtype == torch.bfloat16
+    D = x.shape[-1]
+    x = x.contiguous()
+    h = torch.empty_like(x)
+    if delta is None:
+        s_out = x
+        check(lib().oryon_add_layernorm_bf16(ptr(x), None, ptr(weight), ptr(bias), x.numel() // D, D, eps, None, ptr(h),
+                                             stream_ptr(x.device)), "oryon_add_layernorm_bf16")
+    else:
+        assert delta.shape == x.shape and delta.dtype == torch.bfloat16
+        delta = delta.contiguous()
+        s_out = delta                                  # the sum overwrites the branch output (a temporary of the caller)
+        check(lib().oryon_add_layernorm_bf16(ptr(x), ptr(delta), ptr(weight), ptr(bias), x.numel() // D, D, eps, ptr(s_out), ptr(h),
+                                             stream_ptr(x.device)), "oryon_add_layernorm_bf16")
+    return s_out, h
+
+
 def rgb_resize_bilinear(rgb_hwc: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
     """uint8 [n,HI,WI,3] -> fp32 [n,3,HO,WO] in [0,1] (K-1: /255., CHW, bilinear align_corners=False, fp64 arithmetic)."""
     _lib.require_gpu(rgb_hwc.device)

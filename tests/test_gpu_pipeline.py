@@ -214,6 +214,64 @@ def test_quick_gelu_bf16_fused():
         assert float((y.float() - ref.float()).abs().mean()) < 1e-4
 
 
+def test_add_layernorm_bf16_fused():
+    """B2 against torch's own bf16 chain (add rounded to bf16, nn.LayerNorm with fp32 statistics): at most one bf16 ulp apart."""
+    import torch.nn.functional as F
+    from oryon_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for rows, D in ((577 * 3, 1024), (77 * 5, 768), (7, 8), (130, 4096), (1001, 128), (333, 256), (50, 200), (9, 512)):
+        x = (3.0 * torch.randn(rows, D, generator=g, device="cuda")).to(torch.bfloat16)
+        d = torch.randn(rows, D, generator=g, device="cuda").to(torch.bfloat16)
+        w = (1.0 + 0.2 * torch.randn(D, generator=g, device="cuda")).to(torch.bfloat16)
+        b = (0.1 * torch.randn(D, generator=g, device="cuda")).to(torch.bfloat16)
+        s_ref = x + d
+        h_ref = F.layer_norm(s_ref.float(), (D,), w.float(), b.float(), 1e-5)
+        s, h = ops.add_layernorm_bf16(x, d.clone(), w, b, 1e-5)
+        assert torch.equal(s, s_ref)
+        err = (h.float() - h_ref).abs()
+        assert float((err / h_ref.abs().clamp_min(0.5)).max()) < 2.0 ** -8        # bf16 rounding of an fp32-accurate value
+        s2, h2 = ops.add_layernorm_bf16(x, None, w, b, 1e-5)
+        assert s2.data_ptr() == x.data_ptr()
+        h2_ref = F.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
+        assert float(((h2.float() - h2_ref).abs() / h2_ref.abs().clamp_min(0.5)).max()) < 2.0 ** -8
+
+
+def test_clip_bf16_fused_blocks_match_unfused():
+    """The fused bf16 residual path of the CLIP towers (B1 + B2) against the same weights run through the plain torch blocks."""
+    from oryon_amd.backbone.clip import CLIP, CLIPConfig
+    torch.manual_seed(0)
+    cfg = CLIPConfig(image_size=56, patch=14, v_width=256, v_layers=3, v_heads=4, embed_dim=64, t_width=128, t_layers=2, t_heads=4)
+    m = CLIP(cfg).cuda().eval().to(torch.bfloat16)
+    x = torch.randn(4, 17, 256, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        fused = m.visual.transformer(x)
+        plain = m.visual.transformer.resblocks(x)
+        rgb = torch.rand(2, 3, 56, 56, device="cuda").to(torch.bfloat16)
+        toks = m.patch_tokens(rgb)
+    assert fused.shape == plain.shape and toks.shape == (2, 256, 4, 4)
+    rel = (fused.float() - plain.float()).norm() / plain.float().norm()
+    assert float(rel) < 2e-2                                   # bf16 round-off through three blocks
+
+
+def test_swin_bf16_fast_layernorm_matches_plain():
+    import torch.nn as nn
+    from oryon_amd.backbone import swin
+    torch.manual_seed(0)
+    m = swin.SwinGuidance().cuda().eval().to(torch.bfloat16)
+    img = torch.randn(2, 3, 112, 112, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        fast = m(img)
+        keep = swin._fast_ln
+        swin._fast_ln = lambda x: False
+        try:
+            plain = m(img)
+        finally:
+            swin._fast_ln = keep
+    for k in fast:
+        rel = (fast[k].float() - plain[k].float()).norm() / plain[k].float().norm()
+        assert fast[k].shape == plain[k].shape and float(rel) < 2e-2, (k, float(rel))
+
+
 def test_engine_int8_stage_backs_off_on_ambiguous_descriptors():
     """Descriptor maps made of a few hundred distinct vectors (every anchor has many near-ties): the int8 pre-screen cannot decide
     them, the engine notices (async read-back) and skips it for the following batches - results stay those of the exact matcher."""
