@@ -75,6 +75,17 @@ int oryon_quick_gelu_bf16(const void *x, void *y, int64_t n, void *stream);
 int oryon_add_layernorm_bf16(const void *x, const void *delta, const void *gamma, const void *beta, int64_t rows, int D, float eps,
                              void *x_out, void *h_out, void *stream);
 
+/* B3  shifted-window attention of the Swin guidance backbone (torchvision swin_transformer.shifted_window_attention, the
+ *     swin_b feature extractor of net.py:60-75), window 7, head dim 32, bf16 inference: everything between the q|k|v Linear and
+ *     the output projection in one kernel (pad, cyclic shift, window partition, q scale, QK^T + relative position bias + shift
+ *     mask, softmax, PV, window merge, reverse shift, crop).
+ *     qkv     [B, H, W, 3C] bf16: the q|k|v Linear applied to the un-windowed tokens (it commutes with the partition)
+ *     pad_qkv [3C] bf16: q|k|v of a zero-padded token = the Linear's bias (zeros if it has none)
+ *     bias_t  [heads, 49 (key), 49 (query)] fp32: relative_position_bias_table[relative_position_index], key-major
+ *     out     [B, H, W, C] bf16;  C == heads * 32, heads <= 8, 0 <= shift < 7 (torchvision passes 0 or 3) */
+int oryon_swin_window_attention_bf16(const void *qkv, const void *pad_qkv, const float *bias_t, int B, int H, int W, int C, int heads,
+                                     int shift, void *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K0  mask -> ROI.   Replaces torch.nonzero(mask == 1) (utils/pcd.py:184-185) and the validity test
  *     count_nonzero(mask == 1) > 0 (pipeline.py:391-393).

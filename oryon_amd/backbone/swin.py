@@ -59,6 +59,12 @@ class _WindowAttention(nn.Module):
     def forward(self, x: Tensor) -> Tensor:                               # x: [B, H, W, C]
         B, H, W, C = x.shape
         w, s, nh = self.window, self.shift, self.heads
+        if _fast_ln(x) and w == 7 and C == 32 * nh and nh <= 8 and self.qkv.weight.dtype == torch.bfloat16:
+            from .. import ops                      # bf16 inference: one HIP kernel between the q|k|v Linear and the projection (B3)
+            bias_t = self.relative_position_bias_table[self.relative_position_index].view(w * w, w * w, nh).permute(2, 1, 0)
+            pad = self.qkv.bias if self.qkv.bias is not None else torch.zeros(3 * C, dtype=x.dtype, device=x.device)
+            out = ops.swin_window_attention_bf16(self.qkv(x), pad, bias_t.float().contiguous(), nh, s)
+            return self.proj(out)
         pb, pr = (w - H % w) % w, (w - W % w) % w
         x = F.pad(x, (0, 0, 0, pr, 0, pb))
         Hp, Wp = H + pb, W + pr

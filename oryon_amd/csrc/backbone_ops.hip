@@ -138,6 +138,118 @@ __global__ __launch_bounds__(256) void add_layernorm_bf16_kernel(const unsigned 
     }
 }
 
+// Shifted-window attention of the Swin guidance backbone (torchvision swin_transformer.shifted_window_attention, reached from
+// net.py:60-75 of the reference through swin_b's feature extractor), bf16 inference.  torch runs it as pad + roll + window
+// partition copy, q scaling, two batched 49x49 matmuls, bias add, mask add, softmax, transpose copy, window merge copy and the
+// reverse roll: a dozen bandwidth-bound passes over [tokens, C] and [windows, heads, 49, 49] tensors.  The per-token q|k|v Linear
+// commutes with all of that, so here it runs on the un-windowed tokens and ONE kernel does the rest: a workgroup owns a window,
+// a wave owns a head, a lane owns a query token; roll, padding (pad tokens carry q|k|v = the Linear's bias, exactly what the zero
+// padding produces), relative-position bias and the shift mask are index arithmetic.  fp32 arithmetic, one rounding at the end.
+constexpr int SWIN_WS = 7, SWIN_N = SWIN_WS * SWIN_WS, SWIN_HD = 32, SWIN_LD = SWIN_HD + 4;
+constexpr int SWIN_WAVE_FLOATS = 2 * SWIN_N * SWIN_LD + 64;
+
+__device__ __forceinline__ void load_head_slice(const unsigned short *p, float (&f)[SWIN_HD])
+{
+#pragma unroll
+    for (int c = 0; c < SWIN_HD / 8; ++c) {
+        const uint4 u = *reinterpret_cast<const uint4 *>(p + c * 8);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[c * 8 + 2 * j] = bf16_bits_to_float((unsigned short)(w[j] & 0xffffu));
+            f[c * 8 + 2 * j + 1] = bf16_bits_to_float((unsigned short)(w[j] >> 16));
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void swin_window_attention_bf16_kernel(const unsigned short *__restrict__ qkv,
+                                                                          const unsigned short *__restrict__ pad_qkv,
+                                                                          const float *__restrict__ bias_t, int H, int W, int C,
+                                                                          int shift, unsigned short *__restrict__ out)
+{
+    extern __shared__ float swin_lds[];
+    const int head = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *Ks = swin_lds + head * SWIN_WAVE_FLOATS;
+    float *Vs = Ks + SWIN_N * SWIN_LD;
+    int *labs = reinterpret_cast<int *>(Vs + SWIN_N * SWIN_LD);
+    const int Hp = (H + SWIN_WS - 1) / SWIN_WS * SWIN_WS, Wp = (W + SWIN_WS - 1) / SWIN_WS * SWIN_WS;
+    const int nwx = Wp / SWIN_WS;
+    const int wy = blockIdx.x / nwx, wx = blockIdx.x % nwx, b = blockIdx.y;
+    const bool tok = lane < SWIN_N;
+    float q[SWIN_HD];
+    int label = 0;
+    bool real = false;
+    size_t out_off = 0;
+    if (tok) {
+        const int py = wy * SWIN_WS + lane / SWIN_WS, px = wx * SWIN_WS + lane % SWIN_WS;     // rolled, padded frame
+        const int sy = (py + shift) % Hp, sx = (px + shift) % Wp;                           // torch.roll(x, -shift): out[p] = in[p + shift]
+        real = sy < H && sx < W;
+        if (shift > 0) {
+            const int by = py < Hp - SWIN_WS ? 0 : (py < Hp - shift ? 1 : 2);
+            const int bx = px < Wp - SWIN_WS ? 0 : (px < Wp - shift ? 1 : 2);
+            label = by * 3 + bx;
+        }
+        const size_t t = ((size_t)b * H + sy) * W + sx;
+        out_off = t * C + head * SWIN_HD;
+        const unsigned short *src = real ? qkv + t * 3 * C + head * SWIN_HD : pad_qkv + head * SWIN_HD;
+        float kv[SWIN_HD];
+        load_head_slice(src, q);
+        const float scale = 0.17677669529663687f;                                            // 32^-0.5
+#pragma unroll
+        for (int d = 0; d < SWIN_HD; ++d) q[d] *= scale;
+        load_head_slice(src + C, kv);
+#pragma unroll
+        for (int d = 0; d < SWIN_HD; d += 4) *reinterpret_cast<float4 *>(Ks + lane * SWIN_LD + d) = make_float4(kv[d], kv[d + 1], kv[d + 2], kv[d + 3]);
+        load_head_slice(src + 2 * C, kv);
+#pragma unroll
+        for (int d = 0; d < SWIN_HD; d += 4) *reinterpret_cast<float4 *>(Vs + lane * SWIN_LD + d) = make_float4(kv[d], kv[d + 1], kv[d + 2], kv[d + 3]);
+        labs[lane] = label;
+    }
+    __syncthreads();
+    if (!tok) return;
+    // online softmax over the 49 keys (the fully unrolled two-pass form keeps 49 scores per lane and the compiler then hoists
+    // every LDS read above the arithmetic: 1500 spilled VGPRs)
+    const float *bt = bias_t + (size_t)head * SWIN_N * SWIN_N + lane;
+    float m = -INFINITY, sum = 0.0f;
+    float acc[SWIN_HD];
+#pragma unroll
+    for (int d = 0; d < SWIN_HD; ++d) acc[d] = 0.0f;
+#pragma unroll 1
+    for (int j = 0; j < SWIN_N; ++j) {
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < SWIN_HD; d += 8) {
+            const float4 k4 = *reinterpret_cast<const float4 *>(Ks + j * SWIN_LD + d);
+            const float4 k5 = *reinterpret_cast<const float4 *>(Ks + j * SWIN_LD + d + 4);
+            a0 = fmaf(q[d], k4.x, a0); a0 = fmaf(q[d + 1], k4.y, a0); a0 = fmaf(q[d + 2], k4.z, a0); a0 = fmaf(q[d + 3], k4.w, a0);
+            a1 = fmaf(q[d + 4], k5.x, a1); a1 = fmaf(q[d + 5], k5.y, a1); a1 = fmaf(q[d + 6], k5.z, a1); a1 = fmaf(q[d + 7], k5.w, a1);
+        }
+        float a = a0 + a1 + bt[j * SWIN_N];
+        if (labs[j] != label) a -= 100.0f;
+        const float m_new = fmaxf(m, a);
+        const float corr = __expf(m - m_new);           // exp(-inf) = 0 on the first key
+        const float p = __expf(a - m_new);
+        m = m_new;
+        sum = fmaf(sum, corr, p);
+#pragma unroll
+        for (int d = 0; d < SWIN_HD; d += 4) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(Vs + j * SWIN_LD + d);
+            acc[d] = fmaf(acc[d], corr, p * v4.x); acc[d + 1] = fmaf(acc[d + 1], corr, p * v4.y);
+            acc[d + 2] = fmaf(acc[d + 2], corr, p * v4.z); acc[d + 3] = fmaf(acc[d + 3], corr, p * v4.w);
+        }
+    }
+    if (!real) return;                                                                      // pad tokens are cropped away
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < SWIN_HD / 8; ++c) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = (unsigned)float_to_bf16_bits(acc[c * 8 + 2 * j] * inv) | ((unsigned)float_to_bf16_bits(acc[c * 8 + 2 * j + 1] * inv) << 16);
+        *reinterpret_cast<uint4 *>(out + out_off + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 }  // namespace oryon
 
 using namespace oryon;
@@ -176,6 +288,28 @@ extern "C" int oryon_add_layernorm_bf16(const void *x, const void *delta, const 
     else if (D <= 256) ORYON_LAUNCH_LN(32);
     else ORYON_LAUNCH_LN(64);
 #undef ORYON_LAUNCH_LN
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_swin_window_attention_bf16(const void *qkv, const void *pad_qkv, const float *bias_t, int B, int H, int W, int C,
+                                                int heads, int shift, void *out, void *stream)
+{
+    ORYON_CHECK_ARG(qkv && pad_qkv && bias_t && out && B >= 0 && H > 0 && W > 0 && heads >= 1 && heads <= 8 && C == heads * SWIN_HD);
+    ORYON_CHECK_ARG(shift >= 0 && shift < SWIN_WS);
+    ORYON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)pad_qkv | (uintptr_t)out) & 15) == 0);
+    if (B == 0) return ORYON_OK;
+    const int nwy = (H + SWIN_WS - 1) / SWIN_WS, nwx = (W + SWIN_WS - 1) / SWIN_WS;
+    const size_t lds = (size_t)heads * SWIN_WAVE_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        ORYON_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(swin_window_attention_bf16_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SWIN_WAVE_FLOATS * (int)sizeof(float)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(swin_window_attention_bf16_kernel, dim3(nwy * nwx, B), dim3(64 * heads), lds, as_stream(stream),
+                       static_cast<const unsigned short *>(qkv), static_cast<const unsigned short *>(pad_qkv), bias_t, H, W, C, shift,
+                       static_cast<unsigned short *>(out));
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

@@ -60,6 +60,20 @@ def add_layernorm_bf16(x: torch.Tensor, delta: Optional[torch.Tensor], weight: t
     return s_out, h
 
 
+def swin_window_attention_bf16(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, shift: int) -> torch.Tensor:
+    """Shifted-window attention (window 7, head dim 32) on un-windowed q|k|v tokens [B,H,W,3C] bf16 -> [B,H,W,C] bf16 (B3)."""
+    _lib.require_gpu(qkv.device)
+    assert qkv.dtype == torch.bfloat16 and pad_qkv.dtype == torch.bfloat16 and bias_t.dtype == torch.float32
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    assert C3 == 3 * C and pad_qkv.numel() == C3 and bias_t.shape == (heads, 49, 49)
+    qkv = qkv.contiguous()
+    out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=qkv.device)
+    check(lib().oryon_swin_window_attention_bf16(ptr(qkv), ptr(pad_qkv.contiguous()), ptr(bias_t.contiguous()), B, H, W, C, heads, shift,
+                                                 ptr(out), stream_ptr(qkv.device)), "oryon_swin_window_attention_bf16")
+    return out
+
+
 def rgb_resize_bilinear(rgb_hwc: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
     """uint8 [n,HI,WI,3] -> fp32 [n,3,HO,WO] in [0,1] (K-1: /255., CHW, bilinear align_corners=False, fp64 arithmetic)."""
     _lib.require_gpu(rgb_hwc.device)

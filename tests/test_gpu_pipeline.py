@@ -253,6 +253,29 @@ def test_clip_bf16_fused_blocks_match_unfused():
     assert float(rel) < 2e-2                                   # bf16 round-off through three blocks
 
 
+def test_swin_window_attention_kernel_vs_torch_fp32():
+    """B3 against the torch formulation of the same block (pad, roll, partition, bias, mask, softmax, merge) evaluated in fp32 on the
+    same bf16 parameters and inputs: the kernel's only rounding is the final bf16 one."""
+    from oryon_amd.backbone import swin
+    torch.manual_seed(1)
+    for dim, heads, H, W in ((128, 4, 20, 17), (256, 8, 14, 14), (64, 2, 7, 9)):
+        for shift in (0, 3):
+            att = swin._WindowAttention(dim, heads, 7, shift).cuda().eval()
+            with torch.no_grad():
+                att.relative_position_bias_table.normal_(std=0.5)
+                att.qkv.bias.normal_(std=0.3)
+            att16 = att.to(torch.bfloat16)
+            x = torch.randn(2, H, W, dim, device="cuda").to(torch.bfloat16)
+            with torch.no_grad():
+                fused = att16(x)
+                ref_mod = swin._WindowAttention(dim, heads, 7, shift).cuda().eval()
+                ref_mod.load_state_dict({k: v.float() for k, v in att16.state_dict().items()})
+                ref = ref_mod(x.float())
+            assert fused.dtype == torch.bfloat16 and fused.shape == ref.shape
+            err = (fused.float() - ref).abs().max() / ref.abs().max()
+            assert float(err) < 2e-2, (dim, heads, H, W, shift, float(err))
+
+
 def test_swin_bf16_fast_layernorm_matches_plain():
     import torch.nn as nn
     from oryon_amd.backbone import swin
