@@ -128,7 +128,8 @@ class _Transformer(nn.Module):
         self.resblocks = nn.Sequential(*[_Block(width, heads, causal) for _ in range(layers)])
 
     def forward(self, x: Tensor) -> Tensor:
-        if x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.shape[-1] % 8 == 0:
+        if (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.shape[-1] % 8 == 0
+                and self.resblocks[0].ln_1.weight.dtype == torch.bfloat16):    # bf16 weights, not autocast over fp32 ones
             from .. import ops                      # bf16 inference: residual add + LayerNorm in one pass (B2)
             blocks = list(self.resblocks)
             ln0 = blocks[0].ln_1

@@ -98,7 +98,7 @@ class _SwinBlock(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(dim, 4 * dim), nn.GELU(), nn.Identity(), nn.Linear(4 * dim, dim), nn.Identity())
 
     def forward(self, x: Tensor) -> Tensor:
-        if _fast_ln(x):
+        if _fast_ln(x) and self.norm1.weight.dtype == torch.bfloat16:
             from .. import ops                      # bf16 inference: LayerNorm / residual add + LayerNorm in one pass (B2)
             h = ops.add_layernorm_bf16(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)[1]
             x, h = ops.add_layernorm_bf16(x, self.attn(h), self.norm2.weight, self.norm2.bias, self.norm2.eps)

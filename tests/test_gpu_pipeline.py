@@ -251,6 +251,11 @@ def test_clip_bf16_fused_blocks_match_unfused():
     assert fused.shape == plain.shape and toks.shape == (2, 256, 4, 4)
     rel = (fused.float() - plain.float()).norm() / plain.float().norm()
     assert float(rel) < 2e-2                                   # bf16 round-off through three blocks
+    # autocast over fp32 weights must keep to torch's own ops (the fused kernels take bf16 parameters)
+    m32 = CLIP(cfg).cuda().eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        t32 = m32.patch_tokens(torch.rand(2, 3, 56, 56, device="cuda"))
+    assert t32.shape == (2, 256, 4, 4) and bool(torch.isfinite(t32.float()).all())
 
 
 def test_swin_window_attention_kernel_vs_torch_fp32():
