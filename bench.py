@@ -32,6 +32,7 @@ from oryon_amd.synth import make_pair  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # same table, "Peak BF16/FP16 MFMA" dense
 PEAK_I8_MFMA_TOPS = 5000.0         # dense INT8 = 2x the 16-bit rate (same table: FP8 ~5 PF dense; i8 32x32x32 measured 4.4 POP/s)
+PEAK_HBM_BYTES = 8.0e12            # same guide: HBM3E 8 TB/s
 METRIC = "image-pairs/sec end-to-end (feat+match+reg) @224², C=256; ADD(-S) parity"
 
 
@@ -330,6 +331,11 @@ def main():
             kernel, peak = "match_f32_kernel (LDS-staged, wide descriptors)", PEAK_FP32_MFMA_TFLOPS
         launch_ms = match_ms
         achieved = flops / (launch_ms * 1e-3) / 1e12
+        # the other roofline of SURVEY.md 8(d): operand bytes the kernel has to read once (rows actually used, in the kernel's
+        # operand type) + its per-anchor outputs, against the 8 TB/s HBM peak - far from binding for ROIs of this size
+        opb = 1 if use_i8 else 2 if screened else 4
+        alg_bytes = float((opb * cp * (n_a + n_q) + 12.0 * n_a).sum())
+        hbm_frac = alg_bytes / (launch_ms * 1e-3) / PEAK_HBM_BYTES
         # HBM bytes per launch cannot be counted from inside the process: taken from the committed rocprofv3 PMC passes of this
         # exact workload (profiles/r01_pmc_counters.md), null for any other workload
         traffic, traffic_src = None, None
@@ -357,6 +363,7 @@ def main():
                 "unit": "TFLOP/s", "op": "int8 multiply-accumulate, 2 ops each, i32 accumulate" if use_i8 else "floating-point fma, 2 flops each",
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": flops, "avg_launch_ms": launch_ms,
+                "algorithmic_bytes_per_launch": alg_bytes, "hbm_frac": hbm_frac,
                 "share_of_step": match_ms / (elapsed / a.steps * 1e3),
             },
         }
