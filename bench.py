@@ -162,10 +162,24 @@ def bench_full(a, rank, world, dev):
         model = model.to(torch.bfloat16)
         xs["anchor"]["rgb"], xs["query"]["rgb"] = rgb_a.to(torch.bfloat16), rgb_q.to(torch.bfloat16)
     total = B * world
+    decode_only = a.stages == "decode"
+    if decode_only:
+        # the frozen towers' outputs are inputs of this stage set: evaluated once, outside the timed region
+        with torch.no_grad(), amp:
+            rgb = torch.cat([xs["anchor"]["rgb"], xs["query"]["rgb"]])
+            enc = (model.vlm.encode_image(rgb), model.get_guidance_embeds(rgb))
+            prompt = model.vlm.encode_tokens(toks).unsqueeze(1).to(rgb.dtype)
+            prompt = torch.cat([prompt, prompt])
+
+    def backbone():
+        if not decode_only:
+            return model(xs)
+        mask, fm = model.decoder(model.fusion(enc[0], prompt, enc[1]), enc[1])
+        return {"featmap_a": fm[:B], "featmap_q": fm[B:], "mask_a": mask[:B], "mask_q": mask[B:]}
 
     def step():
         with torch.no_grad(), amp:
-            out = model(xs)
+            out = backbone()
         fa, fq = out["featmap_a"].float().contiguous(), out["featmap_q"].float().contiguous()
         ma = ops.mask_from_logits(out["mask_a"].float().squeeze(1), 0.5)
         mq = ops.mask_from_logits(out["mask_q"].float().squeeze(1), 0.5)
@@ -187,7 +201,7 @@ def bench_full(a, rank, world, dev):
     for _ in range(a.steps):
         e0.record()
         with torch.no_grad(), amp:
-            model(xs)
+            backbone()
         e1.record()
         res, _ = step()
         torch.cuda.synchronize()
@@ -200,9 +214,12 @@ def bench_full(a, rank, world, dev):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     if rank == 0:
-        flops_backbone = B * 2 * 0.39e12          # ~0.39 TFLOP per ViT-L/14@336 image, 2 images per pair
+        # ~0.39 TFLOP per ViT-L/14@336 image, 2 images per pair; fusion + decoder alone: 2.4 + 3.3 GFLOP per image
+        flops_backbone = B * 2 * (5.7e9 if decode_only else 0.39e12)
         rec = {
-            "metric": "image-pairs/sec end-to-end (feat+match+reg), stage set FULL at the reference's shapes (224x224 RGB -> C=32 @192x192)",
+            "metric": ("image-pairs/sec (decode+match+reg), stage set DECODE: fusion + decoder on cached CLIP / Swin encodings (-> C=32 @192x192)"
+                       if decode_only else
+                       "image-pairs/sec end-to-end (feat+match+reg), stage set FULL at the reference's shapes (224x224 RGB -> C=32 @192x192)"),
             "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 backbone GEMMs (autocast), f32 match+pose",
@@ -210,7 +227,7 @@ def bench_full(a, rank, world, dev):
             "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
             "config": {"workload": f"Batch={B} synthetic 224x224 RGB-D pairs per GPU through CLIP ViT-L/14@336 + Swin-B(stages 1-2) + fusion + "
                                    f"decoder (PyTorch-ROCm), then HIP match + lift + PointDSC 12x128",
-                       "stages": "full", "prompt_cache": "80-template text tower evaluated once (identical prompt set), as in eval of one object class",
+                       "stages": a.stages, "prompt_cache": "80-template text tower evaluated once (identical prompt set), as in eval of one object class",
                        "pairs_per_gpu": B, "backbone_ms_per_step": bb_ms / a.steps, "pairs_ok": int((res["status"] == 0).sum())},
             "roofline": {"bound": "mfma", "kernel": "backbone GEMMs (rocBLAS/hipBLASLt via PyTorch-ROCm)", "achieved": flops_backbone / (bb_ms / a.steps * 1e-3) / 1e12,
                          "peak": PEAK_FP32_MFMA_TFLOPS if a.backbone_dtype == "fp32" else PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -232,8 +249,9 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stages", choices=["match+pose", "full"], default="match+pose",
-                    help="match+pose: BASELINE configs[1], descriptor maps given (default, the headline line); full: random-init "
+    ap.add_argument("--stages", choices=["match+pose", "decode", "full"], default="match+pose",
+                    help="match+pose: BASELINE configs[1], descriptor maps given (default, the headline line); decode: fusion + decoder "
+                         "forward on cached CLIP / Swin encodings, then match + pose (SURVEY 8d 'decode+match+pose'); full: random-init "
                          "CLIP ViT-L/14@336 + Swin-B + fusion + decoder forward on 224x224 RGB (-> C=32 @192x192, the reference's own "
                          "shapes), then match + pose - a separate stage set, never mixed into the headline")
     ap.add_argument("--backbone-dtype", choices=["fp32", "bf16", "bf16w"], default="fp32",
@@ -251,7 +269,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B, H, C = a.batch, a.size, a.channels
-    if a.stages == "full":
+    if a.stages in ("full", "decode"):
         return bench_full(a, rank, world, dev)
     inputs = make_inputs(B, H, C, first=rank * B, dev=dev)
     engine = MatchPoseEngine(build_solver(dev), MatchPoseConfig(dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1,
