@@ -55,4 +55,10 @@ __host__ __device__ static inline uint32_t rng_u32(uint64_t seed, uint64_t key, 
     return (uint32_t)(mix64(mix64(seed ^ (key * 0xD1B54A32D192ED03ull)) + ((uint64_t)stream << 32 | i)) >> 32);
 }
 
+// Correctly rounded fp32 square root.  NOT __fsqrt_rn: this toolchain's HIP headers define it as __ocml_native_sqrt_f32 (the
+// approximate one) unless OCML_BASIC_ROUNDED_OPERATIONS is set, and whether the compiler then emits the IEEE fix-up after
+// v_sqrt_f32 depends on the surrounding code.  sqrtf is __ocml_sqrt_f32: correctly rounded with the (default, and explicit in the
+// Makefile) -fhip-fp32-correctly-rounded-divide-sqrt.
+__device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+
 }  // namespace oryon

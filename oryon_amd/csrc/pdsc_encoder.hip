@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void pdsc_sc_kernel(const float *__restrict__ 
             if (k < n) {
                 const float dx = sq[0] - sp[(size_t)k * 3], dy = sq[1] - sp[(size_t)k * 3 + 1], dz = sq[2] - sp[(size_t)k * 3 + 2];
                 const float ex = tq[0] - tp[(size_t)k * 3], ey = tq[1] - tp[(size_t)k * 3 + 1], ez = tq[2] - tp[(size_t)k * 3 + 2];
-                const float ds = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
-                const float dt = __fsqrt_rn(ex * ex + ey * ey + ez * ez);
+                const float ds = sqrt_rn(dx * dx + dy * dy + dz * dz);
+                const float dt = sqrt_rn(ex * ex + ey * ey + ez * ez);
                 const float df = ds - dt;
                 v = 1.0f - df * df * inv_sigma2;
                 v = v > 0.0f ? v : 0.0f;
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void pdsc_normalise_kernel(const float *__rest
     for (int c = lane; c < C; c += 64) s += f[c] * f[c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    float d = __fsqrt_rn(s);
+    float d = sqrt_rn(s);
     d = d < 1e-12f ? 1e-12f : d;
     const bool live = row < n_rows[b];
     for (int c = lane; c < C; c += 64) o[c] = live ? f[c] / d : 0.0f;

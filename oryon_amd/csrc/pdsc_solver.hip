@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void pdsc_seed_keys_kernel(const float *__rest
         const int per = (n + 3) / 4, j0 = part * per, j1 = (j0 + per < n) ? j0 + per : n;
         for (int j = j0; j < j1; ++j) {
             const float dx = x - px[j], dy = y - py[j], dz = z - pz[j];
-            const float d = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+            const float d = sqrt_rn(dx * dx + dy * dy + dz * dz);
             lm = lm && ((s >= sc[j]) || (d >= radius));
         }
     }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
     const int n_pairs = k * (k - 1) / 2;
     for (int e = t; e < n_pairs; e += 256) {
         // e -> (a, c2), a < c2, row-major over the strict upper triangle
-        int a = (int)((2.0f * k - 1.0f - __fsqrt_rn((2.0f * k - 1.0f) * (2.0f * k - 1.0f) - 8.0f * (float)e)) * 0.5f);
+        int a = (int)((2.0f * k - 1.0f - sqrt_rn((2.0f * k - 1.0f) * (2.0f * k - 1.0f) - 8.0f * (float)e)) * 0.5f);
         while (a > 0 && a * (2 * k - a - 1) / 2 > e) --a;
         while ((a + 1) * (2 * k - a - 2) / 2 <= e) ++a;
         const int c2 = a + 1 + (e - a * (2 * k - a - 1) / 2);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
         const float *pa = kc + a * 6, *pb = kc + c2 * 6;
         const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
         const float ex = pa[3] - pb[3], ey = pa[4] - pb[4], ez = pa[5] - pb[5];
-        const float df = __fsqrt_rn(dx * dx + dy * dy + dz * dz) - __fsqrt_rn(ex * ex + ey * ey + ez * ez);
+        const float df = sqrt_rn(dx * dx + dy * dy + dz * dz) - sqrt_rn(ex * ex + ey * ey + ez * ez);
         float smv = 1.0f - df * df * inv_sigma_d2;
         smv = smv > 0.0f ? smv : 0.0f;
         const float v = fm * smv;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void pdsc_power_kernel(const int32_t *__restric
         float sq = u * u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
-        const float vn = u / (__fsqrt_rn(sq) + 1e-6f);
+        const float vn = u / (sqrt_rn(sq) + 1e-6f);
         const bool close = (lane >= k) || (fabsf(vn - vl) <= 1e-8f + 1e-5f * fabsf(vl));
         const bool all = __all(close);
         const size_t h = ((size_t)b * S_cap + s) * num_iterations + it;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64) void pdsc_seed_solve_kernel(const float *__rest
         const float dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - tp[3 * j];
         const float dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - tp[3 * j + 1];
         const float dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - tp[3 * j + 2];
-        cnt += (__fsqrt_rn(dx * dx + dy * dy + dz * dz) < inlier_thr) ? 1 : 0;
+        cnt += (sqrt_rn(dx * dx + dy * dy + dz * dz) < inlier_thr) ? 1 : 0;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void pdsc_seed_select_kernel(const float *__re
                 const float dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - tp[3 * j];
                 const float dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - tp[3 * j + 1];
                 const float dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - tp[3 * j + 2];
-                lab = (__fsqrt_rn(dx * dx + dy * dy + dz * dz) < inlier_thr) ? 1 : 0;
+                lab = (sqrt_rn(dx * dx + dy * dy + dz * dz) < inlier_thr) ? 1 : 0;
             }
             labels[(size_t)b * n_cap + j] = lab;
         }
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void pdsc_refine_kernel(const float *__restric
             const float dx = (T[0] * x + T[1] * y + T[2] * z + T[3]) - bx;
             const float dy = (T[4] * x + T[5] * y + T[6] * z + T[7]) - by;
             const float dz = (T[8] * x + T[9] * y + T[10] * z + T[11]) - bz;
-            const float d = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+            const float d = sqrt_rn(dx * dx + dy * dy + dz * dz);
             if (d < tau) {
                 ++cnt;
                 const float q = d / tau;

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(GN_ROWS) void gather_normalise_kernel(const float *
             const float v = f[(size_t)k * HW + pix];
             n2 = __fmaf_rn(v, v, n2);
         }
-    float d = __fsqrt_rn(n2);
+    float d = sqrt_rn(n2);
     d = d < 1e-8f ? 1e-8f : d;
     float *o = out + ((size_t)m * rows_cap + row0) * Cp;
     for (int k0 = 0; k0 < Cp; k0 += GN_KT) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void gather_normalise_v2_kernel(const float *_
             for (int u = 0; u < 16; ++u)
                 if (k0 + u < C) n2 = __fmaf_rn(x[u], x[u], n2);
         }
-        float d = __fsqrt_rn(n2);
+        float d = sqrt_rn(n2);
         sd[lane] = d < 1e-8f ? 1e-8f : d;
     }
     __syncthreads();
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void gather_normalise_q8_kernel(const float *_
             for (int u = 0; u < 16; ++u)
                 if (k0 + u < C) n2 = __fmaf_rn(x[u], x[u], n2);
         }
-        float d = __fsqrt_rn(n2);
+        float d = sqrt_rn(n2);
         sd[lane] = d < 1e-8f ? 1e-8f : d;
     }
     __syncthreads();
