@@ -13,7 +13,7 @@ read live on the device, bookkeeping stays on the host.  No CPU pixel path exist
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 import torch

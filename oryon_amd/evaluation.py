@@ -9,7 +9,7 @@ path - SURVEY.md §8f-3):
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import Dict, List
 
 import numpy as np
 from scipy.spatial import cKDTree

@@ -27,7 +27,6 @@ if ROOT not in sys.path:
 
 from oryon_amd import evaluation as ev  # noqa: E402
 from oryon_amd.pipeline import Pipeline, default_args  # noqa: E402
-from oryon_amd.pointdsc import PointDSC  # noqa: E402
 from oryon_amd.synth import make_pair  # noqa: E402
 
 

@@ -1,4 +1,4 @@
-import sys, time, torch
+import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oryon_amd.net import Oryon, default_model_args
 dev = "cuda"
