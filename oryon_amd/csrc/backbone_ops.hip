@@ -301,12 +301,7 @@ extern "C" int oryon_swin_window_attention_bf16(const void *qkv, const void *pad
     if (B == 0) return ORYON_OK;
     const int nwy = (H + SWIN_WS - 1) / SWIN_WS, nwx = (W + SWIN_WS - 1) / SWIN_WS;
     const size_t lds = (size_t)heads * SWIN_WAVE_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        ORYON_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(swin_window_attention_bf16_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SWIN_WAVE_FLOATS * (int)sizeof(float)));
-        attr_set = true;
-    }
+    allow_dynamic_lds(reinterpret_cast<const void *>(swin_window_attention_bf16_kernel), 8 * SWIN_WAVE_FLOATS * (int)sizeof(float));
     hipLaunchKernelGGL(swin_window_attention_bf16_kernel, dim3(nwy * nwx, B), dim3(64 * heads), lds, as_stream(stream),
                        static_cast<const unsigned short *>(qkv), static_cast<const unsigned short *>(pad_qkv), bias_t, H, W, C, shift,
                        static_cast<unsigned short *>(out));

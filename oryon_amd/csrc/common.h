@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "../../include/oryon_hip.h"
 
 namespace oryon {
@@ -53,6 +56,18 @@ __host__ __device__ static inline uint64_t mix64(uint64_t x)
 __host__ __device__ static inline uint32_t rng_u32(uint64_t seed, uint64_t key, uint32_t stream, uint32_t i)
 {
     return (uint32_t)(mix64(mix64(seed ^ (key * 0xD1B54A32D192ED03ull)) + ((uint64_t)stream << 32 | i)) >> 32);
+}
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): thread-safe, and right when one process drives several GPUs
+// (the attribute belongs to the device's copy of the function).
+inline void allow_dynamic_lds(const void *kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.insert({kernel, dev}).second) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 // Correctly rounded fp32 square root.  NOT __fsqrt_rn: this toolchain's HIP headers define it as __ocml_native_sqrt_f32 (the

@@ -787,14 +787,7 @@ void launch_screen(int groups, hipStream_t st, const __half *a16, const __half *
                    const int32_t *row_map, int32_t *ws_i1, float *ws_m2)
 {
     constexpr size_t dyn = 2 * screen_tile_bytes(CP) > 65536 ? 2 * screen_tile_bytes(CP) : 0;
-    if (dyn) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_f16_screen_kernel<CP, MODE, 0>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            attr_set = true;
-        }
-    }
+    if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_f16_screen_kernel<CP, MODE, 0>), (int)dyn);
     hipLaunchKernelGGL((match_f16_screen_kernel<CP, MODE, 0>), dim3(groups), dim3(256), dyn, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T,
                        S, valid_cut, ws_max, cnt, cand, S_thr, row_map, ws_i1, ws_m2);
 }
@@ -915,13 +908,7 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
                     const int32_t *n_a, const int32_t *n_q, int T, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
 {
     constexpr size_t dyn = 2 * screen8_tile_bytes(CP) > 65536 ? 2 * screen8_tile_bytes(CP) : 0;
-    if (dyn) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_i8_screen_kernel<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            attr_set = true;
-        }
-    }
+    if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_i8_screen_kernel<CP>), (int)dyn);
     hipLaunchKernelGGL((match_i8_screen_kernel<CP>), dim3(groups), dim3(256), dyn, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S,
                        ws_max, ws_i1, ws_m2);
 }

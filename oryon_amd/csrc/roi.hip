@@ -491,11 +491,7 @@ extern "C" int oryon_gather_normalise_q8(const float *feat, int n_maps, int C, i
     hipStream_t st = as_stream(stream);
     ORYON_CHECK_HIP(hipMemsetAsync(eps_max, 0, (size_t)n_maps * sizeof(float), st));
     const size_t sh = ((size_t)C_pad * 33 + 32 + 8) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_q8_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // 8 / 16 / 32 loads in flight measure the same
-        attr_set = true;
-    }
+    allow_dynamic_lds(reinterpret_cast<const void *>(gather_normalise_q8_kernel<16>), 160 * 1024);   // 8 / 16 / 32 loads in flight measure the same
     hipLaunchKernelGGL((gather_normalise_q8_kernel<16>), dim3(rows_cap / 32, n_maps), dim3(256), sh, st, feat, C, HW, roi, roi_stride, count,
                        rows_cap, C_pad, out, static_cast<__half *>(out_f16), out_i8, slice_scale, reinterpret_cast<unsigned *>(eps_max));
     ORYON_CHECK_LAUNCH();
@@ -516,12 +512,7 @@ extern "C" int oryon_gather_normalise_f32(const float *feat, int n_maps, int C, 
         const size_t sh = ((size_t)C_pad * (rows + 1) + 64) * sizeof(float);
 #define LAUNCH_G2(NLV, RV)                                                                                                 \
     do {                                                                                                                   \
-        static bool attr_set = false;                                                                                      \
-        if (!attr_set) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_normalise_v2_kernel<NLV, RV>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
-            attr_set = true;                                                                                               \
-        }                                                                                                                  \
+        allow_dynamic_lds(reinterpret_cast<const void *>(gather_normalise_v2_kernel<NLV, RV>), 160 * 1024);              \
         hipLaunchKernelGGL((gather_normalise_v2_kernel<NLV, RV>), dim3(rows_cap / RV, n_maps), dim3(256), sh, as_stream(stream), feat, \
                            C, HW, roi, roi_stride, count, rows_cap, C_pad, out, static_cast<__half *>(out_f16));          \
     } while (0)
