@@ -35,6 +35,14 @@ def test_argument_validation_without_gpu():
     assert L.oryon_match_workspace_bytes(512, 5120) == 0                      # batch alone gives >= 16 rounds: no query split
     assert L.oryon_match_workspace_bytes(64, 5120) == 64 * 4 * 5120 * 8       # cfg2: 4 splits x (fp32 + int32) per anchor row
     assert L.oryon_match_workspace_bytes(1, 2048) > 0
+    # the newer entry points reject bad arguments the same way (no HIP call is reached)
+    assert L.oryon_gather_normalise_q8(None, 1, 256, 16, None, 16, None, 256, 256, None, None, None, None, None, None) == -1
+    assert L.oryon_match_screened8(None, None, None, None, None, None, None, 1, 256, 256, 256, 256, None, None, 0.25, None, None, None,
+                                   None, None, 0, None) == -1
+    assert L.oryon_match_screened(None, None, None, None, 1, 256, 256, 256, None, None, 0.25, None, None, None, None, 0, None) == -1
+    assert L.oryon_add_layernorm_bf16(None, None, None, None, 4, 1024, 1e-5, None, None, None) == -1
+    assert L.oryon_swin_window_attention_bf16(None, None, None, 1, 7, 7, 128, 4, 0, None, None) == -1
+    assert L.oryon_match_screened8_workspace_bytes(64, 256, 5120, 50176) > L.oryon_match_screened_workspace_bytes(64, 256, 5120) > 0
 
 
 def test_no_cpu_fallback():
