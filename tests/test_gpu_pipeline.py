@@ -281,6 +281,31 @@ def test_swin_window_attention_kernel_vs_torch_fp32():
             assert float(err) < 2e-2, (dim, heads, H, W, shift, float(err))
 
 
+def test_oryon_forward_bf16_weights_tracks_fp32():
+    """Oryon.forward with bf16 weights (PatchEmbed GEMM + B1 / B2 / B3 kernels in the towers) against the same random-init network in
+    fp32 (torch ops only): descriptor maps and mask logits stay strongly correlated - bf16 round-off, not a different function."""
+    from oryon_amd.backbone.clip import CLIPConfig
+    from oryon_amd.net import Oryon, default_model_args
+    torch.manual_seed(0)
+    net = Oryon(default_model_args(), "cuda", clip_cfg=CLIPConfig(v_layers=2, t_layers=1)).eval()
+    gen = torch.Generator().manual_seed(0)
+    toks = torch.randint(1, 49000, (1, 80, 77), generator=gen)
+    toks[..., 10] = 49407
+    toks[..., 11:] = 0
+    rgb_a, rgb_q = torch.rand(2, 3, 224, 224, generator=gen).cuda(), torch.rand(2, 3, 224, 224, generator=gen).cuda()
+    xs = {"anchor": {"rgb": rgb_a}, "query": {"rgb": rgb_q}, "prompt_tokens": toks.expand(2, 80, 77).contiguous()}
+    with torch.no_grad():
+        ref = net(xs)
+        net16 = net.to(torch.bfloat16)
+        net16.vlm._prompt_cache.clear()
+        out = net16({"anchor": {"rgb": rgb_a.to(torch.bfloat16)}, "query": {"rgb": rgb_q.to(torch.bfloat16)}, "prompt_tokens": xs["prompt_tokens"]})
+    for k in ("featmap_a", "featmap_q", "mask_a", "mask_q"):
+        a, b = ref[k].float().flatten(), out[k].float().flatten()
+        assert out[k].dtype == torch.bfloat16 and bool(torch.isfinite(b).all())
+        corr = torch.corrcoef(torch.stack((a, b)))[0, 1]
+        assert float(corr) > 0.98, (k, float(corr))
+
+
 def test_swin_bf16_fast_layernorm_matches_plain():
     import torch.nn as nn
     from oryon_amd.backbone import swin
