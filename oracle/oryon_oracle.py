@@ -169,14 +169,16 @@ def kabsch(A: torch.Tensor, B: torch.Tensor, w: Optional[torch.Tensor] = None) -
     ca = (A * w[:, :, None]).sum(dim=1, keepdim=True) / den
     cb = (B * w[:, :, None]).sum(dim=1, keepdim=True) / den
     H = (A - ca).transpose(1, 2) @ (w[:, :, None] * (B - cb))
-    U, _, Vh = torch.linalg.svd(H)
+    dev = A.device                                             # the reference takes H to the host for the SVD (common.py:33)
+    U, _, Vh = torch.linalg.svd(H.cpu())
+    U, Vh = U.to(dev), Vh.to(dev)
     V = Vh.transpose(1, 2)
     d = torch.det(V @ U.transpose(1, 2))
-    D = torch.eye(3).repeat(bs, 1, 1)
+    D = torch.eye(3, device=dev).repeat(bs, 1, 1)
     D[:, 2, 2] = d
     R = V @ D @ U.transpose(1, 2)
     t = cb.transpose(1, 2) - R @ ca.transpose(1, 2)
-    T = torch.eye(4).repeat(bs, 1, 1)
+    T = torch.eye(4, device=dev).repeat(bs, 1, 1)
     T[:, :3, :3] = R
     T[:, :3, 3:4] = t
     return T
