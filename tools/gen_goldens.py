@@ -294,6 +294,15 @@ def gen_pointdsc():
     pointdsc_case("l12c128_n500", 500, 12, 128, 44, extent=0.4)   # scene-sized: many local maxima
     pointdsc_case("l12c128_n500_obj", 500, 12, 128, 45, extent=0.12, dup=60)  # object-sized + duplicate rows
     pointdsc_case("l6c128_n200", 200, 6, 128, 46, inlier_ratio=0.3, pseed=1)
+    gen_pointdsc_edge()
+
+
+def gen_pointdsc_edge():
+    """Edge sizes of the reference: k = n - 1 < 40, a single seed (int(n * 0.1) == 1), two seeds, and an outlier-dominated set."""
+    pointdsc_case("l2c32_n10", 10, 2, 32, 47, inlier_ratio=0.8)           # 1 seed, k = 9
+    pointdsc_case("l12c128_n12", 12, 12, 128, 48, inlier_ratio=0.8)       # 1 seed, k = 11
+    pointdsc_case("l6c128_n22", 22, 6, 128, 49, inlier_ratio=0.7)         # 2 seeds, k = 21
+    pointdsc_case("l12c128_n300_out", 300, 12, 128, 50, inlier_ratio=0.15, extent=0.3)
 
 
 # ---------------------------------------------------------------------------------------------- G6
@@ -468,6 +477,8 @@ if __name__ == "__main__":
         gen_kabsch()
     if "pointdsc" in which:
         gen_pointdsc()
+    if "pointdsc_edge" in which:
+        gen_pointdsc_edge()
     if "e2e" in which:
         gen_end_to_end()
     if "backbone" in which:
