@@ -243,8 +243,8 @@ def bench_full(a, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step (cfg2: 64)")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--channels", type=int, default=256)
