@@ -240,6 +240,40 @@ def bench_full(a, rank, world, dev):
         dist.destroy_process_group()
 
 
+def collation_selftest(a):
+    """The N>1 control flow of main() on CPU tensors over gloo: shard keys by rank, barrier + timed region, gather_poses, one JSON
+    line on rank 0.  No kernel runs; the poses are a function of the global pair index so the collated order can be checked."""
+    rank, world, _ = init_from_env("cpu")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    B = a.batch
+    total = B * world
+    idx = torch.arange(rank * B, rank * B + B, dtype=torch.float32)
+    pose = torch.eye(4).repeat(B, 1, 1)
+    pose[:, 0, 3] = idx
+    status = (idx.to(torch.int32) % 3)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        allp, alls = gather_poses(pose, status, total)
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ok = bool(torch.equal(allp[:, 0, 3], torch.arange(total, dtype=torch.float32))) and \
+        bool(torch.equal(alls, torch.arange(total, dtype=torch.int32) % 3))
+    if rank == 0:
+        print(json.dumps({"metric": "collation selftest (no kernels)", "n_gpus": world, "steps": a.steps, "global_pairs": total,
+                          "collated_in_order": ok, "elapsed_s": float(el.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,8 +295,27 @@ def main():
                     help="do not overlap the registration of step k with the matching of step k+1 (second HIP stream)")
     ap.add_argument("--match-mode", choices=["screened", "screened16", "exact"], default="screened",
                     help="screened: fp16-MFMA screening + exact fp32 re-scoring (K1s, identical results); exact: full fp32 scan (K1)")
+    ap.add_argument("--collation-selftest", action="store_true",
+                    help="CPU-only check of the multi-rank launch path (gloo): every rank fabricates its poses, the collation runs, rank 0 "
+                         "prints one JSON line.  Used by tests/test_cabi_and_host.py; measures nothing")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (how the driver calls it): become the launcher - one rank per GPU under torch.distributed.run,
+        # rendezvous on 127.0.0.1 and a free port; the ranks' stdout (rank 0's single JSON line) passes through unchanged
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
+    if a.collation_selftest:
+        return collation_selftest(a)
     rank, world, local = init_from_env("cuda")
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")

@@ -39,20 +39,32 @@ def roi_from_mask(mask: np.ndarray) -> np.ndarray:
     return out[:n].copy()
 
 
-def match_lin(feat_a: np.ndarray, feat_q: np.ndarray, roi_a: np.ndarray, roi_q: np.ndarray, thr: float):
-    """feat_*: [C,H,W] fp32; roi_*: int32 linear pixel indices.  Returns (min_dist, argmin, valid)."""
+def match_lin(feat_a: np.ndarray, feat_q: np.ndarray, roi_a: np.ndarray, roi_q: np.ndarray, thr: float, anchor_rows=None,
+              scalar: bool = False):
+    """feat_*: [C,H,W] fp32; roi_*: int32 linear pixel indices.  Returns (min_dist, argmin, valid).
+    anchor_rows: optional subset of anchor ROW indices to score (against all query rows); outputs then follow that subset.
+    scalar: the plain one-chain-at-a-time loop nest (slow; pins the interleaved default bit for bit)."""
     fa = np.ascontiguousarray(feat_a, dtype=np.float32)
     fq = np.ascontiguousarray(feat_q, dtype=np.float32)
     C, HW = fa.shape[0], fa.shape[1] * fa.shape[2]
     ra = np.ascontiguousarray(roi_a, dtype=np.int32)
     rq = np.ascontiguousarray(roi_q, dtype=np.int32)
     n1, n2 = len(ra), len(rq)
-    md = np.empty(n1, dtype=np.float32)
-    am = np.empty(n1, dtype=np.int32)
-    va = np.empty(n1, dtype=np.uint8)
-    lib().orc_match_f32(_p(fa, ctypes.c_float), _p(fq, ctypes.c_float), C, HW, _p(ra, ctypes.c_int32), n1,
-                        _p(rq, ctypes.c_int32), n2, ctypes.c_float(thr), _p(md, ctypes.c_float),
-                        _p(am, ctypes.c_int32), _p(va, ctypes.c_uint8))
+    rows = None if anchor_rows is None else np.ascontiguousarray(anchor_rows, dtype=np.int32)
+    n_out = n1 if rows is None else len(rows)
+    md = np.empty(n_out, dtype=np.float32)
+    am = np.empty(n_out, dtype=np.int32)
+    va = np.empty(n_out, dtype=np.uint8)
+    if scalar:
+        assert rows is None
+        lib().orc_match_f32_scalar(_p(fa, ctypes.c_float), _p(fq, ctypes.c_float), C, HW, _p(ra, ctypes.c_int32), n1,
+                                   _p(rq, ctypes.c_int32), n2, ctypes.c_float(thr), _p(md, ctypes.c_float),
+                                   _p(am, ctypes.c_int32), _p(va, ctypes.c_uint8))
+    else:
+        lib().orc_match_f32_rows(_p(fa, ctypes.c_float), _p(fq, ctypes.c_float), C, HW, _p(ra, ctypes.c_int32), n1,
+                                 _p(rq, ctypes.c_int32), n2, ctypes.c_float(thr),
+                                 None if rows is None else _p(rows, ctypes.c_int32), n_out, _p(md, ctypes.c_float),
+                                 _p(am, ctypes.c_int32), _p(va, ctypes.c_uint8))
     return md, am, va.astype(bool)
 
 

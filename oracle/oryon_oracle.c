@@ -13,7 +13,7 @@
  *   argmin = first column attaining the row minimum
  * Pinned against the real reference by tests/test_oracle_goldens.py (form "c").
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
- * Build: make -C oracle      (gcc -O2 -ffp-contract=off; no fast-math)
+ * Build: make -C oracle      (gcc -O3 -mfma -mavx2 -ffp-contract=off; no fast-math: fmaf stays one correctly rounded operation)
  */
 #include <math.h>
 #include <stdint.h>
@@ -49,15 +49,69 @@ void orc_gather_normalise(const float *feat, int C, int HW, const int32_t *roi_l
     for (int i = 0; i < n; ++i) gather_normalise(feat, C, HW, roi_lin[i], out + (size_t)i * C);
 }
 
-/* cosine nearest neighbour of every anchor ROI pixel among the query ROI pixels */
+/* cosine nearest neighbour of every anchor ROI pixel among the query ROI pixels.
+ * Every (anchor, query) dot product is its own k-ordered fmaf chain; the loop nest only interleaves QB independent
+ * chains (query rows stored block-transposed, [n2/QB][C][QB]) so the compiler can keep them in vector lanes - the
+ * value of each chain is what the scalar loop gives, bit for bit.  anchor_rows (optional) restricts the scan to a
+ * subset of the anchor rows (full-size parity checks score a sample of rows against ALL query rows). */
+#define QB 16
+void orc_match_f32_rows(const float *feat_a, const float *feat_q, int C, int HW, const int32_t *roi_a, int n1,
+                        const int32_t *roi_q, int n2, float thr, const int32_t *anchor_rows, int n_rows,
+                        float *min_dist, int32_t *argmin, uint8_t *valid)
+{
+    const int nb = (n2 + QB - 1) / QB;
+    float *an = (float *)malloc((size_t)(n1 > 0 ? n1 : 1) * C * sizeof(float));
+    float *qn = (float *)malloc((size_t)(n2 > 0 ? n2 : 1) * C * sizeof(float));
+    float *qt = (float *)calloc((size_t)(nb > 0 ? nb : 1) * C * QB, sizeof(float));
+    orc_gather_normalise(feat_a, C, HW, roi_a, n1, an);
+    orc_gather_normalise(feat_q, C, HW, roi_q, n2, qn);
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < n2; ++j)
+        for (int k = 0; k < C; ++k) qt[((size_t)(j / QB) * C + k) * QB + (j % QB)] = qn[(size_t)j * C + k];
+    const int rows = anchor_rows ? n_rows : n1;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int r = 0; r < rows; ++r) {
+        const int i = anchor_rows ? anchor_rows[r] : r;
+        const float *a = an + (size_t)i * C;
+        float best = INFINITY;
+        int bj = 0;
+        for (int jb = 0; jb < nb; ++jb) {
+            const float *b = qt + (size_t)jb * C * QB;
+            float dot[QB];
+            for (int u = 0; u < QB; ++u) dot[u] = 0.0f;
+            for (int k = 0; k < C; ++k) {
+                const float ak = a[k];
+                for (int u = 0; u < QB; ++u) dot[u] = fmaf(ak, b[(size_t)k * QB + u], dot[u]);
+            }
+            const int lim = (n2 - jb * QB) < QB ? (n2 - jb * QB) : QB;
+            for (int u = 0; u < lim; ++u) {
+                float dist = fmaf(-0.5f, dot[u], 0.5f);
+                if (dist < best) { best = dist; bj = jb * QB + u; }
+            }
+        }
+        min_dist[r] = best;
+        argmin[r] = bj;
+        valid[r] = (uint8_t)(best < thr);
+    }
+    free(an);
+    free(qn);
+    free(qt);
+}
+
 void orc_match_f32(const float *feat_a, const float *feat_q, int C, int HW, const int32_t *roi_a, int n1,
                    const int32_t *roi_q, int n2, float thr, float *min_dist, int32_t *argmin, uint8_t *valid)
+{
+    orc_match_f32_rows(feat_a, feat_q, C, HW, roi_a, n1, roi_q, n2, thr, NULL, 0, min_dist, argmin, valid);
+}
+
+/* the plain scalar loop nest (one chain at a time): kept to pin the interleaved version above, bit for bit */
+void orc_match_f32_scalar(const float *feat_a, const float *feat_q, int C, int HW, const int32_t *roi_a, int n1,
+                          const int32_t *roi_q, int n2, float thr, float *min_dist, int32_t *argmin, uint8_t *valid)
 {
     float *an = (float *)malloc((size_t)(n1 > 0 ? n1 : 1) * C * sizeof(float));
     float *qn = (float *)malloc((size_t)(n2 > 0 ? n2 : 1) * C * sizeof(float));
     orc_gather_normalise(feat_a, C, HW, roi_a, n1, an);
     orc_gather_normalise(feat_q, C, HW, roi_q, n2, qn);
-#pragma omp parallel for schedule(dynamic, 16)
     for (int i = 0; i < n1; ++i) {
         const float *a = an + (size_t)i * C;
         float best = INFINITY;

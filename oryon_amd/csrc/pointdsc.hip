@@ -129,6 +129,11 @@ extern "C" int oryon_pointdsc_create(oryon_pointdsc_t **handle, const oryon_poin
     ORYON_CHECK_ARG(cfg->num_channels == 32 || cfg->num_channels == 64 || cfg->num_channels == 128);
     ORYON_CHECK_ARG(cfg->k >= 1 && cfg->k <= 64 && cfg->num_iterations >= 1 && cfg->ratio > 0.0f && cfg->ratio <= 1.0f);
     ORYON_CHECK_ARG(cfg->sigma_d > 0.0f && cfg->inlier_threshold > 0.0f && cfg->nms_radius >= 0.0f);
+    if (cfg->num_iterations > 16) {      // the power-iteration history (v_hist / close_hist) holds 16 iterates per seed: refuse, never truncate
+        set_error("oryon_pointdsc_create: num_iterations = %d exceeds the 16 iterates the device power iteration keeps per seed "
+                  "(models/pointdsc/PointDSC.py:338-358 would run all of them)", cfg->num_iterations);
+        return ORYON_ERR_INVALID_ARG;
+    }
     auto *h = new oryon_pointdsc();
     h->cfg = *cfg;
     *handle = h;
@@ -257,8 +262,10 @@ extern "C" size_t oryon_pointdsc_workspace_bytes(const oryon_pointdsc_t *h, int 
     return carve(h->cfg, B, n_cap, nullptr, nullptr);
 }
 
+// n_cap <= 4096: pdsc_knn_matrix_kernel sorts one seed's n_cap distances in dynamic LDS (2 * pow2(n_cap) floats + ~35 KB)
 #define PDSC_COMMON_CHECKS()                                                                          \
     ORYON_CHECK_ARG(h && B >= 0 && n_cap > 0 && n_cap % 128 == 0);                                      \
+    if (n_cap > 4096) { set_error("%s: n_cap = %d exceeds 4096 rows per pair (LDS budget of the kNN kernel)", __func__, n_cap); return ORYON_ERR_INVALID_ARG; } \
     if (!h->finalized) { set_error("%s: handle not finalized", __func__); return ORYON_ERR_STATE; }   \
     if (B == 0) return ORYON_OK;
 

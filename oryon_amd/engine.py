@@ -90,7 +90,8 @@ class MatchPoseEngine:
         if pair_key is None:
             pair_key = torch.arange(B, dtype=torch.int64, device=dev)
         main = torch.cuda.current_stream(dev)
-        screened = cfg.match_mode in ("screened", "screened16") and 64 < C <= 512
+        # the screens' validity cut is 1 - 2*dist_th: thresholds above 0.5 (or non-positive) take the exact scan
+        screened = cfg.match_mode in ("screened", "screened16") and 64 < C <= 512 and 0.0 < cfg.dist_th <= 0.5
         use_i8 = screened and cfg.match_mode == "screened" and C > 128
         if use_i8:
             if self._i8_pending is not None and self._i8_pending[1].query():

@@ -43,6 +43,7 @@ def _weights_init_kaiming(m: nn.Module) -> None:
 
 class CLIPEncoder(nn.Module):
     """models/vlm.py:14-99: frozen CLIP, fp32, always in eval mode."""
+    PROMPT_CACHE_MAX = 256        # distinct prompt sets kept (one per object class in the reference's test splits)
 
     def __init__(self, device: str, clip_cfg: Optional[CLIPConfig] = None, bpe_path: Optional[str] = None):
         super().__init__()
@@ -58,6 +59,23 @@ class CLIPEncoder(nn.Module):
     def train(self, mode=True):
         self.training = False
         return self
+
+    # The prompt-embedding cache is valid for ONE set of text-tower parameters: any path that can change them (or their
+    # dtype / device) drops it.
+    def load_state_dict(self, *a, **k):
+        self._prompt_cache.clear()
+        return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):          # reached when a PARENT module's load_state_dict recurses into this one
+        self._prompt_cache.clear()
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):                     # .to() / .half() / .cuda() ...
+        self._prompt_cache.clear()
+        return super()._apply(fn, *a, **k)
+
+    def _text_params_version(self):
+        return tuple((p.data_ptr(), p._version, p.dtype) for p in (self.clip_model.token_embedding.weight, self.clip_model.text_projection))
 
     def eval(self):
         return self.train(False)
@@ -79,9 +97,15 @@ class CLIPEncoder(nn.Module):
         """tokens [B, T, L] int64 -> [B, T, embed]; identical prompt sets are served from the cache."""
         B, T, L = tokens.shape
         out = []
+        ver = self._text_params_version()
+        if getattr(self, "_prompt_cache_ver", None) != ver:           # in-place parameter updates (optimizer step, copy_)
+            self._prompt_cache.clear()
+            self._prompt_cache_ver = ver
         for b in range(B):
             key = tuple(tokens[b].reshape(-1).tolist())
             if key not in self._prompt_cache:
+                if len(self._prompt_cache) >= self.PROMPT_CACHE_MAX:   # bounded: drop the oldest entry (dicts keep insertion order)
+                    self._prompt_cache.pop(next(iter(self._prompt_cache)))
                 with torch.no_grad():
                     self._prompt_cache[key] = self.clip_model.text_features(tokens[b].to(self.device))
             out.append(self._prompt_cache[key])

@@ -4,6 +4,7 @@ Every wrapper takes torch CUDA tensors, allocates outputs with torch (plumbing) 
 kernel on the current torch stream.  Nothing here computes: the arithmetic lives in liboryon_hip.so."""
 from __future__ import annotations
 
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -12,14 +13,31 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
 MATCH_TILE = 128
-ROW_PAD = 256      # oryon_gather_normalise_f32 zero-fills / requires multiples of 256 rows
+ROW_PAD = 256      # row capacities are multiples of 256; K0 zero-fills rows [n, round_up(n, 256)) of every map - rows beyond that
+                   # are NOT written (the matchers never read past ceil(n / 256) * 256)
 K_PAD = 32
+
+
+def _on_tensor_device(fn):
+    """Run the wrapped C-ABI call with the first tensor argument's GPU as the current HIP device: the library launches on the
+    stream it is handed, but kernel attributes (dynamic-LDS opt-in) and hipMemsetAsync target the CURRENT device."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapped
 
 
 def round_up(x: int, m: int) -> int:
     return ((int(x) + m - 1) // m) * m
 
 
+@_on_tensor_device
 def round_to_f16(x: torch.Tensor) -> torch.Tensor:
     """fp32 CUDA tensor rounded to the nearest float16 value, returned as fp32 (K1' input rounding)."""
     _lib.require_gpu(x.device)
@@ -29,6 +47,7 @@ def round_to_f16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def quick_gelu_bf16(x: torch.Tensor) -> torch.Tensor:
     """x * sigmoid(1.702 x) on a bf16 CUDA tensor in one pass (B1); used by the CLIP residual blocks at inference."""
     _lib.require_gpu(x.device)
@@ -39,6 +58,7 @@ def quick_gelu_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+@_on_tensor_device
 def add_layernorm_bf16(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor, eps: float):
     """(x + delta, LayerNorm(x + delta)) for bf16 CUDA tensors in one pass (B2); delta None -> (x, LayerNorm(x)).
     Used by the CLIP residual blocks at inference."""
@@ -60,6 +80,7 @@ def add_layernorm_bf16(x: torch.Tensor, delta: Optional[torch.Tensor], weight: t
     return s_out, h
 
 
+@_on_tensor_device
 def swin_window_attention_bf16(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, shift: int) -> torch.Tensor:
     """Shifted-window attention (window 7, head dim 32) on un-windowed q|k|v tokens [B,H,W,3C] bf16 -> [B,H,W,C] bf16 (B3)."""
     _lib.require_gpu(qkv.device)
@@ -74,6 +95,7 @@ def swin_window_attention_bf16(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t:
     return out
 
 
+@_on_tensor_device
 def rgb_resize_bilinear(rgb_hwc: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
     """uint8 [n,HI,WI,3] -> fp32 [n,3,HO,WO] in [0,1] (K-1: /255., CHW, bilinear align_corners=False, fp64 arithmetic)."""
     _lib.require_gpu(rgb_hwc.device)
@@ -86,6 +108,7 @@ def rgb_resize_bilinear(rgb_hwc: torch.Tensor, out_hw: Tuple[int, int]) -> torch
     return out
 
 
+@_on_tensor_device
 def resize_bilinear(x: torch.Tensor, out_hw: Tuple[int, int], round_output: bool = False) -> torch.Tensor:
     """fp32 [n,HI,WI] -> fp32 [n,HO,WO], torch bilinear (align_corners=False); round_output mimics torchvision on integer images."""
     _lib.require_gpu(x.device)
@@ -97,6 +120,7 @@ def resize_bilinear(x: torch.Tensor, out_hw: Tuple[int, int], round_output: bool
     return out
 
 
+@_on_tensor_device
 def roi_compact(mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """mask [n_maps, H, W] (or [H,W]) int32 -> (roi [n_maps, HW] int32 linear indices, count [n_maps] int32)."""
     if mask.dim() == 2:
@@ -110,6 +134,7 @@ def roi_compact(mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return roi, count
 
 
+@_on_tensor_device
 def mask_from_logits(logits: torch.Tensor, threshold: float) -> torch.Tensor:
     _lib.require_gpu(logits.device)
     logits = logits.to(torch.float32).contiguous()
@@ -119,6 +144,7 @@ def mask_from_logits(logits: torch.Tensor, threshold: float) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def mask_resize_nearest(mask: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
     """uint8 masks [n,HI,WI] -> int32 [n,HO,WO] with torch's legacy 'nearest' index rule."""
     if mask.dim() == 2:
@@ -132,6 +158,7 @@ def mask_resize_nearest(mask: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Te
     return out
 
 
+@_on_tensor_device
 def roi_subsample_(roi: torch.Tensor, count: torch.Tensor, max_keep: int, seed: int, map_key: Optional[torch.Tensor] = None) -> None:
     """In-place device-RNG subsample of every ROI list to at most max_keep entries (order preserved)."""
     _lib.require_gpu(roi.device)
@@ -139,6 +166,7 @@ def roi_subsample_(roi: torch.Tensor, count: torch.Tensor, max_keep: int, seed: 
                                     ptr(map_key), stream_ptr(roi.device)), "oryon_roi_subsample")
 
 
+@_on_tensor_device
 def gather_normalise(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: Optional[int] = None,
                      want_f16: bool = False):
     """feat [n_maps,C,H,W] fp32, roi [n_maps, stride] -> [n_maps, rows_cap, C_pad] unit rows (rows_cap % 256 == 0);
@@ -167,6 +195,7 @@ def unpermute_k(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def match(a_hat: torch.Tensor, q_hat: torch.Tensor, n_a: torch.Tensor, n_q: torch.Tensor, threshold: float):
     """a_hat [B,cap_a,Cp], q_hat [B,cap_q,Cp] -> (min_dist [B,cap_a] f32, argmin [B,cap_a] i32, valid [B,cap_a] u8)."""
     dev = _lib.require_gpu(a_hat.device)
@@ -183,6 +212,7 @@ def match(a_hat: torch.Tensor, q_hat: torch.Tensor, n_a: torch.Tensor, n_q: torc
     return min_dist, argmin, valid
 
 
+@_on_tensor_device
 def match_screened(a_hat, q_hat, a16, q16, n_a, n_q, threshold: float):
     """fp16-screened, fp32-exact matcher (K1s).  Same outputs as `match` on every row that can be valid."""
     dev = _lib.require_gpu(a_hat.device)
@@ -200,6 +230,7 @@ def match_screened(a_hat, q_hat, a16, q16, n_a, n_q, threshold: float):
     return min_dist, argmin, valid
 
 
+@_on_tensor_device
 def gather_normalise_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: int, want_f16: bool = False):
     """K0 with int8 copies: -> (rows fp32 k-permuted, rows fp16 | None, rows int8, slice_scale [n, rows_cap/16], eps_max [n])."""
     dev = _lib.require_gpu(feat.device)
@@ -216,6 +247,7 @@ def gather_normalise_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tens
     return out, out16, out8, scale, eps
 
 
+@_on_tensor_device
 def match_screened8(a_hat, q_hat, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, threshold: float, c_true: int, n_undecided=None):
     """int8 pre-screen + fp16 screen + exact fp32 re-scoring (K1s8).  Same outputs as `match_screened`.
     n_undecided: optional int32 [B] tensor receiving the number of anchors the int8 stage handed to the fp16 stage."""
@@ -233,6 +265,7 @@ def match_screened8(a_hat, q_hat, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, thr
     return min_dist, argmin, valid
 
 
+@_on_tensor_device
 def select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, W: int, max_corrs: int, seed: int, pair_key=None,
                  corr_rows: Optional[int] = None):
     """Device-RNG correspondence sampling -> (corrs [B,corr_rows,4] i32, n_valid [B], n_sel [B], status [B])."""
@@ -251,6 +284,7 @@ def select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, W: int, max_corrs: int, 
     return corrs, n_valid, n_sel, status
 
 
+@_on_tensor_device
 def lift_pairs(corrs: torch.Tensor, n_corr: Optional[torch.Tensor], feat_hw, depth_a: torch.Tensor, depth_q: torch.Tensor,
                cam_a: torch.Tensor, cam_q: torch.Tensor, status: Optional[torch.Tensor] = None):
     """corrs [B,n_cap,4] i32, depth_* [B,H,W] f32 (mm), cam_* [B,9] f32 -> (pcd_a, pcd_q [B,n_cap,3] metres, n_out [B])."""
@@ -269,6 +303,7 @@ def lift_pairs(corrs: torch.Tensor, n_corr: Optional[torch.Tensor], feat_hw, dep
     return pa, pq, n_out
 
 
+@_on_tensor_device
 def lift_points(depth: torch.Tensor, cam9: torch.Tensor, x_idx: torch.Tensor, y_idx: torch.Tensor) -> torch.Tensor:
     """depth [H,W] f32, cam9 [9] f32, pixel indices [n] -> [n,3] f32 in the depth's unit."""
     dev = _lib.require_gpu(depth.device)
@@ -281,6 +316,7 @@ def lift_points(depth: torch.Tensor, cam9: torch.Tensor, x_idx: torch.Tensor, y_
     return out
 
 
+@_on_tensor_device
 def kabsch_batched(A: torch.Tensor, B: torch.Tensor, w: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[nb,m,3] x2 (+ [nb,m]) fp32 -> [nb,4,4] fp32."""
     dev = _lib.require_gpu(A.device)

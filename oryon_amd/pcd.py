@@ -29,11 +29,19 @@ def torch_sample_select(t: Tensor, n: int) -> Tensor:
 
 
 def match_presample(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor, threshold: float,
-                    subsample_source: Optional[int] = None, half_descriptors: bool = False):
+                    subsample_source: Optional[int] = None, half_descriptors: bool = False, mode: str = "exact"):
     """Deterministic half of the matcher (utils/pcd.py:184-205) on the GPU.
 
     Returns dict(roi1 [N1,2] i64 (y,x), roi2 [N2,2] i64, min_dist [N1] f32, argmin [N1] i64, valid [N1] bool).
-    When subsample_source is given and N1 exceeds it, the first RNG draw is made exactly as the reference does."""
+    When subsample_source is given and N1 exceeds it, the first RNG draw is made exactly as the reference does.
+    mode: "exact" = full fp32-MFMA scan (K1); "screened16" = fp16-MFMA screening + exact fp32 re-scoring (K1s);
+    "screened8" = int8-MFMA pre-screen in front of K1s (K1s8, the batched engine's default).  The screened modes return the same
+    `valid` set and, on valid rows, the same argmin / min_dist bits; rows that provably cannot reach the threshold report
+    valid = 0, argmin = 0 and the screening estimate of the distance.  Channels are zero-padded to the kernels' widths."""
+    if mode not in ("exact", "screened16", "screened8"):
+        raise ValueError(f"match_presample: unknown mode {mode!r}")
+    if mode != "exact" and not (0.0 < threshold <= 0.5):
+        mode = "exact"                       # the screens' validity cut needs 1 - 2*threshold >= 0
     dev = require_gpu(feats1.device)
     W = feats1.shape[2]
     W2 = feats2.shape[2]
@@ -61,9 +69,24 @@ def match_presample(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor
         out.update(min_dist=torch.zeros(n1, device=dev), argmin=torch.zeros(n1, dtype=torch.int64, device=dev),
                    valid=torch.zeros(n1, dtype=torch.bool, device=dev))
         return out
-    a_hat = ops.gather_normalise(f1, roi1_lin, c1, ops.round_up(n1, ops.ROW_PAD))
-    q_hat = ops.gather_normalise(f2, roi2_lin, c2, ops.round_up(n2, ops.ROW_PAD))
-    min_dist, argmin, valid = ops.match(a_hat, q_hat, c1, c2, threshold)
+    C = f1.shape[1]
+    cap1, cap2 = ops.round_up(n1, ops.ROW_PAD), ops.round_up(n2, ops.ROW_PAD)
+    if mode != "exact" and C > 512:
+        mode = "exact"                       # the screening kernels are built for C_pad 128 / 256 / 512
+    if mode == "screened8":
+        c_pad = 256 if C <= 256 else 512
+        a_hat, _, a8, a_sc, _ = ops.gather_normalise_q8(f1, roi1_lin, c1, cap1, c_pad)
+        q_hat, _, q8, q_sc, q_eps = ops.gather_normalise_q8(f2, roi2_lin, c2, cap2, c_pad)
+        min_dist, argmin, valid = ops.match_screened8(a_hat, q_hat, a8, q8, a_sc, q_sc, q_eps, c1, c2, threshold, C)
+    elif mode == "screened16":
+        c_pad = 128 if C <= 128 else (256 if C <= 256 else 512)
+        a_hat, a16 = ops.gather_normalise(f1, roi1_lin, c1, cap1, c_pad=c_pad, want_f16=True)
+        q_hat, q16 = ops.gather_normalise(f2, roi2_lin, c2, cap2, c_pad=c_pad, want_f16=True)
+        min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, c1, c2, threshold)
+    else:
+        a_hat = ops.gather_normalise(f1, roi1_lin, c1, cap1)
+        q_hat = ops.gather_normalise(f2, roi2_lin, c2, cap2)
+        min_dist, argmin, valid = ops.match(a_hat, q_hat, c1, c2, threshold)
     out.update(min_dist=min_dist[0, :n1], argmin=argmin[0, :n1].to(torch.int64), valid=valid[0, :n1].bool())
     return out
 

@@ -151,8 +151,14 @@ class Pipeline:
     def test_step(self, batch: Dict, batch_idx: int = 0) -> List[Dict]:
         outputs = self.model.forward(batch)
         BS = outputs["featmap_a"].shape[0]
-        results = self.mask_results(batch, outputs) if self.args.test.mask == "predicted" else {
-            "iou_a": torch.ones(BS), "iou_q": torch.ones(BS)}
+        # the reference evaluates the predicted masks (and logs their IoU) whatever test.mask says (pipeline.py:311,352-354);
+        # only the masks fed to the matcher switch to the external ones
+        if "mask_a" in outputs and "mask_q" in outputs:
+            results = self.mask_results(batch, outputs)
+        elif self.args.test.mask == "predicted":
+            raise KeyError("test.mask='predicted' needs the model's mask logits (outputs['mask_a'], outputs['mask_q'])")
+        else:
+            results = {"iou_a": torch.ones(BS), "iou_q": torch.ones(BS)}
         records = []
         for i_b in range(BS):
             id_a, id_q = batch["anchor"]["instance_id"][i_b], batch["query"]["instance_id"][i_b]

@@ -162,6 +162,7 @@ class PointDSC(nn.Module):
         return ws
 
     # ---- batched registration (the product path) ----------------------------------------------
+    @ops._on_tensor_device
     def register(self, src: Tensor, tgt: Tensor, n: Tensor, status: Optional[Tensor] = None, want_labels: bool = False,
                  ws_slot: int = 0):
         """src,tgt [B,n_cap,3] fp32 CUDA (metres, n_cap % 128 == 0), n [B] int32 -> (T [B,4,4], labels|None, status [B])."""
@@ -179,6 +180,7 @@ class PointDSC(nn.Module):
         return T, labels, st_out
 
     # ---- stage-level views (parity tests) -----------------------------------------------------
+    @ops._on_tensor_device
     def encode(self, src: Tensor, tgt: Tensor, n: Tensor):
         dev = _lib.require_gpu(src.device)
         self._ensure_handle(dev)
@@ -193,6 +195,7 @@ class PointDSC(nn.Module):
     def seed_cap(self, n_cap: int) -> int:
         return int(float(n_cap) * float(torch.tensor(self.ratio, dtype=torch.float32))) + 1
 
+    @ops._on_tensor_device
     def pick_seeds_batched(self, src: Tensor, conf: Tensor, n: Tensor):
         dev = _lib.require_gpu(src.device)
         self._ensure_handle(dev)
@@ -204,6 +207,7 @@ class PointDSC(nn.Module):
                                          stream_ptr(dev)), "oryon_pointdsc_seeds")
         return seeds, n_seeds
 
+    @ops._on_tensor_device
     def hypotheses(self, src: Tensor, tgt: Tensor, feat: Tensor, n: Tensor, seeds: Tensor, n_seeds: Tensor):
         dev = _lib.require_gpu(src.device)
         self._ensure_handle(dev)
@@ -218,6 +222,7 @@ class PointDSC(nn.Module):
                                               ptr(best), stream_ptr(dev)), "oryon_pointdsc_hypotheses")
         return seed_T, fitness, best
 
+    @ops._on_tensor_device
     def refine(self, src: Tensor, tgt: Tensor, n: Tensor, T_in: Tensor) -> Tensor:
         dev = _lib.require_gpu(src.device)
         self._ensure_handle(dev)
@@ -229,14 +234,24 @@ class PointDSC(nn.Module):
 
     # ---- reference-shaped forward -------------------------------------------------------------
     def forward(self, data: Dict) -> Dict:
-        """data: corr_pos [bs,n,6] (ignored: recomputed as cat(src,tgt) - mean, as init.py:18-19 builds it),
-        src_keypts/tgt_keypts [bs,n,3], 'testing' key required.  Returns final_trans [bs,4,4],
-        final_labels [bs,n] float, M None."""
+        """data: corr_pos [bs,n,6], src_keypts/tgt_keypts [bs,n,3], 'testing' key required.  Returns final_trans [bs,4,4],
+        final_labels [bs,n] float, M None.
+        The device encoder builds its input as cat(src,tgt) - mean over the rows (what utils/pointdsc/init.py:18-19 passes as
+        corr_pos); a caller-supplied corr_pos that is anything else cannot be honoured and raises instead of being silently
+        replaced."""
         if "testing" not in data:
             raise NotImplementedError("only the inference branch of PointDSC ('testing' in data) is implemented")
         src, tgt = data["src_keypts"], data["tgt_keypts"]
         dev = _lib.require_gpu(src.device)
         bs, n = src.shape[0], src.shape[1]
+        cp = data.get("corr_pos")
+        if cp is not None and n > 0:
+            want = torch.cat([src, tgt], dim=-1).float()
+            want = want - want.mean(dim=1, keepdim=True)
+            scale = float(want.abs().max()) + 1e-12
+            if tuple(cp.shape) != tuple(want.shape) or float((cp.to(dev).float() - want).abs().max()) > 1e-4 * scale + 1e-6:
+                raise NotImplementedError("PointDSC.forward: corr_pos must be cat(src_keypts, tgt_keypts) minus its mean over the rows "
+                                          "(utils/pointdsc/init.py:18-19); other encoder inputs are not supported by the device path")
         n_cap = ops.round_up(max(n, 1), N_ALIGN)
         sp = torch.zeros((bs, n_cap, 3), dtype=torch.float32, device=dev)
         tp = torch.zeros((bs, n_cap, 3), dtype=torch.float32, device=dev)

@@ -132,3 +132,18 @@ def test_collation_gloo_world2(tmp_path):
                         "127.0.0.1", "--master-port", "29631", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_self_launches_for_gpus_2():
+    """`python bench.py --gpus 2` (no torchrun, exactly how the driver invokes it) must become its own launcher: two ranks rendezvous on
+    127.0.0.1, shard the pairs, run the collation and rank 0 prints ONE JSON line.  --collation-selftest swaps the GPU work for CPU
+    tensors over gloo, everything else is the real control flow."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "5",
+                        "--collation-selftest"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["global_pairs"] == 10 and rec["collated_in_order"] is True
