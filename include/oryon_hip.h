@@ -166,6 +166,29 @@ int oryon_match_screened8(const float *a_hat, const float *q_hat, const int8_t *
                           int32_t *argmin, uint8_t *valid, int32_t *n_undecided /* [B] or NULL: anchors handed to the fp16 stage */,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* K0v3 + K1s8 without an fp32 copy of the query rows (round 2; csrc/gather8.hip).
+ *     Replaces the same reference lines as oryon_gather_normalise_q8 / oryon_match_screened8 (utils/pcd.py:192-193, :28-29, :202-205).
+ *     oryon_gather_q8 reads the raw descriptors of the ROI rows once - from a channel-planar [n_maps,C,H,W] map (ORYON_LAYOUT_NCHW, what
+ *     net.py:162-167 returns) or from a channels_last [n_maps,H,W,C] map (ORYON_LAYOUT_NHWC, zero-copy view of a torch channels_last
+ *     tensor) - and writes the int8 rows, the per-slice scales, eps_max, the canonical row norm d (row_norm [n_maps, rows_cap], may be
+ *     NULL) and, only when out_f32 != NULL, the canonical fp32 unit rows (k-permuted, as oryon_gather_normalise_f32 writes them).
+ *     oryon_match_screened8_raw is oryon_match_screened8 for such operands: anchors come as materialised fp32 + int8 rows, queries as
+ *     int8 rows + row norms + the raw map itself; the exact re-scoring pass recovers a candidate's canonical unit values x_k / d from
+ *     the raw map, so its outputs are bit for bit those of oryon_match_screened8.  Pairs that need the fp32 query rows after all
+ *     (anchors the int8 stage could not decide, overflowed candidate lists) get them materialised inside the call, gated on the device.
+ *     Rows [n, round_up(n,256)) of every output are zero rows; rows beyond are not written. */
+#define ORYON_LAYOUT_NCHW 0
+#define ORYON_LAYOUT_NHWC 1
+int oryon_gather_q8(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
+                    int rows_cap, int C_pad, int8_t *out_i8, float *slice_scale, float *eps_max, float *row_norm, float *out_f32,
+                    void *stream);
+size_t oryon_match_screened8_raw_workspace_bytes(int B, int C, int cap_a, int cap_q);
+int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW,
+                              int layout, const int32_t *roi_q, int roi_stride, const float *q_norm, const int8_t *q_i8,
+                              const float *q_scale, const float *q_eps_max, int B, int C, int cap_a, int cap_q, const int32_t *n_a,
+                              const int32_t *n_q, float threshold, float *min_dist, int32_t *argmin, uint8_t *valid,
+                              int32_t *n_undecided, void *workspace, size_t workspace_bytes, void *stream);
+
 /* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).
  *     Replaces utils/pcd.py:205-214: keep rows with valid, need more than one, sample exactly max_corrs
  *     (with replacement iff fewer are available).

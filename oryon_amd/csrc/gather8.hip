@@ -1,0 +1,304 @@
+// K0v3: ROI rows of a descriptor map -> the operands of the int8 screening matcher, moving only the bytes the path needs.
+// Replaces utils/pcd.py:192-193 (`feats[:, roi[:,0], roi[:,1]].T`) + the normalisation inside torch's cosine_similarity
+// (utils/pcd.py:28-29) for the K1s8 matcher.  Per ROI row it reads the C raw fp32 channel values ONCE and writes
+//     out8  [n_maps, rows_cap, CP] int8   q = rint(x^ * 2^E), one exponent E per 16-row slice of the screening kernel's accumulator
+//                                         layout (rows {0-3,8-11,16-19,24-27} + 4h of a 32-row block, h = 0/1)
+//     scale [n_maps, rows_cap/16]  fp32   2^-E of the slice  (slice id = (row / 32) * 2 + h)
+//     eps   [n_maps]               fp32   max over the map's live slices of 2^-(E+1)   (atomic max on the bits; caller zeroes)
+//     norm  [n_maps, rows_cap]     fp32   d = max(sqrt(sum_k x_k^2), 1e-8) in the canonical k-ordered fmaf chain: with it the exact
+//                                         re-scoring pass recovers the canonical unit value x_k / d of ANY row from the raw map
+//     out32 [n_maps, rows_cap, CP] fp32   (optional, anchors and fall-back only) the canonical unit rows x_k / d, k-permuted for K1
+// i.e. 4*C bytes in and C + 4.25 bytes out per row instead of 4*C in and 5*C out (round 1 wrote an fp32 copy of every query row
+// although the re-scoring pass touches about one candidate per anchor).
+//
+// Structure.  A WAVE owns ROWS = 64 / LPR consecutive ROI rows and keeps their raw values in registers (KPL = CP / LPR per lane):
+// lane -> (row, channel segment).  NCHW maps: for a fixed channel the lanes of a segment read one run of ROWS consecutive
+// pixels (a single 256-byte / 128-byte request when the ROI is contiguous), up to 64 such loads in flight per wave, no LDS and no
+// barrier on the read side.  The canonical norm is a serial chain in k, so a lane simply runs it over its own registers (LPR = 2:
+// the second segment's lanes restart the chain from the first segment's result).  NHWC (channels_last) maps: rows are contiguous, so
+// they are loaded 4 rows x 256 bytes per instruction and transposed to lane = row through the wave's LDS staging buffer, 64 channels
+// at a time.  Outputs leave through the same 16 KB-per-wave staging buffer so that every global store instruction writes whole
+// 128-byte lines.  Waves never synchronise with each other.
+//
+// Quantisation bound (used by match_decide_kernel): q = rint(x * rs), rs = RN(2^E / d), so |q - x^ 2^E| <= 1/2 + 127 * 3 * 2^-24:
+// |q 2^-E - x^| <= 2^-(E+1) * (1 + 4.6e-5).  2^E * max|x^| <= 127 by the choice of E, so |q| <= 127.
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+#include "common.h"
+
+namespace oryon {
+
+constexpr int G8_STAGE_BYTES = 16384;          // per wave
+
+template <int N>
+__device__ __forceinline__ float chain_sq(const float (&v)[N], float acc)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc = __fmaf_rn(v[i], v[i], acc);
+    return acc;
+}
+
+// staging-buffer address of 16-byte slot `s` of tile-lane `t` (row length RB bytes, RB >= 256 a multiple of 256): slots are
+// XOR-swizzled inside each 256-byte line so that lane-per-row writes and slot-per-lane reads both spread over the banks
+__device__ __forceinline__ unsigned stage_addr(int t, int s, int RB)
+{
+    const int L = RB >= 256 ? 16 : RB / 16;                  // slots that share one swizzle group (a 256-byte line, or a shorter row)
+    return (unsigned)(t * RB + (s & ~(L - 1)) * 16 + (((s & (L - 1)) ^ (t & (L - 1))) << 4));
+}
+
+template <int CP, int LPR, bool NHWC>
+__global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_kernel(
+    const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride,
+    const int32_t *__restrict__ count, const int32_t *__restrict__ map_enable, int rows_cap, int n_maps, int chunk_tiles,
+    int chunks_per_map, int8_t *__restrict__ out8, float *__restrict__ scale, unsigned *__restrict__ eps_max,
+    float *__restrict__ norm, float *__restrict__ out32)
+{
+    constexpr int ROWS = 64 / LPR;             // ROI rows per wave
+    constexpr int KPL = CP / LPR;              // channels per lane
+    constexpr int WG_ROWS = 4 * ROWS;
+    static_assert(KPL % 64 == 0 && (LPR == 1 || LPR == 2), "geometry");
+    extern __shared__ __attribute__((aligned(256))) char stage_all[];
+
+    // XCD-aware unit map: a unit is a contiguous chunk of a map's tiles and lives on ONE XCD (block b runs on XCD b % 8), so tiles that
+    // share a 128-byte line at their common border share it through that XCD's L2 and a map's channel planes are walked in order
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int unit = (pos / chunk_tiles) * 8 + xcd;
+    if (unit >= n_maps * chunks_per_map) return;
+    const int m = unit / chunks_per_map;
+    const int wg_tile = (unit % chunks_per_map) * chunk_tiles + pos % chunk_tiles;
+    if (map_enable && !map_enable[m]) return;
+    const int n = count[m];
+    const int n_fill = (n + 255) / 256 * 256;                 // rows [n, n_fill) are written as zero rows
+    const int wg_row0 = wg_tile * WG_ROWS;
+    if (wg_row0 >= n_fill || wg_row0 >= rows_cap) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char *stage = stage_all + wave * G8_STAGE_BYTES;
+    const int row0 = wg_row0 + wave * ROWS;
+    if (row0 >= n_fill) return;                               // waves are independent: no workgroup barrier anywhere below
+    const int lrow = lane % ROWS, seg = lane / ROWS;
+    const int my_row = row0 + lrow;
+    const bool live = my_row < n;
+    const int pix = live ? roi[(size_t)m * roi_stride + my_row] : 0;
+    const bool tile_full = (row0 + ROWS <= n) && (C == CP);   // wave-uniform
+
+    float v[KPL];
+    if constexpr (!NHWC) {
+        // channel-planar map: value (k, pix) at feat[m][k][pix]
+        const char *fb = reinterpret_cast<const char *>(feat + (size_t)m * C * HW);
+        const unsigned voff = (unsigned)pix * 4u + (unsigned)seg * (unsigned)KPL * (unsigned)HW * 4u;
+        if (tile_full) {
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) v[i] = *reinterpret_cast<const float *>(fb + (size_t)i * HW * 4 + voff);
+        } else {
+            // ragged tile (last rows of a map, or C < CP): every lane loads from a clamped, valid address; dead rows / channels are
+            // zeroed afterwards.  The bounds go through opaque copies so that the compiler neither shares the 256 plane addresses
+            // with the fast path nor keeps 256 predicate masks alive across the loads (it spilled 434 SGPRs doing that).
+            int hw_b = HW, c_b = C;
+            asm volatile("" : "+s"(hw_b), "+s"(c_b));
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                int k = seg * KPL + i;
+                k = k < c_b ? k : c_b - 1;
+                v[i] = *reinterpret_cast<const float *>(fb + (size_t)k * hw_b * 4 + (unsigned)pix * 4u);
+            }
+            int c_c = C;
+            asm volatile("" : "+s"(c_c));
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) v[i] = (live && (seg * KPL + i < c_c)) ? v[i] : 0.0f;
+        }
+    } else {
+        // channels_last map: value (k, pix) at feat[m][pix][k].  64 channels of the wave's 64 / LPR rows at a time: 4 rows x 256 bytes
+        // per load instruction -> staging buffer -> lane = (row, segment)
+        const float *fb = feat + (size_t)m * C * HW;
+        const int sub = lane >> 4, slot = lane & 15;          // load role: row sub-index, 16-byte slot of a 256-byte run
+#pragma unroll
+        for (int c = 0; c < KPL / 64; ++c) {
+            // tile-lane t = sg * ROWS + r holds channels sg*KPL + 64c .. +63 of row r
+            float4 x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int t = j * 4 + sub, r = t % ROWS, sg = t / ROWS;
+                const int rr = row0 + r;
+                const int k0 = sg * KPL + 64 * c + slot * 4;
+                const int px = rr < n ? roi[(size_t)m * roi_stride + rr] : 0;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rr < n) {
+                    if (C == CP) val = *reinterpret_cast<const float4 *>(fb + (size_t)px * C + k0);
+                    else {
+                        const float *src = fb + (size_t)px * C;
+                        val.x = k0 + 0 < C ? src[k0 + 0] : 0.f; val.y = k0 + 1 < C ? src[k0 + 1] : 0.f;
+                        val.z = k0 + 2 < C ? src[k0 + 2] : 0.f; val.w = k0 + 3 < C ? src[k0 + 3] : 0.f;
+                    }
+                }
+                x[j] = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // previous chunk's reads are done (same wave, in order)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) *reinterpret_cast<float4 *>(stage + stage_addr(j * 4 + sub, slot, 256)) = x[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float4 q = *reinterpret_cast<const float4 *>(stage + stage_addr(lane, s, 256));
+                v[64 * c + 4 * s + 0] = q.x; v[64 * c + 4 * s + 1] = q.y; v[64 * c + 4 * s + 2] = q.z; v[64 * c + 4 * s + 3] = q.w;
+            }
+        }
+    }
+
+    // canonical norm: ONE k-ordered fmaf chain per row.  LPR = 2: lanes of segment 1 continue from segment 0's result.
+    float n2 = chain_sq<KPL>(v, 0.0f);
+    if constexpr (LPR == 2) {
+        const float lo = __shfl(n2, lrow);                    // segment 0's partial chain of the same row
+        const float full = chain_sq<KPL>(v, lo);              // meaningful on segment-1 lanes
+        n2 = __shfl(full, ROWS + lrow);
+    }
+    float d = sqrt_rn(n2);
+    d = d < 1e-8f ? 1e-8f : d;
+    float mx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) mx = fmaxf(mx, fabsf(v[i]));
+    if constexpr (LPR == 2) mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float mxs = __fdiv_rn(mx, d);                             // = max_k |x_k / d| (IEEE division is monotone)
+    // slice = 16 rows {0-3,8-11,16-19,24-27} + 4h of a 32-row block: the lanes that differ in row bits 0,1,3,4
+    mxs = fmaxf(mxs, __shfl_xor(mxs, 1));
+    mxs = fmaxf(mxs, __shfl_xor(mxs, 2));
+    mxs = fmaxf(mxs, __shfl_xor(mxs, 8));
+    mxs = fmaxf(mxs, __shfl_xor(mxs, 16));
+    int E = mxs > 0.0f ? ilogbf(127.0f / mxs) : 30;
+    E = E > 30 ? 30 : (E < 0 ? 0 : E);
+    const float sc = ldexpf(1.0f, E);
+    const float rs = __fdiv_rn(sc, d);
+    const int h = (lrow >> 2) & 1;
+    if (seg == 0 && (lrow & 27) == 0) scale[(size_t)m * (rows_cap / 16) + (my_row >> 5) * 2 + h] = ldexpf(1.0f, -E);
+    {
+        // per-map quantisation bound: slices that hold at least one live row
+        float e = live ? ldexpf(1.0f, -E - 1) : 0.0f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
+        if (lane == 0 && e > 0.0f) atomicMax(&eps_max[m], __float_as_uint(e));
+    }
+    if (seg == 0 && norm) norm[(size_t)m * rows_cap + my_row] = d;
+
+    // int8 rows: magic-number rounding (RN-even, like rintf) - the low byte of (x*rs + 1.5*2^23) is the two's complement of the integer
+    {
+        constexpr int RB8 = KPL;                              // bytes per tile-lane row
+#pragma unroll
+        for (int s = 0; s < KPL / 16; ++s) {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = __float_as_uint(__fmaf_rn(v[16 * s + 4 * j + e], rs, 12582912.0f));
+                const unsigned lo = __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);      // bytes: b0[0], b1[0], 0, 0
+                const unsigned hi2 = __builtin_amdgcn_perm(b[3], b[2], 0x04000c0cu);     // bytes: 0, 0, b2[0], b3[0]
+                w[j] = lo | hi2;
+            }
+            *reinterpret_cast<uint4 *>(stage + stage_addr(lane, s, RB8)) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int SPR = RB8 / 16;                         // 16-byte slots per tile-lane row
+        char *o8 = reinterpret_cast<char *>(out8) + ((size_t)m * rows_cap + row0) * CP;
+#pragma unroll
+        for (int j = 0; j < SPR; ++j) {
+            const int f = j * 64 + lane, t = f / SPR, s = f % SPR;
+            const uint4 q = *reinterpret_cast<const uint4 *>(stage + stage_addr(t, s, RB8));
+            *reinterpret_cast<uint4 *>(o8 + (size_t)(t % ROWS) * CP + (t / ROWS) * KPL + s * 16) = q;
+        }
+    }
+
+    if (out32) {
+        // canonical unit rows, k-permuted inside groups of 8 (position 8g + 4h + j holds k = 8g + 2j + h): 64 channels per pass
+        float *o32 = out32 + ((size_t)m * rows_cap + row0) * CP;
+#pragma unroll
+        for (int c = 0; c < KPL / 64; ++c) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    float4 q;
+                    q.x = __fdiv_rn(v[64 * c + 8 * g + 0 + hh], d);
+                    q.y = __fdiv_rn(v[64 * c + 8 * g + 2 + hh], d);
+                    q.z = __fdiv_rn(v[64 * c + 8 * g + 4 + hh], d);
+                    q.w = __fdiv_rn(v[64 * c + 8 * g + 6 + hh], d);
+                    *reinterpret_cast<float4 *>(stage + stage_addr(lane, 2 * g + hh, 256)) = q;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int t = j * 4 + (lane >> 4), s = lane & 15;
+                const float4 q = *reinterpret_cast<const float4 *>(stage + stage_addr(t, s, 256));
+                *reinterpret_cast<float4 *>(o32 + (size_t)(t % ROWS) * CP + (t / ROWS) * KPL + 64 * c + s * 4) = q;
+            }
+        }
+    }
+}
+
+}  // namespace oryon
+
+using namespace oryon;
+
+namespace {
+template <int CP, int LPR, bool NHWC>
+void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride, const int32_t *count,
+               const int32_t *map_enable, int rows_cap, int8_t *out8, float *scale, float *eps, float *norm, float *out32)
+{
+    constexpr int WG_ROWS = 4 * (64 / LPR);
+    const int T = (rows_cap + WG_ROWS - 1) / WG_ROWS;                 // workgroup tiles per map
+    const int chunks_per_map = n_maps >= 8 ? 1 : (8 + n_maps - 1) / n_maps;
+    const int chunk_tiles = (T + chunks_per_map - 1) / chunks_per_map;
+    const int units = n_maps * chunks_per_map;
+    const int groups = ((units + 7) / 8) * 8 * chunk_tiles;
+    auto kern = gather_q8_v3_kernel<CP, LPR, NHWC>;
+    allow_dynamic_lds(reinterpret_cast<const void *>(kern), 4 * G8_STAGE_BYTES);
+    hipLaunchKernelGGL(kern, dim3(groups), dim3(256), 4 * G8_STAGE_BYTES, st, feat, C, HW, roi, roi_stride, count, map_enable, rows_cap,
+                       n_maps, chunk_tiles, chunks_per_map, out8, scale, reinterpret_cast<unsigned *>(eps), norm, out32);
+}
+}  // namespace
+
+namespace oryon {
+// internal entry (also used by the matcher's lazy fp32 fall-back): map_enable gates whole maps on the device; zero_eps = false when
+// the call must not touch eps_max (fall-back pass)
+int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
+                     const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
+                     float *out32, int lanes_per_row, hipStream_t st)
+{
+    const int lpr = C_pad == 512 ? 2 : (lanes_per_row == 2 ? 2 : 1);
+#define G8(CPV, LPRV)                                                                                                          \
+    do {                                                                                                                       \
+        if (layout == ORYON_LAYOUT_NHWC) launch_g8<CPV, LPRV, true>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32); \
+        else launch_g8<CPV, LPRV, false>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32); \
+    } while (0)
+    if (C_pad == 512) G8(512, 2);
+    else if (lpr == 2) G8(256, 2);
+    else G8(256, 1);
+#undef G8
+    return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+}
+}  // namespace oryon
+
+extern "C" int oryon_gather_q8(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride,
+                               const int32_t *count, int rows_cap, int C_pad, int8_t *out_i8, float *slice_scale, float *eps_max,
+                               float *row_norm, float *out_f32, void *stream)
+{
+    ORYON_CHECK_ARG(feat && roi && count && out_i8 && slice_scale && eps_max);                 // row_norm, out_f32 may be NULL
+    ORYON_CHECK_ARG(n_maps >= 0 && C > 0 && HW > 0 && roi_stride > 0 && C_pad >= C && (C_pad == 256 || C_pad == 512));
+    ORYON_CHECK_ARG(layout == ORYON_LAYOUT_NCHW || layout == ORYON_LAYOUT_NHWC);
+    ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % 256 == 0 && (size_t)C * (size_t)HW * 4u < (1ull << 32));
+    if (n_maps == 0) return ORYON_OK;
+    hipStream_t st = as_stream(stream);
+    ORYON_CHECK_HIP(hipMemsetAsync(eps_max, 0, (size_t)n_maps * sizeof(float), st));
+    static const int lpr_env = getenv("ORYON_GATHER8_LPR") ? atoi(getenv("ORYON_GATHER8_LPR")) : 1;
+    const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad, out_i8, slice_scale,
+                                    eps_max, row_norm, out_f32, lpr_env, st);
+    if (rc) { set_error("oryon_gather_q8: launch failed"); return rc; }
+    return ORYON_OK;
+}

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void match_decide_kernel(const __half *__restr
         sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];   // 2^-E of the anchor's slice
         m1 *= sa;                                             // exact: power of two
         m2 *= sa;
-        const float ea = 0.5f * sa, eq = eps_q8[p];
+        // K0's rounding: |q 2^-E - x^| <= 2^-(E+1) * (1 + 4.6e-5)  (gather8.hip: q = rint(x * RN(2^E / d)))
+        const float ea = 0.50003f * sa, eq = 1.00006f * eps_q8[p];
         (void)eps_a8;
         // |s8 - a^.q^| <= ea*|q^|_1 + eq*|a^|_1 + C*ea*eq <= (ea + eq)*sqrt(C) + C*ea*eq   (+ fp32 accumulation slack of the exact scan)
         const float delta = (ea + eq) * sqrt_c + c_true * ea * eq + 4e-5f;
@@ -479,6 +480,96 @@ __global__ __launch_bounds__(256) void match_rescore_kernel(const float *__restr
         argmin[arow] = j;
         valid[arow] = (d < thr) ? 1 : 0;
     }
+}
+
+// pass 2 for the K1s8 path fed by K0v3 (gather8.hip), which writes NO fp32 copy of the query rows: a candidate's canonical unit
+// values are recovered on the fly as x_k / d from the raw descriptor map and the row norm d K0 stored (the same IEEE division K0's
+// fp32 rows come from, so the chain below is bit for bit the one match_rescore_kernel runs on materialised rows).  Anchor rows are
+// the materialised, k-permuted fp32 rows (5000 per pair).  Candidates of neighbouring anchors are neighbouring query pixels on real
+// (and synthetic) rigid pairs, so the strided 4-byte reads of an NCHW map share their 64-byte sectors across a wave.
+template <int L, bool NHWC>
+__global__ __launch_bounds__(256) void match_rescore_raw_kernel(
+    const float *__restrict__ a_hat, const float *__restrict__ feat_q, int C_true, int HW, const int32_t *__restrict__ roi_q,
+    int roi_stride, const float *__restrict__ norm_q, int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
+    const int32_t *__restrict__ n_q, float thr, const float *__restrict__ m_final, const int32_t *__restrict__ cnt,
+    const int32_t *__restrict__ cand, float *__restrict__ min_dist, int32_t *__restrict__ argmin, uint8_t *__restrict__ valid,
+    uint8_t *__restrict__ row_flag, int32_t *__restrict__ panel_flag, int32_t *__restrict__ need_f32)
+{
+    const int p = blockIdx.y;
+    const int a = blockIdx.x * (256 / L) + (threadIdx.x / L), sub = threadIdx.x % L;
+    const bool live = a < n_a[p];
+    const size_t arow = (size_t)p * cap_a + (live ? a : 0);
+    const int c_raw = live ? cnt[arow] : 0;
+    const bool possible = live && c_raw >= 0;                 // count -1: ruled out by the int8 stage
+    const int c = possible ? c_raw : 0;
+    const bool overflow = c > SCREEN_CAP;
+    float d = INFINITY;
+    int j = 0x7fffffff;
+    if (!overflow) {
+        const float *ar = a_hat + arow * Cp;
+        const int nq_p = n_q[p];
+        const float *fq = feat_q + (size_t)p * C_true * HW;
+        for (int ci = sub; ci < c; ci += L) {
+            const int jj = cand[arow * SCREEN_CAP + ci];
+            if (jj >= nq_p) continue;
+            const int pix = roi_q[(size_t)p * roi_stride + jj];
+            const float dq = norm_q[(size_t)p * cap_q + jj];
+            float dot = 0.0f;
+            for (int g = 0; g < C_true; g += 8) {
+                // anchor positions 0..3 of a group hold k = 8g+0,2,4,6 and 4..7 hold k = 8g+1,3,5,7
+                const float4 a0 = *reinterpret_cast<const float4 *>(ar + g), a1 = *reinterpret_cast<const float4 *>(ar + g + 4);
+                float x[8];
+                if constexpr (NHWC) {
+                    if (g + 8 <= C_true) {
+                        const float4 q0 = *reinterpret_cast<const float4 *>(fq + (size_t)pix * C_true + g);
+                        const float4 q1 = *reinterpret_cast<const float4 *>(fq + (size_t)pix * C_true + g + 4);
+                        x[0] = q0.x; x[1] = q0.y; x[2] = q0.z; x[3] = q0.w; x[4] = q1.x; x[5] = q1.y; x[6] = q1.z; x[7] = q1.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = g + e < C_true ? fq[(size_t)pix * C_true + g + e] : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = g + e < C_true ? fq[(size_t)(g + e) * HW + pix] : 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = __fdiv_rn(x[e], dq);
+                dot = __fmaf_rn(a0.x, x[0], dot); dot = __fmaf_rn(a1.x, x[1], dot);
+                dot = __fmaf_rn(a0.y, x[2], dot); dot = __fmaf_rn(a1.y, x[3], dot);
+                dot = __fmaf_rn(a0.z, x[4], dot); dot = __fmaf_rn(a1.z, x[5], dot);
+                dot = __fmaf_rn(a0.w, x[6], dot); dot = __fmaf_rn(a1.w, x[7], dot);
+            }
+            // channels C_true .. Cp-1 are zero on both sides: fma(0, 0, dot) leaves dot unchanged, nothing to add
+            lex_min(d, j, __fmaf_rn(-0.5f, dot, 0.5f), jj);
+        }
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) {
+        const float od = __shfl_xor(d, off);
+        const int oj = __shfl_xor(j, off);
+        lex_min(d, j, od, oj);
+    }
+    if (!live || sub != 0) return;
+    if (!possible) {
+        min_dist[arow] = __fmaf_rn(-0.5f, m_final[arow], 0.5f);
+        argmin[arow] = 0;
+        valid[arow] = 0;
+    } else if (overflow) {
+        row_flag[arow] = 1;
+        panel_flag[(size_t)p * (cap_a / ORYON_MATCH_TILE) + a / ORYON_MATCH_TILE] = 1;
+        need_f32[p] = 1;
+    } else {
+        min_dist[arow] = d;
+        argmin[arow] = j;
+        valid[arow] = (d < thr) ? 1 : 0;
+    }
+}
+
+// pairs that need materialised fp32 query rows: undecided anchors (fp16 stage) or an overflowed candidate list (exact panel scan)
+__global__ void match_need_f32_kernel(int B, const int32_t *__restrict__ n_amb, int32_t *__restrict__ need_f32)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < B && n_amb[p] > 0) need_f32[p] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------ K1s8: int8 pre-screen
@@ -966,6 +1057,119 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
     hipLaunchKernelGGL(match_make_q16_kernel, dim3(64, B), dim3(256), 0, st, q_hat, C, cap_q, n_q, w.n_amb, w8.q16);
     ORYON_CHECK_LAUNCH();
     rc = oryon_match_screened(w8.a_hat_c, q_hat, w.a16c, w8.q16, B, C, cap_a, cap_q, w.n_amb, n_q, threshold, w8.md_c, w8.am_c, w8.va_c,
+                              w8.nested, w8.nested_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_scatter8_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, w.n_amb, w.amb_idx, w8.md_c, w8.am_c, w8.va_c,
+                       min_dist, argmin, valid);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ K1s8 on K0v3 operands (no fp32 query rows)
+namespace oryon {
+int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
+                     const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
+                     float *out32, int lanes_per_row, hipStream_t st);
+}
+
+namespace {
+struct Screen8RawWs {
+    Screen8Ws base;
+    float *q_hat, *scale_scratch, *eps_scratch;
+    int8_t *q8_scratch;
+    int32_t *need_f32;
+    size_t bytes;
+};
+
+Screen8RawWs carve_screen8_raw(void *base, int B, int C, int cap_a, int cap_q, int S)
+{
+    Screen8RawWs w;
+    w.base = carve_screen8(base, B, C, cap_a, cap_q, S);
+    char *p = static_cast<char *>(base);
+    size_t off = (w.base.bytes + 255) / 256 * 256;
+    auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) / 256 * 256; return o; };
+    const size_t o_qh = take((size_t)B * cap_q * C * sizeof(float));
+    const size_t o_q8 = take((size_t)B * cap_q * C);                       // the fall-back pass rewrites the same int8 rows here
+    const size_t o_sc = take((size_t)B * (cap_q / 16) * sizeof(float));
+    const size_t o_ep = take((size_t)B * sizeof(float));
+    const size_t o_nf = take((size_t)B * sizeof(int32_t));
+    w.bytes = off;
+    w.q_hat = base ? reinterpret_cast<float *>(p + o_qh) : nullptr;
+    w.q8_scratch = base ? reinterpret_cast<int8_t *>(p + o_q8) : nullptr;
+    w.scale_scratch = base ? reinterpret_cast<float *>(p + o_sc) : nullptr;
+    w.eps_scratch = base ? reinterpret_cast<float *>(p + o_ep) : nullptr;
+    w.need_f32 = base ? reinterpret_cast<int32_t *>(p + o_nf) : nullptr;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t oryon_match_screened8_raw_workspace_bytes(int B, int C, int cap_a, int cap_q)
+{
+    if (B <= 0 || C <= 0 || cap_a <= 0 || cap_a % MT16 || cap_q <= 0) return 0;
+    return carve_screen8_raw(nullptr, B, C, cap_a, cap_q, pick_split16(B, cap_a / MT16)).bytes;
+}
+
+extern "C" int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true,
+                                         int HW, int layout, const int32_t *roi_q, int roi_stride, const float *q_norm,
+                                         const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C, int cap_a,
+                                         int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
+                                         int32_t *argmin, uint8_t *valid, int32_t *n_undecided, void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    ORYON_CHECK_ARG(a_hat && a_i8 && a_scale && feat_q && roi_q && q_norm && q_i8 && q_scale && q_eps_max && n_a && n_q);
+    ORYON_CHECK_ARG(min_dist && argmin && valid && B >= 0 && (C == 256 || C == 512) && C_true > 0 && C_true <= C && HW > 0);
+    ORYON_CHECK_ARG(layout == ORYON_LAYOUT_NCHW || layout == ORYON_LAYOUT_NHWC);
+    ORYON_CHECK_ARG(cap_a > 0 && cap_a % MT16 == 0 && cap_q > 0 && cap_q % 256 == 0 && threshold > 0.0f && threshold <= 0.5f);
+    if (B == 0) return ORYON_OK;
+    const int T = cap_a / MT16;
+    const int S = pick_split16(B, T);
+    Screen8RawWs wr = carve_screen8_raw(workspace, B, C, cap_a, cap_q, S);
+    if (!workspace || workspace_bytes < wr.bytes) {
+        set_error("oryon_match_screened8_raw: workspace too small (%zu < %zu)", workspace_bytes, wr.bytes);
+        return ORYON_ERR_WORKSPACE;
+    }
+    Screen8Ws &w8 = wr.base;
+    ScreenWs &w = w8.top;
+    hipStream_t st = as_stream(stream);
+    ORYON_CHECK_HIP(hipMemsetAsync(static_cast<char *>(workspace) + w.zero_off, 0, w.zero_bytes, st));
+    ORYON_CHECK_HIP(hipMemsetAsync(wr.need_f32, 0, (size_t)B * sizeof(int32_t), st));
+    const float cut0 = 1.0f - 2.0f * threshold;
+    const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
+    const int groups = ((B * S + 7) / 8) * 8 * T;
+    profile_begin(st);
+    if (C == 256) launch_screen8<256>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
+    else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
+    profile_end(st);
+    ORYON_CHECK_LAUNCH();
+    hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 64, B), dim3(256), 0, st, static_cast<const __half *>(nullptr),
+                       static_cast<const __half *>(nullptr), C, cap_a, cap_q, n_a, n_q, S, valid_cut16,
+                       w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, a_scale, nullptr, q_eps_max, cut0,
+                       sqrtf((float)C_true), (float)C_true, a_i8, q_i8, q_scale);
+    ORYON_CHECK_LAUNCH();
+    static const int resc_l = getenv("ORYON_RESCORE_LANES") ? atoi(getenv("ORYON_RESCORE_LANES")) : 2;
+#define RESCORE_RAW(LV, NHWCV)                                                                                                 \
+    hipLaunchKernelGGL((match_rescore_raw_kernel<LV, NHWCV>), dim3(cap_a / (256 / LV), B), dim3(256), 0, st, a_hat, feat_q, C_true, HW, \
+                       roi_q, roi_stride, q_norm, C, cap_a, cap_q, n_a, n_q, threshold, w.m_final, w.cnt, w.cand, min_dist, argmin,  \
+                       valid, w.row_flag, w.panel_flag, wr.need_f32)
+    if (layout == ORYON_LAYOUT_NHWC) { if (resc_l == 1) RESCORE_RAW(1, true); else if (resc_l == 4) RESCORE_RAW(4, true); else RESCORE_RAW(2, true); }
+    else { if (resc_l == 1) RESCORE_RAW(1, false); else if (resc_l == 4) RESCORE_RAW(4, false); else RESCORE_RAW(2, false); }
+#undef RESCORE_RAW
+    ORYON_CHECK_LAUNCH();
+    if (n_undecided) ORYON_CHECK_HIP(hipMemcpyAsync(n_undecided, w.n_amb, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    // Fall-backs (both rare, both gated per pair on the device): pairs with undecided anchors or an overflowed candidate list get their
+    // canonical fp32 query rows materialised now - the price round 1 paid for EVERY pair - and then take the round-1 route.
+    hipLaunchKernelGGL(match_need_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, w.n_amb, wr.need_f32);
+    int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride, n_q, wr.need_f32, cap_q, C, wr.q8_scratch, wr.scale_scratch,
+                              wr.eps_scratch, nullptr, wr.q_hat, 1, st);
+    if (rc) { set_error("oryon_match_screened8_raw: fall-back gather launch failed"); return rc; }
+    rc = match_f32_flagged(a_hat, wr.q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag, w.row_flag,
+                           stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_compact8_kernel, dim3(cap_a / 64, B), dim3(256), 0, st, a_hat, static_cast<const __half *>(nullptr), C, cap_a,
+                       w.n_amb, w.amb_idx, w8.a_hat_c, w.a16c);
+    hipLaunchKernelGGL(match_make_q16_kernel, dim3(64, B), dim3(256), 0, st, wr.q_hat, C, cap_q, n_q, w.n_amb, w8.q16);
+    ORYON_CHECK_LAUNCH();
+    rc = oryon_match_screened(w8.a_hat_c, wr.q_hat, w.a16c, w8.q16, B, C, cap_a, cap_q, w.n_amb, n_q, threshold, w8.md_c, w8.am_c, w8.va_c,
                               w8.nested, w8.nested_bytes, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(match_scatter8_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, w.n_amb, w.amb_idx, w8.md_c, w8.am_c, w8.va_c,

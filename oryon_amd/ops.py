@@ -247,6 +247,68 @@ def gather_normalise_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tens
     return out, out16, out8, scale, eps
 
 
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+
+
+def map_layout(feat: torch.Tensor):
+    """(tensor whose storage the C ABI can read, layout code) for a logical [n,C,H,W] descriptor map: contiguous -> NCHW,
+    torch.channels_last -> NHWC (zero-copy), anything else is made contiguous first."""
+    if feat.is_contiguous():
+        return feat, LAYOUT_NCHW
+    if feat.dim() == 4 and feat.is_contiguous(memory_format=torch.channels_last):
+        return feat, LAYOUT_NHWC
+    return feat.contiguous(), LAYOUT_NCHW
+
+
+@_on_tensor_device
+def gather_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: int, want_f32: bool = False):
+    """K0v3 (gather8.hip): ROI rows of [n,C,H,W] fp32 maps (contiguous or channels_last) -> (rows int8 [n,rows_cap,c_pad],
+    slice_scale [n,rows_cap/16], eps_max [n], row_norm [n,rows_cap], rows fp32 k-permuted [n,rows_cap,c_pad] | None)."""
+    dev = _lib.require_gpu(feat.device)
+    assert feat.dtype == torch.float32 and feat.dim() == 4
+    feat, layout = map_layout(feat)
+    n_maps, C, H, W = feat.shape
+    assert c_pad in (256, 512) and C <= c_pad and rows_cap % ROW_PAD == 0
+    out8 = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.int8, device=dev)
+    scale = torch.empty((n_maps, rows_cap // 16), dtype=torch.float32, device=dev)
+    eps = torch.empty((n_maps,), dtype=torch.float32, device=dev)
+    norm = torch.empty((n_maps, rows_cap), dtype=torch.float32, device=dev)
+    out32 = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.float32, device=dev) if want_f32 else None
+    check(lib().oryon_gather_q8(feat.data_ptr(), n_maps, C, H * W, layout, ptr(roi), roi.shape[1], ptr(count), rows_cap, c_pad, ptr(out8),
+                                ptr(scale), ptr(eps), ptr(norm), ptr(out32), stream_ptr(dev)), "oryon_gather_q8")
+    return out8, scale, eps, norm, out32
+
+
+_raw_ws = {}
+
+
+@_on_tensor_device
+def match_screened8_raw(a_hat, a8, a_scale, feat_q, roi_q, q_norm, q8, q_scale, q_eps, n_a, n_q, threshold: float, n_undecided=None):
+    """K1s8 on K0v3 operands: no fp32 copy of the query rows exists; the exact re-scoring reads candidates from the raw map feat_q
+    ([B,C,H,W] contiguous or channels_last).  Same outputs as `match_screened8`."""
+    dev = _lib.require_gpu(a_hat.device)
+    feat_q, layout = map_layout(feat_q)
+    B, cap_a, Cp = a_hat.shape
+    cap_q = q8.shape[1]
+    C_true, HW = feat_q.shape[1], feat_q.shape[2] * feat_q.shape[3]
+    min_dist = torch.empty((B, cap_a), dtype=torch.float32, device=dev)
+    argmin = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
+    valid = torch.empty((B, cap_a), dtype=torch.uint8, device=dev)
+    wsb = lib().oryon_match_screened8_raw_workspace_bytes(B, Cp, cap_a, cap_q)
+    # the workspace holds room for the (rarely used) fp32 fall-back rows of every pair: cached per (device, stream) instead of
+    # being re-requested from the allocator on every call
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _raw_ws.get(key)
+    if ws is None or ws.numel() < wsb:
+        ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+        _raw_ws[key] = ws
+    check(lib().oryon_match_screened8_raw(ptr(a_hat), ptr(a8), ptr(a_scale), feat_q.data_ptr(), C_true, HW, layout, ptr(roi_q),
+                                          roi_q.shape[1], ptr(q_norm), ptr(q8), ptr(q_scale), ptr(q_eps), B, Cp, cap_a, cap_q, ptr(n_a),
+                                          ptr(n_q), float(threshold), ptr(min_dist), ptr(argmin), ptr(valid), ptr(n_undecided), ptr(ws),
+                                          ws.numel(), stream_ptr(dev)), "oryon_match_screened8_raw")
+    return min_dist, argmin, valid
+
+
 @_on_tensor_device
 def match_screened8(a_hat, q_hat, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, threshold: float, c_true: int, n_undecided=None):
     """int8 pre-screen + fp16 screen + exact fp32 re-scoring (K1s8).  Same outputs as `match_screened`.

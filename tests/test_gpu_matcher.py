@@ -368,3 +368,125 @@ def test_screened_paths_randomised_stress():
         mq = (torch.rand(B, H, W, generator=g, device=dev) < dens_q).int()
         c_pad = 256 if C <= 256 else 512
         _screen_vs_exact(fa.contiguous(), fq.contiguous(), ma, mq, c_pad, thr=thr)
+
+
+# ------------------------------------------------------------------------------------------------ K0v3 (gather8.hip) + raw re-scoring
+def _k0v3_vs_round1(feat_a, feat_q, mask_a, mask_q, C_pad, thr=0.25, subsample=None, channels_last=False):
+    """oryon_gather_q8 / oryon_match_screened8_raw against the round-1 operands and the exact scan:
+      * fp32 unit rows and row norms bit-identical to oryon_gather_normalise_f32 (hence to the C oracle's canonical chain),
+      * int8 rows within the documented quantisation bound of the canonical unit values, |q| <= 127, scales powers of two,
+      * matcher outputs: valid set identical to the exact fp32 scan, argmin / min_dist bit-identical on valid rows."""
+    from oryon_amd import ops
+    roi_a, na = ops.roi_compact(mask_a)
+    roi_q, nq = ops.roi_compact(mask_q)
+    if subsample:
+        ops.roi_subsample_(roi_a, na, subsample, seed=3)
+    cap_a = ops.round_up(max(1, int(na.max())), 256)
+    cap_q = ops.round_up(max(1, int(nq.max())), 256)
+    C = feat_a.shape[1]
+    fa = feat_a.contiguous(memory_format=torch.channels_last) if channels_last else feat_a
+    fq = feat_q.contiguous(memory_format=torch.channels_last) if channels_last else feat_q
+    a8, a_sc, a_eps, a_norm, a_hat = ops.gather_q8(fa, roi_a, na, cap_a, C_pad, want_f32=True)
+    q8, q_sc, q_eps, q_norm, q_hat = ops.gather_q8(fq, roi_q, nq, cap_q, C_pad, want_f32=True)
+    r_a = ops.gather_normalise(feat_a, roi_a, na, cap_a, c_pad=C_pad)
+    r_q = ops.gather_normalise(feat_q, roi_q, nq, cap_q, c_pad=C_pad)
+    for b in range(feat_q.shape[0]):
+        for got, ref, n_, norm, x8, sc, eps in ((a_hat, r_a, int(na[b]), a_norm, a8, a_sc, a_eps), (q_hat, r_q, int(nq[b]), q_norm, q8, q_sc, q_eps)):
+            nf = ops.round_up(n_, 256)
+            assert torch.equal(got[b, :nf].view(torch.int32), ref[b, :nf].view(torch.int32)), "fp32 unit rows differ from round-1 K0"
+            if n_ == 0:
+                continue
+            xk = ops.unpermute_k(ref[b, :nf])[:, :C]
+            rows = torch.arange(nf, device=x8.device)
+            sl = (rows // 32) * 2 + ((rows // 4) % 2)
+            s_row = sc[b][sl][:, None]
+            assert bool((torch.log2(s_row) == torch.log2(s_row).round()).all())
+            err = (x8[b, :nf, :C].float() * s_row - xk).abs()
+            assert bool((err <= 0.5 * s_row * (1 + 5e-5) + 1e-12).all()) and int(x8[b, :nf].abs().max()) <= 127
+            assert float(x8[b, :nf, C:].abs().max() if C < C_pad else 0) == 0
+            assert int(x8[b, n_:nf].abs().max() if nf > n_ else 0) == 0
+            live_sl = sl[:n_].unique()
+            assert abs(float(eps[b]) - float(0.5 * sc[b][live_sl].max())) <= 1e-12
+            # canonical norm: d * x^_k reproduces the raw value to 1 ulp; d itself equals sqrt of the k-ordered chain (checked through x^)
+            assert float(norm[b, :n_].min()) >= 1e-8
+    md0, am0, va0 = ops.match(r_a, r_q, na, nq, thr)
+    und = torch.zeros((feat_a.shape[0],), dtype=torch.int32, device=feat_a.device)
+    md1, am1, va1 = ops.match_screened8_raw(a_hat, a8, a_sc, fq, roi_q, q_norm, q8, q_sc, q_eps, na, nq, thr, und)
+    for b in range(feat_a.shape[0]):
+        n = int(na[b])
+        v0, v1 = va0[b, :n].bool(), va1[b, :n].bool()
+        assert torch.equal(v0, v1), "valid set differs (K0v3 / raw path)"
+        assert torch.equal(am0[b, :n][v0], am1[b, :n][v0]), "argmin differs on valid rows (K0v3 / raw path)"
+        assert torch.equal(md0[b, :n][v0].view(torch.int32), md1[b, :n][v0].view(torch.int32)), "min_dist differs on valid rows (K0v3 / raw path)"
+    return va0, na, und
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_k0v3_synthetic_and_ragged(channels_last):
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    for C, H in ((256, 64), (200, 48), (512, 40), (400, 36), (130, 33)):            # C = 200 / 130 pad to 256, 400 to 512
+        pairs = [make_pair(i, H, H, C, device=dev) for i in range(3)]
+        st = lambda k: torch.stack([p[k] for p in pairs])
+        fq = st("feat_q")
+        fq[2] = torch.randn_like(fq[2])
+        ma = st("mask_a").clone()
+        ma[1, :, : H // 2] = 0                                                     # different ROI sizes inside the batch
+        va, na, _ = _k0v3_vs_round1(st("feat_a"), fq, ma, st("mask_q"), 256 if C <= 256 else 512, channels_last=channels_last)
+        assert int(va[2, : int(na[2])].sum()) == 0 and int(va[0, : int(na[0])].sum()) > 100
+
+
+@pytest.mark.parametrize("C", [256, 512])
+def test_k0v3_duplicates_overflow_and_undecided(C):
+    """Duplicate crowds (candidate lists overflow -> exact panel recomputation) and a smooth field (most anchors undecided -> fp16
+    stage): both fall-backs need the fp32 query rows, which the raw path must materialise on demand, for the right pairs only."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(5)
+    H = 40
+    base = torch.randn(C, 200, generator=g, device=dev)
+    idx = torch.randint(0, 200, (H * H,), generator=g, device=dev)
+    fq0 = base[:, idx].reshape(C, H, H).contiguous()
+    fa0 = (base[:, idx.flip(0)] + 0.02 * torch.randn(C, H * H, generator=g, device=dev)).reshape(C, H, H).contiguous()
+    crowd = fq0[:, 0, 0].clone()
+    fq0[:, :4, :] = crowd[:, None, None]
+    fa0[:, 0, :8] = crowd[:, None] + 0.001
+    fq1 = torch.randn(C, H, H, generator=g, device=dev)                            # pair 1: plain planted matches, needs no fall-back
+    fa1 = fq1.flip(-1) + 0.05 * torch.randn(C, H, H, generator=g, device=dev)
+    basis = torch.randn(C, 6, generator=g, device=dev)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, H, device=dev), indexing="ij")
+    coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy)])
+    fq2 = torch.einsum("ck,khw->chw", basis, coef) + 0.01 * torch.randn(C, H, H, generator=g, device=dev)
+    fa2 = fq2 + 0.005 * torch.randn(C, H, H, generator=g, device=dev)
+    fa, fq = torch.stack((fa0, fa1, fa2)), torch.stack((fq0, fq1, fq2))
+    ones = torch.ones((3, H, H), dtype=torch.int32, device=dev)
+    for cl in (False, True):
+        va, na, und = _k0v3_vs_round1(fa, fq, ones, ones, C, channels_last=cl)
+        assert int(va[0, : int(na[0])].sum()) > 1000 and int(und[2]) > 100
+
+
+@pytest.mark.parametrize("H,C", [(224, 256), (384, 512)])
+def test_k0v3_full_size_pair_vs_c_oracle(H, C):
+    """BASELINE cfg2 / cfg4 pair sizes through K0v3 + the raw re-scoring matcher, against the C oracle's full scan."""
+    from oracle import c_oracle
+    from oryon_amd import ops
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    p = make_pair(3, H, H, C, device=dev)
+    roi_a, na = ops.roi_compact(p["mask_a"])
+    roi_q, nq = ops.roi_compact(p["mask_q"])
+    ops.roi_subsample_(roi_a, na, 5000, seed=1)
+    n1, n2 = int(na), int(nq)
+    ref_md, ref_am, ref_va = c_oracle.match_lin(p["feat_a"].cpu().numpy(), p["feat_q"].cpu().numpy(), roi_a[0, :n1].cpu().numpy(),
+                                                roi_q[0, :n2].cpu().numpy(), 0.25)
+    cap_a, cap_q = ops.round_up(n1, 256), ops.round_up(n2, 256)
+    for cl in (False, True):
+        fa, fq = p["feat_a"][None], p["feat_q"][None]
+        if cl:
+            fa, fq = fa.contiguous(memory_format=torch.channels_last), fq.contiguous(memory_format=torch.channels_last)
+        a8, a_sc, _, _, a_hat = ops.gather_q8(fa, roi_a, na, cap_a, C, want_f32=True)
+        q8, q_sc, q_eps, q_norm, _ = ops.gather_q8(fq, roi_q, nq, cap_q, C)
+        md, am, va = ops.match_screened8_raw(a_hat, a8, a_sc, fq, roi_q, q_norm, q8, q_sc, q_eps, na, nq, 0.25)
+        va_ = va[0, :n1].cpu().numpy().astype(bool)
+        assert np.array_equal(va_, ref_va) and ref_va.mean() > 0.6
+        assert np.array_equal(am[0, :n1].cpu().numpy()[ref_va], ref_am[ref_va])
+        assert np.array_equal(md[0, :n1].cpu().numpy().view(np.uint32)[ref_va], ref_md.view(np.uint32)[ref_va])
