@@ -283,6 +283,9 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", choices=["nchw", "nhwc"], default="nchw",
+                    help="memory layout of the given descriptor maps: nchw = contiguous [B,C,H,W] as net.py:162-167 returns them (default, "
+                         "the headline); nhwc = the same logical tensor in torch.channels_last storage (what a channels_last decoder emits)")
     ap.add_argument("--stages", choices=["match+pose", "decode", "full"], default="match+pose",
                     help="match+pose: BASELINE configs[1], descriptor maps given (default, the headline line); decode: fusion + decoder "
                          "forward on cached CLIP / Swin encodings, then match + pose (SURVEY 8d 'decode+match+pose'); full: random-init "
@@ -325,6 +328,9 @@ def main():
     if a.stages in ("full", "decode"):
         return bench_full(a, rank, world, dev)
     inputs = make_inputs(B, H, C, first=rank * B, dev=dev)
+    if a.layout == "nhwc":
+        inputs["feat_a"] = inputs["feat_a"].contiguous(memory_format=torch.channels_last)
+        inputs["feat_q"] = inputs["feat_q"].contiguous(memory_format=torch.channels_last)
     engine = MatchPoseEngine(build_solver(dev), MatchPoseConfig(dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1,
                                                                 match_mode=a.match_mode), overlap_registration=not a.no_overlap,
                              overlap_gather=a.overlap_gather and not a.no_overlap)
@@ -367,7 +373,7 @@ def main():
     barrier()
     screened = a.match_mode in ("screened", "screened16") and 64 < C <= 512
     use_i8 = screened and a.match_mode == "screened" and C > 128
-    with MatchTimer("match_screened8" if use_i8 else "match_screened" if screened else "match") as mt:
+    with MatchTimer("match_corrs_i8" if use_i8 else "match_screened" if screened else "match") as mt:
         t0 = time.perf_counter()
         out, pose, status = run_steps(a.steps)
         barrier()
@@ -423,6 +429,7 @@ def main():
                 "workload": f"{'cfg2' if (H, C) == (224, 256) else 'cfg4 geometry' if (H, C) == (384, 512) else 'custom'}: Batch={B} synthetic {H}x{H} pairs per GPU, C={C} fp32 descriptors given (HIP matcher + lift + "
                             f"PointDSC 12x128), N1<=5000, n_corrs=500",
                 "stages": "match+lift+registration (descriptor maps resident in HBM; backbone not in the timed region)",
+                "descriptor_layout": "NCHW contiguous fp32 (as Oryon.forward returns them)" if a.layout == "nchw" else "channels_last (NHWC storage) fp32",
                 "match_mode": a.match_mode + (" (int8-MFMA pre-screen, fp16-MFMA screening of the undecided anchors, exact fp32 re-scoring: outputs identical to the fp32 scan)" if use_i8 else " (fp16-MFMA screening, exact fp32 re-scoring: outputs identical to the fp32 scan)" if screened else ""),
                 "pairs_per_gpu": B, "global_pairs": total, "parallelism": f"pairs sharded over {world} GPU(s), all_gather of poses",
                 "pipelining": "none" if a.no_overlap else "registration of step k on a second HIP stream under the matching of step k+1",

@@ -189,6 +189,22 @@ int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8, const floa
                               const int32_t *n_q, float threshold, float *min_dist, int32_t *argmin, uint8_t *valid,
                               int32_t *n_undecided, void *workspace, size_t workspace_bytes, void *stream);
 
+/* K1s8 + K1b fused and LAZY (round 2): from the K0v3 operands straight to the sampled correspondences of every pair
+ * (utils/pcd.py:202-214).  The int8 bound settles the validity flag of almost every anchor without its argmin; candidate generation
+ * and exact re-scoring then run for the <= max_corrs sampled anchors only.  Anchors whose validity the bound cannot settle are resolved
+ * exactly before the sampling; a pair with an ambiguous possibly-valid anchor (or every pair when force_eager != 0) takes the eager
+ * route of oryon_match_screened8_raw.  corrs / n_valid / n_sel / status are exactly what oryon_select_corrs returns on the outputs of
+ * oryon_match_screened8_raw.  valid [B,cap_a] is exact on every row; min_dist / argmin are exact on sampled rows and on every row of
+ * an eager pair, and hold the screening estimate / 0 elsewhere. */
+size_t oryon_match_corrs_i8_workspace_bytes(int B, int C, int cap_a, int cap_q, int corr_rows);
+int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW, int layout,
+                         const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q, const float *q_norm,
+                         const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C, int cap_a, int cap_q,
+                         const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs, int corr_rows, uint64_t seed,
+                         const int64_t *pair_key, int force_eager, float *min_dist, int32_t *argmin, uint8_t *valid, int32_t *corrs,
+                         int32_t *n_valid, int32_t *n_sel, int32_t *status, int32_t *n_undecided, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).
  *     Replaces utils/pcd.py:205-214: keep rows with valid, need more than one, sample exactly max_corrs
  *     (with replacement iff fewer are available).

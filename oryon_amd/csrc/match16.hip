@@ -740,6 +740,215 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_kernel
     }
 }
 
+// Round-2 restructuring of the int8 screening loop (same operands, same outputs, same tiles as match_i8_screen_kernel).
+// Round 1 ran all 8 (query block, anchor block) accumulators of a tile through the k loop together, then reduced them: ~180 VALU +
+// 128 accumulator zeroings per 64 MFMAs, none of which overlapped matrix work (PMC: 68 % MFMA-pipe utilisation).  Here a query
+// block's TWO anchor-block chains (8 k-steps each, alternating so no MFMA waits on its predecessor's accumulator) run to completion
+// before the next query block starts, so
+//   * the slice-maximum epilogue of query block qb-1 (2 x {v_max3 tree, convert, scale, running (m1, slice, m2) update}) is issued
+//     in the shadow of query block qb's 16 MFMAs - the matrix pipe executes 32 cycles per MFMA, the wave issues one every ~32;
+//   * accumulators start from the inline constant 0 (first MFMA of a chain takes C = 0): no zeroing;
+//   * 4 accumulators are live instead of 8, which pays for a double-buffered A operand (the 8 ds_read_b128 of query block qb+1
+//     also issue under qb's MFMAs).
+// sched_group_barrier pins the interleave (1 MFMA : 2 VALU : <=1 LDS read) in the emitted code.
+template <int CP, int VAR = 0>     // VAR != 0: timing ablations only (ORYON_SCREEN8_ABLATE): 1 no epilogue, 2 no DMA / barrier, 4 no LDS reads
+__global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_kernel(
+    const int8_t *__restrict__ a8, const int8_t *__restrict__ q8, const float *__restrict__ q_scale, int B, int cap_a, int cap_q,
+    const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max,
+    int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
+{
+    constexpr int RB = CP;
+    constexpr int TILE_BYTES = screen8_tile_bytes(CP);
+    constexpr int ROWS = 128, NQB = 4, NAB = 2;
+    constexpr int NKS = CP / 32;
+    constexpr int NI = TILE_BYTES / 4096;
+    constexpr int LPR = RB / 256;
+    char *smem;
+    if constexpr (2 * TILE_BYTES > 65536) {
+        extern __shared__ __attribute__((aligned(256))) char smem_dyn8b[];
+        smem = smem_dyn8b;
+    } else {
+        __shared__ __attribute__((aligned(256))) char smem_st8b[2 * TILE_BYTES];
+        smem = smem_st8b;
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = (slot / T) * 8 + xcd;
+    if (unit >= B * S) return;
+    const int panel = slot % T;
+    const int p = unit / S, split = unit % S;
+    const int na = n_a[p], nq = n_q[p];
+    const int a0 = panel * MT16;
+    if (a0 >= na) return;
+    const int nqt = (nq + ROWS - 1) / ROWS;
+    const int qt_per = (nqt + S - 1) / S;
+    const int qt_begin = split * qt_per;
+    const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const char *qp = reinterpret_cast<const char *>(q8) + (size_t)p * cap_q * RB;
+    const float2 *qs = reinterpret_cast<const float2 *>(q_scale + (size_t)p * (cap_q / 16));
+
+    i32x4 breg[NAB][NKS];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const char *arow = reinterpret_cast<const char *>(a8) + ((size_t)p * cap_a + a0 + wave * 64 + ab * 32 + l31) * RB + 16 * hi;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) breg[ab][s] = *reinterpret_cast<const i32x4 *>(arow + 32 * s);
+    }
+    unsigned dma_off[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        const int row = line / LPR;
+        const int cc = sl ^ (row & 15);
+        dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_one = [&](int qt, int buf, int j) {
+        const char *qb = qp + (size_t)qt * TILE_BYTES;
+        char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    // VAR & 16: the next tile travels HBM/L2 -> registers (global_load_dwordx4, issued under the first query block) -> LDS
+    // (ds_write_b128, issued under the last one) instead of by LDS-DMA
+    uint4 stg[NI];
+    auto gload = [&](int qt) {
+        const char *qb = qp + (size_t)qt * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) stg[j] = *reinterpret_cast<const uint4 *>(qb + dma_off[j]);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            *reinterpret_cast<uint4 *>(smem + buf * TILE_BYTES + (wave * NI + j) * 1024 + lane * 16) = stg[j];
+    };
+    unsigned koff[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) koff[c] = (unsigned)(l31 * RB) + ((((unsigned)(hi ^ (l31 & 15))) ^ (2u * c)) << 4);
+    auto rd = [&](int s, int qb, unsigned tile) -> i32x4 {
+        return *reinterpret_cast<const i32x4 *>(smem + koff[s & 7] + tile + (unsigned)(qb * 32 * RB + (s >> 3) * 256));
+    };
+
+    float runmax[NAB], run2[NAB];
+    int runidx[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; run2[ab] = -INFINITY; runidx[ab] = 0; }
+    // slice epilogue of one finished 32x32 block: integer maximum of the lane's 16 rows (exact: one exponent per slice), one
+    // convert, one multiply, running (best, slice of best, best other slice)
+    auto reduce_block = [&](const i32x16 &c, float sc, int sid, int ab) {
+        int m0 = max(max(c[0], c[1]), c[2]), m1 = max(max(c[3], c[4]), c[5]), m2 = max(max(c[6], c[7]), c[8]);
+        int m3 = max(max(c[9], c[10]), c[11]), m4 = max(max(c[12], c[13]), c[14]);
+        int xi = max(max(max(m0, m1), m2), max(max(m3, m4), c[15]));
+        const float x = (float)xi * sc;
+        const bool improved = x > runmax[ab];
+        run2[ab] = fmaxf(fminf(runmax[ab], x), run2[ab]);
+        runmax[ab] = fmaxf(runmax[ab], x);
+        runidx[ab] = improved ? sid : runidx[ab];
+    };
+    const i32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    if (qt_end > qt_begin) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) issue_one(qt_begin, 0, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    i32x4 areg[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, 0u);
+    // finished accumulators of the previous query block, reduced under the next block's MFMAs.  The steady-state loop has no branch:
+    // before the first block `prev` is a dummy that can never win (score -2^30), and the last tile re-issues its own DMA into the idle
+    // buffer instead of testing for "one more tile".
+    i32x16 prev[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[ab][r] = -(1 << 30);
+    float prev_sc = 1.0f;
+    int prev_sid = 0;
+    int buf = 0;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        const unsigned tile = buf * TILE_BYTES;
+        const int qt_next = qt + 1 < qt_end ? qt + 1 : qt;
+        float2 sc2[NQB];
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) sc2[qb] = qs[qt * NQB + qb];
+        // ONE A-operand buffer: after both anchor blocks have consumed k-step s of query block qb, areg[s] is re-loaded with k-step s of
+        // query block qb+1 (needed 16 MFMAs ~ 500 cycles later)
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            i32x16 acc[NAB];
+            // the whole next tile is requested under the FIRST query block's MFMAs: ~1500 cycles before the wait at the tile's end
+            // (spreading the 8 requests over the four blocks left the last ones ~500 cycles, less than an L2 miss: +4 %)
+            if ((VAR & 16) && qb == 0) gload(qt_next);
+            if ((VAR & 16) && qb == NQB - 1) lstore(buf ^ 1);
+            if (!(VAR & 18) && (((VAR & 8) && qb < 2) || (!(VAR & 8) && qb == 0))) {
+#pragma unroll
+                for (int j = ((VAR & 8) ? qb * (NI / 2) : 0); j < ((VAR & 8) ? (qb + 1) * (NI / 2) : NI); ++j) issue_one(qt_next, buf ^ 1, j);
+            }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab)
+                    acc[ab] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[s], breg[ab][s], s == 0 ? zero16 : acc[ab], 0, 0, 0);
+                if (qb + 1 < NQB && !(VAR & 4)) areg[s] = rd(s, qb + 1, tile);
+            }
+            if (!(VAR & 1)) {
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sc, prev_sid, ab);
+            } else {
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(prev[ab][r]));
+            }
+            // pin the interleave: per MFMA pair two VALU of the previous block's epilogue and one LDS read of the next A operand
+#pragma unroll
+            for (int i = 0; i < NKS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if (qb + 1 < NQB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if ((VAR & 16) && qb == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if ((VAR & 16) && qb == NQB - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) prev[ab] = acc[ab];
+            prev_sc = hi ? sc2[qb].y : sc2[qb].x;
+            prev_sid = (qt * NQB + qb) * 2 + hi;
+        }
+        if (!(VAR & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+        // first A operand of the next tile (its DMA has landed: barrier above)
+        if (!(VAR & 4)) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
+        }
+    }
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sc, prev_sid, ab);
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const float om1 = __shfl_xor(runmax[ab], 32), om2 = __shfl_xor(run2[ab], 32);
+        const int oi1 = __shfl_xor(runidx[ab], 32);
+        const float m1 = fmaxf(runmax[ab], om1);
+        const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
+        const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
+        const int a = a0 + wave * 64 + ab * 32 + l31;
+        if (hi == 0) {
+            const size_t o = ((size_t)p * S + split) * cap_a + a;
+            ws_max[o] = m1;
+            ws_i1[o] = i1;
+            ws_m2[o] = m2;
+        }
+    }
+}
+
 // fp32 rows (k permuted inside groups of 8: position 8g+4h+j holds k = 8g+2j+h) -> fp16 rows in natural k order, the values K0's
 // fp16 output would hold.  One lane per group of 8.
 __device__ __forceinline__ uint4 half_group_from_permuted(const float4 lo, const float4 hi4)
@@ -999,8 +1208,22 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
                     const int32_t *n_a, const int32_t *n_q, int T, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
 {
     constexpr size_t dyn = 2 * screen8_tile_bytes(CP) > 65536 ? 2 * screen8_tile_bytes(CP) : 0;
-    if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_i8_screen_kernel<CP>), (int)dyn);
-    hipLaunchKernelGGL((match_i8_screen_kernel<CP>), dim3(groups), dim3(256), dyn, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S,
+    static const int variant = getenv("ORYON_SCREEN8_VARIANT") ? atoi(getenv("ORYON_SCREEN8_VARIANT")) : 2;
+    if (variant == 1) {                 // round-1 loop (kept for A/B timing)
+        if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_i8_screen_kernel<CP>), (int)dyn);
+        hipLaunchKernelGGL((match_i8_screen_kernel<CP>), dim3(groups), dim3(256), dyn, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S,
+                           ws_max, ws_i1, ws_m2);
+        return;
+    }
+    static const int ablate = getenv("ORYON_SCREEN8_ABLATE") ? atoi(getenv("ORYON_SCREEN8_ABLATE")) : 0;
+    if (ablate && CP == 256) {
+#define ABL(V) case V: hipLaunchKernelGGL((match_i8_screen_v2_kernel<256, V>), dim3(groups), dim3(256), 0, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, ws_max, ws_i1, ws_m2); break
+        switch (ablate) { ABL(1); ABL(2); ABL(3); ABL(8); ABL(16); default: ABL(17); }
+#undef ABL
+        return;
+    }
+    if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_i8_screen_v2_kernel<CP>), (int)dyn);
+    hipLaunchKernelGGL((match_i8_screen_v2_kernel<CP>), dim3(groups), dim3(256), dyn, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S,
                        ws_max, ws_i1, ws_m2);
 }
 }  // namespace
@@ -1174,6 +1397,361 @@ extern "C" int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8,
     if (rc) return rc;
     hipLaunchKernelGGL(match_scatter8_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, w.n_amb, w.amb_idx, w8.md_c, w8.am_c, w8.va_c,
                        min_dist, argmin, valid);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ lazy tail: K1s8 -> sampled correspondences
+// The batched engine consumes the matcher through oryon_select_corrs only: it needs the VALID FLAG of every anchor and the argmin of the
+// <= max_corrs anchors that get sampled (utils/pcd.py:205-214).  The int8 bound decides validity outright for almost every anchor:
+//     m1 - DELTA8 > 1 - 2 thr   =>  the exact distance is below the threshold   (valid, whatever the argmin)
+//     m1 + DELTA8 < 1 - 2 thr   =>  it is not                                   (as before)
+// so candidate generation (16 int8 rows per anchor) and exact re-scoring (256 strided reads per candidate) are deferred to the sampled
+// anchors - 500 per pair instead of 5000.  Anchors whose validity the bound cannot settle are resolved (exactly) before the sampling;
+// a pair in which a possibly-valid anchor is AMBIGUOUS (runner-up slice within the int8 margin: its argmin needs the fp16 stage) takes
+// the eager route of oryon_match_screened8_raw for all of its anchors.  Outputs are what select(match_screened8_raw(...)) gives,
+// bit for bit: same valid set, same sampled rows (the sampling keys depend on the valid set only), same argmin for every sampled row.
+namespace oryon {
+int select_corrs_launch(const int32_t *roi_a, const int32_t *roi_q, int roi_stride_a, int roi_stride_q, const int32_t *n_a,
+                        const int32_t *n_q, const int32_t *argmin, const uint8_t *valid, int cap_a, int B, int W, int max_corrs,
+                        int corr_rows, uint64_t seed, const int64_t *pair_key, int32_t *scratch, int32_t *corrs, int32_t *n_valid,
+                        int32_t *n_sel, int32_t *status, int32_t *sel_rows, const int32_t *pair_eager, hipStream_t st);
+
+constexpr uint8_t LZ_INVALID = 0, LZ_VALID = 1, LZ_UNCERTAIN = 2, LZ_AMBIGUOUS = 3, LZ_RESOLVED = 4;
+
+// one THREAD per anchor: merge the per-split (m1, slice, m2) triples and classify
+__global__ __launch_bounds__(256) void match_decide_lite_kernel(
+    int cap_a, const int32_t *__restrict__ n_a, int S, const float *__restrict__ ws_m1, const int32_t *__restrict__ ws_i1,
+    const float *__restrict__ ws_m2, const float *__restrict__ a_scale8, const float *__restrict__ eps_q8, float cut0, float sqrt_c,
+    float c_true, int force_eager, float *__restrict__ m_final, int32_t *__restrict__ sid_final, float *__restrict__ margin_out,
+    uint8_t *__restrict__ state, uint8_t *__restrict__ valid, float *__restrict__ min_dist, int32_t *__restrict__ argmin,
+    int32_t *__restrict__ pair_eager, int32_t *__restrict__ n_unc, int32_t *__restrict__ unc_idx)
+{
+    const int p = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= n_a[p]) return;
+    const size_t arow = (size_t)p * cap_a + a;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int sid = 0;
+    for (int s = 0; s < S; ++s) {
+        const size_t o = ((size_t)p * S + s) * cap_a + a;
+        const float x1 = ws_m1[o], x2 = ws_m2[o];
+        m2 = fmaxf(fminf(m1, x1), fmaxf(m2, x2));
+        if (x1 > m1) { m1 = x1; sid = ws_i1[o]; }
+    }
+    const float sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];
+    m1 *= sa;
+    m2 *= sa;
+    const float ea = 0.50003f * sa, eq = 1.00006f * eps_q8[p];
+    const float delta = (ea + eq) * sqrt_c + c_true * ea * eq + 4e-5f;
+    const bool usable = delta < 0.2f;
+    const float margin = usable ? 2.0f * delta + 2e-7f : INFINITY;
+    m_final[arow] = m1;
+    sid_final[arow] = sid;
+    margin_out[arow] = margin;
+    uint8_t st;
+    if (usable && !(m1 >= cut0 - delta - 1e-6f)) st = LZ_INVALID;
+    else if (!(m1 - m2 > margin)) st = LZ_AMBIGUOUS;
+    else if (m1 > cut0 + delta + 1e-5f) st = LZ_VALID;
+    else st = LZ_UNCERTAIN;
+    state[arow] = st;
+    // provisional outputs: the distance is the screening estimate until (unless) the row is resolved exactly
+    min_dist[arow] = __fmaf_rn(-0.5f, m1, 0.5f);
+    argmin[arow] = 0;
+    valid[arow] = st == LZ_VALID ? 1 : 0;
+    if (st == LZ_AMBIGUOUS || force_eager) pair_eager[p] = 1;
+    if (st == LZ_UNCERTAIN) unc_idx[(size_t)p * cap_a + atomicAdd(&n_unc[p], 1)] = a;
+}
+
+__global__ void match_mask_counts_kernel(int B, const int32_t *__restrict__ n_a, const int32_t *__restrict__ pair_eager,
+                                         int32_t *__restrict__ n_a_eager, int32_t *__restrict__ n_a_lazy)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    n_a_eager[p] = pair_eager[p] ? n_a[p] : 0;
+    n_a_lazy[p] = pair_eager[p] ? 0 : n_a[p];
+}
+
+// Exact resolution of ONE unambiguous anchor by one wave: candidates = rows of the winning 16-row slice within the int8 margin of its
+// maximum (re-scored from the int8 rows, as match_decide_kernel does), then the canonical fp32 chain per candidate on x_k / d read
+// from the raw map (as match_rescore_raw_kernel does).  Returns (distance, first index of the minimum) in lane 0.
+template <bool NHWC>
+__device__ __forceinline__ void resolve_anchor(int p, int a, const float *__restrict__ a_hat, const int8_t *__restrict__ a8,
+                                               const int8_t *__restrict__ q8, const float *__restrict__ q_scale8,
+                                               const float *__restrict__ a_scale8, const float *__restrict__ feat_q, int C_true, int HW,
+                                               const int32_t *__restrict__ roi_q, int roi_stride, const float *__restrict__ norm_q,
+                                               int Cp, int cap_a, int cap_q, int nq, float m1, int sid, float margin, float *lds /*[2*Cp]*/,
+                                               float &d_out, int &j_out)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t arow = (size_t)p * cap_a + a;
+    const int half = sid & 1, blk = sid >> 1;
+    const int r = lane >> 2, seg = lane & 3;
+    const int q = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const float sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];
+    int idot = 0;
+    if (q < nq) {
+        const uint4 *ar = reinterpret_cast<const uint4 *>(a8 + arow * Cp) + seg * (Cp / 64);
+        const uint4 *qr = reinterpret_cast<const uint4 *>(q8 + ((size_t)p * cap_q + q) * Cp) + seg * (Cp / 64);
+        for (int i0 = 0; i0 < Cp / 64; ++i0) {
+            const uint4 av = ar[i0], qv = qr[i0];
+            idot = __builtin_amdgcn_sdot4((int)av.x, (int)qv.x, idot, false);
+            idot = __builtin_amdgcn_sdot4((int)av.y, (int)qv.y, idot, false);
+            idot = __builtin_amdgcn_sdot4((int)av.z, (int)qv.z, idot, false);
+            idot = __builtin_amdgcn_sdot4((int)av.w, (int)qv.w, idot, false);
+        }
+    }
+    idot += __shfl_xor(idot, 1);
+    idot += __shfl_xor(idot, 2);
+    const float s8 = (float)idot * q_scale8[(size_t)p * (cap_q / 16) + sid] * sa;
+    const bool hit = (seg == 0) && (q < nq) && (s8 >= m1 - margin);
+    unsigned long long hits = __ballot(hit);
+    // anchor row (k-permuted: position 8g + 4h + j holds k = 8g + 2j + h) -> natural order in LDS
+    float *A = lds, *Q = lds + Cp;
+    for (int pos = lane; pos < Cp; pos += 64) {
+        const int g = pos >> 3, hh = (pos >> 2) & 1, jj = pos & 3;
+        A[8 * g + 2 * jj + hh] = a_hat[arow * Cp + pos];
+    }
+    float d = INFINITY;
+    int j = 0x7fffffff;
+    const float *fq = feat_q + (size_t)p * C_true * HW;
+    while (hits) {
+        const int src = __ffsll((long long)hits) - 1;
+        hits &= hits - 1;
+        const int jj = __shfl(q, src);
+        const int pix = roi_q[(size_t)p * roi_stride + jj];
+        const float dq = norm_q[(size_t)p * cap_q + jj];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < Cp; k += 64) {
+            float x = 0.0f;
+            if (k < C_true) x = NHWC ? fq[(size_t)pix * C_true + k] : fq[(size_t)k * HW + pix];
+            Q[k] = __fdiv_rn(x, dq);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float dot = 0.0f;                               // every lane runs the same chain on broadcast LDS reads
+        for (int k = 0; k < C_true; k += 8) {
+            float av[8], qv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { av[e] = A[k + e]; qv[e] = Q[k + e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (k + e < C_true) dot = __fmaf_rn(av[e], qv[e], dot);
+        }
+        lex_min(d, j, __fmaf_rn(-0.5f, dot, 0.5f), jj);
+    }
+    d_out = d;
+    j_out = j;
+}
+
+// anchors whose VALIDITY the int8 bound could not settle (pairs on the lazy route only): exact distance now, before the sampling
+template <bool NHWC>
+__global__ __launch_bounds__(256) void match_resolve_uncertain_kernel(
+    const float *__restrict__ a_hat, const int8_t *__restrict__ a8, const int8_t *__restrict__ q8, const float *__restrict__ q_scale8,
+    const float *__restrict__ a_scale8, const float *__restrict__ feat_q, int C_true, int HW, const int32_t *__restrict__ roi_q,
+    int roi_stride, const float *__restrict__ norm_q, int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_q, float thr,
+    const float *__restrict__ m_final, const int32_t *__restrict__ sid_final, const float *__restrict__ margin_in,
+    const int32_t *__restrict__ n_unc, const int32_t *__restrict__ unc_idx, const int32_t *__restrict__ pair_eager,
+    uint8_t *__restrict__ state, uint8_t *__restrict__ valid, float *__restrict__ min_dist, int32_t *__restrict__ argmin)
+{
+    extern __shared__ float lds_res[];
+    const int p = blockIdx.y;
+    if (pair_eager[p]) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = n_unc[p];
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        const int a = unc_idx[(size_t)p * cap_a + i];
+        const size_t arow = (size_t)p * cap_a + a;
+        float d;
+        int j;
+        resolve_anchor<NHWC>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q, n_q[p],
+                             m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, d, j);
+        if (lane == 0) {
+            min_dist[arow] = d;
+            argmin[arow] = j;
+            valid[arow] = (d < thr) ? 1 : 0;
+            state[arow] = LZ_RESOLVED;
+        }
+    }
+}
+
+// the sampled rows of the lazy pairs: exact argmin -> query half of the correspondence
+template <bool NHWC>
+__global__ __launch_bounds__(256) void match_resolve_selected_kernel(
+    const float *__restrict__ a_hat, const int8_t *__restrict__ a8, const int8_t *__restrict__ q8, const float *__restrict__ q_scale8,
+    const float *__restrict__ a_scale8, const float *__restrict__ feat_q, int C_true, int HW, const int32_t *__restrict__ roi_q,
+    int roi_stride, const float *__restrict__ norm_q, int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_q, int W,
+    const float *__restrict__ m_final, const int32_t *__restrict__ sid_final, const float *__restrict__ margin_in,
+    const uint8_t *__restrict__ state, const int32_t *__restrict__ pair_eager, const int32_t *__restrict__ n_sel,
+    const int32_t *__restrict__ sel_rows, int corr_rows, float *__restrict__ min_dist, int32_t *__restrict__ argmin,
+    int32_t *__restrict__ corrs)
+{
+    extern __shared__ float lds_res[];
+    const int p = blockIdx.y;
+    if (pair_eager[p]) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= n_sel[p]) return;
+    const int a = sel_rows[(size_t)p * corr_rows + slot];
+    const size_t arow = (size_t)p * cap_a + a;
+    float d = 0.0f;
+    int j;
+    if (state[arow] == LZ_RESOLVED) {
+        j = argmin[arow];
+    } else {
+        resolve_anchor<NHWC>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q, n_q[p],
+                             m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, d, j);
+        if (lane == 0) { min_dist[arow] = d; argmin[arow] = j; }        // same value from every slot that drew this row
+    }
+    if (lane == 0) {
+        j = (j < 0 || j >= n_q[p]) ? 0 : j;                            // cannot happen for a row that passed the validity cut
+        const int pq = roi_q[(size_t)p * roi_stride + j];
+        corrs[((size_t)p * corr_rows + slot) * 4 + 2] = pq / W;
+        corrs[((size_t)p * corr_rows + slot) * 4 + 3] = pq % W;
+    }
+}
+}  // namespace oryon
+
+namespace {
+struct LazyWs {
+    Screen8RawWs raw;
+    float *margin;
+    int32_t *sid_final, *pair_eager, *n_unc, *unc_idx, *n_a_eager, *n_a_lazy, *sel_rows, *scratch;
+    uint8_t *state;
+    size_t bytes, zero_off, zero_bytes;
+};
+
+LazyWs carve_lazy(void *base, int B, int C, int cap_a, int cap_q, int S, int corr_rows)
+{
+    LazyWs w;
+    w.raw = carve_screen8_raw(base, B, C, cap_a, cap_q, S);
+    char *p = static_cast<char *>(base);
+    size_t off = (w.raw.bytes + 255) / 256 * 256;
+    auto take = [&](size_t n) { size_t o = off; off = (off + n + 255) / 256 * 256; return o; };
+    const size_t o_mg = take((size_t)B * cap_a * sizeof(float));
+    const size_t o_sf = take((size_t)B * cap_a * sizeof(int32_t));
+    const size_t o_ui = take((size_t)B * cap_a * sizeof(int32_t));
+    const size_t o_st = take((size_t)B * cap_a);
+    const size_t o_sr = take((size_t)B * corr_rows * sizeof(int32_t));
+    const size_t o_sc = take((size_t)B * cap_a * sizeof(int32_t));
+    const size_t o_ne = take((size_t)B * sizeof(int32_t));
+    const size_t o_nl = take((size_t)B * sizeof(int32_t));
+    w.zero_off = off;
+    const size_t o_pe = take((size_t)B * sizeof(int32_t));
+    const size_t o_nu = take((size_t)B * sizeof(int32_t));
+    w.zero_bytes = off - w.zero_off;
+    w.bytes = off;
+    auto at = [&](size_t o) { return base ? p + o : nullptr; };
+    w.margin = reinterpret_cast<float *>(at(o_mg));
+    w.sid_final = reinterpret_cast<int32_t *>(at(o_sf));
+    w.unc_idx = reinterpret_cast<int32_t *>(at(o_ui));
+    w.state = reinterpret_cast<uint8_t *>(at(o_st));
+    w.sel_rows = reinterpret_cast<int32_t *>(at(o_sr));
+    w.scratch = reinterpret_cast<int32_t *>(at(o_sc));
+    w.n_a_eager = reinterpret_cast<int32_t *>(at(o_ne));
+    w.n_a_lazy = reinterpret_cast<int32_t *>(at(o_nl));
+    w.pair_eager = reinterpret_cast<int32_t *>(at(o_pe));
+    w.n_unc = reinterpret_cast<int32_t *>(at(o_nu));
+    return w;
+}
+}  // namespace
+
+extern "C" size_t oryon_match_corrs_i8_workspace_bytes(int B, int C, int cap_a, int cap_q, int corr_rows)
+{
+    if (B <= 0 || C <= 0 || cap_a <= 0 || cap_a % MT16 || cap_q <= 0 || corr_rows <= 0) return 0;
+    return carve_lazy(nullptr, B, C, cap_a, cap_q, pick_split16(B, cap_a / MT16), corr_rows).bytes;
+}
+
+extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW,
+                                    int layout, const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q,
+                                    const float *q_norm, const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C,
+                                    int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs,
+                                    int corr_rows, uint64_t seed, const int64_t *pair_key, int force_eager, float *min_dist,
+                                    int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
+                                    int32_t *n_undecided, void *workspace, size_t workspace_bytes, void *stream)
+{
+    ORYON_CHECK_ARG(a_hat && a_i8 && a_scale && feat_q && roi_a && roi_q && q_norm && q_i8 && q_scale && q_eps_max && n_a && n_q);
+    ORYON_CHECK_ARG(min_dist && argmin && valid && corrs && n_valid && n_sel && status);
+    ORYON_CHECK_ARG(B >= 0 && (C == 256 || C == 512) && C_true > 0 && C_true <= C && HW > 0 && W > 0 && max_corrs > 0 && corr_rows >= max_corrs);
+    ORYON_CHECK_ARG(layout == ORYON_LAYOUT_NCHW || layout == ORYON_LAYOUT_NHWC);
+    ORYON_CHECK_ARG(cap_a > 0 && cap_a % MT16 == 0 && cap_q > 0 && cap_q % 256 == 0 && threshold > 0.0f && threshold <= 0.5f);
+    if (B == 0) return ORYON_OK;
+    const int T = cap_a / MT16;
+    const int S = pick_split16(B, T);
+    LazyWs lw = carve_lazy(workspace, B, C, cap_a, cap_q, S, corr_rows);
+    if (!workspace || workspace_bytes < lw.bytes) {
+        set_error("oryon_match_corrs_i8: workspace too small (%zu < %zu)", workspace_bytes, lw.bytes);
+        return ORYON_ERR_WORKSPACE;
+    }
+    Screen8RawWs &wr = lw.raw;
+    Screen8Ws &w8 = wr.base;
+    ScreenWs &w = w8.top;
+    hipStream_t st = as_stream(stream);
+    ORYON_CHECK_HIP(hipMemsetAsync(static_cast<char *>(workspace) + w.zero_off, 0, w.zero_bytes, st));
+    ORYON_CHECK_HIP(hipMemsetAsync(wr.need_f32, 0, (size_t)B * sizeof(int32_t), st));
+    ORYON_CHECK_HIP(hipMemsetAsync(static_cast<char *>(workspace) + lw.zero_off, 0, lw.zero_bytes, st));
+    const float cut0 = 1.0f - 2.0f * threshold;
+    const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
+    const int groups = ((B * S + 7) / 8) * 8 * T;
+    profile_begin(st);
+    if (C == 256) launch_screen8<256>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
+    else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
+    profile_end(st);
+    ORYON_CHECK_LAUNCH();
+    const float sqrt_c = sqrtf((float)C_true);
+    hipLaunchKernelGGL(match_decide_lite_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, n_a, S, w.ws_max, w.ws_i1, w.ws_m2, a_scale,
+                       q_eps_max, cut0, sqrt_c, (float)C_true, force_eager, w.m_final, lw.sid_final, lw.margin, lw.state, valid, min_dist,
+                       argmin, lw.pair_eager, lw.n_unc, lw.unc_idx);
+    hipLaunchKernelGGL(match_mask_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_a, lw.pair_eager, lw.n_a_eager, lw.n_a_lazy);
+    ORYON_CHECK_LAUNCH();
+    // ---- eager route (the complete tail of oryon_match_screened8_raw) for the flagged pairs: every launch below sees 0 anchors elsewhere
+    const int32_t *nae = lw.n_a_eager;
+    hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 64, B), dim3(256), 0, st, static_cast<const __half *>(nullptr),
+                       static_cast<const __half *>(nullptr), C, cap_a, cap_q, nae, n_q, S, valid_cut16, w.ws_max, w.ws_i1, w.ws_m2, w.m_final,
+                       w.cnt, w.cand, w.n_amb, w.amb_idx, a_scale, nullptr, q_eps_max, cut0, sqrt_c, (float)C_true, a_i8, q_i8, q_scale);
+#define RESCORE_RAW_E(NHWCV)                                                                                                   \
+    hipLaunchKernelGGL((match_rescore_raw_kernel<2, NHWCV>), dim3(cap_a / 128, B), dim3(256), 0, st, a_hat, feat_q, C_true, HW, roi_q,  \
+                       roi_stride_q, q_norm, C, cap_a, cap_q, nae, n_q, threshold, w.m_final, w.cnt, w.cand, min_dist, argmin, valid,    \
+                       w.row_flag, w.panel_flag, wr.need_f32)
+    if (layout == ORYON_LAYOUT_NHWC) RESCORE_RAW_E(true); else RESCORE_RAW_E(false);
+#undef RESCORE_RAW_E
+    ORYON_CHECK_LAUNCH();
+    if (n_undecided) ORYON_CHECK_HIP(hipMemcpyAsync(n_undecided, w.n_amb, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(match_need_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, w.n_amb, wr.need_f32);
+    int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, wr.need_f32, cap_q, C, wr.q8_scratch, wr.scale_scratch,
+                              wr.eps_scratch, nullptr, wr.q_hat, 1, st);
+    if (rc) { set_error("oryon_match_corrs_i8: fall-back gather launch failed"); return rc; }
+    rc = match_f32_flagged(a_hat, wr.q_hat, B, C, cap_a, cap_q, nae, n_q, threshold, min_dist, argmin, valid, w.panel_flag, w.row_flag, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_compact8_kernel, dim3(cap_a / 64, B), dim3(256), 0, st, a_hat, static_cast<const __half *>(nullptr), C, cap_a,
+                       w.n_amb, w.amb_idx, w8.a_hat_c, w.a16c);
+    hipLaunchKernelGGL(match_make_q16_kernel, dim3(64, B), dim3(256), 0, st, wr.q_hat, C, cap_q, n_q, w.n_amb, w8.q16);
+    ORYON_CHECK_LAUNCH();
+    rc = oryon_match_screened(w8.a_hat_c, wr.q_hat, w.a16c, w8.q16, B, C, cap_a, cap_q, w.n_amb, n_q, threshold, w8.md_c, w8.am_c, w8.va_c,
+                              w8.nested, w8.nested_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_scatter8_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, w.n_amb, w.amb_idx, w8.md_c, w8.am_c, w8.va_c,
+                       min_dist, argmin, valid);
+    ORYON_CHECK_LAUNCH();
+    // ---- lazy route: settle the undecided validity flags, sample, resolve the sampled rows
+    const size_t lds_res = (size_t)4 * 2 * C * sizeof(float);
+#define RESOLVE_U(NHWCV)                                                                                                       \
+    hipLaunchKernelGGL((match_resolve_uncertain_kernel<NHWCV>), dim3(64, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8, q_scale, a_scale,     \
+                       feat_q, C_true, HW, roi_q, roi_stride_q, q_norm, C, cap_a, cap_q, n_q, threshold, w.m_final, lw.sid_final, lw.margin,   \
+                       lw.n_unc, lw.unc_idx, lw.pair_eager, lw.state, valid, min_dist, argmin)
+    if (layout == ORYON_LAYOUT_NHWC) RESOLVE_U(true); else RESOLVE_U(false);
+#undef RESOLVE_U
+    ORYON_CHECK_LAUNCH();
+    rc = select_corrs_launch(roi_a, roi_q, roi_stride_a, roi_stride_q, n_a, n_q, argmin, valid, cap_a, B, W, max_corrs, corr_rows, seed,
+                             pair_key, lw.scratch, corrs, n_valid, n_sel, status, lw.sel_rows, lw.pair_eager, st);
+    if (rc) { set_error("oryon_match_corrs_i8: select launch failed"); return rc; }
+#define RESOLVE_S(NHWCV)                                                                                                       \
+    hipLaunchKernelGGL((match_resolve_selected_kernel<NHWCV>), dim3((max_corrs + 3) / 4, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8,       \
+                       q_scale, a_scale, feat_q, C_true, HW, roi_q, roi_stride_q, q_norm, C, cap_a, cap_q, n_q, W, w.m_final, lw.sid_final,    \
+                       lw.margin, lw.state, lw.pair_eager, n_sel, lw.sel_rows, corr_rows, min_dist, argmin, corrs)
+    if (layout == ORYON_LAYOUT_NHWC) RESOLVE_S(true); else RESOLVE_S(false);
+#undef RESOLVE_S
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

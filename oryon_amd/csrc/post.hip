@@ -36,8 +36,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_corrs_kernel(
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, const int32_t *__restrict__ argmin,
     const uint8_t *__restrict__ valid, int cap_a, int W, int max_corrs, int corr_rows, uint64_t seed,
     const int64_t *__restrict__ pair_key, int32_t *__restrict__ scratch, int32_t *__restrict__ corrs,
-    int32_t *__restrict__ n_valid, int32_t *__restrict__ n_sel, int32_t *__restrict__ status)
+    int32_t *__restrict__ n_valid, int32_t *__restrict__ n_sel, int32_t *__restrict__ status,
+    int32_t *__restrict__ sel_rows, const int32_t *__restrict__ pair_eager)
 {
+    // sel_rows != NULL (lazy matcher, match16.hip): also record WHICH anchor row fills every slot; for pairs whose argmin column is
+    // not materialised yet (pair_eager[p] == 0) the query half of the row is left to match_resolve_selected_kernel
     __shared__ int s_wave[SEL_WAVES];
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_prefix, s_remaining;
@@ -69,11 +72,17 @@ __global__ __launch_bounds__(SEL_THREADS) void select_corrs_kernel(
     if (nv <= 1) return;
     const uint64_t key = pair_key ? (uint64_t)pair_key[p] : (uint64_t)p;
     const int32_t *ra = roi_a + (size_t)p * stride_a, *rq = roi_q + (size_t)p * stride_q;
+    const bool query_known = !sel_rows || !pair_eager || pair_eager[p] != 0;
     auto emit = [&](int slot, int row) {
-        const int pa = ra[row], pq = rq[am[row]];
+        const int pa = ra[row];
         int4 c;
-        c.x = pa / W; c.y = pa % W; c.z = pq / W; c.w = pq % W;
+        c.x = pa / W; c.y = pa % W; c.z = 0; c.w = 0;
+        if (query_known) {
+            const int pq = rq[am[row]];
+            c.z = pq / W; c.w = pq % W;
+        }
         *reinterpret_cast<int4 *>(out + (size_t)slot * 4) = c;
+        if (sel_rows) sel_rows[(size_t)p * corr_rows + slot] = row;
     };
     if (nv < max_corrs) {
         // with replacement (utils/misc.py:251-252): max_corrs independent uniform draws
@@ -222,6 +231,19 @@ __global__ __launch_bounds__(256) void kabsch_batched_kernel(const float *__rest
 
 using namespace oryon;
 
+namespace oryon {
+// internal entry shared with the lazy matcher (match16.hip)
+int select_corrs_launch(const int32_t *roi_a, const int32_t *roi_q, int roi_stride_a, int roi_stride_q, const int32_t *n_a,
+                        const int32_t *n_q, const int32_t *argmin, const uint8_t *valid, int cap_a, int B, int W, int max_corrs,
+                        int corr_rows, uint64_t seed, const int64_t *pair_key, int32_t *scratch, int32_t *corrs, int32_t *n_valid,
+                        int32_t *n_sel, int32_t *status, int32_t *sel_rows, const int32_t *pair_eager, hipStream_t st)
+{
+    hipLaunchKernelGGL(select_corrs_kernel, dim3(B), dim3(SEL_THREADS), 0, st, roi_a, roi_q, roi_stride_a, roi_stride_q, n_a, n_q, argmin,
+                       valid, cap_a, W, max_corrs, corr_rows, seed, pair_key, scratch, corrs, n_valid, n_sel, status, sel_rows, pair_eager);
+    return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+}
+}  // namespace oryon
+
 extern "C" int oryon_select_corrs(const int32_t *roi_a, const int32_t *roi_q, int roi_stride_a, int roi_stride_q,
                                   const int32_t *n_a, const int32_t *n_q, const int32_t *argmin, const uint8_t *valid,
                                   int cap_a, int B, int W, int max_corrs, int corr_rows, uint64_t seed,
@@ -233,7 +255,7 @@ extern "C" int oryon_select_corrs(const int32_t *roi_a, const int32_t *roi_q, in
     if (B == 0) return ORYON_OK;
     hipLaunchKernelGGL(select_corrs_kernel, dim3(B), dim3(SEL_THREADS), 0, as_stream(stream), roi_a, roi_q, roi_stride_a,
                        roi_stride_q, n_a, n_q, argmin, valid, cap_a, W, max_corrs, corr_rows, seed, pair_key, scratch, corrs,
-                       n_valid, n_sel, status);
+                       n_valid, n_sel, status, static_cast<int32_t *>(nullptr), static_cast<const int32_t *>(nullptr));
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

@@ -95,8 +95,8 @@ class MatchPoseEngine:
         use_i8 = screened and cfg.match_mode == "screened" and C > 128
         if use_i8:
             if self._i8_pending is not None and self._i8_pending[1].query():
-                und, tot = self._i8_pending[0].tolist()
-                self._i8_frac = und / max(1, tot)
+                h = self._i8_pending[0]
+                self._i8_frac = int(h[0].sum()) / max(1, int(h[1].sum()))
                 self._i8_pending = None
             if self._i8_frac > self.i8_max_undecided:
                 self._i8_skipped += 1
@@ -124,44 +124,54 @@ class MatchPoseEngine:
         else:
             cap_a = ops.round_up(FH * FW, ops.ROW_PAD)
         cap_q = ops.round_up(FH * FW, ops.ROW_PAD)
-        a16 = q16 = a8 = q8 = a_sc = q_sc = q_eps = None
+        a16 = q16 = a8 = q8 = a_sc = q_sc = q_eps = q_norm = q_hat = None
         if use_i8:
+            # K0v3: anchors -> fp32 + int8 rows, queries -> int8 rows + row norms only (the re-scoring pass reads its few candidates
+            # from the raw map); contiguous and channels_last maps are both read in place
             c_pad = 256 if C <= 256 else 512
-            a_hat, _, a8, a_sc, _ = ops.gather_normalise_q8(feat_a, roi_a, n_a, cap_a, c_pad)
-            q_hat, _, q8, q_sc, q_eps = ops.gather_normalise_q8(feat_q, roi_q, n_q, cap_q, c_pad)
+            a8, a_sc, _, _, a_hat = ops.gather_q8(feat_a, roi_a, n_a, cap_a, c_pad, want_f32=True)
+            q8, q_sc, q_eps, q_norm, _ = ops.gather_q8(feat_q, roi_q, n_q, cap_q, c_pad)
         elif screened:
             c_pad = 128 if C <= 128 else (256 if C <= 256 else 512)
-            a_hat, a16 = ops.gather_normalise(feat_a, roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
-            q_hat, q16 = ops.gather_normalise(feat_q, roi_q, n_q, cap_q, c_pad=c_pad, want_f16=True)
+            a_hat, a16 = ops.gather_normalise(feat_a.contiguous(), roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
+            q_hat, q16 = ops.gather_normalise(feat_q.contiguous(), roi_q, n_q, cap_q, c_pad=c_pad, want_f16=True)
         else:
-            a_hat = ops.gather_normalise(feat_a, roi_a, n_a, cap_a)
-            q_hat = ops.gather_normalise(feat_q, roi_q, n_q, cap_q)
+            a_hat = ops.gather_normalise(feat_a.contiguous(), roi_a, n_a, cap_a)
+            q_hat = ops.gather_normalise(feat_q.contiguous(), roi_q, n_q, cap_q)
         if self.overlap_gather:
             gathered = torch.cuda.Event()
             gathered.record(self._gather_stream)
             gctx.__exit__(None, None, None)
             main.wait_event(gathered)
-            for t_ in (roi, cnt, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps):
+            for t_ in (roi, cnt, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, q_norm):
                 if t_ is not None:
                     t_.record_stream(main)
         if use_i8:
+            # lazy K1s8 + K1b: validity of every anchor from the int8 bound, exact argmin for the sampled anchors only; `keep` (the
+            # caller wants the complete min_dist / argmin arrays) forces the eager route
             n_und = torch.empty((B,), dtype=torch.int32, device=dev)
-            min_dist, argmin, valid = ops.match_screened8(a_hat, q_hat, a8, q8, a_sc, q_sc, q_eps, n_a, n_q, cfg.dist_th, C, n_und)
+            corrs, n_valid, n_sel, status, min_dist, argmin, valid = ops.match_corrs_i8(
+                a_hat, a8, a_sc, feat_q, roi_a, roi_q, q_norm, q8, q_sc, q_eps, n_a, n_q, cfg.dist_th, FW, cfg.n_corrs, cfg.seed,
+                pair_key, corr_rows=self.n_cap, force_eager=keep, n_undecided=n_und)
             if self._i8_pending is None:
-                stats = torch.stack((n_und.sum(dtype=torch.int64), n_a.sum(dtype=torch.int64)))
                 if self._i8_host is None:
-                    self._i8_host = torch.empty((2,), dtype=torch.int64, pin_memory=True)
-                host = self._i8_host
-                host.copy_(stats, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
-                self._i8_pending = (host, ev)
-        elif screened:
-            min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)
+                    self._i8_host = torch.empty((2, B), dtype=torch.int32, pin_memory=True)
+                    self._i8_dev = torch.empty((2, B), dtype=torch.int32, device=dev)
+                if self._i8_host.shape[1] == B:
+                    # two device-to-device copies into one staging tensor + one async D2H: no torch arithmetic in the step
+                    self._i8_dev[0].copy_(n_und)
+                    self._i8_dev[1].copy_(n_a)
+                    self._i8_host.copy_(self._i8_dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    self._i8_pending = (self._i8_host, ev)
         else:
-            min_dist, argmin, valid = ops.match(a_hat, q_hat, n_a, n_q, cfg.dist_th)
-        corrs, n_valid, n_sel, status = ops.select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, FW, cfg.n_corrs, cfg.seed,
-                                                         pair_key, corr_rows=self.n_cap)
+            if screened:
+                min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)
+            else:
+                min_dist, argmin, valid = ops.match(a_hat, q_hat, n_a, n_q, cfg.dist_th)
+            corrs, n_valid, n_sel, status = ops.select_corrs(roi_a, roi_q, n_a, n_q, argmin, valid, FW, cfg.n_corrs, cfg.seed,
+                                                             pair_key, corr_rows=self.n_cap)
         cam_a = cam_a.reshape(B, 9).to(torch.float32).contiguous()
         cam_q = cam_q.reshape(B, 9).to(torch.float32).contiguous()
         pcd_a, pcd_q, n_lift = ops.lift_pairs(corrs, n_sel, (FH, FW), depth_a, depth_q, cam_a, cam_q, status)

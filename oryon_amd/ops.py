@@ -310,6 +310,38 @@ def match_screened8_raw(a_hat, a8, a_scale, feat_q, roi_q, q_norm, q8, q_scale, 
 
 
 @_on_tensor_device
+def match_corrs_i8(a_hat, a8, a_scale, feat_q, roi_a, roi_q, q_norm, q8, q_scale, q_eps, n_a, n_q, threshold: float, W: int, max_corrs: int,
+                   seed: int, pair_key=None, corr_rows: Optional[int] = None, force_eager: bool = False, n_undecided=None):
+    """Lazy K1s8 + K1b (oryon_match_corrs_i8): -> (corrs [B,corr_rows,4] i32, n_valid [B], n_sel [B], status [B], min_dist, argmin, valid).
+    Same correspondences as select_corrs(match_screened8_raw(...)); min_dist / argmin are exact only on sampled rows unless force_eager."""
+    dev = _lib.require_gpu(a_hat.device)
+    feat_q, layout = map_layout(feat_q)
+    B, cap_a, Cp = a_hat.shape
+    cap_q = q8.shape[1]
+    C_true, HW = feat_q.shape[1], feat_q.shape[2] * feat_q.shape[3]
+    corr_rows = int(corr_rows or max_corrs)
+    min_dist = torch.empty((B, cap_a), dtype=torch.float32, device=dev)
+    argmin = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
+    valid = torch.empty((B, cap_a), dtype=torch.uint8, device=dev)
+    corrs = torch.zeros((B, corr_rows, 4), dtype=torch.int32, device=dev)
+    n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
+    n_sel = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    wsb = lib().oryon_match_corrs_i8_workspace_bytes(B, Cp, cap_a, cap_q, corr_rows)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _raw_ws.get(key)
+    if ws is None or ws.numel() < wsb:
+        ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+        _raw_ws[key] = ws
+    check(lib().oryon_match_corrs_i8(ptr(a_hat), ptr(a8), ptr(a_scale), feat_q.data_ptr(), C_true, HW, layout, ptr(roi_a), roi_a.shape[1],
+                                     ptr(roi_q), roi_q.shape[1], ptr(q_norm), ptr(q8), ptr(q_scale), ptr(q_eps), B, Cp, cap_a, cap_q,
+                                     ptr(n_a), ptr(n_q), float(threshold), int(W), int(max_corrs), corr_rows, int(seed) & (2**64 - 1),
+                                     ptr(pair_key), int(bool(force_eager)), ptr(min_dist), ptr(argmin), ptr(valid), ptr(corrs), ptr(n_valid),
+                                     ptr(n_sel), ptr(status), ptr(n_undecided), ptr(ws), ws.numel(), stream_ptr(dev)), "oryon_match_corrs_i8")
+    return corrs, n_valid, n_sel, status, min_dist, argmin, valid
+
+
+@_on_tensor_device
 def match_screened8(a_hat, q_hat, a8, q8, a_scale, q_scale, q_eps, n_a, n_q, threshold: float, c_true: int, n_undecided=None):
     """int8 pre-screen + fp16 screen + exact fp32 re-scoring (K1s8).  Same outputs as `match_screened`.
     n_undecided: optional int32 [B] tensor receiving the number of anchors the int8 stage handed to the fp16 stage."""

@@ -490,3 +490,78 @@ def test_k0v3_full_size_pair_vs_c_oracle(H, C):
         assert np.array_equal(va_, ref_va) and ref_va.mean() > 0.6
         assert np.array_equal(am[0, :n1].cpu().numpy()[ref_va], ref_am[ref_va])
         assert np.array_equal(md[0, :n1].cpu().numpy().view(np.uint32)[ref_va], ref_md.view(np.uint32)[ref_va])
+
+
+# ------------------------------------------------------------------------------------------------ lazy K1s8 + K1b (oryon_match_corrs_i8)
+def _lazy_vs_eager(fa, fq, ma, mq, C_pad, thr, max_corrs=500, subsample=None, channels_last=False):
+    """oryon_match_corrs_i8 with force_eager = 0 against force_eager = 1 (= select_corrs on the complete, exact matcher outputs) and
+    against the exact fp32 scan: same valid set, same status / counts, same sampled correspondences bit for bit."""
+    from oryon_amd import ops
+    roi_a, na = ops.roi_compact(ma)
+    roi_q, nq = ops.roi_compact(mq)
+    if subsample:
+        ops.roi_subsample_(roi_a, na, subsample, seed=3)
+    B, C, H, W = fa.shape
+    cap_a = ops.round_up(max(1, int(na.max())), 256)
+    cap_q = ops.round_up(max(1, int(nq.max())), 256)
+    if channels_last:
+        fa, fq = fa.contiguous(memory_format=torch.channels_last), fq.contiguous(memory_format=torch.channels_last)
+    a8, a_sc, _, _, a_hat = ops.gather_q8(fa, roi_a, na, cap_a, C_pad, want_f32=True)
+    q8, q_sc, q_eps, q_norm, q_hat = ops.gather_q8(fq, roi_q, nq, cap_q, C_pad, want_f32=True)
+    key = torch.arange(40, 40 + B, dtype=torch.int64, device=fa.device)
+    und = torch.zeros((B,), dtype=torch.int32, device=fa.device)
+    lazy = ops.match_corrs_i8(a_hat, a8, a_sc, fq, roi_a, roi_q, q_norm, q8, q_sc, q_eps, na, nq, thr, W, max_corrs, 1, key,
+                              corr_rows=ops.round_up(max_corrs, 128), n_undecided=und)
+    eager = ops.match_corrs_i8(a_hat, a8, a_sc, fq, roi_a, roi_q, q_norm, q8, q_sc, q_eps, na, nq, thr, W, max_corrs, 1, key,
+                               corr_rows=ops.round_up(max_corrs, 128), force_eager=True)
+    md0, am0, va0 = ops.match(a_hat, q_hat, na, nq, thr)
+    c_ref, nv_ref, ns_ref, st_ref = ops.select_corrs(roi_a, roi_q, na, nq, am0, va0, W, max_corrs, 1, key, corr_rows=ops.round_up(max_corrs, 128))
+    for name, out in (("lazy", lazy), ("eager", eager)):
+        corrs, n_valid, n_sel, status, md, am, va = out
+        assert torch.equal(status, st_ref) and torch.equal(n_valid, nv_ref) and torch.equal(n_sel, ns_ref), name
+        for b in range(B):
+            n = int(na[b])
+            assert torch.equal(va[b, :n], va0[b, :n]), f"{name}: valid set differs from the exact scan (pair {b})"
+            k = int(ns_ref[b])
+            assert torch.equal(corrs[b, :k], c_ref[b, :k]), f"{name}: sampled correspondences differ (pair {b})"
+    return lazy, und, va0, na
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_lazy_corrs_equal_eager(channels_last):
+    """Planted matches (validity settled by the int8 bound), a pair whose matched distances straddle the threshold (uncertain rows
+    resolved exactly before the sampling), a smooth field (ambiguous -> that pair goes eager), an unrelated pair (NO_CORR), a pair with
+    fewer valid rows than max_corrs (sampling with replacement), an empty query mask (NO_MASK)."""
+    dev = "cuda"
+    C, H = 256, 40
+    g = torch.Generator(device=dev).manual_seed(21)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+    fq0 = rn(C, H, H); fa0 = fq0.flip(-1) + 0.05 * rn(C, H, H)
+    fq1 = rn(C, H, H); fa1 = fq1.flip(-2) + 1.7 * rn(C, H, H)                      # cos ~ 0.5: straddles 1 - 2*0.25
+    basis = rn(C, 6)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, H, device=dev), indexing="ij")
+    coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy)])
+    fq2 = torch.einsum("ck,khw->chw", basis, coef) + 0.01 * rn(C, H, H); fa2 = fq2 + 0.005 * rn(C, H, H)
+    fq3 = rn(C, H, H); fa3 = rn(C, H, H)
+    fq4 = rn(C, H, H); fa4 = rn(C, H, H); fa4[:, :3, :] = fq4[:, 5:8, :] + 0.05 * rn(C, 3, H)      # 120 matches < 500
+    fq5 = rn(C, H, H); fa5 = fq5 + 0.05 * rn(C, H, H)
+    fa, fq = torch.stack((fa0, fa1, fa2, fa3, fa4, fa5)), torch.stack((fq0, fq1, fq2, fq3, fq4, fq5))
+    ma = torch.ones((6, H, H), dtype=torch.int32, device=dev)
+    mq = torch.ones((6, H, H), dtype=torch.int32, device=dev)
+    mq[5] = 0
+    (corrs, n_valid, n_sel, status, md, am, va), und, va0, na = _lazy_vs_eager(fa, fq, ma, mq, 256, 0.25, channels_last=channels_last)
+    assert status.tolist() == [0, 0, 0, 2, 0, 1]
+    nv = n_valid.tolist()
+    assert nv[0] > 1400 and 100 < nv[1] < 1500 and nv[2] > 1000 and nv[3] <= 1 and 100 <= nv[4] < 500 and nv[5] == 0
+    assert int(und[2]) > 100 and int(und[0]) == 0                                  # only the smooth pair needed the fp16 stage
+
+
+def test_lazy_corrs_full_size_and_c512():
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    p = [make_pair(i, 224, 224, 256, device=dev) for i in (0, 1)]
+    st = lambda k: torch.stack([q[k] for q in p])
+    _lazy_vs_eager(st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), 256, 0.25, subsample=5000)
+    p = [make_pair(i, 64, 64, 400, device=dev) for i in (0, 1)]                    # C = 400 -> C_pad 512
+    _lazy_vs_eager(st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), 512, 0.25)
+    _lazy_vs_eager(st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), 512, 0.4, max_corrs=64)
