@@ -126,7 +126,7 @@ def cpu_baseline(H, C, budget_rows=512):
     t_rest = time.perf_counter() - t0
     per_pair = t_match_rows * (n1 / rows) + t_rest
     return {
-        "value": 1.0 / per_pair, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+        "value": 1.0 / per_pair, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port", "extrapolated": True,
         "sample": f"1 pair of the workload; reference-form broadcast matcher timed on {rows} of {n1} anchor rows x {f2.shape[0]} "
                   f"query rows x C={C} ({t_match_rows:.1f} s, extrapolated x{n1 / rows:.0f}); lift + PointDSC(12x128, n={corrs.shape[0]}) "
                   f"in full ({t_rest * 1e3:.0f} ms); same matcher as a normalised GEMM on CPU: {t_gemm:.2f} s/pair",
@@ -134,9 +134,12 @@ def cpu_baseline(H, C, budget_rows=512):
     }
 
 
-def bench_full(a, rank, world, dev):
-    """Stage set 'full': Oryon.forward (random-init, reference architecture and shapes) + predicted masks + match + lift +
-    PointDSC for B pairs per GPU.  Reported under its own metric label; configs[1] (descriptors given) stays the headline."""
+def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp32"):
+    """Stage sets beyond the headline, at the reference's own shapes (224x224 RGB -> C=32 @192x192), random-init weights:
+       'full'   = Oryon.forward (CLIP ViT-L/14@336 + Swin-B stages 1-2 + fusion + decoder) + predicted masks + match + lift + PointDSC
+       'decode' = fusion + decoder on cached CLIP / Swin encodings, then the same (SURVEY 8d 'decode+match+pose')
+    Returns the record (rank 0) or None.  Timed exactly like the headline: `steps` complete steps between two barrier + synchronize
+    brackets, max over ranks; the backbone alone is timed in a second, separate loop of the same length."""
     from oryon_amd.net import Oryon, default_model_args
     B, H = a.batch, 224
     torch.manual_seed(4321 + rank)
@@ -156,13 +159,12 @@ def bench_full(a, rank, world, dev):
                                                                 match_mode=a.match_mode))
     key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
     xs = {"anchor": {"rgb": rgb_a}, "query": {"rgb": rgb_q}, "prompt_tokens": toks}
-    amp = torch.autocast("cuda", dtype=torch.bfloat16) if a.backbone_dtype == "bf16" else torch.autocast("cuda", enabled=False)
-    if a.backbone_dtype == "bf16w":
-        # frozen towers converted once: no per-call weight casts, LayerNorm / softmax / activations on bf16 tensors
+    amp = torch.autocast("cuda", dtype=torch.bfloat16) if backbone_dtype == "bf16" else torch.autocast("cuda", enabled=False)
+    if backbone_dtype == "bf16w":
         model = model.to(torch.bfloat16)
         xs["anchor"]["rgb"], xs["query"]["rgb"] = rgb_a.to(torch.bfloat16), rgb_q.to(torch.bfloat16)
     total = B * world
-    decode_only = a.stages == "decode"
+    decode_only = stage == "decode"
     if decode_only:
         # the frozen towers' outputs are inputs of this stage set: evaluated once, outside the timed region
         with torch.no_grad(), amp:
@@ -192,48 +194,58 @@ def bench_full(a, rank, world, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    bb_ms = 0.0
-    for _ in range(a.steps):
-        e0.record()
-        with torch.no_grad(), amp:
-            backbone()
-        e1.record()
+    for _ in range(steps):
         res, _ = step()
-        torch.cuda.synchronize()
-        bb_ms += e0.elapsed_time(e1)
     barrier()
     elapsed = time.perf_counter() - t0
-    # the loop above runs the backbone twice per iteration (once timed alone): subtract the extra pass
-    el = torch.tensor([elapsed - bb_ms * 1e-3], dtype=torch.float64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        with torch.no_grad(), amp:
+            backbone()
+    e1.record()
+    torch.cuda.synchronize()
+    bb_ms = e0.elapsed_time(e1) / steps
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    pairs_ok = int((res["status"] == 0).sum())
+    del model, engine
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    # ~0.39 TFLOP per ViT-L/14@336 image, 2 images per pair; fusion + decoder alone: 2.4 + 3.3 GFLOP per image
+    flops_backbone = B * 2 * (5.7e9 if decode_only else 0.39e12)
+    peak = PEAK_FP32_MFMA_TFLOPS if backbone_dtype == "fp32" else PEAK_F16_MFMA_TFLOPS
+    achieved = flops_backbone / (bb_ms * 1e-3) / 1e12
+    return {
+        "metric": ("image-pairs/sec (decode+match+reg): fusion + decoder on cached CLIP / Swin encodings (-> C=32 @192x192), then match + pose"
+                   if decode_only else
+                   "image-pairs/sec end-to-end (feat+match+reg) at the reference's shapes (224x224 RGB -> CLIP ViT-L/14@336 + Swin-B + fusion "
+                   "+ decoder -> C=32 @192x192 -> match + lift + PointDSC)"),
+        "value": total * steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "backbone_ms_per_step": bb_ms, "pairs_per_gpu": B, "pairs_ok": pairs_ok,
+        "dtype": {"fp32": "f32 (PyTorch-ROCm fp32 GEMMs / convolutions, TF32-style shortcuts off)",
+                  "bf16": "bf16 backbone GEMMs (autocast), f32 match+pose",
+                  "bf16w": "bf16 backbone (weights + activations), f32 match+pose"}[backbone_dtype],
+        "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
+        "prompt_cache": "80-template text tower evaluated once (identical prompt set), as in eval of one object class",
+        "roofline": {"bound": "mfma", "kernel": "backbone GEMMs / convolutions (hipBLASLt / MIOpen through PyTorch-ROCm)",
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None},
+    }
+
+
+def bench_full(a, rank, world, dev):
+    """`--stages full|decode`: that stage set alone, as its own JSON line (never mixed into the headline `value`)."""
+    rec = run_stage_set(a, rank, world, dev, a.stages, a.steps, a.warmup, a.backbone_dtype)
     if rank == 0:
-        # ~0.39 TFLOP per ViT-L/14@336 image, 2 images per pair; fusion + decoder alone: 2.4 + 3.3 GFLOP per image
-        flops_backbone = B * 2 * (5.7e9 if decode_only else 0.39e12)
-        rec = {
-            "metric": ("image-pairs/sec (decode+match+reg), stage set DECODE: fusion + decoder on cached CLIP / Swin encodings (-> C=32 @192x192)"
-                       if decode_only else
-                       "image-pairs/sec end-to-end (feat+match+reg), stage set FULL at the reference's shapes (224x224 RGB -> C=32 @192x192)"),
-            "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 backbone GEMMs (autocast), f32 match+pose",
-                      "bf16w": "bf16 backbone (weights + activations), f32 match+pose"}[a.backbone_dtype],
-            "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
-            "config": {"workload": f"Batch={B} synthetic 224x224 RGB-D pairs per GPU through CLIP ViT-L/14@336 + Swin-B(stages 1-2) + fusion + "
-                                   f"decoder (PyTorch-ROCm), then HIP match + lift + PointDSC 12x128",
-                       "stages": a.stages, "prompt_cache": "80-template text tower evaluated once (identical prompt set), as in eval of one object class",
-                       "pairs_per_gpu": B, "backbone_ms_per_step": bb_ms / a.steps, "pairs_ok": int((res["status"] == 0).sum())},
-            "roofline": {"bound": "mfma", "kernel": "backbone GEMMs (rocBLAS/hipBLASLt via PyTorch-ROCm)", "achieved": flops_backbone / (bb_ms / a.steps * 1e-3) / 1e12,
-                         "peak": PEAK_FP32_MFMA_TFLOPS if a.backbone_dtype == "fp32" else PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None, "traffic": None},
-        }
-        rec["roofline"]["frac"] = rec["roofline"]["achieved"] / rec["roofline"]["peak"]
+        rec.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "config": {"workload": f"Batch={a.batch} synthetic 224x224 RGB-D pairs per GPU, stage set {a.stages}", "stages": a.stages}})
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
@@ -298,6 +310,8 @@ def main():
                     help="do not overlap the registration of step k with the matching of step k+1 (second HIP stream)")
     ap.add_argument("--match-mode", choices=["screened", "screened16", "exact"], default="screened",
                     help="screened: fp16-MFMA screening + exact fp32 re-scoring (K1s, identical results); exact: full fp32 scan (K1)")
+    ap.add_argument("--no-stage-sets", action="store_true",
+                    help="skip the 'decode+match+pose' and 'full' stage sets that the default run measures after the headline")
     ap.add_argument("--collation-selftest", action="store_true",
                     help="CPU-only check of the multi-rank launch path (gloo): every rank fabricates its poses, the collation runs, rank 0 "
                          "prints one JSON line.  Used by tests/test_cabi_and_host.py; measures nothing")
@@ -413,14 +427,21 @@ def main():
         opb = 1 if use_i8 else 2 if screened else 4
         alg_bytes = float((opb * cp * (n_a + n_q) + 12.0 * n_a).sum())
         hbm_frac = alg_bytes / (launch_ms * 1e-3) / PEAK_HBM_BYTES
-        # HBM bytes per launch cannot be counted from inside the process: taken from the committed rocprofv3 PMC passes of this
-        # exact workload (profiles/r01_pmc_counters.md), null for any other workload
-        traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if use_i8 and (B, H, C) == (64, 224, 256) and os.path.exists(tpath):
+        # HBM bytes per launch cannot be counted from inside the process (PMC needs rocprofv3 around it): the value comes from the committed
+        # rocprofv3 --pmc passes of this exact workload AND this exact kernel source - the record carries the sha256 of the kernel's
+        # source file, and a mismatch (the kernel changed since the counters were collected) reports null instead of a stale number
+        traffic, traffic_src = None, "no PMC record for this workload"
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if use_i8 and (B, H, C) == (64, 224, 256) and a.layout == "nchw" and os.path.exists(tpath):
+            import hashlib
             with open(tpath) as fh:
                 tj = json.load(fh)
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_pmc_counters.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)"
+            with open(os.path.join(ROOT, "oryon_amd", "csrc", "match16.hip"), "rb") as fh:
+                sha = hashlib.sha256(fh.read()).hexdigest()
+            if tj.get("kernel_source_sha256") == sha:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source", "profiles/r02_pmc_counters.md")
+            else:
+                traffic_src = "profiles/r02_traffic.json is stale (match16.hip changed since the PMC passes): not reported"
         rec = {
             "metric": METRIC, "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -447,6 +468,18 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(H, C)
+    # the other two stage sets of SURVEY 8(d), measured in this same run (short: 3 steps each) and carried in the same line; `value`
+    # stays the configs[1] number (descriptors given)
+    stage_recs = {}
+    if not a.no_stage_sets:
+        del inputs, engine
+        torch.cuda.empty_cache()
+        for stage in ("decode", "full"):
+            r = run_stage_set(a, rank, world, dev, stage, steps=3, warmup=1)
+            if rank == 0:
+                stage_recs["decode+match+pose" if stage == "decode" else "full (feat+match+pose)"] = r
+    if rank == 0:
+        rec["stages"] = stage_recs or None
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

@@ -176,18 +176,21 @@ int oryon_match_screened8(const float *a_hat, const float *q_hat, const int8_t *
  *     int8 rows + row norms + the raw map itself; the exact re-scoring pass recovers a candidate's canonical unit values x_k / d from
  *     the raw map, so its outputs are bit for bit those of oryon_match_screened8.  Pairs that need the fp32 query rows after all
  *     (anchors the int8 stage could not decide, overflowed candidate lists) get them materialised inside the call, gated on the device.
- *     Rows [n, round_up(n,256)) of every output are zero rows; rows beyond are not written. */
+ *     Rows [n, round_up(n,256)) of every output are zero rows; rows beyond are not written.
+ *     round_f16 != 0 selects the reference's half-descriptor branch (utils/pcd.py:195-197, `corrs_device='cuda'`: feats.half() before
+ *     pdist): every raw descriptor value is rounded to the nearest float16 on the way in, in all three calls alike; the arithmetic on
+ *     the rounded values is unchanged (fp32), which is what BASELINE configs[4] ("fp16 descriptors") runs. */
 #define ORYON_LAYOUT_NCHW 0
 #define ORYON_LAYOUT_NHWC 1
 int oryon_gather_q8(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
                     int rows_cap, int C_pad, int8_t *out_i8, float *slice_scale, float *eps_max, float *row_norm, float *out_f32,
-                    void *stream);
+                    int round_f16, void *stream);
 size_t oryon_match_screened8_raw_workspace_bytes(int B, int C, int cap_a, int cap_q);
 int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW,
                               int layout, const int32_t *roi_q, int roi_stride, const float *q_norm, const int8_t *q_i8,
                               const float *q_scale, const float *q_eps_max, int B, int C, int cap_a, int cap_q, const int32_t *n_a,
                               const int32_t *n_q, float threshold, float *min_dist, int32_t *argmin, uint8_t *valid,
-                              int32_t *n_undecided, void *workspace, size_t workspace_bytes, void *stream);
+                              int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream);
 
 /* K1s8 + K1b fused and LAZY (round 2): from the K0v3 operands straight to the sampled correspondences of every pair
  * (utils/pcd.py:202-214).  The int8 bound settles the validity flag of almost every anchor without its argmin; candidate generation
@@ -202,7 +205,7 @@ int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, const float *a_
                          const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C, int cap_a, int cap_q,
                          const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs, int corr_rows, uint64_t seed,
                          const int64_t *pair_key, int force_eager, float *min_dist, int32_t *argmin, uint8_t *valid, int32_t *corrs,
-                         int32_t *n_valid, int32_t *n_sel, int32_t *status, int32_t *n_undecided, void *workspace,
+                         int32_t *n_valid, int32_t *n_sel, int32_t *status, int32_t *n_undecided, int round_f16, void *workspace,
                          size_t workspace_bytes, void *stream);
 
 /* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).

@@ -46,13 +46,13 @@ _PROTOS = {
     "oryon_match_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "oryon_match_screened_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "oryon_gather_normalise_q8": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
-    "oryon_gather_q8": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "oryon_gather_q8": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "oryon_match_screened8_raw_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oryon_match_screened8_raw": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
-                                          _P, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                          _P, _P, c_float, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "oryon_match_corrs_i8_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "oryon_match_corrs_i8": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
-                                     _P, _P, c_float, c_int, c_int, c_int, c_uint64, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, c_float, c_int, c_int, c_int, c_uint64, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),
     "oryon_match_screened8_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oryon_match_screened8": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P,

@@ -30,6 +30,16 @@ namespace oryon {
 
 constexpr int G8_STAGE_BYTES = 16384;          // per wave
 
+// Ordering point between LDS writes and LDS reads of ONE wave through its private staging buffer.  The LDS executes a wave's
+// DS instructions in issue order, so all that is needed is that the compiler keeps the program order: a scheduling barrier plus a
+// compiler-level memory clobber.  (A memory fence would also work but drains vmcnt, i.e. it waits for the prefetched global loads of
+// the NEXT chunk: measured 1.8 -> 1.08 ms on the channels_last path.)
+#define WAVE_LDS_ORDER()                    \
+    do {                                    \
+        __builtin_amdgcn_wave_barrier();    \
+        asm volatile("" ::: "memory");      \
+    } while (0)
+
 template <int N>
 __device__ __forceinline__ float chain_sq(const float (&v)[N], float acc)
 {
@@ -51,7 +61,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
     const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride,
     const int32_t *__restrict__ count, const int32_t *__restrict__ map_enable, int rows_cap, int n_maps, int chunk_tiles,
     int chunks_per_map, int8_t *__restrict__ out8, float *__restrict__ scale, unsigned *__restrict__ eps_max,
-    float *__restrict__ norm, float *__restrict__ out32)
+    float *__restrict__ norm, float *__restrict__ out32, int round_f16)
 {
     constexpr int ROWS = 64 / LPR;             // ROI rows per wave
     constexpr int KPL = CP / LPR;              // channels per lane
@@ -109,42 +119,58 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
         }
     } else {
         // channels_last map: value (k, pix) at feat[m][pix][k].  64 channels of the wave's 64 / LPR rows at a time: 4 rows x 256 bytes
-        // per load instruction -> staging buffer -> lane = (row, segment)
+        // per load instruction -> staging buffer -> lane = (row, segment).  The loads of chunk c+1 are in flight while chunk c goes
+        // through the staging buffer (two register sets of 16 x 16 bytes).
         const float *fb = feat + (size_t)m * C * HW;
         const int sub = lane >> 4, slot = lane & 15;          // load role: row sub-index, 16-byte slot of a 256-byte run
+        constexpr int NCH = KPL / 64;
+        // pixel of the 16 rows this lane loads from (tile-lane t = j*4 + sub -> row t % ROWS), -1 = dead row
+        int px[16];
 #pragma unroll
-        for (int c = 0; c < KPL / 64; ++c) {
-            // tile-lane t = sg * ROWS + r holds channels sg*KPL + 64c .. +63 of row r
-            float4 x[16];
+        for (int j = 0; j < 16; ++j) {
+            const int rr = row0 + (j * 4 + sub) % ROWS;
+            px[j] = rr < n ? roi[(size_t)m * roi_stride + rr] : -1;
+        }
+        auto load_chunk = [&](int c, float4 (&x)[16]) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int t = j * 4 + sub, r = t % ROWS, sg = t / ROWS;
-                const int rr = row0 + r;
+                const int sg = (j * 4 + sub) / ROWS;
                 const int k0 = sg * KPL + 64 * c + slot * 4;
-                const int px = rr < n ? roi[(size_t)m * roi_stride + rr] : 0;
                 float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rr < n) {
-                    if (C == CP) val = *reinterpret_cast<const float4 *>(fb + (size_t)px * C + k0);
-                    else {
-                        const float *src = fb + (size_t)px * C;
-                        val.x = k0 + 0 < C ? src[k0 + 0] : 0.f; val.y = k0 + 1 < C ? src[k0 + 1] : 0.f;
-                        val.z = k0 + 2 < C ? src[k0 + 2] : 0.f; val.w = k0 + 3 < C ? src[k0 + 3] : 0.f;
-                    }
+                if (tile_full) {
+                    val = *reinterpret_cast<const float4 *>(fb + (size_t)px[j] * C + k0);
+                } else if (px[j] >= 0) {
+                    const float *src = fb + (size_t)px[j] * C;
+                    val.x = k0 + 0 < C ? src[k0 + 0] : 0.f; val.y = k0 + 1 < C ? src[k0 + 1] : 0.f;
+                    val.z = k0 + 2 < C ? src[k0 + 2] : 0.f; val.w = k0 + 3 < C ? src[k0 + 3] : 0.f;
                 }
                 x[j] = val;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // previous chunk's reads are done (same wave, in order)
+        };
+        float4 xa[16], xb[16];
+        load_chunk(0, xa);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) *reinterpret_cast<float4 *>(stage + stage_addr(j * 4 + sub, slot, 256)) = x[j];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int c = 0; c < NCH; ++c) {
+            float4 (&cur)[16] = (c & 1) ? xb : xa;
+            float4 (&nxt)[16] = (c & 1) ? xa : xb;
+            if (c + 1 < NCH) load_chunk(c + 1, nxt);
+            WAVE_LDS_ORDER();                                           // previous chunk's staging reads precede these writes
+#pragma unroll
+            for (int j = 0; j < 16; ++j) *reinterpret_cast<float4 *>(stage + stage_addr(j * 4 + sub, slot, 256)) = cur[j];
+            WAVE_LDS_ORDER();
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const float4 q = *reinterpret_cast<const float4 *>(stage + stage_addr(lane, s, 256));
                 v[64 * c + 4 * s + 0] = q.x; v[64 * c + 4 * s + 1] = q.y; v[64 * c + 4 * s + 2] = q.z; v[64 * c + 4 * s + 3] = q.w;
             }
         }
+    }
+
+    // the reference's half-descriptor branch (utils/pcd.py:195-197: feats.half() before pdist): every raw value is rounded to the
+    // nearest float16 first; everything downstream runs unchanged on the rounded values
+    if (round_f16) {
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) v[i] = __half2float(__float2half_rn(v[i]));
     }
 
     // canonical norm: ONE k-ordered fmaf chain per row.  LPR = 2: lanes of segment 1 continue from segment 0's result.
@@ -198,9 +224,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
             }
             *reinterpret_cast<uint4 *>(stage + stage_addr(lane, s, RB8)) = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        WAVE_LDS_ORDER();
         constexpr int SPR = RB8 / 16;                         // 16-byte slots per tile-lane row
         char *o8 = reinterpret_cast<char *>(out8) + ((size_t)m * rows_cap + row0) * CP;
 #pragma unroll
@@ -216,8 +240,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
         float *o32 = out32 + ((size_t)m * rows_cap + row0) * CP;
 #pragma unroll
         for (int c = 0; c < KPL / 64; ++c) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            WAVE_LDS_ORDER();
 #pragma unroll
             for (int g = 0; g < 8; ++g)
 #pragma unroll
@@ -229,9 +252,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
                     q.w = __fdiv_rn(v[64 * c + 8 * g + 6 + hh], d);
                     *reinterpret_cast<float4 *>(stage + stage_addr(lane, 2 * g + hh, 256)) = q;
                 }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            WAVE_LDS_ORDER();
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int t = j * 4 + (lane >> 4), s = lane & 15;
@@ -249,7 +270,7 @@ using namespace oryon;
 namespace {
 template <int CP, int LPR, bool NHWC>
 void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride, const int32_t *count,
-               const int32_t *map_enable, int rows_cap, int8_t *out8, float *scale, float *eps, float *norm, float *out32)
+               const int32_t *map_enable, int rows_cap, int8_t *out8, float *scale, float *eps, float *norm, float *out32, int round_f16)
 {
     constexpr int WG_ROWS = 4 * (64 / LPR);
     const int T = (rows_cap + WG_ROWS - 1) / WG_ROWS;                 // workgroup tiles per map
@@ -260,7 +281,7 @@ void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, con
     auto kern = gather_q8_v3_kernel<CP, LPR, NHWC>;
     allow_dynamic_lds(reinterpret_cast<const void *>(kern), 4 * G8_STAGE_BYTES);
     hipLaunchKernelGGL(kern, dim3(groups), dim3(256), 4 * G8_STAGE_BYTES, st, feat, C, HW, roi, roi_stride, count, map_enable, rows_cap,
-                       n_maps, chunk_tiles, chunks_per_map, out8, scale, reinterpret_cast<unsigned *>(eps), norm, out32);
+                       n_maps, chunk_tiles, chunks_per_map, out8, scale, reinterpret_cast<unsigned *>(eps), norm, out32, round_f16);
 }
 }  // namespace
 
@@ -269,13 +290,13 @@ namespace oryon {
 // the call must not touch eps_max (fall-back pass)
 int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
                      const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
-                     float *out32, int lanes_per_row, hipStream_t st)
+                     float *out32, int lanes_per_row, int round_f16, hipStream_t st)
 {
     const int lpr = C_pad == 512 ? 2 : (lanes_per_row == 2 ? 2 : 1);
 #define G8(CPV, LPRV)                                                                                                          \
     do {                                                                                                                       \
-        if (layout == ORYON_LAYOUT_NHWC) launch_g8<CPV, LPRV, true>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32); \
-        else launch_g8<CPV, LPRV, false>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32); \
+        if (layout == ORYON_LAYOUT_NHWC) launch_g8<CPV, LPRV, true>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
+        else launch_g8<CPV, LPRV, false>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
     } while (0)
     if (C_pad == 512) G8(512, 2);
     else if (lpr == 2) G8(256, 2);
@@ -287,7 +308,7 @@ int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, c
 
 extern "C" int oryon_gather_q8(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride,
                                const int32_t *count, int rows_cap, int C_pad, int8_t *out_i8, float *slice_scale, float *eps_max,
-                               float *row_norm, float *out_f32, void *stream)
+                               float *row_norm, float *out_f32, int round_f16, void *stream)
 {
     ORYON_CHECK_ARG(feat && roi && count && out_i8 && slice_scale && eps_max);                 // row_norm, out_f32 may be NULL
     ORYON_CHECK_ARG(n_maps >= 0 && C > 0 && HW > 0 && roi_stride > 0 && C_pad >= C && (C_pad == 256 || C_pad == 512));
@@ -298,7 +319,7 @@ extern "C" int oryon_gather_q8(const float *feat, int n_maps, int C, int HW, int
     ORYON_CHECK_HIP(hipMemsetAsync(eps_max, 0, (size_t)n_maps * sizeof(float), st));
     static const int lpr_env = getenv("ORYON_GATHER8_LPR") ? atoi(getenv("ORYON_GATHER8_LPR")) : 1;
     const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad, out_i8, slice_scale,
-                                    eps_max, row_norm, out_f32, lpr_env, st);
+                                    eps_max, row_norm, out_f32, lpr_env, round_f16, st);
     if (rc) { set_error("oryon_gather_q8: launch failed"); return rc; }
     return ORYON_OK;
 }

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void match_rescore_raw_kernel(
     int roi_stride, const float *__restrict__ norm_q, int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
     const int32_t *__restrict__ n_q, float thr, const float *__restrict__ m_final, const int32_t *__restrict__ cnt,
     const int32_t *__restrict__ cand, float *__restrict__ min_dist, int32_t *__restrict__ argmin, uint8_t *__restrict__ valid,
-    uint8_t *__restrict__ row_flag, int32_t *__restrict__ panel_flag, int32_t *__restrict__ need_f32)
+    uint8_t *__restrict__ row_flag, int32_t *__restrict__ panel_flag, int32_t *__restrict__ need_f32, int round_f16)
 {
     const int p = blockIdx.y;
     const int a = blockIdx.x * (256 / L) + (threadIdx.x / L), sub = threadIdx.x % L;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void match_rescore_raw_kernel(
                     for (int e = 0; e < 8; ++e) x[e] = g + e < C_true ? fq[(size_t)(g + e) * HW + pix] : 0.0f;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = __fdiv_rn(x[e], dq);
+                for (int e = 0; e < 8; ++e) x[e] = __fdiv_rn(round_f16 ? __half2float(__float2half_rn(x[e])) : x[e], dq);
                 dot = __fmaf_rn(a0.x, x[0], dot); dot = __fmaf_rn(a1.x, x[1], dot);
                 dot = __fmaf_rn(a0.y, x[2], dot); dot = __fmaf_rn(a1.y, x[3], dot);
                 dot = __fmaf_rn(a0.z, x[4], dot); dot = __fmaf_rn(a1.z, x[5], dot);
@@ -1292,7 +1292,7 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
 namespace oryon {
 int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
                      const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
-                     float *out32, int lanes_per_row, hipStream_t st);
+                     float *out32, int lanes_per_row, int round_f16, hipStream_t st);
 }
 
 namespace {
@@ -1336,8 +1336,8 @@ extern "C" int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8,
                                          int HW, int layout, const int32_t *roi_q, int roi_stride, const float *q_norm,
                                          const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C, int cap_a,
                                          int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, float *min_dist,
-                                         int32_t *argmin, uint8_t *valid, int32_t *n_undecided, void *workspace, size_t workspace_bytes,
-                                         void *stream)
+                                         int32_t *argmin, uint8_t *valid, int32_t *n_undecided, int round_f16, void *workspace,
+                                         size_t workspace_bytes, void *stream)
 {
     ORYON_CHECK_ARG(a_hat && a_i8 && a_scale && feat_q && roi_q && q_norm && q_i8 && q_scale && q_eps_max && n_a && n_q);
     ORYON_CHECK_ARG(min_dist && argmin && valid && B >= 0 && (C == 256 || C == 512) && C_true > 0 && C_true <= C && HW > 0);
@@ -1373,7 +1373,7 @@ extern "C" int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8,
 #define RESCORE_RAW(LV, NHWCV)                                                                                                 \
     hipLaunchKernelGGL((match_rescore_raw_kernel<LV, NHWCV>), dim3(cap_a / (256 / LV), B), dim3(256), 0, st, a_hat, feat_q, C_true, HW, \
                        roi_q, roi_stride, q_norm, C, cap_a, cap_q, n_a, n_q, threshold, w.m_final, w.cnt, w.cand, min_dist, argmin,  \
-                       valid, w.row_flag, w.panel_flag, wr.need_f32)
+                       valid, w.row_flag, w.panel_flag, wr.need_f32, round_f16)
     if (layout == ORYON_LAYOUT_NHWC) { if (resc_l == 1) RESCORE_RAW(1, true); else if (resc_l == 4) RESCORE_RAW(4, true); else RESCORE_RAW(2, true); }
     else { if (resc_l == 1) RESCORE_RAW(1, false); else if (resc_l == 4) RESCORE_RAW(4, false); else RESCORE_RAW(2, false); }
 #undef RESCORE_RAW
@@ -1383,7 +1383,7 @@ extern "C" int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8,
     // canonical fp32 query rows materialised now - the price round 1 paid for EVERY pair - and then take the round-1 route.
     hipLaunchKernelGGL(match_need_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, w.n_amb, wr.need_f32);
     int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride, n_q, wr.need_f32, cap_q, C, wr.q8_scratch, wr.scale_scratch,
-                              wr.eps_scratch, nullptr, wr.q_hat, 1, st);
+                              wr.eps_scratch, nullptr, wr.q_hat, 1, round_f16, st);
     if (rc) { set_error("oryon_match_screened8_raw: fall-back gather launch failed"); return rc; }
     rc = match_f32_flagged(a_hat, wr.q_hat, B, C, cap_a, cap_q, n_a, n_q, threshold, min_dist, argmin, valid, w.panel_flag, w.row_flag,
                            stream);
@@ -1480,7 +1480,7 @@ __device__ __forceinline__ void resolve_anchor(int p, int a, const float *__rest
                                                const float *__restrict__ a_scale8, const float *__restrict__ feat_q, int C_true, int HW,
                                                const int32_t *__restrict__ roi_q, int roi_stride, const float *__restrict__ norm_q,
                                                int Cp, int cap_a, int cap_q, int nq, float m1, int sid, float margin, float *lds /*[2*Cp]*/,
-                                               float &d_out, int &j_out)
+                                               int round_f16, float &d_out, int &j_out)
 {
     const int lane = threadIdx.x & 63;
     const size_t arow = (size_t)p * cap_a + a;
@@ -1525,6 +1525,7 @@ __device__ __forceinline__ void resolve_anchor(int p, int a, const float *__rest
         for (int k = lane; k < Cp; k += 64) {
             float x = 0.0f;
             if (k < C_true) x = NHWC ? fq[(size_t)pix * C_true + k] : fq[(size_t)k * HW + pix];
+            if (round_f16) x = __half2float(__float2half_rn(x));
             Q[k] = __fdiv_rn(x, dq);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1553,7 +1554,7 @@ __global__ __launch_bounds__(256) void match_resolve_uncertain_kernel(
     int roi_stride, const float *__restrict__ norm_q, int Cp, int cap_a, int cap_q, const int32_t *__restrict__ n_q, float thr,
     const float *__restrict__ m_final, const int32_t *__restrict__ sid_final, const float *__restrict__ margin_in,
     const int32_t *__restrict__ n_unc, const int32_t *__restrict__ unc_idx, const int32_t *__restrict__ pair_eager,
-    uint8_t *__restrict__ state, uint8_t *__restrict__ valid, float *__restrict__ min_dist, int32_t *__restrict__ argmin)
+    uint8_t *__restrict__ state, uint8_t *__restrict__ valid, float *__restrict__ min_dist, int32_t *__restrict__ argmin, int round_f16)
 {
     extern __shared__ float lds_res[];
     const int p = blockIdx.y;
@@ -1566,7 +1567,7 @@ __global__ __launch_bounds__(256) void match_resolve_uncertain_kernel(
         float d;
         int j;
         resolve_anchor<NHWC>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q, n_q[p],
-                             m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, d, j);
+                             m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, round_f16, d, j);
         if (lane == 0) {
             min_dist[arow] = d;
             argmin[arow] = j;
@@ -1585,7 +1586,7 @@ __global__ __launch_bounds__(256) void match_resolve_selected_kernel(
     const float *__restrict__ m_final, const int32_t *__restrict__ sid_final, const float *__restrict__ margin_in,
     const uint8_t *__restrict__ state, const int32_t *__restrict__ pair_eager, const int32_t *__restrict__ n_sel,
     const int32_t *__restrict__ sel_rows, int corr_rows, float *__restrict__ min_dist, int32_t *__restrict__ argmin,
-    int32_t *__restrict__ corrs)
+    int32_t *__restrict__ corrs, int round_f16)
 {
     extern __shared__ float lds_res[];
     const int p = blockIdx.y;
@@ -1601,7 +1602,7 @@ __global__ __launch_bounds__(256) void match_resolve_selected_kernel(
         j = argmin[arow];
     } else {
         resolve_anchor<NHWC>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q, n_q[p],
-                             m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, d, j);
+                             m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, round_f16, d, j);
         if (lane == 0) { min_dist[arow] = d; argmin[arow] = j; }        // same value from every slot that drew this row
     }
     if (lane == 0) {
@@ -1669,7 +1670,7 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
                                     int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs,
                                     int corr_rows, uint64_t seed, const int64_t *pair_key, int force_eager, float *min_dist,
                                     int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
-                                    int32_t *n_undecided, void *workspace, size_t workspace_bytes, void *stream)
+                                    int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream)
 {
     ORYON_CHECK_ARG(a_hat && a_i8 && a_scale && feat_q && roi_a && roi_q && q_norm && q_i8 && q_scale && q_eps_max && n_a && n_q);
     ORYON_CHECK_ARG(min_dist && argmin && valid && corrs && n_valid && n_sel && status);
@@ -1713,14 +1714,14 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
 #define RESCORE_RAW_E(NHWCV)                                                                                                   \
     hipLaunchKernelGGL((match_rescore_raw_kernel<2, NHWCV>), dim3(cap_a / 128, B), dim3(256), 0, st, a_hat, feat_q, C_true, HW, roi_q,  \
                        roi_stride_q, q_norm, C, cap_a, cap_q, nae, n_q, threshold, w.m_final, w.cnt, w.cand, min_dist, argmin, valid,    \
-                       w.row_flag, w.panel_flag, wr.need_f32)
+                       w.row_flag, w.panel_flag, wr.need_f32, round_f16)
     if (layout == ORYON_LAYOUT_NHWC) RESCORE_RAW_E(true); else RESCORE_RAW_E(false);
 #undef RESCORE_RAW_E
     ORYON_CHECK_LAUNCH();
     if (n_undecided) ORYON_CHECK_HIP(hipMemcpyAsync(n_undecided, w.n_amb, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(match_need_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, w.n_amb, wr.need_f32);
     int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, wr.need_f32, cap_q, C, wr.q8_scratch, wr.scale_scratch,
-                              wr.eps_scratch, nullptr, wr.q_hat, 1, st);
+                              wr.eps_scratch, nullptr, wr.q_hat, 1, round_f16, st);
     if (rc) { set_error("oryon_match_corrs_i8: fall-back gather launch failed"); return rc; }
     rc = match_f32_flagged(a_hat, wr.q_hat, B, C, cap_a, cap_q, nae, n_q, threshold, min_dist, argmin, valid, w.panel_flag, w.row_flag, stream);
     if (rc) return rc;
@@ -1739,7 +1740,7 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
 #define RESOLVE_U(NHWCV)                                                                                                       \
     hipLaunchKernelGGL((match_resolve_uncertain_kernel<NHWCV>), dim3(64, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8, q_scale, a_scale,     \
                        feat_q, C_true, HW, roi_q, roi_stride_q, q_norm, C, cap_a, cap_q, n_q, threshold, w.m_final, lw.sid_final, lw.margin,   \
-                       lw.n_unc, lw.unc_idx, lw.pair_eager, lw.state, valid, min_dist, argmin)
+                       lw.n_unc, lw.unc_idx, lw.pair_eager, lw.state, valid, min_dist, argmin, round_f16)
     if (layout == ORYON_LAYOUT_NHWC) RESOLVE_U(true); else RESOLVE_U(false);
 #undef RESOLVE_U
     ORYON_CHECK_LAUNCH();
@@ -1749,7 +1750,7 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
 #define RESOLVE_S(NHWCV)                                                                                                       \
     hipLaunchKernelGGL((match_resolve_selected_kernel<NHWCV>), dim3((max_corrs + 3) / 4, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8,       \
                        q_scale, a_scale, feat_q, C_true, HW, roi_q, roi_stride_q, q_norm, C, cap_a, cap_q, n_q, W, w.m_final, lw.sid_final,    \
-                       lw.margin, lw.state, lw.pair_eager, n_sel, lw.sel_rows, corr_rows, min_dist, argmin, corrs)
+                       lw.margin, lw.state, lw.pair_eager, n_sel, lw.sel_rows, corr_rows, min_dist, argmin, corrs, round_f16)
     if (layout == ORYON_LAYOUT_NHWC) RESOLVE_S(true); else RESOLVE_S(false);
 #undef RESOLVE_S
     ORYON_CHECK_LAUNCH();

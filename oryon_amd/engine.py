@@ -37,6 +37,9 @@ class MatchPoseConfig:
     # "screened16": the same without the int8 stage
     # "exact":      full fp32-MFMA scan (K1) for every row
     match_mode: str = "screened"
+    # True = the reference's half-descriptor branch (utils/pcd.py:195-197, corrs_device='cuda'; BASELINE configs[4] "fp16 descriptors"):
+    # every descriptor value is rounded to float16 before anything else; the contraction itself is unchanged
+    half_descriptors: bool = False
 
 
 class MatchPoseEngine:
@@ -104,6 +107,9 @@ class MatchPoseEngine:
                     use_i8 = False
                 else:
                     self._i8_skipped, self._i8_frac = 0, 0.0
+        if cfg.half_descriptors and not use_i8:
+            # every route but the int8 one takes pre-rounded maps (one extra pass; K0v3 rounds on the way in)
+            feat_a, feat_q = ops.round_to_f16(feat_a), ops.round_to_f16(feat_q)
         if self.overlap_gather:
             if self._gather_stream is None:
                 self._gather_stream = torch.cuda.Stream(device=dev)
@@ -129,8 +135,8 @@ class MatchPoseEngine:
             # K0v3: anchors -> fp32 + int8 rows, queries -> int8 rows + row norms only (the re-scoring pass reads its few candidates
             # from the raw map); contiguous and channels_last maps are both read in place
             c_pad = 256 if C <= 256 else 512
-            a8, a_sc, _, _, a_hat = ops.gather_q8(feat_a, roi_a, n_a, cap_a, c_pad, want_f32=True)
-            q8, q_sc, q_eps, q_norm, _ = ops.gather_q8(feat_q, roi_q, n_q, cap_q, c_pad)
+            a8, a_sc, _, _, a_hat = ops.gather_q8(feat_a, roi_a, n_a, cap_a, c_pad, want_f32=True, round_f16=cfg.half_descriptors)
+            q8, q_sc, q_eps, q_norm, _ = ops.gather_q8(feat_q, roi_q, n_q, cap_q, c_pad, round_f16=cfg.half_descriptors)
         elif screened:
             c_pad = 128 if C <= 128 else (256 if C <= 256 else 512)
             a_hat, a16 = ops.gather_normalise(feat_a.contiguous(), roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
@@ -152,7 +158,7 @@ class MatchPoseEngine:
             n_und = torch.empty((B,), dtype=torch.int32, device=dev)
             corrs, n_valid, n_sel, status, min_dist, argmin, valid = ops.match_corrs_i8(
                 a_hat, a8, a_sc, feat_q, roi_a, roi_q, q_norm, q8, q_sc, q_eps, n_a, n_q, cfg.dist_th, FW, cfg.n_corrs, cfg.seed,
-                pair_key, corr_rows=self.n_cap, force_eager=keep, n_undecided=n_und)
+                pair_key, corr_rows=self.n_cap, force_eager=keep, n_undecided=n_und, round_f16=cfg.half_descriptors)
             if self._i8_pending is None:
                 if self._i8_host is None:
                     self._i8_host = torch.empty((2, B), dtype=torch.int32, pin_memory=True)

@@ -261,7 +261,8 @@ def map_layout(feat: torch.Tensor):
 
 
 @_on_tensor_device
-def gather_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: int, want_f32: bool = False):
+def gather_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: int, want_f32: bool = False,
+              round_f16: bool = False):
     """K0v3 (gather8.hip): ROI rows of [n,C,H,W] fp32 maps (contiguous or channels_last) -> (rows int8 [n,rows_cap,c_pad],
     slice_scale [n,rows_cap/16], eps_max [n], row_norm [n,rows_cap], rows fp32 k-permuted [n,rows_cap,c_pad] | None)."""
     dev = _lib.require_gpu(feat.device)
@@ -275,7 +276,7 @@ def gather_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_c
     norm = torch.empty((n_maps, rows_cap), dtype=torch.float32, device=dev)
     out32 = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.float32, device=dev) if want_f32 else None
     check(lib().oryon_gather_q8(feat.data_ptr(), n_maps, C, H * W, layout, ptr(roi), roi.shape[1], ptr(count), rows_cap, c_pad, ptr(out8),
-                                ptr(scale), ptr(eps), ptr(norm), ptr(out32), stream_ptr(dev)), "oryon_gather_q8")
+                                ptr(scale), ptr(eps), ptr(norm), ptr(out32), int(bool(round_f16)), stream_ptr(dev)), "oryon_gather_q8")
     return out8, scale, eps, norm, out32
 
 
@@ -283,7 +284,8 @@ _raw_ws = {}
 
 
 @_on_tensor_device
-def match_screened8_raw(a_hat, a8, a_scale, feat_q, roi_q, q_norm, q8, q_scale, q_eps, n_a, n_q, threshold: float, n_undecided=None):
+def match_screened8_raw(a_hat, a8, a_scale, feat_q, roi_q, q_norm, q8, q_scale, q_eps, n_a, n_q, threshold: float, n_undecided=None,
+                        round_f16: bool = False):
     """K1s8 on K0v3 operands: no fp32 copy of the query rows exists; the exact re-scoring reads candidates from the raw map feat_q
     ([B,C,H,W] contiguous or channels_last).  Same outputs as `match_screened8`."""
     dev = _lib.require_gpu(a_hat.device)
@@ -304,14 +306,15 @@ def match_screened8_raw(a_hat, a8, a_scale, feat_q, roi_q, q_norm, q8, q_scale, 
         _raw_ws[key] = ws
     check(lib().oryon_match_screened8_raw(ptr(a_hat), ptr(a8), ptr(a_scale), feat_q.data_ptr(), C_true, HW, layout, ptr(roi_q),
                                           roi_q.shape[1], ptr(q_norm), ptr(q8), ptr(q_scale), ptr(q_eps), B, Cp, cap_a, cap_q, ptr(n_a),
-                                          ptr(n_q), float(threshold), ptr(min_dist), ptr(argmin), ptr(valid), ptr(n_undecided), ptr(ws),
-                                          ws.numel(), stream_ptr(dev)), "oryon_match_screened8_raw")
+                                          ptr(n_q), float(threshold), ptr(min_dist), ptr(argmin), ptr(valid), ptr(n_undecided),
+                                          int(bool(round_f16)), ptr(ws), ws.numel(), stream_ptr(dev)), "oryon_match_screened8_raw")
     return min_dist, argmin, valid
 
 
 @_on_tensor_device
 def match_corrs_i8(a_hat, a8, a_scale, feat_q, roi_a, roi_q, q_norm, q8, q_scale, q_eps, n_a, n_q, threshold: float, W: int, max_corrs: int,
-                   seed: int, pair_key=None, corr_rows: Optional[int] = None, force_eager: bool = False, n_undecided=None):
+                   seed: int, pair_key=None, corr_rows: Optional[int] = None, force_eager: bool = False, n_undecided=None,
+                   round_f16: bool = False):
     """Lazy K1s8 + K1b (oryon_match_corrs_i8): -> (corrs [B,corr_rows,4] i32, n_valid [B], n_sel [B], status [B], min_dist, argmin, valid).
     Same correspondences as select_corrs(match_screened8_raw(...)); min_dist / argmin are exact only on sampled rows unless force_eager."""
     dev = _lib.require_gpu(a_hat.device)
@@ -337,7 +340,8 @@ def match_corrs_i8(a_hat, a8, a_scale, feat_q, roi_a, roi_q, q_norm, q8, q_scale
                                      ptr(roi_q), roi_q.shape[1], ptr(q_norm), ptr(q8), ptr(q_scale), ptr(q_eps), B, Cp, cap_a, cap_q,
                                      ptr(n_a), ptr(n_q), float(threshold), int(W), int(max_corrs), corr_rows, int(seed) & (2**64 - 1),
                                      ptr(pair_key), int(bool(force_eager)), ptr(min_dist), ptr(argmin), ptr(valid), ptr(corrs), ptr(n_valid),
-                                     ptr(n_sel), ptr(status), ptr(n_undecided), ptr(ws), ws.numel(), stream_ptr(dev)), "oryon_match_corrs_i8")
+                                     ptr(n_sel), ptr(status), ptr(n_undecided), int(bool(round_f16)), ptr(ws), ws.numel(), stream_ptr(dev)),
+          "oryon_match_corrs_i8")
     return corrs, n_valid, n_sel, status, min_dist, argmin, valid
 
 

@@ -361,3 +361,39 @@ def test_run_test_driver_batched_and_per_sample(tmp_path):
         assert s["pairs"] == 4 and s["failures"] == 0 and s["rot_err_deg_max"] < 1.0 and s["trans_err_cm_max"] < 1.0
         assert s["ADD_0.1d_accuracy"] == 1.0
         assert len(read_pred_csv(out)) == 4
+
+
+def test_engine_half_descriptor_mode_matches_reference_half_branch():
+    """BASELINE configs[4] / utils/pcd.py:195-197: descriptors rounded to float16 before the matcher.  The batched engine in
+    half_descriptors mode (int8 route: K0v3 rounds on the way in; and the exact route on pre-rounded maps) must reproduce, row for row,
+    what the per-sample facade's corrs_device='cuda' branch computes (exact fp32 scan of the rounded descriptors) - that branch is
+    pinned to the reference's own half-precision pdist by tests/golden/g1_matcher_half.npz."""
+    from oryon_amd import pcd
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    C, H = 256, 48
+    pairs = [make_pair(i, H, H, C, device=dev) for i in range(3)]
+    st = lambda k: torch.stack([p[k] for p in pairs])
+    fa, fq = st("feat_a") * 3.7, st("feat_q") * 0.31               # scales that make the half rounding visible in different binades
+    solver = _solver()
+    cam = st("camera").to(dev)
+    outs = {}
+    for mode in ("screened", "exact"):
+        eng = MatchPoseEngine(solver, MatchPoseConfig(match_mode=mode, half_descriptors=True, src_sampling=None))
+        outs[mode] = eng.run(fa, fq, st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"), cam, cam, keep=True)
+    torch.cuda.synchronize()
+    for b in range(3):
+        pre = pcd.match_presample(fa[b], fq[b], pairs[b]["mask_a"], pairs[b]["mask_q"], 0.25, half_descriptors=True)
+        n = int(outs["exact"]["n_a"][b])
+        v = pre["valid"]
+        assert int(v.sum()) > 100
+        for mode in ("screened", "exact"):
+            o = outs[mode]
+            assert torch.equal(o["valid"][b, :n].bool(), v), mode
+            assert torch.equal(o["argmin"][b, :n][v].long(), pre["argmin"][v]), mode
+            assert torch.equal(o["min_dist"][b, :n][v].view(torch.int32), pre["min_dist"][v].view(torch.int32)), mode
+        # and the rounding is not a no-op on this input: the fp32 branch gives different distances
+        ref32 = pcd.match_presample(fa[b], fq[b], pairs[b]["mask_a"], pairs[b]["mask_q"], 0.25)
+        assert not torch.equal(ref32["min_dist"][v], pre["min_dist"][v])
+    assert torch.equal(outs["screened"]["pose"], outs["exact"]["pose"])
