@@ -46,7 +46,7 @@ def preprocess_item(item: dict) -> dict:
     item["hw_size"] = tuple(item["mask"].shape)
     for k, v in list(item.items()):
         if isinstance(v, np.ndarray):
-            item[k] = torch.from_numpy(np.ascontiguousarray(v))
+            item[k] = torch.from_numpy(np.array(v, copy=True))          # PIL hands out read-only buffers
     item["orig_rgb"] = item["rgb"]
     item["orig_depth"] = item["depth"].clone()
     item["eval_depth"] = item["depth"].clone()

@@ -188,8 +188,12 @@ class Pipeline:
         outputs = self.model.forward(batch)
         BS = outputs["featmap_a"].shape[0]
         FH, FW = outputs["featmap_a"].shape[2:]
-        if self.args.test.mask == "predicted":
+        res = None
+        if "mask_a" in outputs and "mask_q" in outputs:          # the predicted masks are evaluated (IoU) whatever test.mask says
             res = self.mask_results(batch, outputs)
+        if self.args.test.mask == "predicted":
+            if res is None:
+                raise KeyError("test.mask='predicted' needs the model's mask logits (outputs['mask_a'], outputs['mask_q'])")
             mask_a, mask_q = res["mask_a"], res["mask_q"]
         else:
             mask_a = ops.mask_resize_nearest(batch["anchor"]["mask"].to(dev), (FH, FW))
@@ -207,4 +211,6 @@ class Pipeline:
                                mask_q, depth_a, depth_q, batch["anchor"]["camera"].to(dev), batch["query"]["camera"].to(dev), key)
         anchor_pose = batch["anchor"]["pose"].to(dev, torch.float32)
         out["pred_q"] = torch.bmm(out["pose"], anchor_pose)
+        if res is not None:
+            out["iou_a"], out["iou_q"] = res["iou_a"], res["iou_q"]
         return out

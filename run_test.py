@@ -10,6 +10,18 @@ reference-shaped per-sample loop  Pipeline.test_step), appends one prediction li
     python run_test.py --pairs 2 --batch 2 --backbone           # random-init Oryon.forward in front (CLIP ViT-L + Swin + fusion + decoder)
     python run_test.py --pairs 4 --batch 2 --per-sample         # reference-shaped loop, host RNG
 
+Real assets (BASELINE.json configs[2] / configs[4]; the reference's `python run_test.py -cp exp_data/baseline ...`):
+
+    python run_test.py --data-root data --dataset nocs --split cross_scene_test --obj all --mask predicted \
+        --ckpt exp_data/baseline/models/epoch=0019.ckpt --catseg pretrained_models/catseg.pth \
+        --pointdsc pretrained_models/pointdsc --bpe pretrained_models/bpe_simple_vocab_16e6.txt.gz [--half-descriptors]
+
+reads the fixed split through oryon_amd.datasets.FixedSplit (PNG decode on the host, resize / collate on the device), loads the
+Lightning checkpoint's `model.*` weights into Oryon (after the CATSeg remap, net.py:102-134) and the released PointDSC weights,
+runs the batched pipeline and reports ADD(S)-0.1d, rotation / translation errors and mask IoU per the reference's evaluator
+(utils/evaluator.py:206-256); the prediction CSV has the reference's format.  VSD / MSSD / MSPD need the BOP toolkit and an OpenGL
+renderer (out of scope).
+
 Needs an MI355X (the match / lift / registration path has no CPU fallback by design).
 """
 import argparse
@@ -49,6 +61,110 @@ def synthetic_batch(first, B, H, C, dev):
     return batch, pairs
 
 
+def load_oryon_checkpoint(model, ckpt_path: str) -> dict:
+    """Weights of a reference Lightning checkpoint (`trainer.test(..., ckpt_path=args.eval.ckpt)`, run_test.py:42): the LightningModule
+    keeps the network under `self.model`, so its tensors are the `model.*` entries of `state_dict`.  Returns load statistics."""
+    blob = torch.load(ckpt_path, map_location="cpu")
+    sd = blob.get("state_dict", blob)
+    mine = {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")} or dict(sd)
+    res = model.load_state_dict(mine, strict=False)
+    return {"tensors": len(mine), "missing": len(res.missing_keys), "unexpected": len(res.unexpected_keys)}
+
+
+def hashed_prompt_tokens(prompts) -> torch.Tensor:
+    """[B, 80, 77] CLIP-shaped token ids from prompt strings WITHOUT the BPE vocabulary (smoke runs only: `--hash-prompts`): words are
+    hashed into the vocabulary range, <start> / <end> markers placed as the real tokenizer would.  The first entry of every prompt
+    list (the bare object name) is dropped like models/vlm.py:67 does."""
+    import zlib
+    out = torch.zeros((len(prompts), len(prompts[0]) - 1, 77), dtype=torch.int64)
+    for b, plist in enumerate(prompts):
+        for t, text in enumerate(plist[1:]):
+            ids = [49406] + [1 + zlib.crc32(w.encode()) % 49000 for w in text.lower().split()][:75] + [49407]
+            out[b, t, :len(ids)] = torch.tensor(ids)
+    return out
+
+
+def run_real(a) -> dict:
+    """One pass over a fixed split of REAL275 ('nocs') or TOYL with real weights: the reference's test loop
+    (pipeline.py:306-355 + utils/evaluator.py:206-256) on the batched engine."""
+    from oryon_amd.data import DeviceCollate
+    from oryon_amd.datasets import FixedSplit, extent_diameter
+    from oryon_amd.net import Oryon, default_model_args
+    from oryon_amd.pointdsc import get_pointdsc_solver
+    dev = "cuda"
+    name = a.dataset_name or {"nocs": "nocs", "toyl": "toyl"}[a.dataset]
+    split = FixedSplit(a.dataset, a.data_root, name, a.split, a.obj, mask_type=a.mask)
+    margs = default_model_args()
+    margs.model.use_catseg_ckpt = False
+    torch.manual_seed(0)
+    model = Oryon(margs, dev, bpe_path=a.bpe).eval()
+    loaded = {}
+    if a.catseg:
+        model.load_catseg_checkpoint(a.catseg)
+        loaded["catseg"] = a.catseg
+    if a.ckpt:
+        loaded["ckpt"] = load_oryon_checkpoint(model, a.ckpt)
+    if a.pointdsc:
+        solver = get_pointdsc_solver(a.pointdsc, dev)
+    else:
+        from bench import build_solver as bench_solver
+        solver = bench_solver(torch.device(dev))
+    args = default_args(**{"test.mask": a.mask, "seed": a.seed})
+    pipe = Pipeline(args, model=model, pointdsc_solver=solver)
+    if a.half_descriptors:
+        from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+        pipe._engine = MatchPoseEngine(solver, MatchPoseConfig(dist_th=args.test.dist_th, n_corrs=args.test.n_corrs,
+                                                               src_sampling=args.test.src_sampling, seed=a.seed, half_descriptors=True))
+    collate = DeviceCollate(args.dataset.max_corrs, args.dataset.img_size, dev)
+    n = len(split) if a.pairs <= 0 else min(a.pairs, len(split))
+    rows, t0 = [], time.perf_counter()
+    for first in range(0, n, a.batch):
+        idx = list(range(first, min(first + a.batch, n)))
+        batch = collate([split[i] for i in idx])
+        if a.hash_prompts:
+            batch["prompt_tokens"] = hashed_prompt_tokens(batch["prompt"])
+        if a.per_sample:
+            recs = pipe.test_step(batch, first // a.batch)
+            pose_rel = torch.stack([r["pred_pose_rel"].cpu() for r in recs])
+            status = [r["status"] for r in recs]
+            iou = None
+        else:
+            out = pipe.test_step_batched(batch, first_pair_index=first)
+            pose_rel, status = out["pose"].cpu(), out["status"].cpu().tolist()
+            iou = (out["iou_a"].cpu(), out["iou_q"].cpu()) if "iou_a" in out else None
+            for i in range(len(idx)):
+                ia = float(iou[0][i]) if iou is not None else 1.0
+                iq = float(iou[1][i]) if iou is not None else 1.0
+                pipe.add_pred_pose(batch["anchor"]["instance_id"][i], batch["query"]["instance_id"][i], ia, iq, pose_rel[i].numpy())
+        anchor_pose = batch["anchor"]["pose"].to(torch.float32)
+        gt_q = batch["query"]["pose"].double().numpy()
+        for i in range(len(idx)):
+            pred_q = (pose_rel[i] @ anchor_pose[i]).double().numpy()          # pipeline.py:320
+            obj = split.object_info(batch["cls_id"][i])
+            pts_m = obj["pts"] / 1000.0
+            err = ev.compute_adds(pts_m, pred_q, gt_q[i]) if obj["symmetric"] else ev.compute_add(pts_m, pred_q, gt_q[i])
+            theta, shift = ev.compute_RT_distances(pred_q, gt_q[i])
+            rows.append(dict(instance=batch["instance_id"][i], status=int(status[i]), add_s=float(err),
+                             add_diam=extent_diameter(obj["pts"]) / 1000.0, rot_deg=float(theta[0]), trans_cm=float(shift[0])))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    with open(a.out, "w") as f:
+        f.writelines(pipe.pred_lines)
+    add_ok = [float(r["add_s"] <= 0.1 * r["add_diam"]) for r in rows]
+    summary = {
+        "dataset": a.dataset, "split": a.split, "obj": a.obj, "mask": a.mask, "pairs": len(rows),
+        "failures": sum(1 for r in rows if r["status"] != 0), "ADD(S)-0.1d": float(np.mean(add_ok)) if rows else None,
+        "R_error_deg_mean": float(np.mean([r["rot_deg"] for r in rows])) if rows else None,
+        "T_error_cm_mean": float(np.mean([r["trans_cm"] for r in rows])) if rows else None,
+        "pairs_per_s": len(rows) / wall if wall > 0 else None, "wall_s": round(wall, 3), "csv": a.out, "weights": loaded,
+        "half_descriptors": bool(a.half_descriptors),
+        "not_computed": "VSD / MSSD / MSPD / AR (BOP toolkit + OpenGL renderer; SURVEY.md 2.1 out of scope)",
+    }
+    print(json.dumps(summary))
+    return summary
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--pairs", type=int, default=8)
@@ -58,7 +174,23 @@ def main(argv=None):
     ap.add_argument("--per-sample", action="store_true", help="reference-shaped per-sample loop (Pipeline.test_step)")
     ap.add_argument("--backbone", action="store_true", help="run a random-init Oryon.forward in front (mask = oracle)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "run_test_predictions.csv"))
+    g = ap.add_argument_group("real assets (fixed test splits + checkpoints; every path as in the reference's configs/config.yaml)")
+    g.add_argument("--data-root", default=None, help="dataset.root: the folder that holds <name>/fixed_split/... (switches real-asset mode on)")
+    g.add_argument("--dataset", choices=["nocs", "toyl"], default="nocs", help="REAL275 ('nocs') or TOYL")
+    g.add_argument("--dataset-name", default=None, help="dataset.test.name (sub-folder of --data-root; default = --dataset)")
+    g.add_argument("--split", default="cross_scene_test", help="dataset.test.split")
+    g.add_argument("--obj", default="all", help="dataset.test.obj (key of object_splits.json)")
+    g.add_argument("--mask", default="predicted", help="test.mask: predicted | oracle | ovseg | san | oryon")
+    g.add_argument("--ckpt", default=None, help="eval.ckpt: Lightning checkpoint of the trained Oryon")
+    g.add_argument("--catseg", default=None, help="pretrained_models/catseg.pth (loaded first, as net.py:102-134)")
+    g.add_argument("--pointdsc", default=None, help="pretrained.pointdsc folder (snapshot/PointDSC_3DMatch_release/...)")
+    g.add_argument("--bpe", default=None, help="pretrained.vocabulary: CLIP BPE file")
+    g.add_argument("--half-descriptors", action="store_true", help="BASELINE configs[4]: descriptors rounded to float16 (utils/pcd.py:195-197)")
+    g.add_argument("--hash-prompts", action="store_true", help="smoke runs without the BPE file: hash prompt words to token ids")
+    g.add_argument("--seed", type=int, default=1)
     a = ap.parse_args(argv)
+    if a.data_root:
+        return run_real(a)
     dev = "cuda"
     H, C = a.size, a.channels
     args = default_args(**{"test.mask": "oracle", "model.image_encoder.img_size": [H, H], "dataset.img_size": [H, H]})

@@ -1,0 +1,157 @@
+"""Numeric pins of the two third-party towers.  Their source (openai `clip`,
+torchvision `swin_b`) is not in the reference tree, so parity with the reference is formally unpinned; what CAN be pinned here is
+that this build's restatement computes the published architectures: the same parameters are copied into the independent
+`transformers` implementations (CLIPModel, SwinModel) and the outputs the reference consumes are compared.
+
+  * Swin-B guidance tower (net.py:45-75): stage-1 output, first and second patch-merging outputs - the three feature-extractor
+    nodes - on CPU at 112x112 (no window padding) and 100x100 (25x25 tokens: padding to 28, odd-size patch merging), and on the
+    GPU at the reference's 384x384 (96x96 tokens -> padded to 98).
+  * CLIP at the ViT-L/14@336 widths (1024 / 16 heads / patch 14 / 577 positions; text 768 / 12 heads / ctx 77 / vocab 49408)
+    with 2 layers per tower, on the GPU.
+Bar: <= 2e-4 relative (the two implementations order their fp32 sums differently)."""
+import pytest
+import torch
+
+
+def _swin_pair(size, device="cpu", seed=0):
+    tr = pytest.importorskip("transformers")
+    from oryon_amd.backbone.swin import SwinGuidance
+    torch.manual_seed(seed)
+    m = SwinGuidance().eval()
+    for p in m.parameters():
+        p.data.normal_(0, 0.3 if p.dim() == 1 else 0.05)
+    # three stages so that stage 2 (index 1) owns a patch-merging layer; the third stage's block is never looked at
+    cfg = tr.SwinConfig(image_size=size, patch_size=4, embed_dim=128, depths=[2, 2, 1], num_heads=[4, 8, 16], window_size=7, num_channels=3,
+                        drop_path_rate=0.0, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    hf = tr.SwinModel(cfg).eval()
+    P, sd = dict(hf.named_parameters()), m.state_dict()
+
+    def cp(dst, src):
+        assert P[dst].shape == sd[src].shape, (dst, src)
+        P[dst].data.copy_(sd[src])
+    cp("embeddings.patch_embeddings.projection.weight", "features.0.0.weight")
+    cp("embeddings.patch_embeddings.projection.bias", "features.0.0.bias")
+    cp("embeddings.norm.weight", "features.0.2.weight")
+    cp("embeddings.norm.bias", "features.0.2.bias")
+    for st, (f, dim) in enumerate(((1, 128), (3, 256))):
+        for b in range(2):
+            pre, src = f"encoder.layers.{st}.blocks.{b}.", f"features.{f}.{b}."
+            w, bias = sd[src + "attn.qkv.weight"], sd[src + "attn.qkv.bias"]
+            names = ("q_proj", "k_proj", "v_proj") if pre + "attention.q_proj.weight" in P else ("self.query", "self.key", "self.value")
+            for i, n in enumerate(names):
+                P[pre + f"attention.{n}.weight"].data.copy_(w[i * dim:(i + 1) * dim])
+                P[pre + f"attention.{n}.bias"].data.copy_(bias[i * dim:(i + 1) * dim])
+            o = "attention.o_proj" if pre + "attention.o_proj.weight" in P else "attention.output.dense"
+            cp(pre + o + ".weight", src + "attn.proj.weight")
+            cp(pre + o + ".bias", src + "attn.proj.bias")
+            tbl = [k for k in P if k.startswith(pre) and k.endswith("relative_position_bias_table")][0]
+            cp(tbl, src + "attn.relative_position_bias_table")
+            fc1 = "mlp.fc1" if pre + "mlp.fc1.weight" in P else "intermediate.dense"
+            fc2 = "mlp.fc2" if pre + "mlp.fc2.weight" in P else "output.dense"
+            for a, bn in (("layernorm_before", "norm1"), ("layernorm_after", "norm2"), (fc1, "mlp.0"), (fc2, "mlp.3")):
+                cp(pre + a + ".weight", src + bn + ".weight")
+                cp(pre + a + ".bias", src + bn + ".bias")
+        pre, src = f"encoder.layers.{st}.downsample.", f"features.{f + 1}."
+        cp(pre + "reduction.weight", src + "reduction.weight")
+        cp(pre + "norm.weight", src + "norm.weight")
+        cp(pre + "norm.bias", src + "norm.bias")
+    return m.to(device), hf.to(device)
+
+
+def _swin_check(size, device, B=2):
+    m, hf = _swin_pair(size, device)
+    x = torch.randn(B, 3, size, size, device=device)
+    with torch.no_grad():
+        mine = m(x)
+        emb, dims = hf.embeddings(x)
+        before = hf.encoder(emb, dims, output_hidden_states=True, output_hidden_states_before_downsampling=True).reshaped_hidden_states
+        after = hf.encoder(emb, dims, output_hidden_states=True, output_hidden_states_before_downsampling=False).reshaped_hidden_states
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    # reshaped_hidden_states are NCHW; index 0 is the stem, 1 / 2 the first two stages
+    ref3 = before[1].permute(0, 2, 3, 1)                # stage 1 before merging     = features.1.1.add_1
+    ref2 = after[1].permute(0, 2, 3, 1)                 # after the first merging    = features.2.reduction
+    ref1 = after[2].permute(0, 2, 3, 1)                 # after the second merging   = features.4.reduction
+    assert mine["guidance3"].shape == ref3.shape and mine["guidance2"].shape == ref2.shape and mine["guidance1"].shape == ref1.shape
+    errs = (rel(mine["guidance3"], ref3), rel(mine["guidance2"], ref2), rel(mine["guidance1"], ref1))
+    assert max(errs) < 2e-4, errs
+    return errs
+
+
+@pytest.mark.parametrize("size", [112, 100])
+def test_swin_guidance_matches_transformers_cpu(size):
+    _swin_check(size, "cpu")
+
+
+@pytest.mark.gpu
+def test_swin_guidance_matches_transformers_gpu_384():
+    torch.backends.cuda.matmul.allow_tf32 = False
+    _swin_check(384, "cuda", B=2)
+
+
+@pytest.mark.gpu
+def test_clip_vit_l14_336_widths_match_transformers_gpu():
+    """Two-layer towers at the real ViT-L/14@336 widths: patch tokens after ln_post (what vlm.py:46-59 hands to the fusion) and the
+    projected EOT text embedding (vlm.py:74-83)."""
+    tr = pytest.importorskip("transformers")
+    from oryon_amd.backbone.clip import CLIP, CLIPConfig
+    torch.backends.cuda.matmul.allow_tf32 = False
+    dev = "cuda"
+    cfg = CLIPConfig.vit_l14_336()
+    cfg.v_layers, cfg.t_layers = 2, 2
+    torch.manual_seed(0)
+    m = CLIP(cfg).eval()
+    for p in m.parameters():
+        if p.dim() == 1:
+            p.data.normal_(0, 0.2)
+    hf_cfg = tr.CLIPConfig(
+        text_config=dict(vocab_size=cfg.vocab, hidden_size=cfg.t_width, intermediate_size=4 * cfg.t_width, num_hidden_layers=2,
+                         num_attention_heads=cfg.t_heads, max_position_embeddings=cfg.ctx, hidden_act="quick_gelu", eos_token_id=cfg.vocab - 1,
+                         bos_token_id=cfg.vocab - 2, pad_token_id=0),
+        vision_config=dict(hidden_size=cfg.v_width, intermediate_size=4 * cfg.v_width, num_hidden_layers=2, num_attention_heads=cfg.v_heads,
+                           image_size=cfg.image_size, patch_size=cfg.patch, hidden_act="quick_gelu"),
+        projection_dim=cfg.embed_dim)
+    hf = tr.CLIPModel(hf_cfg).eval()
+    sd, P = m.state_dict(), dict(hf.named_parameters())
+
+    def copy_block(prefix_hf, prefix, width):
+        w, b = sd[prefix + ".attn.in_proj_weight"], sd[prefix + ".attn.in_proj_bias"]
+        for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            P[f"{prefix_hf}.self_attn.{n}.weight"].data.copy_(w[i * width:(i + 1) * width])
+            P[f"{prefix_hf}.self_attn.{n}.bias"].data.copy_(b[i * width:(i + 1) * width])
+        for a, c in ((".self_attn.out_proj", ".attn.out_proj"), (".layer_norm1", ".ln_1"), (".layer_norm2", ".ln_2"),
+                     (".mlp.fc1", ".mlp.c_fc"), (".mlp.fc2", ".mlp.c_proj")):
+            P[prefix_hf + a + ".weight"].data.copy_(sd[prefix + c + ".weight"])
+            P[prefix_hf + a + ".bias"].data.copy_(sd[prefix + c + ".bias"])
+    with torch.no_grad():
+        P["vision_model.embeddings.patch_embedding.weight"].copy_(sd["visual.conv1.weight"])
+        P["vision_model.embeddings.class_embedding"].copy_(sd["visual.class_embedding"])
+        P["vision_model.embeddings.position_embedding.weight"].copy_(sd["visual.positional_embedding"])
+        name_pre = "vision_model.pre_layrnorm" if "vision_model.pre_layrnorm.weight" in P else "vision_model.pre_layernorm"
+        P[name_pre + ".weight"].copy_(sd["visual.ln_pre.weight"]); P[name_pre + ".bias"].copy_(sd["visual.ln_pre.bias"])
+        P["vision_model.post_layernorm.weight"].copy_(sd["visual.ln_post.weight"]); P["vision_model.post_layernorm.bias"].copy_(sd["visual.ln_post.bias"])
+        P["text_model.embeddings.token_embedding.weight"].copy_(sd["token_embedding.weight"])
+        P["text_model.embeddings.position_embedding.weight"].copy_(sd["positional_embedding"])
+        P["text_model.final_layer_norm.weight"].copy_(sd["ln_final.weight"]); P["text_model.final_layer_norm.bias"].copy_(sd["ln_final.bias"])
+        P["text_projection.weight"].copy_(sd["text_projection"].T)
+        for i in range(2):
+            copy_block(f"vision_model.encoder.layers.{i}", f"visual.transformer.resblocks.{i}", cfg.v_width)
+            copy_block(f"text_model.encoder.layers.{i}", f"transformer.resblocks.{i}", cfg.t_width)
+    m, hf = m.to(dev), hf.to(dev)
+    img = torch.randn(2, 3, cfg.image_size, cfg.image_size, device=dev)
+    toks = torch.randint(1, cfg.vocab - 2, (6, cfg.ctx), device=dev)
+    toks[:, 0] = cfg.vocab - 2
+    for r, e in enumerate((5, 9, 76, 3, 40, 12)):
+        toks[r, e] = cfg.vocab - 1                           # EOT = highest id -> argmax position (vlm.py:81)
+        toks[r, e + 1:] = 0
+    g = cfg.image_size // cfg.patch
+    with torch.no_grad():
+        ours_v = m.patch_tokens(img)
+        hv = hf.vision_model(pixel_values=img).last_hidden_state
+        ref_v = hf.vision_model.post_layernorm(hv[:, 1:, :]).transpose(1, 2).reshape(2, cfg.v_width, g, g)
+        ours_t = m.text_features(toks)
+        ref_t = hf.get_text_features(input_ids=toks, attention_mask=torch.ones_like(toks))
+        if not torch.is_tensor(ref_t):
+            ref_t = ref_t.pooler_output if hasattr(ref_t, "pooler_output") else ref_t[0]
+    assert tuple(ours_v.shape) == (2, 1024, 24, 24) and tuple(ours_t.shape) == (6, 768)
+    assert float((ours_v - ref_v).abs().max()) < 2e-4 * float(ref_v.abs().max())
+    assert float((ours_t - ref_t).abs().max()) < 2e-4 * float(ref_t.abs().max())
