@@ -292,6 +292,15 @@ int oryon_pointdsc_hypotheses(oryon_pointdsc_t *handle, const float *src, const 
 int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const float *tgt, const int32_t *n, int B,
                           int n_cap, const float *T_in, float *T_out, uint8_t *labels, void *stream);
 
+/* f3  pose-accuracy metrics on the device for a batch of pairs.
+ *     Replaces utils/metrics.py:194-220 (compute_add / compute_adds, with the FLOAT16 model transform of utils/pcd.py:127-133) and
+ *     utils/metrics.py:222-259 (compute_RT_distances) of the reference's evaluator (utils/evaluator.py:206-256).
+ * pred_pose / gt_pose [B,16] row-major 4x4 (metres); model_pts [sum M, 3] fp32 (metres) with pts_offset [n_models+1] (prefix sums) and
+ * model_of_pair [B] (NULL: every pair uses model 0); max_pts = largest model; workspace [B,2] fp32.
+ * out [B,4] = (ADD, ADD-S, rotation error in degrees, translation error in centimetres). */
+int oryon_pose_metrics(const float *pred_pose, const float *gt_pose, int B, const float *model_pts, const int32_t *pts_offset, int n_models,
+                       int max_pts, const int32_t *model_of_pair, float *workspace, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,7 @@ _PROTOS = {
                                  _P, _P, _P]),
     "oryon_lift_points": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "oryon_kabsch_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "oryon_pose_metrics": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "oryon_pointdsc_create": (c_int, [POINTER(c_void_p), POINTER(PointDSCConfig)]),
     "oryon_pointdsc_destroy": (None, [c_void_p]),
     "oryon_pointdsc_load_param": (c_int, [c_void_p, c_char_p, _P, c_int64]),

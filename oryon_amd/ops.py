@@ -425,3 +425,26 @@ def kabsch_batched(A: torch.Tensor, B: torch.Tensor, w: Optional[torch.Tensor] =
     T = torch.empty((nb, 4, 4), dtype=torch.float32, device=dev)
     check(lib().oryon_kabsch_batched(ptr(A), ptr(B), ptr(w), nb, m, ptr(T), stream_ptr(dev)), "oryon_kabsch_batched")
     return T
+
+
+@_on_tensor_device
+def pose_metrics(pred_pose: torch.Tensor, gt_pose: torch.Tensor, model_pts: torch.Tensor, pts_offset: Optional[torch.Tensor] = None,
+                 model_of_pair: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pred/gt [B,4,4] (metres), model_pts [M,3] (or the concatenation of several models with pts_offset [n+1] int32 and
+    model_of_pair [B] int32) -> [B,4] = (ADD, ADD-S, rotation error deg, translation error cm), all on the device (f3)."""
+    dev = _lib.require_gpu(pred_pose.device)
+    B = pred_pose.shape[0]
+    pred = pred_pose.to(dev, torch.float32).reshape(B, 16).contiguous()
+    gt = gt_pose.to(dev, torch.float32).reshape(B, 16).contiguous()
+    pts = model_pts.to(dev, torch.float32).contiguous()
+    if pts_offset is None:
+        pts_offset = torch.tensor([0, pts.shape[0]], dtype=torch.int32, device=dev)
+    off_host = pts_offset.cpu()
+    n_models = off_host.numel() - 1
+    max_pts = int((off_host[1:] - off_host[:-1]).max()) if n_models > 0 else 0
+    ws = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    mop = None if model_of_pair is None else model_of_pair.to(dev, torch.int32).contiguous()
+    check(lib().oryon_pose_metrics(ptr(pred), ptr(gt), B, ptr(pts), ptr(pts_offset.to(dev, torch.int32).contiguous()), n_models, max(1, max_pts),
+                                   ptr(mop), ptr(ws), ptr(out), stream_ptr(dev)), "oryon_pose_metrics")
+    return out

@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from oryon_amd import evaluation as ev  # noqa: E402
+from oryon_amd import ops  # noqa: E402
 from oryon_amd.pipeline import Pipeline, default_args  # noqa: E402
 from oryon_amd.synth import make_pair  # noqa: E402
 
@@ -136,16 +137,20 @@ def run_real(a) -> dict:
                 ia = float(iou[0][i]) if iou is not None else 1.0
                 iq = float(iou[1][i]) if iou is not None else 1.0
                 pipe.add_pred_pose(batch["anchor"]["instance_id"][i], batch["query"]["instance_id"][i], ia, iq, pose_rel[i].numpy())
-        anchor_pose = batch["anchor"]["pose"].to(torch.float32)
-        gt_q = batch["query"]["pose"].double().numpy()
+        # evaluation on the device (f3): pred_q = pose_rel @ anchor.pose (pipeline.py:320), ADD / ADD-S with the float16 model transform,
+        # rotation / translation errors - one call per batch over the concatenated object models
+        anchor_pose = batch["anchor"]["pose"].to(dev, torch.float32)
+        pred_q = torch.bmm(pose_rel.to(dev), anchor_pose)
+        keys = list(dict.fromkeys(batch["cls_id"]))
+        objs = [split.object_info(k) for k in keys]
+        pts = torch.cat([torch.from_numpy(o["pts"] / 1000.0).float() for o in objs]).to(dev)
+        off = torch.tensor(np.concatenate(([0], np.cumsum([o["pts"].shape[0] for o in objs]))), dtype=torch.int32)
+        which = torch.tensor([keys.index(k) for k in batch["cls_id"]], dtype=torch.int32)
+        met = ops.pose_metrics(pred_q, batch["query"]["pose"].to(dev, torch.float32), pts, off, which).cpu().numpy()
         for i in range(len(idx)):
-            pred_q = (pose_rel[i] @ anchor_pose[i]).double().numpy()          # pipeline.py:320
-            obj = split.object_info(batch["cls_id"][i])
-            pts_m = obj["pts"] / 1000.0
-            err = ev.compute_adds(pts_m, pred_q, gt_q[i]) if obj["symmetric"] else ev.compute_add(pts_m, pred_q, gt_q[i])
-            theta, shift = ev.compute_RT_distances(pred_q, gt_q[i])
-            rows.append(dict(instance=batch["instance_id"][i], status=int(status[i]), add_s=float(err),
-                             add_diam=extent_diameter(obj["pts"]) / 1000.0, rot_deg=float(theta[0]), trans_cm=float(shift[0])))
+            obj = objs[keys.index(batch["cls_id"][i])]
+            rows.append(dict(instance=batch["instance_id"][i], status=int(status[i]), add_s=float(met[i, 1] if obj["symmetric"] else met[i, 0]),
+                             add_diam=extent_diameter(obj["pts"]) / 1000.0, rot_deg=float(met[i, 2]), trans_cm=float(met[i, 3])))
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)

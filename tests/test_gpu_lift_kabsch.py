@@ -99,3 +99,27 @@ def test_kabsch_large_batch_vs_oracle():
     # size-independent property: residual of the fitted transform is at the noise level
     res = (A @ T[:, :3, :3].transpose(1, 2) + T[:, None, :3, 3] - Bp).norm(dim=-1).mean()
     assert float(res) < 0.01
+
+
+def test_pose_metrics_on_device_match_reference_golden():
+    """f3: oryon_pose_metrics against the outputs of the reference's utils/metrics.py (tests/golden/g7_metrics.npz): ADD within 2e-3
+    relative of the reference's float16 statistic (same float16 point transform, fp32 instead of half norms / mean), ADD-S within 1e-5,
+    rotation / translation errors within 1e-3 deg / 1e-4 cm; and a two-model batch through the offset table."""
+    import os
+    from oryon_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_metrics.npz"))
+    dev = "cuda"
+    pred, gt = torch.from_numpy(g["pred"]).float().to(dev), torch.from_numpy(g["gt"]).float().to(dev)
+    pts = torch.from_numpy(g["pcd"]).float().to(dev)
+    out = ops.pose_metrics(pred, gt, pts).cpu().numpy()
+    np.testing.assert_allclose(out[:, 0], g["add"].astype(np.float64), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(out[:, 1], g["adds"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out[:, 2], g["theta"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(out[:, 3], g["shift"], rtol=1e-5, atol=1e-4)
+    # two models of different sizes in one call
+    pts2 = torch.cat((pts, pts[:37] * 0.5))
+    off = torch.tensor([0, pts.shape[0], pts.shape[0] + 37], dtype=torch.int32)
+    which = torch.tensor([i % 2 for i in range(pred.shape[0])], dtype=torch.int32)
+    out2 = ops.pose_metrics(pred, gt, pts2, off, which).cpu().numpy()
+    small = ops.pose_metrics(pred, gt, pts[:37] * 0.5).cpu().numpy()
+    assert np.allclose(out2[0::2], out[0::2], rtol=1e-6) and np.allclose(out2[1::2], small[1::2], rtol=1e-6)
