@@ -155,3 +155,56 @@ def test_clip_vit_l14_336_widths_match_transformers_gpu():
     assert tuple(ours_v.shape) == (2, 1024, 24, 24) and tuple(ours_t.shape) == (6, 768)
     assert float((ours_v - ref_v).abs().max()) < 2e-4 * float(ref_v.abs().max())
     assert float((ours_t - ref_t).abs().max()) < 2e-4 * float(ref_t.abs().max())
+
+
+@pytest.mark.gpu
+def test_oryon_forward_gpu_equals_cpu_and_prompt_cache():
+    """Rows a1 / f2 on the MI355X: the whole Oryon.forward (CLIP at ViT-L/14@336 widths with 2 layers per tower for speed, Swin-B
+    stages 1-2, fusion, decoder; random init) evaluated by PyTorch-ROCm must reproduce the CPU fp32 evaluation of the same module -
+    descriptor maps and mask logits <= 1e-4 relative (the north-star descriptor bar) - and the prompt-embedding cache must serve the
+    second batch without touching the text tower."""
+    import copy
+    from oryon_amd.backbone.clip import CLIPConfig
+    from oryon_amd.net import Oryon, default_model_args
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    cfg = CLIPConfig.vit_l14_336()
+    cfg.v_layers, cfg.t_layers = 2, 2
+    torch.manual_seed(0)
+    cpu = Oryon(default_model_args(), "cpu", clip_cfg=cfg).eval()
+    gpu = copy.deepcopy(cpu)
+    gpu.device = "cuda"
+    gpu.vlm.device = "cuda"
+    gpu = gpu.to("cuda").eval()
+    B = 2
+    gen = torch.Generator().manual_seed(3)
+    toks = torch.randint(1, 49000, (1, 80, 77), generator=gen)
+    toks[..., 11] = 49407
+    toks[..., 12:] = 0
+    xs = {"anchor": {"rgb": torch.rand(B, 3, 224, 224, generator=gen)}, "query": {"rgb": torch.rand(B, 3, 224, 224, generator=gen)},
+          "prompt_tokens": toks.expand(B, 80, 77).contiguous()}
+    xg = {"anchor": {"rgb": xs["anchor"]["rgb"].cuda()}, "query": {"rgb": xs["query"]["rgb"].cuda()}, "prompt_tokens": xs["prompt_tokens"]}
+    with torch.no_grad():
+        ref = cpu(xs)
+        out = gpu(xg)
+    for k in ("featmap_a", "featmap_q", "mask_a", "mask_q"):
+        err = float((out[k].cpu() - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-4, (k, err)
+    # f2: a second batch with the same prompt set is served from the cache (the text tower must not run)
+    calls = []
+    orig = gpu.vlm.clip_model.text_features
+    gpu.vlm.clip_model.text_features = lambda t: (calls.append(1), orig(t))[1]
+    with torch.no_grad():
+        out2 = gpu(xg)
+    # (two GPU evaluations are not bit-identical: MIOpen / hipBLASLt pick their kernels per call)
+    assert calls == [] and float((out2["featmap_q"] - out["featmap_q"]).abs().max()) <= 1e-4 * float(out["featmap_q"].abs().max())
+    other = xs["prompt_tokens"].clone()
+    other[:, 0, 1] += 1
+    with torch.no_grad():
+        gpu({"anchor": xg["anchor"], "query": xg["query"], "prompt_tokens": other})
+    assert len(calls) == 1                                        # one new prompt set, shared by the B samples of the batch
+    # ... and an in-place weight update invalidates it
+    with torch.no_grad():
+        gpu.vlm.clip_model.text_projection.mul_(1.5)
+        gpu(xg)
+    assert len(calls) == 2

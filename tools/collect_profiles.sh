@@ -7,17 +7,17 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$R/gpurun_out/profiles}
 mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
 cd /tmp
-python $R/bench.py --no-cpu-baseline > "$OUT/bench_line.json" 2> /tmp/bench.err
+python $R/bench.py --no-cpu-baseline --no-stage-sets > "$OUT/bench_line.json" 2> /tmp/bench.err
 D=/tmp/prof_trace; rm -rf $D
-rocprofv3 --kernel-trace --stats -d $D -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $D -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-sets > /tmp/trace.log 2>&1
 python $R/tools/rocpd_summary.py $D/bench_results.db > "$OUT/kernel_stats.md"
-RX='screen_kernel|gather_normalise|pdsc_attention_kernel|match_decide|pdsc_linear'
+RX='screen_v2_kernel|gather_q8_v3|pdsc_attention|match_decide|match_resolve|pdsc_linear'
 {
   echo "# rocprofv3 PMC passes: bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap (2 engine passes, B=64), kernels /$RX/"
   for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
              "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     P=/tmp/prof_pmc; rm -rf $P
-    rocprofv3 --pmc $SET --kernel-trace --kernel-include-regex "$RX" -d $P -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap > /tmp/pmc.log 2>&1
+    rocprofv3 --pmc $SET --kernel-trace --kernel-include-regex "$RX" -d $P -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stage-sets --no-overlap > /tmp/pmc.log 2>&1
     echo; echo "## pass: $SET"; echo
     python $R/tools/rocpd_summary.py $P/p_results.db | sed -n '/## PMC counters/,$p' | tail -n +3
   done
