@@ -160,6 +160,8 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
     key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
     xs = {"anchor": {"rgb": rgb_a}, "query": {"rgb": rgb_q}, "prompt_tokens": toks}
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if backbone_dtype == "bf16" else torch.autocast("cuda", enabled=False)
+    from oryon_amd.backbone import clip as clip_mod
+    clip_mod.FP16X3_LINEAR = backbone_dtype == "fp16x3"       # fp32 tensors, linears on the fp16 pipe with split operands (B4)
     if backbone_dtype == "bf16w":
         model = model.to(torch.bfloat16)
         xs["anchor"]["rgb"], xs["query"]["rgb"] = rgb_a.to(torch.bfloat16), rgb_q.to(torch.bfloat16)
@@ -221,7 +223,7 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
         return None
     # ~0.39 TFLOP per ViT-L/14@336 image, 2 images per pair; fusion + decoder alone: 2.4 + 3.3 GFLOP per image
     flops_backbone = B * 2 * (5.7e9 if decode_only else 0.39e12)
-    peak = PEAK_FP32_MFMA_TFLOPS if backbone_dtype == "fp32" else PEAK_F16_MFMA_TFLOPS
+    peak = PEAK_FP32_MFMA_TFLOPS if backbone_dtype in ("fp32", "fp16x3") else PEAK_F16_MFMA_TFLOPS
     achieved = flops_backbone / (bb_ms * 1e-3) / 1e12
     return {
         "metric": ("image-pairs/sec (decode+match+reg): fusion + decoder on cached CLIP / Swin encodings (-> C=32 @192x192), then match + pose"
@@ -231,6 +233,8 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
         "value": total * steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "backbone_ms_per_step": bb_ms, "pairs_per_gpu": B, "pairs_ok": pairs_ok,
         "dtype": {"fp32": "f32 (PyTorch-ROCm fp32 GEMMs / convolutions, TF32-style shortcuts off)",
+                  "fp16x3": "f32 tensors; CLIP linears as error-compensated fp16x3 MFMA GEMMs (oryon_linear_f16x3: ~1e-6 relative, fp32-grade), "
+                            "everything else PyTorch-ROCm fp32",
                   "bf16": "bf16 backbone GEMMs (autocast), f32 match+pose",
                   "bf16w": "bf16 backbone (weights + activations), f32 match+pose"}[backbone_dtype],
         "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
@@ -303,7 +307,7 @@ def main():
                          "forward on cached CLIP / Swin encodings, then match + pose (SURVEY 8d 'decode+match+pose'); full: random-init "
                          "CLIP ViT-L/14@336 + Swin-B + fusion + decoder forward on 224x224 RGB (-> C=32 @192x192, the reference's own "
                          "shapes), then match + pose - a separate stage set, never mixed into the headline")
-    ap.add_argument("--backbone-dtype", choices=["fp32", "bf16", "bf16w"], default="fp32",
+    ap.add_argument("--backbone-dtype", choices=["fp32", "fp16x3", "bf16", "bf16w"], default="fp32",
                     help="fp32 | bf16 (autocast over fp32 weights) | bf16w (weights converted to bf16 once)")
     ap.add_argument("--overlap-gather", action="store_true", help="K0 gather of step k+1 on its own stream under the screening of step k")
     ap.add_argument("--no-overlap", action="store_true",
@@ -474,10 +478,11 @@ def main():
     if not a.no_stage_sets:
         del inputs, engine
         torch.cuda.empty_cache()
-        for stage in ("decode", "full"):
-            r = run_stage_set(a, rank, world, dev, stage, steps=3, warmup=1)
+        for stage, bdt, label in (("decode", "fp32", "decode+match+pose"), ("full", "fp32", "full (feat+match+pose), fp32 torch linears"),
+                                  ("full", "fp16x3", "full (feat+match+pose), fp16x3 linears")):
+            r = run_stage_set(a, rank, world, dev, stage, steps=3, warmup=1, backbone_dtype=bdt)
             if rank == 0:
-                stage_recs["decode+match+pose" if stage == "decode" else "full (feat+match+pose)"] = r
+                stage_recs[label] = r
     if rank == 0:
         rec["stages"] = stage_recs or None
         print(json.dumps(rec), flush=True)

@@ -292,6 +292,16 @@ int oryon_pointdsc_hypotheses(oryon_pointdsc_t *handle, const float *src, const 
 int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const float *tgt, const int32_t *n, int B,
                           int n_cap, const float *T_in, float *T_out, uint8_t *labels, void *stream);
 
+/* B4  error-compensated fp16x3 linear layer for the frozen fp32 towers (CLIP ViT-L/14@336, Swin) of Oryon.forward
+ *     (net.py:142-167, models/vlm.py:43-61; the reference evaluates them with fp32 torch linears):
+ *         C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]),   W = W_hi + W_lo (two fp16 matrices made once by oryon_split_f16x3)
+ *     with every product accumulated as Ahi*Whi + Ahi*Wlo + Alo*Whi on the fp16 matrix pipe (fp32 accumulate): ~2^-22 relative, i.e.
+ *     fp32-grade results at ~3x the fp32-MFMA rate.  act: 0 = none, 1 = QuickGELU x*sigmoid(1.702x) fused into the epilogue.
+ *     K % 32 == 0, N % 256 == 0, |values| < 65504. */
+int oryon_split_f16x3(const float *x, int64_t n, void *hi_f16, void *lo_f16, void *stream);
+int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,
+                       void *stream);
+
 /* f3  pose-accuracy metrics on the device for a batch of pairs.
  *     Replaces utils/metrics.py:194-220 (compute_add / compute_adds, with the FLOAT16 model transform of utils/pcd.py:127-133) and
  *     utils/metrics.py:222-259 (compute_RT_distances) of the reference's evaluator (utils/evaluator.py:206-256).

@@ -65,6 +65,20 @@ class PatchEmbed(nn.Conv2d):
         return self.tokens(x).permute(0, 3, 1, 2)
 
 
+# Inference switch: evaluate the towers' linear layers with the error-compensated fp16x3 kernel (ops.linear_f16x3, B4) instead of
+# torch's fp32 GEMMs.  Results stay fp32-grade (descriptor maps within ~1e-5 of the fp32 evaluation, tests/test_backbone_pins.py).
+FP16X3_LINEAR = False
+
+
+def _linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], quick_gelu: bool = False) -> Tensor:
+    if FP16X3_LINEAR:
+        from .. import ops
+        if ops.linear_f16x3_supported(x, weight):
+            return ops.linear_f16x3(x, weight, bias, quick_gelu=quick_gelu)
+    y = F.linear(x, weight, bias)
+    return y * torch.sigmoid(1.702 * y) if quick_gelu else y
+
+
 class _Attention(nn.Module):
     """Packed-qkv multi-head attention with nn.MultiheadAttention's parameter names."""
 
@@ -78,10 +92,10 @@ class _Attention(nn.Module):
 
     def forward(self, x: Tensor, causal: bool) -> Tensor:            # x: [N, L, D]
         N, L, D = x.shape
-        qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias).view(N, L, 3, self.heads, D // self.heads)
+        qkv = _linear(x, self.in_proj_weight, self.in_proj_bias).view(N, L, 3, self.heads, D // self.heads)
         q, k, v = qkv.permute(2, 0, 3, 1, 4)                          # [N, H, L, d] each
         o = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
-        return self.out_proj(o.transpose(1, 2).reshape(N, L, D))
+        return _linear(o.transpose(1, 2).reshape(N, L, D), self.out_proj.weight, self.out_proj.bias)
 
 
 class _MLP(nn.Module):
@@ -91,11 +105,16 @@ class _MLP(nn.Module):
         self.c_proj = nn.Linear(4 * width, width)
 
     def forward(self, x: Tensor) -> Tensor:
+        if FP16X3_LINEAR and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
+            return self.forward_x3(x)
         h = self.c_fc(x)
         if h.is_cuda and h.dtype == torch.bfloat16 and not torch.is_grad_enabled():
             from .. import ops                      # fused QuickGELU (B1): one pass instead of three bandwidth-bound ones
             return self.c_proj(ops.quick_gelu_bf16(h))
         return self.c_proj(h * torch.sigmoid(1.702 * h))
+
+    def forward_x3(self, x: Tensor) -> Tensor:
+        return _linear(_linear(x, self.c_fc.weight, self.c_fc.bias, quick_gelu=True), self.c_proj.weight, self.c_proj.bias)
 
 
 class _Block(nn.Module):

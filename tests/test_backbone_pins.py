@@ -208,3 +208,43 @@ def test_oryon_forward_gpu_equals_cpu_and_prompt_cache():
         gpu.vlm.clip_model.text_projection.mul_(1.5)
         gpu(xg)
     assert len(calls) == 2
+
+
+@pytest.mark.gpu
+def test_fp16x3_linear_and_clip_tower_match_fp32():
+    """B4 (oryon_linear_f16x3): the error-compensated fp16x3 linear against an fp64 reference (must be at least as accurate as torch's
+    fp32 linear), ragged M, fused QuickGELU; and the CLIP image tower evaluated with it against the fp32 torch evaluation: patch tokens
+    within 1e-5 relative - an order of magnitude inside the 1e-4 descriptor bar that bf16 cannot meet."""
+    from oryon_amd import ops
+    from oryon_amd.backbone import clip as clip_mod
+    from oryon_amd.backbone.clip import CLIP, CLIPConfig
+    torch.backends.cuda.matmul.allow_tf32 = False
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(1)
+    for M, K, N, gelu in ((577 * 3, 1024, 3072, False), (1000, 1024, 4096, True), (130, 4096, 1024, False), (1, 64, 256, False)):
+        x = torch.randn(M, K, generator=g, device=dev) * 3.0
+        w = torch.randn(N, K, generator=g, device=dev) * K ** -0.5
+        b = torch.randn(N, generator=g, device=dev)
+        assert ops.linear_f16x3_supported(x, w)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        f32 = torch.nn.functional.linear(x, w, b)
+        if gelu:
+            ref, f32 = ref * torch.sigmoid(1.702 * ref), f32 * torch.sigmoid(1.702 * f32)
+        got = ops.linear_f16x3(x, w, b, quick_gelu=gelu)
+        scale = float(ref.abs().max())
+        e_x3, e_32 = float((got.double() - ref).abs().max()) / scale, float((f32.double() - ref).abs().max()) / scale
+        assert e_x3 < 5e-6 and e_x3 <= 2.0 * e_32 + 1e-7, (M, K, N, e_x3, e_32)
+    assert not ops.linear_f16x3_supported(torch.zeros(4, 100, device=dev), torch.zeros(256, 100, device=dev))    # K % 32
+    cfg = CLIPConfig.vit_l14_336()
+    cfg.v_layers, cfg.t_layers = 3, 1
+    torch.manual_seed(0)
+    m = CLIP(cfg).to(dev).eval()
+    img = torch.randn(2, 3, 336, 336, device=dev)
+    with torch.no_grad():
+        ref = m.patch_tokens(img)
+        clip_mod.FP16X3_LINEAR = True
+        try:
+            got = m.patch_tokens(img)
+        finally:
+            clip_mod.FP16X3_LINEAR = False
+    assert float((got - ref).abs().max()) < 1e-5 * float(ref.abs().max())
