@@ -220,6 +220,7 @@ def test_fp16x3_linear_and_clip_tower_match_fp32():
     from oryon_amd.backbone.clip import CLIP, CLIPConfig
     torch.backends.cuda.matmul.allow_tf32 = False
     dev = "cuda"
+    torch.set_grad_enabled(False)                # inference-only kernel: the dispatch refuses to run under autograd
     g = torch.Generator(device=dev).manual_seed(1)
     for M, K, N, gelu in ((577 * 3, 1024, 3072, False), (1000, 1024, 4096, True), (130, 4096, 1024, False), (1, 64, 256, False)):
         x = torch.randn(M, K, generator=g, device=dev) * 3.0
@@ -247,4 +248,5 @@ def test_fp16x3_linear_and_clip_tower_match_fp32():
             got = m.patch_tokens(img)
         finally:
             clip_mod.FP16X3_LINEAR = False
+    torch.set_grad_enabled(True)
     assert float((got - ref).abs().max()) < 1e-5 * float(ref.abs().max())
