@@ -854,6 +854,8 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    if ((VAR & 32) && wave_u >= 2) __builtin_amdgcn_s_setprio(1);          // experiment: static priority for half of the waves
+    if (VAR & 64) __builtin_amdgcn_s_setprio(2);                            // experiment: every screening wave above co-resident kernels
     i32x4 areg[NKS];
 #pragma unroll
     for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, 0u);
@@ -1218,7 +1220,7 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
     static const int ablate = getenv("ORYON_SCREEN8_ABLATE") ? atoi(getenv("ORYON_SCREEN8_ABLATE")) : 0;
     if (ablate && CP == 256) {
 #define ABL(V) case V: hipLaunchKernelGGL((match_i8_screen_v2_kernel<256, V>), dim3(groups), dim3(256), 0, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, ws_max, ws_i1, ws_m2); break
-        switch (ablate) { ABL(1); ABL(2); ABL(3); ABL(8); ABL(16); default: ABL(17); }
+        switch (ablate) { ABL(1); ABL(2); ABL(3); ABL(8); ABL(32); default: ABL(64); }
 #undef ABL
         return;
     }

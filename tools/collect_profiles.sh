@@ -22,4 +22,11 @@ RX='screen_v2_kernel|gather_q8_v3|pdsc_attention|match_decide|match_resolve|pdsc
     python $R/tools/rocpd_summary.py $P/p_results.db | sed -n '/## PMC counters/,$p' | tail -n +3
   done
 } > "$OUT/pmc_counters.md"
+# FETCH_SIZE calibration for 4 B/lane loads (the NCHW gather's access width): 1 GiB read once per kernel
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_fetch $R/tools/probe_fetch_calib.hip 2>/dev/null && {
+  P=/tmp/prof_cal; rm -rf $P
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P -o c -- /tmp/probe_fetch > /tmp/cal.log 2>&1
+  { echo; echo "## FETCH_SIZE calibration: 1 GiB (1048576 KiB) read once by each kernel"; echo
+    python $R/tools/rocpd_summary.py $P/c_results.db | sed -n '/## PMC counters/,$p' | tail -n +3; } >> "$OUT/pmc_counters.md"
+}
 ls -la "$OUT"
