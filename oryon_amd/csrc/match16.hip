@@ -1021,7 +1021,8 @@ __global__ __launch_bounds__(256) void match_scatter8_kernel(int cap_a, const in
 
 static int pick_split16(int B, int T)
 {
-    int S = (8192 + B * T - 1) / (B * T);
+    static const int target = getenv("ORYON_SCREEN_WGS") ? atoi(getenv("ORYON_SCREEN_WGS")) : 8192;     // timing experiments only
+    int S = (target + B * T - 1) / (B * T);
     if (S < 1) S = 1;
     if (S > 16) S = 16;
     return S;

@@ -120,10 +120,9 @@ class MatchPoseEngine:
             gctx.__enter__()
             if inputs_event is not None:
                 self._gather_stream.wait_event(inputs_event)
-        masks = torch.cat((mask_a.reshape(B, FH, FW), mask_q.reshape(B, FH, FW)), dim=0)
-        roi, cnt = ops.roi_compact(masks)
-        roi_a, roi_q = roi[:B], roi[B:]
-        n_a, n_q = cnt[:B], cnt[B:]
+        # two launches on the callers' tensors instead of a torch.cat + one launch: no torch arithmetic inside the step
+        roi_a, n_a = ops.roi_compact(mask_a.reshape(B, FH, FW))
+        roi_q, n_q = ops.roi_compact(mask_q.reshape(B, FH, FW))
         if cfg.src_sampling is not None:
             ops.roi_subsample_(roi_a, n_a, cfg.src_sampling, cfg.seed, pair_key)
             cap_a = ops.round_up(min(cfg.src_sampling, FH * FW), ops.ROW_PAD)
@@ -149,7 +148,7 @@ class MatchPoseEngine:
             gathered.record(self._gather_stream)
             gctx.__exit__(None, None, None)
             main.wait_event(gathered)
-            for t_ in (roi, cnt, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, q_norm):
+            for t_ in (roi_a, roi_q, n_a, n_q, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, q_norm):
                 if t_ is not None:
                     t_.record_stream(main)
         if use_i8:

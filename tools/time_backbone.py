@@ -4,6 +4,9 @@ from oryon_amd.net import Oryon, default_model_args
 dev = "cuda"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dt = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
+if len(sys.argv) > 2 and sys.argv[2] == "fp16x3":
+    from oryon_amd.backbone import clip as _c
+    _c.FP16X3_LINEAR = True
 torch.manual_seed(0)
 m = Oryon(default_model_args(), dev).eval().to(dt)
 rgb = torch.rand(2 * B, 3, 224, 224, device=dev, dtype=dt)
