@@ -162,6 +162,8 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if backbone_dtype == "bf16" else torch.autocast("cuda", enabled=False)
     from oryon_amd.backbone import clip as clip_mod
     clip_mod.FP16X3_LINEAR = backbone_dtype == "fp16x3"       # fp32 tensors, linears on the fp16 pipe with split operands (B4)
+    from oryon_amd.backbone import swin as swin_mod
+    swin_mod.FUSED_F32_ATTENTION = backbone_dtype == "fp16x3"  # ... and the Swin window attention as one fp32 kernel (B3 on fp32 tensors)
     if backbone_dtype == "bf16w":
         model = model.to(torch.bfloat16)
         xs["anchor"]["rgb"], xs["query"]["rgb"] = rgb_a.to(torch.bfloat16), rgb_q.to(torch.bfloat16)

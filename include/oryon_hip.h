@@ -85,6 +85,9 @@ int oryon_add_layernorm_bf16(const void *x, const void *delta, const void *gamma
  *     out     [B, H, W, C] bf16;  C == heads * 32, heads <= 8, 0 <= shift < 7 (torchvision passes 0 or 3) */
 int oryon_swin_window_attention_bf16(const void *qkv, const void *pad_qkv, const float *bias_t, int B, int H, int W, int C, int heads,
                                      int shift, void *out, void *stream);
+/* the same kernel on fp32 tensors (fp32 evaluation of the guidance tower; arithmetic identical, no rounding at the ends) */
+int oryon_swin_window_attention_f32(const float *qkv, const float *pad_qkv, const float *bias_t, int B, int H, int W, int C, int heads,
+                                    int shift, float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K0  mask -> ROI.   Replaces torch.nonzero(mask == 1) (utils/pcd.py:184-185) and the validity test

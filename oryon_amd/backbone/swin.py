@@ -25,6 +25,11 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
+# fp32 inference switch: shifted-window attention as ONE HIP kernel (oryon_swin_window_attention_f32) instead of torch's dozen
+# bandwidth-bound passes; fp32 arithmetic, results within ~1e-6 of the plain path (tests/test_backbone_pins.py)
+FUSED_F32_ATTENTION = False
+
+
 def _relative_index(w: int) -> Tensor:
     ys, xs = torch.meshgrid(torch.arange(w), torch.arange(w), indexing="ij")
     pos = torch.stack((ys.reshape(-1), xs.reshape(-1)))                 # [2, w*w]
@@ -64,6 +69,12 @@ class _WindowAttention(nn.Module):
             bias_t = self.relative_position_bias_table[self.relative_position_index].view(w * w, w * w, nh).permute(2, 1, 0)
             pad = self.qkv.bias if self.qkv.bias is not None else torch.zeros(3 * C, dtype=x.dtype, device=x.device)
             out = ops.swin_window_attention_bf16(self.qkv(x), pad, bias_t.float().contiguous(), nh, s)
+            return self.proj(out)
+        if FUSED_F32_ATTENTION and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and w == 7 and C == 32 * nh and nh <= 8:
+            from .. import ops                      # fp32 inference: the same single kernel on fp32 tensors
+            bias_t = self.relative_position_bias_table[self.relative_position_index].view(w * w, w * w, nh).permute(2, 1, 0)
+            pad = self.qkv.bias if self.qkv.bias is not None else torch.zeros(3 * C, dtype=x.dtype, device=x.device)
+            out = ops.swin_window_attention_f32(self.qkv(x), pad.detach(), bias_t.detach().contiguous(), nh, s)
             return self.proj(out)
         pb, pr = (w - H % w) % w, (w - W % w) % w
         x = F.pad(x, (0, 0, 0, pr, 0, pb))

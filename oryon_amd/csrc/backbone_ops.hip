@@ -162,11 +162,23 @@ __device__ __forceinline__ void load_head_slice(const unsigned short *p, float (
     }
 }
 
-__global__ __launch_bounds__(512) void swin_window_attention_bf16_kernel(const unsigned short *__restrict__ qkv,
-                                                                          const unsigned short *__restrict__ pad_qkv,
-                                                                          const float *__restrict__ bias_t, int H, int W, int C,
-                                                                          int shift, unsigned short *__restrict__ out)
+__device__ __forceinline__ void load_head_slice(const float *p, float (&f)[SWIN_HD])
 {
+#pragma unroll
+    for (int c = 0; c < SWIN_HD / 4; ++c) {
+        const float4 u = *reinterpret_cast<const float4 *>(p + c * 4);
+        f[c * 4] = u.x; f[c * 4 + 1] = u.y; f[c * 4 + 2] = u.z; f[c * 4 + 3] = u.w;
+    }
+}
+
+// IO = unsigned short (bf16 bits) or float: the arithmetic is fp32 either way.  The float instantiation serves the fp32 evaluation
+// of the guidance tower (`full` stage set: torch's dozen passes cost 54 ms per 128 images).
+template <typename IO>
+__global__ __launch_bounds__(512) void swin_window_attention_kernel(const IO *__restrict__ qkv, const IO *__restrict__ pad_qkv,
+                                                                     const float *__restrict__ bias_t, int H, int W, int C, int shift,
+                                                                     IO *__restrict__ out)
+{
+    constexpr bool F32 = sizeof(IO) == 4;
     extern __shared__ float swin_lds[];
     const int head = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *Ks = swin_lds + head * SWIN_WAVE_FLOATS;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(512) void swin_window_attention_bf16_kernel(const u
         }
         const size_t t = ((size_t)b * H + sy) * W + sx;
         out_off = t * C + head * SWIN_HD;
-        const unsigned short *src = real ? qkv + t * 3 * C + head * SWIN_HD : pad_qkv + head * SWIN_HD;
+        const IO *src = real ? qkv + t * 3 * C + head * SWIN_HD : pad_qkv + head * SWIN_HD;
         float kv[SWIN_HD];
         load_head_slice(src, q);
         const float scale = 0.17677669529663687f;                                            // 32^-0.5
@@ -227,8 +239,8 @@ __global__ __launch_bounds__(512) void swin_window_attention_bf16_kernel(const u
         float a = a0 + a1 + bt[j * SWIN_N];
         if (labs[j] != label) a -= 100.0f;
         const float m_new = fmaxf(m, a);
-        const float corr = __expf(m - m_new);           // exp(-inf) = 0 on the first key
-        const float p = __expf(a - m_new);
+        const float corr = F32 ? expf(m - m_new) : __expf(m - m_new);           // exp(-inf) = 0 on the first key
+        const float p = F32 ? expf(a - m_new) : __expf(a - m_new);
         m = m_new;
         sum = fmaf(sum, corr, p);
 #pragma unroll
@@ -240,13 +252,18 @@ __global__ __launch_bounds__(512) void swin_window_attention_bf16_kernel(const u
     }
     if (!real) return;                                                                      // pad tokens are cropped away
     const float inv = 1.0f / sum;
+    if constexpr (F32) {
+#pragma unroll
+        for (int c = 0; c < SWIN_HD / 4; ++c)
+            *reinterpret_cast<float4 *>(out + out_off + c * 4) = make_float4(acc[c * 4] * inv, acc[c * 4 + 1] * inv, acc[c * 4 + 2] * inv, acc[c * 4 + 3] * inv);
+    } else
 #pragma unroll
     for (int c = 0; c < SWIN_HD / 8; ++c) {
         unsigned w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             w[j] = (unsigned)float_to_bf16_bits(acc[c * 8 + 2 * j] * inv) | ((unsigned)float_to_bf16_bits(acc[c * 8 + 2 * j + 1] * inv) << 16);
-        *reinterpret_cast<uint4 *>(out + out_off + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(out) + out_off + c * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -301,10 +318,26 @@ extern "C" int oryon_swin_window_attention_bf16(const void *qkv, const void *pad
     if (B == 0) return ORYON_OK;
     const int nwy = (H + SWIN_WS - 1) / SWIN_WS, nwx = (W + SWIN_WS - 1) / SWIN_WS;
     const size_t lds = (size_t)heads * SWIN_WAVE_FLOATS * sizeof(float);
-    allow_dynamic_lds(reinterpret_cast<const void *>(swin_window_attention_bf16_kernel), 8 * SWIN_WAVE_FLOATS * (int)sizeof(float));
-    hipLaunchKernelGGL(swin_window_attention_bf16_kernel, dim3(nwy * nwx, B), dim3(64 * heads), lds, as_stream(stream),
+    allow_dynamic_lds(reinterpret_cast<const void *>(swin_window_attention_kernel<unsigned short>), 8 * SWIN_WAVE_FLOATS * (int)sizeof(float));
+    hipLaunchKernelGGL(swin_window_attention_kernel<unsigned short>, dim3(nwy * nwx, B), dim3(64 * heads), lds, as_stream(stream),
                        static_cast<const unsigned short *>(qkv), static_cast<const unsigned short *>(pad_qkv), bias_t, H, W, C, shift,
                        static_cast<unsigned short *>(out));
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_swin_window_attention_f32(const float *qkv, const float *pad_qkv, const float *bias_t, int B, int H, int W, int C,
+                                               int heads, int shift, float *out, void *stream)
+{
+    ORYON_CHECK_ARG(qkv && pad_qkv && bias_t && out && B >= 0 && H > 0 && W > 0 && heads >= 1 && heads <= 8 && C == heads * SWIN_HD);
+    ORYON_CHECK_ARG(shift >= 0 && shift < SWIN_WS);
+    ORYON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)pad_qkv | (uintptr_t)out) & 15) == 0);
+    if (B == 0) return ORYON_OK;
+    const int nwy = (H + SWIN_WS - 1) / SWIN_WS, nwx = (W + SWIN_WS - 1) / SWIN_WS;
+    const size_t lds = (size_t)heads * SWIN_WAVE_FLOATS * sizeof(float);
+    allow_dynamic_lds(reinterpret_cast<const void *>(swin_window_attention_kernel<float>), 8 * SWIN_WAVE_FLOATS * (int)sizeof(float));
+    hipLaunchKernelGGL(swin_window_attention_kernel<float>, dim3(nwy * nwx, B), dim3(64 * heads), lds, as_stream(stream), qkv, pad_qkv, bias_t,
+                       H, W, C, shift, out);
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

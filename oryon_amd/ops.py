@@ -96,6 +96,21 @@ def swin_window_attention_bf16(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t:
 
 
 @_on_tensor_device
+def swin_window_attention_f32(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, shift: int) -> torch.Tensor:
+    """The B3 kernel on fp32 tensors: [B,H,W,3C] fp32 -> [B,H,W,C] fp32 (fp32 evaluation of the Swin guidance tower)."""
+    _lib.require_gpu(qkv.device)
+    assert qkv.dtype == torch.float32 and pad_qkv.dtype == torch.float32 and bias_t.dtype == torch.float32
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    assert C3 == 3 * C and pad_qkv.numel() == C3 and bias_t.shape == (heads, 49, 49)
+    qkv = qkv.contiguous()
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=qkv.device)
+    check(lib().oryon_swin_window_attention_f32(ptr(qkv), ptr(pad_qkv.contiguous()), ptr(bias_t.contiguous()), B, H, W, C, heads, shift,
+                                                ptr(out), stream_ptr(qkv.device)), "oryon_swin_window_attention_f32")
+    return out
+
+
+@_on_tensor_device
 def rgb_resize_bilinear(rgb_hwc: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
     """uint8 [n,HI,WI,3] -> fp32 [n,3,HO,WO] in [0,1] (K-1: /255., CHW, bilinear align_corners=False, fp64 arithmetic)."""
     _lib.require_gpu(rgb_hwc.device)

@@ -7,6 +7,8 @@ dt = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.
 if len(sys.argv) > 2 and sys.argv[2] == "fp16x3":
     from oryon_amd.backbone import clip as _c
     _c.FP16X3_LINEAR = True
+    from oryon_amd.backbone import swin as _s
+    _s.FUSED_F32_ATTENTION = True
 torch.manual_seed(0)
 m = Oryon(default_model_args(), dev).eval().to(dt)
 rgb = torch.rand(2 * B, 3, 224, 224, device=dev, dtype=dt)
