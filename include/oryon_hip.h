@@ -198,8 +198,10 @@ int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8, const floa
 /* K1s8 + K1b fused and LAZY (round 2): from the K0v3 operands straight to the sampled correspondences of every pair
  * (utils/pcd.py:202-214).  The int8 bound settles the validity flag of almost every anchor without its argmin; candidate generation
  * and exact re-scoring then run for the <= max_corrs sampled anchors only.  Anchors whose validity the bound cannot settle are resolved
- * exactly before the sampling; a pair with an ambiguous possibly-valid anchor (or every pair when force_eager != 0) takes the eager
- * route of oryon_match_screened8_raw.  corrs / n_valid / n_sel / status are exactly what oryon_select_corrs returns on the outputs of
+ * exactly before the sampling.  AMBIGUOUS anchors (runner-up slice within the int8 margin of the best one) are resolved by the exact
+ * fp32 scan K1 on a compacted list of just those rows - before the sampling if their validity is open, after it (sampled rows only)
+ * if the bound already proves them valid - against fp32 query rows materialised for that pair inside the call.  force_eager != 0
+ * sends every pair through the complete tail of oryon_match_screened8_raw instead (all of min_dist / argmin exact).  corrs / n_valid / n_sel / status are exactly what oryon_select_corrs returns on the outputs of
  * oryon_match_screened8_raw.  valid [B,cap_a] is exact on every row; min_dist / argmin are exact on sampled rows and on every row of
  * an eager pair, and hold the screening estimate / 0 elsewhere. */
 size_t oryon_match_corrs_i8_workspace_bytes(int B, int C, int cap_a, int cap_q, int corr_rows);

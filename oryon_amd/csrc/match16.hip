@@ -1420,7 +1420,11 @@ int select_corrs_launch(const int32_t *roi_a, const int32_t *roi_q, int roi_stri
                         int corr_rows, uint64_t seed, const int64_t *pair_key, int32_t *scratch, int32_t *corrs, int32_t *n_valid,
                         int32_t *n_sel, int32_t *status, int32_t *sel_rows, const int32_t *pair_eager, hipStream_t st);
 
-constexpr uint8_t LZ_INVALID = 0, LZ_VALID = 1, LZ_UNCERTAIN = 2, LZ_AMBIGUOUS = 3, LZ_RESOLVED = 4;
+// INVALID / VALID: settled by the int8 bound.  UNCERTAIN: unambiguous winner slice, validity not settled (resolved from that slice before
+// the sampling).  AMB_VALID: validity settled (valid) but the runner-up slice is within the int8 margin - the exact argmin is computed
+// only if the row gets sampled.  AMB_UNCERTAIN: neither settled - resolved before the sampling.  Both AMB kinds are resolved by the EXACT
+// fp32 scan (K1) on a compacted list of just those anchor rows against the pair's materialised fp32 query rows.
+constexpr uint8_t LZ_INVALID = 0, LZ_VALID = 1, LZ_UNCERTAIN = 2, LZ_AMB_VALID = 3, LZ_RESOLVED = 4, LZ_AMB_UNCERTAIN = 5;
 
 // one THREAD per anchor: merge the per-split (m1, slice, m2) triples and classify
 __global__ __launch_bounds__(256) void match_decide_lite_kernel(
@@ -1428,7 +1432,8 @@ __global__ __launch_bounds__(256) void match_decide_lite_kernel(
     const float *__restrict__ ws_m2, const float *__restrict__ a_scale8, const float *__restrict__ eps_q8, float cut0, float sqrt_c,
     float c_true, int force_eager, float *__restrict__ m_final, int32_t *__restrict__ sid_final, float *__restrict__ margin_out,
     uint8_t *__restrict__ state, uint8_t *__restrict__ valid, float *__restrict__ min_dist, int32_t *__restrict__ argmin,
-    int32_t *__restrict__ pair_eager, int32_t *__restrict__ n_unc, int32_t *__restrict__ unc_idx)
+    int32_t *__restrict__ pair_eager, int32_t *__restrict__ n_unc, int32_t *__restrict__ unc_idx, int32_t *__restrict__ n_ambu,
+    int32_t *__restrict__ ambu_idx, int32_t *__restrict__ need_f32_lazy, int32_t *__restrict__ n_amb_total)
 {
     const int p = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
     if (a >= n_a[p]) return;
@@ -1452,17 +1457,23 @@ __global__ __launch_bounds__(256) void match_decide_lite_kernel(
     sid_final[arow] = sid;
     margin_out[arow] = margin;
     uint8_t st;
+    const bool certain_valid = usable && m1 > cut0 + delta + 1e-5f;
     if (usable && !(m1 >= cut0 - delta - 1e-6f)) st = LZ_INVALID;
-    else if (!(m1 - m2 > margin)) st = LZ_AMBIGUOUS;
-    else if (m1 > cut0 + delta + 1e-5f) st = LZ_VALID;
+    else if (!(m1 - m2 > margin)) st = certain_valid ? LZ_AMB_VALID : LZ_AMB_UNCERTAIN;
+    else if (certain_valid) st = LZ_VALID;
     else st = LZ_UNCERTAIN;
     state[arow] = st;
     // provisional outputs: the distance is the screening estimate until (unless) the row is resolved exactly
     min_dist[arow] = __fmaf_rn(-0.5f, m1, 0.5f);
     argmin[arow] = 0;
-    valid[arow] = st == LZ_VALID ? 1 : 0;
-    if (st == LZ_AMBIGUOUS || force_eager) pair_eager[p] = 1;
+    valid[arow] = (st == LZ_VALID || st == LZ_AMB_VALID) ? 1 : 0;
+    if (force_eager) { pair_eager[p] = 1; return; }
     if (st == LZ_UNCERTAIN) unc_idx[(size_t)p * cap_a + atomicAdd(&n_unc[p], 1)] = a;
+    if (st == LZ_AMB_UNCERTAIN) ambu_idx[(size_t)p * cap_a + atomicAdd(&n_ambu[p], 1)] = a;
+    if (st == LZ_AMB_VALID || st == LZ_AMB_UNCERTAIN) {
+        need_f32_lazy[p] = 1;                                  // this pair's fp32 query rows get materialised (device-gated launch)
+        atomicAdd(&n_amb_total[p], 1);
+    }
 }
 
 __global__ void match_mask_counts_kernel(int B, const int32_t *__restrict__ n_a, const int32_t *__restrict__ pair_eager,
@@ -1472,6 +1483,70 @@ __global__ void match_mask_counts_kernel(int B, const int32_t *__restrict__ n_a,
     if (p >= B) return;
     n_a_eager[p] = pair_eager[p] ? n_a[p] : 0;
     n_a_lazy[p] = pair_eager[p] ? 0 : n_a[p];
+}
+
+__global__ void match_sum_counts_kernel(int B, const int32_t *__restrict__ a, const int32_t *__restrict__ b, int32_t *__restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < B) out[p] = a[p] + b[p];
+}
+
+// fp32 anchor rows of a work list -> dense panels for the exact scan (rows [count, round_up(count, 128)) zero-filled)
+__global__ __launch_bounds__(256) void match_compact_f32_kernel(const float *__restrict__ a_hat, int Cp, int cap_a, int cap_c,
+                                                                 const int32_t *__restrict__ count, const int32_t *__restrict__ idx,
+                                                                 int idx_stride, float *__restrict__ a_c)
+{
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
+    const int n = count[p] < cap_c ? count[p] : cap_c;
+    const int n_fill = (n + 127) / 128 * 128;
+    for (int g = 0; g < 16; ++g) {
+        const int sl = (blockIdx.x * 16 + g) * 4 + (threadIdx.x >> 6);
+        if (sl >= n_fill || sl >= cap_c) break;
+        uint4 *d = reinterpret_cast<uint4 *>(a_c + ((size_t)p * cap_c + sl) * Cp);
+        if (sl >= n) {
+            for (int i = lane; i < Cp / 4; i += 64) d[i] = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        const uint4 *src = reinterpret_cast<const uint4 *>(a_hat + ((size_t)p * cap_a + idx[(size_t)p * idx_stride + sl]) * Cp);
+        for (int i = lane; i < Cp / 4; i += 64) d[i] = src[i];
+    }
+}
+
+// results of an exact scan on a compacted work list -> the anchors' rows; the rows are marked RESOLVED (argmin / min_dist exact)
+__global__ __launch_bounds__(256) void match_scatter_exact_kernel(int cap_a, int cap_c, const int32_t *__restrict__ count,
+                                                                   const int32_t *__restrict__ idx, int idx_stride,
+                                                                   const float *__restrict__ md_c, const int32_t *__restrict__ am_c,
+                                                                   const uint8_t *__restrict__ va_c, float *__restrict__ min_dist,
+                                                                   int32_t *__restrict__ argmin, uint8_t *__restrict__ valid,
+                                                                   uint8_t *__restrict__ state)
+{
+    const int p = blockIdx.y, sl = blockIdx.x * 256 + threadIdx.x;
+    const int n = count[p] < cap_c ? count[p] : cap_c;
+    if (sl >= n) return;
+    const size_t src = (size_t)p * cap_c + sl, dst = (size_t)p * cap_a + idx[(size_t)p * idx_stride + sl];
+    min_dist[dst] = md_c[src];
+    argmin[dst] = am_c[src];
+    valid[dst] = va_c[src];
+    state[dst] = LZ_RESOLVED;
+}
+
+// the sampled slots whose anchor row is AMB_VALID (argmin still unknown) -> work list for the post-sampling exact scan.  One
+// workgroup per pair.
+__global__ __launch_bounds__(256) void match_list_sampled_amb_kernel(int cap_a, const uint8_t *__restrict__ state,
+                                                                      const int32_t *__restrict__ pair_eager, const int32_t *__restrict__ n_sel,
+                                                                      const int32_t *__restrict__ sel_rows, int corr_rows,
+                                                                      int32_t *__restrict__ mark, int32_t *__restrict__ n_list,
+                                                                      int32_t *__restrict__ list)
+{
+    const int p = blockIdx.x;
+    if (pair_eager[p]) return;
+    const int n = n_sel[p];
+    for (int s = threadIdx.x; s < n; s += 256) {
+        const int a = sel_rows[(size_t)p * corr_rows + s];
+        // a row drawn several times (sampling with replacement) is listed once
+        if (state[(size_t)p * cap_a + a] == LZ_AMB_VALID && atomicExch(&mark[(size_t)p * cap_a + a], 1) == 0)
+            list[(size_t)p * corr_rows + atomicAdd(&n_list[p], 1)] = a;
+    }
 }
 
 // Exact resolution of ONE unambiguous anchor by one wave: candidates = rows of the winning 16-row slice within the int8 margin of its
@@ -1622,6 +1697,9 @@ struct LazyWs {
     Screen8RawWs raw;
     float *margin;
     int32_t *sid_final, *pair_eager, *n_unc, *unc_idx, *n_a_eager, *n_a_lazy, *sel_rows, *scratch;
+    int32_t *n_ambu, *ambu_idx, *n_ambv, *ambv_idx, *need_f32_lazy, *n_amb_total, *mark;
+    void *exact_ws;
+    size_t exact_ws_bytes;
     uint8_t *state;
     size_t bytes, zero_off, zero_bytes;
 };
@@ -1641,9 +1719,21 @@ LazyWs carve_lazy(void *base, int B, int C, int cap_a, int cap_q, int S, int cor
     const size_t o_sc = take((size_t)B * cap_a * sizeof(int32_t));
     const size_t o_ne = take((size_t)B * sizeof(int32_t));
     const size_t o_nl = take((size_t)B * sizeof(int32_t));
+    const size_t o_au = take((size_t)B * cap_a * sizeof(int32_t));
+    const size_t o_av = take((size_t)B * corr_rows * sizeof(int32_t));
+    const int cap_s0 = (corr_rows + 127) / 128 * 128;
+    const int cap_s = cap_s0 < cap_a ? cap_s0 : cap_a;
+    const size_t e1 = oryon_match_workspace_bytes(B, cap_a), e2 = oryon_match_workspace_bytes(B, cap_s);
+    w.exact_ws_bytes = e1 > e2 ? e1 : e2;                                  // split-merge scratch of the exact scan (either list capacity)
+    const size_t o_ew = take(w.exact_ws_bytes > 16 ? w.exact_ws_bytes : 16);
     w.zero_off = off;
     const size_t o_pe = take((size_t)B * sizeof(int32_t));
     const size_t o_nu = take((size_t)B * sizeof(int32_t));
+    const size_t o_nau = take((size_t)B * sizeof(int32_t));
+    const size_t o_nav = take((size_t)B * sizeof(int32_t));
+    const size_t o_nfl = take((size_t)B * sizeof(int32_t));
+    const size_t o_nat = take((size_t)B * sizeof(int32_t));
+    const size_t o_mk = take((size_t)B * cap_a * sizeof(int32_t));
     w.zero_bytes = off - w.zero_off;
     w.bytes = off;
     auto at = [&](size_t o) { return base ? p + o : nullptr; };
@@ -1657,6 +1747,14 @@ LazyWs carve_lazy(void *base, int B, int C, int cap_a, int cap_q, int S, int cor
     w.n_a_lazy = reinterpret_cast<int32_t *>(at(o_nl));
     w.pair_eager = reinterpret_cast<int32_t *>(at(o_pe));
     w.n_unc = reinterpret_cast<int32_t *>(at(o_nu));
+    w.ambu_idx = reinterpret_cast<int32_t *>(at(o_au));
+    w.ambv_idx = reinterpret_cast<int32_t *>(at(o_av));
+    w.exact_ws = at(o_ew);
+    w.n_ambu = reinterpret_cast<int32_t *>(at(o_nau));
+    w.n_ambv = reinterpret_cast<int32_t *>(at(o_nav));
+    w.need_f32_lazy = reinterpret_cast<int32_t *>(at(o_nfl));
+    w.n_amb_total = reinterpret_cast<int32_t *>(at(o_nat));
+    w.mark = reinterpret_cast<int32_t *>(at(o_mk));
     return w;
 }
 }  // namespace
@@ -1706,7 +1804,7 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     const float sqrt_c = sqrtf((float)C_true);
     hipLaunchKernelGGL(match_decide_lite_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, n_a, S, w.ws_max, w.ws_i1, w.ws_m2, a_scale,
                        q_eps_max, cut0, sqrt_c, (float)C_true, force_eager, w.m_final, lw.sid_final, lw.margin, lw.state, valid, min_dist,
-                       argmin, lw.pair_eager, lw.n_unc, lw.unc_idx);
+                       argmin, lw.pair_eager, lw.n_unc, lw.unc_idx, lw.n_ambu, lw.ambu_idx, lw.need_f32_lazy, lw.n_amb_total);
     hipLaunchKernelGGL(match_mask_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_a, lw.pair_eager, lw.n_a_eager, lw.n_a_lazy);
     ORYON_CHECK_LAUNCH();
     // ---- eager route (the complete tail of oryon_match_screened8_raw) for the flagged pairs: every launch below sees 0 anchors elsewhere
@@ -1721,7 +1819,6 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     if (layout == ORYON_LAYOUT_NHWC) RESCORE_RAW_E(true); else RESCORE_RAW_E(false);
 #undef RESCORE_RAW_E
     ORYON_CHECK_LAUNCH();
-    if (n_undecided) ORYON_CHECK_HIP(hipMemcpyAsync(n_undecided, w.n_amb, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(match_need_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, w.n_amb, wr.need_f32);
     int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, wr.need_f32, cap_q, C, wr.q8_scratch, wr.scale_scratch,
                               wr.eps_scratch, nullptr, wr.q_hat, 1, round_f16, st);
@@ -1738,7 +1835,21 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     hipLaunchKernelGGL(match_scatter8_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, w.n_amb, w.amb_idx, w8.md_c, w8.am_c, w8.va_c,
                        min_dist, argmin, valid);
     ORYON_CHECK_LAUNCH();
-    // ---- lazy route: settle the undecided validity flags, sample, resolve the sampled rows
+    // ---- lazy route.  (1) pairs with ambiguous possibly-valid anchors get their fp32 query rows (device-gated, as on the eager route)
+    rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, lw.need_f32_lazy, cap_q, C, wr.q8_scratch, wr.scale_scratch,
+                          wr.eps_scratch, nullptr, wr.q_hat, 1, round_f16, st);
+    if (rc) { set_error("oryon_match_corrs_i8: lazy fp32 gather launch failed"); return rc; }
+    // (2) ambiguous anchors whose VALIDITY is open: exact fp32 scan (K1) of exactly those rows, before the sampling
+    hipLaunchKernelGGL(match_compact_f32_kernel, dim3(cap_a / 64, B), dim3(256), 0, st, a_hat, C, cap_a, cap_a, lw.n_ambu, lw.ambu_idx, cap_a,
+                       w8.a_hat_c);
+    ORYON_CHECK_LAUNCH();
+    rc = oryon_match_f32(w8.a_hat_c, wr.q_hat, B, C, cap_a, cap_q, lw.n_ambu, n_q, threshold, w8.md_c, w8.am_c, w8.va_c, lw.exact_ws,
+                         lw.exact_ws_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_scatter_exact_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, cap_a, lw.n_ambu, lw.ambu_idx, cap_a, w8.md_c,
+                       w8.am_c, w8.va_c, min_dist, argmin, valid, lw.state);
+    ORYON_CHECK_LAUNCH();
+    // (3) unambiguous anchors whose validity is open: exact distance from the winning slice's candidates
     const size_t lds_res = (size_t)4 * 2 * C * sizeof(float);
 #define RESOLVE_U(NHWCV)                                                                                                       \
     hipLaunchKernelGGL((match_resolve_uncertain_kernel<NHWCV>), dim3(64, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8, q_scale, a_scale,     \
@@ -1747,9 +1858,25 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     if (layout == ORYON_LAYOUT_NHWC) RESOLVE_U(true); else RESOLVE_U(false);
 #undef RESOLVE_U
     ORYON_CHECK_LAUNCH();
+    // (4) the sampling, on the exact valid set
     rc = select_corrs_launch(roi_a, roi_q, roi_stride_a, roi_stride_q, n_a, n_q, argmin, valid, cap_a, B, W, max_corrs, corr_rows, seed,
                              pair_key, lw.scratch, corrs, n_valid, n_sel, status, lw.sel_rows, lw.pair_eager, st);
     if (rc) { set_error("oryon_match_corrs_i8: select launch failed"); return rc; }
+    // (5) sampled rows that are ambiguous (valid for sure, argmin open): exact fp32 scan of just those <= max_corrs rows per pair
+    const int cap_s0 = (corr_rows + 127) / 128 * 128;
+    const int cap_s = cap_s0 < cap_a ? cap_s0 : cap_a;           // distinct sampled rows <= min(max_corrs, n_a)
+    hipLaunchKernelGGL(match_list_sampled_amb_kernel, dim3(B), dim3(256), 0, st, cap_a, lw.state, lw.pair_eager, n_sel, lw.sel_rows, corr_rows,
+                       lw.mark, lw.n_ambv, lw.ambv_idx);
+    hipLaunchKernelGGL(match_compact_f32_kernel, dim3((cap_s + 63) / 64, B), dim3(256), 0, st, a_hat, C, cap_a, cap_s, lw.n_ambv, lw.ambv_idx,
+                       corr_rows, w8.a_hat_c);
+    ORYON_CHECK_LAUNCH();
+    rc = oryon_match_f32(w8.a_hat_c, wr.q_hat, B, C, cap_s, cap_q, lw.n_ambv, n_q, threshold, w8.md_c, w8.am_c, w8.va_c, lw.exact_ws,
+                         lw.exact_ws_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_scatter_exact_kernel, dim3((cap_s + 255) / 256, B), dim3(256), 0, st, cap_a, cap_s, lw.n_ambv, lw.ambv_idx, corr_rows,
+                       w8.md_c, w8.am_c, w8.va_c, min_dist, argmin, valid, lw.state);
+    ORYON_CHECK_LAUNCH();
+    // (6) query half of every sampled correspondence: resolved rows read their argmin, the others get it from their winning slice
 #define RESOLVE_S(NHWCV)                                                                                                       \
     hipLaunchKernelGGL((match_resolve_selected_kernel<NHWCV>), dim3((max_corrs + 3) / 4, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8,       \
                        q_scale, a_scale, feat_q, C_true, HW, roi_q, roi_stride_q, q_norm, C, cap_a, cap_q, n_q, W, w.m_final, lw.sid_final,    \
@@ -1757,5 +1884,9 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     if (layout == ORYON_LAYOUT_NHWC) RESOLVE_S(true); else RESOLVE_S(false);
 #undef RESOLVE_S
     ORYON_CHECK_LAUNCH();
+    if (n_undecided) {       // anchors the int8 stage could not fully decide: the fp16-stage anchors of eager pairs + the ambiguous anchors of lazy pairs
+        hipLaunchKernelGGL(match_sum_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, w.n_amb, lw.n_amb_total, n_undecided);
+        ORYON_CHECK_LAUNCH();
+    }
     return ORYON_OK;
 }

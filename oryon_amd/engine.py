@@ -61,7 +61,9 @@ class MatchPoseEngine:
         # adaptive use of the int8 pre-screen: the fraction of anchors it had to hand to the fp16 stage is read back
         # asynchronously (pinned buffer + event, never a sync); above `i8_max_undecided` the next batches skip the int8 stage
         # and it is tried again every `i8_retry_every` batches.  Exactness never depends on this - only the run time does.
-        self.i8_max_undecided = 0.25
+        # (round 2: the lazy tail resolves ambiguous anchors with an exact scan of the sampled rows only, which is cheaper than the fp16
+        # route on every distribution tried, so the back-off is off by default - thresholds >= 1 never trigger)
+        self.i8_max_undecided = 2.0
         self.i8_retry_every = 16
         self._i8_pending = None        # (pinned [2] int64 tensor, event)
         self._i8_host = None           # pinned buffer, allocated once
