@@ -307,6 +307,11 @@ int oryon_split_f16x3(const float *x, int64_t n, void *hi_f16, void *lo_f16, voi
 int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,
                        void *stream);
 
+/* B5  multi-head self-attention of the frozen CLIP image tower (clip's ResidualAttentionBlock.attention reached through
+ *     models/vlm.py:46-56; nn.MultiheadAttention without mask) in fp32-grade arithmetic on the fp16 matrix pipe (both products
+ *     error-compensated like B4, flash-style, fp32 softmax): qkv [N, L, 3*heads*64] fp32 = the in_proj output, out [N, L, heads*64]. */
+int oryon_mha_f16x3(const float *qkv, int N, int L, int heads, int head_dim, float *out, void *stream);
+
 /* f3  pose-accuracy metrics on the device for a batch of pairs.
  *     Replaces utils/metrics.py:194-220 (compute_add / compute_adds, with the FLOAT16 model transform of utils/pcd.py:127-133) and
  *     utils/metrics.py:222-259 (compute_RT_distances) of the reference's evaluator (utils/evaluator.py:206-256).

@@ -67,6 +67,7 @@ _PROTOS = {
     "oryon_kabsch_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "oryon_split_f16x3": (c_int, [_P, c_int64, _P, _P, _P]),
     "oryon_linear_f16x3": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
+    "oryon_mha_f16x3": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "oryon_pose_metrics": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "oryon_pointdsc_create": (c_int, [POINTER(c_void_p), POINTER(PointDSCConfig)]),
     "oryon_pointdsc_destroy": (None, [c_void_p]),

@@ -92,6 +92,11 @@ class _Attention(nn.Module):
 
     def forward(self, x: Tensor, causal: bool) -> Tensor:            # x: [N, L, D]
         N, L, D = x.shape
+        if (FP16X3_LINEAR and not causal and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and D == 64 * self.heads):
+            from .. import ops                      # B5: the whole attention between the two linears as one fp16x3 kernel
+            o = ops.mha_f16x3(_linear(x, self.in_proj_weight, self.in_proj_bias), self.heads)
+            return _linear(o, self.out_proj.weight, self.out_proj.bias)
         qkv = _linear(x, self.in_proj_weight, self.in_proj_bias).view(N, L, 3, self.heads, D // self.heads)
         q, k, v = qkv.permute(2, 0, 3, 1, 4)                          # [N, H, L, d] each
         o = F.scaled_dot_product_attention(q, k, v, is_causal=causal)

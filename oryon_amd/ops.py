@@ -501,3 +501,16 @@ def linear_f16x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     check(lib().oryon_linear_f16x3(ptr(x2), x2.shape[0], K, ptr(hi), ptr(lo), ptr(b), N, 1 if quick_gelu else 0, ptr(out), stream_ptr(dev)),
           "oryon_linear_f16x3")
     return out.view(*x.shape[:-1], N)
+
+
+@_on_tensor_device
+def mha_f16x3(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """Self-attention on the packed in_proj output qkv [N, L, 3*D] fp32 (head dim 64, no mask) -> [N, L, D] fp32 (B5)."""
+    dev = _lib.require_gpu(qkv.device)
+    N, L, D3 = qkv.shape
+    D = D3 // 3
+    assert qkv.dtype == torch.float32 and D == heads * 64 and D3 == 3 * D
+    qkv = qkv.contiguous()
+    out = torch.empty((N, L, D), dtype=torch.float32, device=dev)
+    check(lib().oryon_mha_f16x3(ptr(qkv), N, L, heads, 64, ptr(out), stream_ptr(dev)), "oryon_mha_f16x3")
+    return out

@@ -274,3 +274,23 @@ def test_swin_fused_f32_attention_matches_plain_path():
             swin_mod.FUSED_F32_ATTENTION = False
     for k in ("guidance1", "guidance2", "guidance3"):
         assert float((got[k] - ref[k]).abs().max()) < 2e-5 * float(ref[k].abs().max()), k
+
+
+@pytest.mark.gpu
+def test_mha_f16x3_matches_fp64_attention():
+    """B5 (oryon_mha_f16x3) on the CLIP image tower's shapes (L = 577: ragged last key tile and query block, 16 heads of 64) against an
+    fp64 evaluation of softmax(Q K^T / 8) V; must be at least as accurate as torch's fp32 scaled_dot_product_attention."""
+    from oryon_amd import ops
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(2)
+    for N, L, H in ((3, 577, 16), (2, 64, 2), (1, 130, 1)):
+        D = 64 * H
+        qkv = torch.randn(N, L, 3 * D, generator=g, device=dev) * 1.5
+        got = ops.mha_f16x3(qkv, H)
+        q, k, v = qkv.view(N, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+        ref = torch.softmax(q.double() @ k.double().transpose(-2, -1) / 8.0, dim=-1) @ v.double()
+        ref = ref.transpose(1, 2).reshape(N, L, D)
+        f32 = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(N, L, D)
+        scale = float(ref.abs().max())
+        e_x3, e_32 = float((got.double() - ref).abs().max()) / scale, float((f32.double() - ref).abs().max()) / scale
+        assert e_x3 < 5e-6 and e_x3 <= 3.0 * e_32 + 2e-7, (N, L, H, e_x3, e_32)
