@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_kernel
 //   * 4 accumulators are live instead of 8, which pays for a double-buffered A operand (the 8 ds_read_b128 of query block qb+1
 //     also issue under qb's MFMAs).
 // sched_group_barrier pins the interleave (1 MFMA : 2 VALU : <=1 LDS read) in the emitted code.
-template <int CP, int VAR = 0>     // VAR != 0: timing ablations only (ORYON_SCREEN8_ABLATE): 1 no epilogue, 2 no DMA / barrier, 4 no LDS reads
+template <int CP, int VAR = 0>     // VAR != 0: timing ablations only (ORYON_SCREEN8_ABLATE): 1 no epilogue, 2 no DMA / barrier, 8 DMA spread over two blocks
 __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_kernel(
     const int8_t *__restrict__ a8, const int8_t *__restrict__ q8, const float *__restrict__ q_scale, int B, int cap_a, int cap_q,
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max,
@@ -809,19 +809,6 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    // VAR & 16: the next tile travels HBM/L2 -> registers (global_load_dwordx4, issued under the first query block) -> LDS
-    // (ds_write_b128, issued under the last one) instead of by LDS-DMA
-    uint4 stg[NI];
-    auto gload = [&](int qt) {
-        const char *qb = qp + (size_t)qt * TILE_BYTES;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) stg[j] = *reinterpret_cast<const uint4 *>(qb + dma_off[j]);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-            *reinterpret_cast<uint4 *>(smem + buf * TILE_BYTES + (wave * NI + j) * 1024 + lane * 16) = stg[j];
-    };
     unsigned koff[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) koff[c] = (unsigned)(l31 * RB) + ((((unsigned)(hi ^ (l31 & 15))) ^ (2u * c)) << 4);
@@ -854,8 +841,6 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    if ((VAR & 32) && wave_u >= 2) __builtin_amdgcn_s_setprio(1);          // experiment: static priority for half of the waves
-    if (VAR & 64) __builtin_amdgcn_s_setprio(2);                            // experiment: every screening wave above co-resident kernels
     i32x4 areg[NKS];
 #pragma unroll
     for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, 0u);
@@ -883,9 +868,7 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
             i32x16 acc[NAB];
             // the whole next tile is requested under the FIRST query block's MFMAs: ~1500 cycles before the wait at the tile's end
             // (spreading the 8 requests over the four blocks left the last ones ~500 cycles, less than an L2 miss: +4 %)
-            if ((VAR & 16) && qb == 0) gload(qt_next);
-            if ((VAR & 16) && qb == NQB - 1) lstore(buf ^ 1);
-            if (!(VAR & 18) && (((VAR & 8) && qb < 2) || (!(VAR & 8) && qb == 0))) {
+            if (!(VAR & 2) && (((VAR & 8) && qb < 2) || (!(VAR & 8) && qb == 0))) {
 #pragma unroll
                 for (int j = ((VAR & 8) ? qb * (NI / 2) : 0); j < ((VAR & 8) ? (qb + 1) * (NI / 2) : NI); ++j) issue_one(qt_next, buf ^ 1, j);
             }
@@ -894,7 +877,7 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
 #pragma unroll
                 for (int ab = 0; ab < NAB; ++ab)
                     acc[ab] = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[s], breg[ab][s], s == 0 ? zero16 : acc[ab], 0, 0, 0);
-                if (qb + 1 < NQB && !(VAR & 4)) areg[s] = rd(s, qb + 1, tile);
+                if (qb + 1 < NQB) areg[s] = rd(s, qb + 1, tile);
             }
             if (!(VAR & 1)) {
 #pragma unroll
@@ -913,8 +896,6 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 if (qb + 1 < NQB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if ((VAR & 16) && qb == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if ((VAR & 16) && qb == NQB - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
 #pragma unroll
             for (int ab = 0; ab < NAB; ++ab) prev[ab] = acc[ab];
@@ -927,10 +908,8 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
             buf ^= 1;
         }
         // first A operand of the next tile (its DMA has landed: barrier above)
-        if (!(VAR & 4)) {
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
-        }
+        for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
     }
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sc, prev_sid, ab);
@@ -1221,7 +1200,7 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
     static const int ablate = getenv("ORYON_SCREEN8_ABLATE") ? atoi(getenv("ORYON_SCREEN8_ABLATE")) : 0;
     if (ablate && CP == 256) {
 #define ABL(V) case V: hipLaunchKernelGGL((match_i8_screen_v2_kernel<256, V>), dim3(groups), dim3(256), 0, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, ws_max, ws_i1, ws_m2); break
-        switch (ablate) { ABL(1); ABL(2); ABL(3); ABL(8); ABL(32); default: ABL(64); }
+        switch (ablate) { ABL(1); ABL(2); ABL(3); default: ABL(8); }
 #undef ABL
         return;
     }
@@ -1807,7 +1786,9 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
                        argmin, lw.pair_eager, lw.n_unc, lw.unc_idx, lw.n_ambu, lw.ambu_idx, lw.need_f32_lazy, lw.n_amb_total);
     hipLaunchKernelGGL(match_mask_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_a, lw.pair_eager, lw.n_a_eager, lw.n_a_lazy);
     ORYON_CHECK_LAUNCH();
-    // ---- eager route (the complete tail of oryon_match_screened8_raw) for the flagged pairs: every launch below sees 0 anchors elsewhere
+    if (force_eager) {
+    // ---- eager route: the complete tail of oryon_match_screened8_raw for every pair (pair_eager is set only by force_eager since the
+    // ambiguous anchors of lazy pairs are resolved by compacted exact scans), then the sampler on the complete outputs
     const int32_t *nae = lw.n_a_eager;
     hipLaunchKernelGGL((match_decide_kernel<128>), dim3(cap_a / 64, B), dim3(256), 0, st, static_cast<const __half *>(nullptr),
                        static_cast<const __half *>(nullptr), C, cap_a, cap_q, nae, n_q, S, valid_cut16, w.ws_max, w.ws_i1, w.ws_m2, w.m_final,
@@ -1835,8 +1816,14 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     hipLaunchKernelGGL(match_scatter8_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, w.n_amb, w.amb_idx, w8.md_c, w8.am_c, w8.va_c,
                        min_dist, argmin, valid);
     ORYON_CHECK_LAUNCH();
+    rc = select_corrs_launch(roi_a, roi_q, roi_stride_a, roi_stride_q, n_a, n_q, argmin, valid, cap_a, B, W, max_corrs, corr_rows, seed,
+                             pair_key, lw.scratch, corrs, n_valid, n_sel, status, lw.sel_rows, lw.pair_eager, st);
+    if (rc) { set_error("oryon_match_corrs_i8: select launch failed"); return rc; }
+    if (n_undecided) ORYON_CHECK_HIP(hipMemcpyAsync(n_undecided, w.n_amb, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return ORYON_OK;
+    }
     // ---- lazy route.  (1) pairs with ambiguous possibly-valid anchors get their fp32 query rows (device-gated, as on the eager route)
-    rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, lw.need_f32_lazy, cap_q, C, wr.q8_scratch, wr.scale_scratch,
+    int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, lw.need_f32_lazy, cap_q, C, wr.q8_scratch, wr.scale_scratch,
                           wr.eps_scratch, nullptr, wr.q_hat, 1, round_f16, st);
     if (rc) { set_error("oryon_match_corrs_i8: lazy fp32 gather launch failed"); return rc; }
     // (2) ambiguous anchors whose VALIDITY is open: exact fp32 scan (K1) of exactly those rows, before the sampling
