@@ -213,6 +213,18 @@ int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, const float *a_
                          int32_t *n_valid, int32_t *n_sel, int32_t *status, int32_t *n_undecided, int round_f16, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* "Sample first" (optional engine schedule, off by default).  Only max_corrs correspondences per pair leave the matcher
+ * (utils/pcd.py:205-214), drawn uniformly from the valid anchor rows - so a uniformly random first-stage subset of the anchors that
+ * already holds >= max_corrs valid rows yields an identically distributed sample.  The engine runs the matcher on such a subset;
+ * oryon_sample_first_gate computes, on the device, which pairs must be redone on all of their anchors (n_a2 = n_a where the first stage
+ * found fewer than max_corrs valid rows although anchors were left out, else 0 - every second-stage launch then sees no anchors for the
+ * other pairs) and oryon_sample_first_merge copies the second stage's rows / counts / status over the first stage's for those pairs. */
+int oryon_sample_first_gate(const int32_t *n_valid1, const int32_t *n_a1, const int32_t *n_a, int B, int max_corrs, int32_t *n_a2,
+                            void *stream);
+int oryon_sample_first_merge(const int32_t *n_a2, const int32_t *corrs2, const int32_t *n_valid2, const int32_t *n_sel2,
+                             const int32_t *status2, int B, int corr_rows, int32_t *corrs1, int32_t *n_valid1, int32_t *n_sel1,
+                             int32_t *status1, void *stream);
+
 /* K1b turn matcher outputs into sampled correspondences (device RNG; batched path only).
  *     Replaces utils/pcd.py:205-214: keep rows with valid, need more than one, sample exactly max_corrs
  *     (with replacement iff fewer are available).

@@ -59,6 +59,8 @@ _PROTOS = {
     "oryon_match_screened8": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P,
                                       _P, _P, c_size_t, _P]),
     "oryon_match_screened": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "oryon_sample_first_gate": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
+    "oryon_sample_first_merge": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "oryon_select_corrs": (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_uint64, _P, _P,
                                    _P, _P, _P, _P, _P]),
     "oryon_lift_pairs": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P,

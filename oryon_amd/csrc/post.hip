@@ -232,6 +232,30 @@ __global__ __launch_bounds__(256) void kabsch_batched_kernel(const float *__rest
 using namespace oryon;
 
 namespace oryon {
+// "sample first" (engine option): the matcher runs on a random first-stage subset of the anchors; a pair whose first stage found fewer
+// than max_corrs valid rows - and had more anchors than that subset - is redone on all of its anchors.  These two kernels gate the
+// second stage on the device and merge its results over the first stage's.
+__global__ void sample_first_gate_kernel(int B, const int32_t *__restrict__ n_valid1, const int32_t *__restrict__ n_a1,
+                                         const int32_t *__restrict__ n_a, int max_corrs, int32_t *__restrict__ n_a2)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < B) n_a2[p] = (n_valid1[p] < max_corrs && n_a[p] > n_a1[p]) ? n_a[p] : 0;
+}
+
+__global__ __launch_bounds__(256) void sample_first_merge_kernel(int corr_rows, const int32_t *__restrict__ n_a2,
+                                                                  const int32_t *__restrict__ corrs2, const int32_t *__restrict__ n_valid2,
+                                                                  const int32_t *__restrict__ n_sel2, const int32_t *__restrict__ status2,
+                                                                  int32_t *__restrict__ corrs1, int32_t *__restrict__ n_valid1,
+                                                                  int32_t *__restrict__ n_sel1, int32_t *__restrict__ status1)
+{
+    const int p = blockIdx.x;
+    if (n_a2[p] <= 0) return;                                // first stage stands
+    const int4 *src = reinterpret_cast<const int4 *>(corrs2 + (size_t)p * corr_rows * 4);
+    int4 *dst = reinterpret_cast<int4 *>(corrs1 + (size_t)p * corr_rows * 4);
+    for (int i = threadIdx.x; i < corr_rows; i += 256) dst[i] = src[i];
+    if (threadIdx.x == 0) { n_valid1[p] = n_valid2[p]; n_sel1[p] = n_sel2[p]; status1[p] = status2[p]; }
+}
+
 // internal entry shared with the lazy matcher (match16.hip)
 int select_corrs_launch(const int32_t *roi_a, const int32_t *roi_q, int roi_stride_a, int roi_stride_q, const int32_t *n_a,
                         const int32_t *n_q, const int32_t *argmin, const uint8_t *valid, int cap_a, int B, int W, int max_corrs,
@@ -256,6 +280,28 @@ extern "C" int oryon_select_corrs(const int32_t *roi_a, const int32_t *roi_q, in
     hipLaunchKernelGGL(select_corrs_kernel, dim3(B), dim3(SEL_THREADS), 0, as_stream(stream), roi_a, roi_q, roi_stride_a,
                        roi_stride_q, n_a, n_q, argmin, valid, cap_a, W, max_corrs, corr_rows, seed, pair_key, scratch, corrs,
                        n_valid, n_sel, status, static_cast<int32_t *>(nullptr), static_cast<const int32_t *>(nullptr));
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_sample_first_gate(const int32_t *n_valid1, const int32_t *n_a1, const int32_t *n_a, int B, int max_corrs, int32_t *n_a2,
+                                       void *stream)
+{
+    ORYON_CHECK_ARG(n_valid1 && n_a1 && n_a && n_a2 && B >= 0 && max_corrs > 0);
+    if (B == 0) return ORYON_OK;
+    hipLaunchKernelGGL(sample_first_gate_kernel, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), B, n_valid1, n_a1, n_a, max_corrs, n_a2);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_sample_first_merge(const int32_t *n_a2, const int32_t *corrs2, const int32_t *n_valid2, const int32_t *n_sel2,
+                                        const int32_t *status2, int B, int corr_rows, int32_t *corrs1, int32_t *n_valid1, int32_t *n_sel1,
+                                        int32_t *status1, void *stream)
+{
+    ORYON_CHECK_ARG(n_a2 && corrs2 && n_valid2 && n_sel2 && status2 && corrs1 && n_valid1 && n_sel1 && status1 && B >= 0 && corr_rows > 0);
+    if (B == 0) return ORYON_OK;
+    hipLaunchKernelGGL(sample_first_merge_kernel, dim3(B), dim3(256), 0, as_stream(stream), corr_rows, n_a2, corrs2, n_valid2, n_sel2, status2,
+                       corrs1, n_valid1, n_sel1, status1);
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

@@ -40,6 +40,12 @@ class MatchPoseConfig:
     # True = the reference's half-descriptor branch (utils/pcd.py:195-197, corrs_device='cuda'; BASELINE configs[4] "fp16 descriptors"):
     # every descriptor value is rounded to float16 before anything else; the contraction itself is unchanged
     half_descriptors: bool = False
+    # > 0: "sample first" schedule of the int8 route - the matcher runs on a uniformly random subset of this many anchors per pair first;
+    # since only n_corrs correspondences leave it, drawn uniformly from the valid rows (utils/pcd.py:205-214), a subset that already holds
+    # >= n_corrs valid rows gives an identically distributed sample at a fraction of the contraction.  Pairs whose subset came up short
+    # are redone on all of their anchors (device-gated, no host round trip).  Off (0) by default: the default route computes the
+    # validity of every one of the <= src_sampling anchors, as the reference does.
+    sample_first: int = 0
 
 
 class MatchPoseEngine:
@@ -132,12 +138,20 @@ class MatchPoseEngine:
             cap_a = ops.round_up(FH * FW, ops.ROW_PAD)
         cap_q = ops.round_up(FH * FW, ops.ROW_PAD)
         a16 = q16 = a8 = q8 = a_sc = q_sc = q_eps = q_norm = q_hat = None
+        stage1 = use_i8 and cfg.sample_first > 0 and not keep
         if use_i8:
             # K0v3: anchors -> fp32 + int8 rows, queries -> int8 rows + row norms only (the re-scoring pass reads its few candidates
             # from the raw map); contiguous and channels_last maps are both read in place
             c_pad = 256 if C <= 256 else 512
-            a8, a_sc, _, _, a_hat = ops.gather_q8(feat_a, roi_a, n_a, cap_a, c_pad, want_f32=True, round_f16=cfg.half_descriptors)
             q8, q_sc, q_eps, q_norm, _ = ops.gather_q8(feat_q, roi_q, n_q, cap_q, c_pad, round_f16=cfg.half_descriptors)
+            if stage1:
+                # first-stage anchors: a random subset (second-level device-RNG subsample, row-major order kept) of the pair's anchors
+                roi_a1, n_a1 = roi_a.clone(), n_a.clone()
+                ops.roi_subsample_(roi_a1, n_a1, cfg.sample_first, cfg.seed ^ 0x5A17F125, pair_key)
+                cap_a1 = ops.round_up(min(cfg.sample_first, FH * FW), ops.ROW_PAD)
+                a8, a_sc, _, _, a_hat = ops.gather_q8(feat_a, roi_a1, n_a1, cap_a1, c_pad, want_f32=True, round_f16=cfg.half_descriptors)
+            else:
+                a8, a_sc, _, _, a_hat = ops.gather_q8(feat_a, roi_a, n_a, cap_a, c_pad, want_f32=True, round_f16=cfg.half_descriptors)
         elif screened:
             c_pad = 128 if C <= 128 else (256 if C <= 256 else 512)
             a_hat, a16 = ops.gather_normalise(feat_a.contiguous(), roi_a, n_a, cap_a, c_pad=c_pad, want_f16=True)
@@ -157,9 +171,21 @@ class MatchPoseEngine:
             # lazy K1s8 + K1b: validity of every anchor from the int8 bound, exact argmin for the sampled anchors only; `keep` (the
             # caller wants the complete min_dist / argmin arrays) forces the eager route
             n_und = torch.empty((B,), dtype=torch.int32, device=dev)
-            corrs, n_valid, n_sel, status, min_dist, argmin, valid = ops.match_corrs_i8(
-                a_hat, a8, a_sc, feat_q, roi_a, roi_q, q_norm, q8, q_sc, q_eps, n_a, n_q, cfg.dist_th, FW, cfg.n_corrs, cfg.seed,
-                pair_key, corr_rows=self.n_cap, force_eager=keep, n_undecided=n_und, round_f16=cfg.half_descriptors)
+            if stage1:
+                corrs, n_valid, n_sel, status, min_dist, argmin, valid = ops.match_corrs_i8(
+                    a_hat, a8, a_sc, feat_q, roi_a1, roi_q, q_norm, q8, q_sc, q_eps, n_a1, n_q, cfg.dist_th, FW, cfg.n_corrs, cfg.seed,
+                    pair_key, corr_rows=self.n_cap, n_undecided=n_und, round_f16=cfg.half_descriptors)
+                # second stage, gated on the device: all anchors of the pairs whose subset held fewer than n_corrs valid rows
+                n_a2 = ops.sample_first_gate(n_valid, n_a1, n_a, cfg.n_corrs)
+                a8b, a_scb, _, _, a_hatb = ops.gather_q8(feat_a, roi_a, n_a2, cap_a, c_pad, want_f32=True, round_f16=cfg.half_descriptors)
+                c2, nv2, ns2, st2, _, _, _ = ops.match_corrs_i8(
+                    a_hatb, a8b, a_scb, feat_q, roi_a, roi_q, q_norm, q8, q_sc, q_eps, n_a2, n_q, cfg.dist_th, FW, cfg.n_corrs, cfg.seed,
+                    pair_key, corr_rows=self.n_cap, round_f16=cfg.half_descriptors)
+                ops.sample_first_merge_(n_a2, c2, nv2, ns2, st2, corrs, n_valid, n_sel, status)
+            else:
+                corrs, n_valid, n_sel, status, min_dist, argmin, valid = ops.match_corrs_i8(
+                    a_hat, a8, a_sc, feat_q, roi_a, roi_q, q_norm, q8, q_sc, q_eps, n_a, n_q, cfg.dist_th, FW, cfg.n_corrs, cfg.seed,
+                    pair_key, corr_rows=self.n_cap, force_eager=keep, n_undecided=n_und, round_f16=cfg.half_descriptors)
             if self._i8_pending is None:
                 if self._i8_host is None:
                     self._i8_host = torch.empty((2, B), dtype=torch.int32, pin_memory=True)

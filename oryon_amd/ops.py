@@ -514,3 +514,22 @@ def mha_f16x3(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     out = torch.empty((N, L, D), dtype=torch.float32, device=dev)
     check(lib().oryon_mha_f16x3(ptr(qkv), N, L, heads, 64, ptr(out), stream_ptr(dev)), "oryon_mha_f16x3")
     return out
+
+
+@_on_tensor_device
+def sample_first_gate(n_valid1: torch.Tensor, n_a1: torch.Tensor, n_a: torch.Tensor, max_corrs: int) -> torch.Tensor:
+    """Per-pair anchor counts of the second matcher stage: n_a where the first stage came up short although anchors were left out, else 0."""
+    dev = _lib.require_gpu(n_a.device)
+    out = torch.empty_like(n_a)
+    check(lib().oryon_sample_first_gate(ptr(n_valid1), ptr(n_a1), ptr(n_a), n_a.shape[0], int(max_corrs), ptr(out), stream_ptr(dev)),
+          "oryon_sample_first_gate")
+    return out
+
+
+@_on_tensor_device
+def sample_first_merge_(n_a2, corrs2, n_valid2, n_sel2, status2, corrs1, n_valid1, n_sel1, status1) -> None:
+    """In place: the second stage's correspondences / counts / status replace the first stage's for the pairs that were redone."""
+    dev = _lib.require_gpu(corrs1.device)
+    assert corrs1.shape == corrs2.shape
+    check(lib().oryon_sample_first_merge(ptr(n_a2), ptr(corrs2), ptr(n_valid2), ptr(n_sel2), ptr(status2), corrs1.shape[0], corrs1.shape[1],
+                                         ptr(corrs1), ptr(n_valid1), ptr(n_sel1), ptr(status1), stream_ptr(dev)), "oryon_sample_first_merge")
