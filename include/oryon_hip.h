@@ -74,6 +74,9 @@ int oryon_quick_gelu_bf16(const void *x, void *y, int64_t n, void *stream);
  *     or delta, h_out must not alias an input. */
 int oryon_add_layernorm_bf16(const void *x, const void *delta, const void *gamma, const void *beta, int64_t rows, int D, float eps,
                              void *x_out, void *h_out, void *stream);
+/*     fp32 twin for the fp32 / fp16x3 inference path (same formula without the bf16 roundings; D % 4 == 0, D <= 2048). */
+int oryon_add_layernorm_f32(const float *x, const float *delta, const float *gamma, const float *beta, int64_t rows, int D, float eps,
+                            float *x_out, float *h_out, void *stream);
 
 /* B3  shifted-window attention of the Swin guidance backbone (torchvision swin_transformer.shifted_window_attention, the
  *     swin_b feature extractor of net.py:60-75), window 7, head dim 32, bf16 inference: everything between the q|k|v Linear and

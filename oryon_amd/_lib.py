@@ -33,6 +33,7 @@ _PROTOS = {
     "oryon_profile_events": (c_int, [_P, _P]),
     "oryon_quick_gelu_bf16": (c_int, [_P, _P, ctypes.c_int64, _P]),
     "oryon_add_layernorm_bf16": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int, c_float, _P, _P, _P]),
+    "oryon_add_layernorm_f32": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int, c_float, _P, _P, _P]),
     "oryon_swin_window_attention_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "oryon_swin_window_attention_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "oryon_round_to_f16_f32": (c_int, [_P, _P, ctypes.c_int64, _P]),

@@ -136,14 +136,14 @@ class _Block(nn.Module):
         return x + self.mlp(self.ln_2(x))
 
     def forward_fused(self, x: Tensor, h: Tensor, next_ln: Optional[nn.LayerNorm]):
-        """Same block with the residual adds fused into the following LayerNorm (ops.add_layernorm_bf16): takes the stream x and
+        """Same block with the residual adds fused into the following LayerNorm (ops.add_layernorm): takes the stream x and
         h = ln_1(x), returns the new stream and next_ln(new stream) (None for the last block)."""
         from .. import ops
-        x, h = ops.add_layernorm_bf16(x, self.attn(h, self.causal), self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+        x, h = ops.add_layernorm(x, self.attn(h, self.causal), self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
         d = self.mlp(h)
         if next_ln is None:
             return x + d, None
-        return ops.add_layernorm_bf16(x, d, next_ln.weight, next_ln.bias, next_ln.eps)
+        return ops.add_layernorm(x, d, next_ln.weight, next_ln.bias, next_ln.eps)
 
 
 class _Transformer(nn.Module):
@@ -152,12 +152,13 @@ class _Transformer(nn.Module):
         self.resblocks = nn.Sequential(*[_Block(width, heads, causal) for _ in range(layers)])
 
     def forward(self, x: Tensor) -> Tensor:
-        if (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.shape[-1] % 8 == 0
-                and self.resblocks[0].ln_1.weight.dtype == torch.bfloat16):    # bf16 weights, not autocast over fp32 ones
-            from .. import ops                      # bf16 inference: residual add + LayerNorm in one pass (B2)
+        w_dtype = self.resblocks[0].ln_1.weight.dtype
+        if (x.is_cuda and not torch.is_grad_enabled() and x.shape[-1] % 8 == 0 and x.dtype == w_dtype    # not autocast over fp32 weights
+                and (x.dtype == torch.bfloat16 or (FP16X3_LINEAR and x.dtype == torch.float32 and x.shape[-1] <= 2048))):
+            from .. import ops                      # inference: residual add + LayerNorm in one pass (B2; fp32 twin on the fp16x3 path)
             blocks = list(self.resblocks)
             ln0 = blocks[0].ln_1
-            x, h = ops.add_layernorm_bf16(x, None, ln0.weight, ln0.bias, ln0.eps)
+            x, h = ops.add_layernorm(x, None, ln0.weight, ln0.bias, ln0.eps)
             for i, blk in enumerate(blocks):
                 x, h = blk.forward_fused(x, h, blocks[i + 1].ln_1 if i + 1 < len(blocks) else None)
             return x

@@ -109,26 +109,28 @@ class _SwinBlock(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(dim, 4 * dim), nn.GELU(), nn.Identity(), nn.Linear(4 * dim, dim), nn.Identity())
 
     def forward(self, x: Tensor) -> Tensor:
-        if _fast_ln(x) and self.norm1.weight.dtype == torch.bfloat16:
-            from .. import ops                      # bf16 inference: LayerNorm / residual add + LayerNorm in one pass (B2)
-            h = ops.add_layernorm_bf16(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)[1]
-            x, h = ops.add_layernorm_bf16(x, self.attn(h), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        if _fast_ln(x) and self.norm1.weight.dtype == x.dtype:
+            from .. import ops                      # inference: LayerNorm / residual add + LayerNorm in one pass (B2)
+            h = ops.add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)[1]
+            x, h = ops.add_layernorm(x, self.attn(h), self.norm2.weight, self.norm2.bias, self.norm2.eps)
             return x + self.mlp(h)
         x = x + self.attn(self.norm1(x))
         return x + self.mlp(self.norm2(x))
 
 
 def _fast_ln(x: Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.shape[-1] % 8 == 0
+    if not (x.is_cuda and not torch.is_grad_enabled() and x.shape[-1] % 8 == 0):
+        return False
+    return x.dtype == torch.bfloat16 or (FUSED_F32_ATTENTION and x.dtype == torch.float32 and x.shape[-1] <= 2048)
 
 
 class _FastLayerNorm(nn.LayerNorm):
     """nn.LayerNorm whose bf16 CUDA inference path is the one-pass HIP kernel (torch's runs at ~1.3 TB/s on these row widths)."""
 
     def forward(self, x: Tensor) -> Tensor:
-        if _fast_ln(x) and self.weight.dtype == torch.bfloat16:
+        if _fast_ln(x) and self.weight.dtype == x.dtype:
             from .. import ops
-            return ops.add_layernorm_bf16(x, None, self.weight, self.bias, self.eps)[1]
+            return ops.add_layernorm(x, None, self.weight, self.bias, self.eps)[1]
         return super().forward(x)
 
 

@@ -138,6 +138,71 @@ __global__ __launch_bounds__(256) void add_layernorm_bf16_kernel(const unsigned 
     }
 }
 
+// fp32 twin of the kernel above for the fp32 / fp16x3 inference path (the towers' residual stream stays fp32 there): s = x + delta,
+// two-pass fp32 statistics over s, h = (s - mean) * rstd * gamma + beta.  4 floats per lane per chunk (16-byte accesses).
+constexpr int LN_F32_CHUNKS = 8;                 // 8 chunks x 64 lanes x 4 values = rows up to 2048 wide
+template <int LPR>
+__global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float *__restrict__ x, const float *__restrict__ delta,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 int64_t rows, int D, float eps, float *__restrict__ x_out,
+                                                                 float *__restrict__ h_out)
+{
+    constexpr int CH = LPR == 64 ? LN_F32_CHUNKS : 1;
+    constexpr int RPB = 256 / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    const int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x / LPR);
+    if (row >= rows) return;
+    const int chunks = (D + LPR * 4 - 1) / (LPR * 4);
+    float4 v[CH];
+    float sum = 0.0f;
+    const float *xr = x + row * D;
+    const float *dr = delta ? delta + row * D : nullptr;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = c * LPR * 4 + lane * 4;
+        v[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (c < chunks && col < D) {
+            float4 a = *reinterpret_cast<const float4 *>(xr + col);
+            if (dr) {
+                const float4 b = *reinterpret_cast<const float4 *>(dr + col);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                *reinterpret_cast<float4 *>(x_out + row * D + col) = a;
+            }
+            v[c] = a;
+            sum += (a.x + a.y) + (a.z + a.w);
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)D;
+    float sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = c * LPR * 4 + lane * 4;
+        if (c < chunks && col < D) {
+            const float d0 = v[c].x - mean, d1 = v[c].y - mean, d2 = v[c].z - mean, d3 = v[c].w - mean;
+            sq = fmaf(d0, d0, sq); sq = fmaf(d1, d1, sq); sq = fmaf(d2, d2, sq); sq = fmaf(d3, d3, sq);
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = c * LPR * 4 + lane * 4;
+        if (c < chunks && col < D) {
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + col);
+            const float4 b = *reinterpret_cast<const float4 *>(beta + col);
+            float4 o;
+            o.x = fmaf((v[c].x - mean) * rstd, g.x, b.x);
+            o.y = fmaf((v[c].y - mean) * rstd, g.y, b.y);
+            o.z = fmaf((v[c].z - mean) * rstd, g.z, b.z);
+            o.w = fmaf((v[c].w - mean) * rstd, g.w, b.w);
+            *reinterpret_cast<float4 *>(h_out + row * D + col) = o;
+        }
+    }
+}
+
 // Shifted-window attention of the Swin guidance backbone (torchvision swin_transformer.shifted_window_attention, reached from
 // net.py:60-75 of the reference through swin_b's feature extractor), bf16 inference.  torch runs it as pad + roll + window
 // partition copy, q scaling, two batched 49x49 matmuls, bias add, mask add, softmax, transpose copy, window merge copy and the
@@ -305,6 +370,24 @@ extern "C" int oryon_add_layernorm_bf16(const void *x, const void *delta, const 
     else if (D <= 256) ORYON_LAUNCH_LN(32);
     else ORYON_LAUNCH_LN(64);
 #undef ORYON_LAUNCH_LN
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+extern "C" int oryon_add_layernorm_f32(const float *x, const float *delta, const float *gamma, const float *beta, int64_t rows, int D,
+                                       float eps, float *x_out, float *h_out, void *stream)
+{
+    ORYON_CHECK_ARG(x && gamma && beta && h_out && rows >= 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_F32_CHUNKS && eps > 0.0f);
+    ORYON_CHECK_ARG(!delta || x_out);
+    ORYON_CHECK_ARG((((uintptr_t)x | (uintptr_t)delta | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)x_out | (uintptr_t)h_out) & 15) == 0);
+    if (rows == 0) return ORYON_OK;
+#define ORYON_LAUNCH_LN32(LPR)                                                                                                     \
+    hipLaunchKernelGGL((add_layernorm_f32_kernel<LPR>), dim3((unsigned)((rows + 256 / LPR - 1) / (256 / LPR))), dim3(256), 0,       \
+                       as_stream(stream), x, delta, gamma, beta, rows, D, eps, x_out, h_out)
+    if (D <= 64) ORYON_LAUNCH_LN32(16);
+    else if (D <= 128) ORYON_LAUNCH_LN32(32);
+    else ORYON_LAUNCH_LN32(64);
+#undef ORYON_LAUNCH_LN32
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

@@ -81,6 +81,32 @@ def add_layernorm_bf16(x: torch.Tensor, delta: Optional[torch.Tensor], weight: t
 
 
 @_on_tensor_device
+def add_layernorm_f32(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor, eps: float):
+    """fp32 twin of add_layernorm_bf16 (the fp32 / fp16x3 inference path of the towers): (x + delta, LayerNorm(x + delta))."""
+    _lib.require_gpu(x.device)
+    assert x.dtype == torch.float32 and weight.dtype == torch.float32 and bias.dtype == torch.float32
+    D = x.shape[-1]
+    x = x.contiguous()
+    h = torch.empty_like(x)
+    if delta is None:
+        s_out = x
+        check(lib().oryon_add_layernorm_f32(ptr(x), None, ptr(weight), ptr(bias), x.numel() // D, D, eps, None, ptr(h),
+                                            stream_ptr(x.device)), "oryon_add_layernorm_f32")
+    else:
+        assert delta.shape == x.shape and delta.dtype == torch.float32
+        delta = delta.contiguous()
+        s_out = delta
+        check(lib().oryon_add_layernorm_f32(ptr(x), ptr(delta), ptr(weight), ptr(bias), x.numel() // D, D, eps, ptr(s_out), ptr(h),
+                                            stream_ptr(x.device)), "oryon_add_layernorm_f32")
+    return s_out, h
+
+
+def add_layernorm(x, delta, weight, bias, eps):
+    """Dispatch on the stream's dtype (bf16 or fp32)."""
+    return (add_layernorm_bf16 if x.dtype == torch.bfloat16 else add_layernorm_f32)(x, delta, weight, bias, eps)
+
+
+@_on_tensor_device
 def swin_window_attention_bf16(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t: torch.Tensor, heads: int, shift: int) -> torch.Tensor:
     """Shifted-window attention (window 7, head dim 32) on un-windowed q|k|v tokens [B,H,W,3C] bf16 -> [B,H,W,C] bf16 (B3)."""
     _lib.require_gpu(qkv.device)

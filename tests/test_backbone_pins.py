@@ -294,3 +294,25 @@ def test_mha_f16x3_matches_fp64_attention():
         scale = float(ref.abs().max())
         e_x3, e_32 = float((got.double() - ref).abs().max()) / scale, float((f32.double() - ref).abs().max()) / scale
         assert e_x3 < 5e-6 and e_x3 <= 3.0 * e_32 + 2e-7, (N, L, H, e_x3, e_32)
+
+
+@pytest.mark.gpu
+def test_add_layernorm_f32_matches_fp64():
+    """fp32 twin of B2 (oryon_add_layernorm_f32): (x + delta, LayerNorm(x + delta)) against an fp64 evaluation on every row width the
+    towers use (Swin 128..2048, CLIP 768 / 1024) plus a ragged row count; must be at least as accurate as torch's fp32 LayerNorm."""
+    from oryon_amd import ops
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+    for rows, D in ((1000, 128), (999, 256), (577 * 2, 1024), (77 * 3, 768), (50, 2048), (7, 64), (3, 40)):
+        x = torch.randn(rows, D, generator=g, device=dev) * 2.0 + 0.5
+        d = torch.randn(rows, D, generator=g, device=dev)
+        w = torch.randn(D, generator=g, device=dev)
+        b = torch.randn(D, generator=g, device=dev)
+        for delta in (None, d):
+            s_ref = x if delta is None else x + delta
+            h_ref = torch.nn.functional.layer_norm(s_ref.double(), (D,), w.double(), b.double(), 1e-5)
+            h_32 = torch.nn.functional.layer_norm(s_ref, (D,), w, b, 1e-5)
+            s, h = ops.add_layernorm_f32(x, None if delta is None else delta.clone(), w, b, 1e-5)
+            assert torch.equal(s, s_ref)
+            e, e32 = float((h.double() - h_ref).abs().max()), float((h_32.double() - h_ref).abs().max())
+            assert e < 5e-6 and e <= 2.0 * e32 + 1e-7, (rows, D, e, e32)

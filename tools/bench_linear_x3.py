@@ -18,7 +18,7 @@ for K, N, name in ((1024, 3072, "qkv"), (1024, 1024, "out"), (1024, 4096, "fc1+g
         ref = ref * torch.sigmoid(1.702 * ref)
     e32 = float((f32()[:4096].double() - ref).abs().max() / ref.abs().max())
     ex3 = float((x3()[:4096].double() - ref).abs().max() / ref.abs().max())
-    def t(fn, n=5):
+    def t(fn, n=int(os.environ.get("REPS", "5"))):
         fn(); fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
