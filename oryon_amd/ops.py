@@ -5,6 +5,7 @@ kernel on the current torch stream.  Nothing here computes: the arithmetic lives
 from __future__ import annotations
 
 import functools
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -495,9 +496,12 @@ _x3_weights = {}
 
 
 def _split_weight_f16x3(weight: torch.Tensor):
-    """(hi, lo) fp16 halves of an fp32 weight, made once per (storage, version) and cached."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device.index)
+    """(hi, lo) fp16 halves of an fp32 weight, made once per live tensor and in-place version and cached.  The entry holds a weak
+    reference to the tensor it was made from: an address re-used by another tensor after a free can not hit a stale split."""
+    key = id(weight)
     hit = _x3_weights.get(key)
+    if hit is not None and (hit[0]() is not weight or hit[1] != (weight._version, weight.data_ptr(), tuple(weight.shape))):
+        hit = None
     if hit is None:
         w = weight.detach().to(torch.float32).contiguous()
         hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
@@ -505,8 +509,9 @@ def _split_weight_f16x3(weight: torch.Tensor):
         check(lib().oryon_split_f16x3(ptr(w), w.numel(), ptr(hi), ptr(lo), stream_ptr(w.device)), "oryon_split_f16x3")
         if len(_x3_weights) > 4096:
             _x3_weights.clear()
-        hit = _x3_weights[key] = (hi, lo)
-    return hit
+        ref = weakref.ref(weight, lambda _r, k=key: _x3_weights.pop(k, None))
+        hit = _x3_weights[key] = (ref, (weight._version, weight.data_ptr(), tuple(weight.shape)), hi, lo)
+    return hit[2], hit[3]
 
 
 def linear_f16x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
