@@ -316,7 +316,8 @@ int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const floa
  *     (net.py:142-167, models/vlm.py:43-61; the reference evaluates them with fp32 torch linears):
  *         C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]),   W = W_hi + W_lo (two fp16 matrices made once by oryon_split_f16x3)
  *     with every product accumulated as Ahi*Whi + Ahi*Wlo + Alo*Whi on the fp16 matrix pipe (fp32 accumulate): ~2^-22 relative, i.e.
- *     fp32-grade results at ~3x the fp32-MFMA rate.  act: 0 = none, 1 = QuickGELU x*sigmoid(1.702x) fused into the epilogue.
+ *     fp32-grade results at ~3x the fp32-MFMA rate.  act: 0 = none, 1 = QuickGELU x*sigmoid(1.702x) (CLIP), 2 = GELU x*Phi(x) with erf (Swin's nn.GELU), fused
+ *     into the epilogue.
  *     K % 32 == 0, N % 256 == 0, |values| < 65504. */
 int oryon_split_f16x3(const float *x, int64_t n, void *hi_f16, void *lo_f16, void *stream);
 int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,

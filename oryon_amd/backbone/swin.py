@@ -25,9 +25,22 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-# fp32 inference switch: shifted-window attention as ONE HIP kernel (oryon_swin_window_attention_f32) instead of torch's dozen
-# bandwidth-bound passes; fp32 arithmetic, results within ~1e-6 of the plain path (tests/test_backbone_pins.py)
+# fp32 inference switch for the whole guidance backbone: shifted-window attention as ONE HIP kernel
+# (oryon_swin_window_attention_f32) instead of torch's dozen bandwidth-bound passes, residual add + LayerNorm in one pass
+# (oryon_add_layernorm_f32), and the linears whose shapes allow it (N % 256 == 0: stages 2 and 3, the patch mergings) on the
+# error-compensated fp16x3 kernel with the erf-GELU fused (B4).  Results stay fp32-grade: within ~2e-5 of the plain path
+# (tests/test_backbone_pins.py).
 FUSED_F32_ATTENTION = False
+
+
+def _lin(m: nn.Linear, x: Tensor, gelu: bool = False) -> Tensor:
+    """nn.Linear (+ erf-GELU) of the fp32 inference path: the fp16x3 kernel (B4) where its shape constraints hold, torch otherwise."""
+    if FUSED_F32_ATTENTION and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
+        from .. import ops
+        if ops.linear_f16x3_supported(x, m.weight):
+            return ops.linear_f16x3(x, m.weight, m.bias, gelu=gelu)
+    y = m(x)
+    return F.gelu(y) if gelu else y
 
 
 def _relative_index(w: int) -> Tensor:
@@ -74,8 +87,8 @@ class _WindowAttention(nn.Module):
             from .. import ops                      # fp32 inference: the same single kernel on fp32 tensors
             bias_t = self.relative_position_bias_table[self.relative_position_index].view(w * w, w * w, nh).permute(2, 1, 0)
             pad = self.qkv.bias if self.qkv.bias is not None else torch.zeros(3 * C, dtype=x.dtype, device=x.device)
-            out = ops.swin_window_attention_f32(self.qkv(x), pad.detach(), bias_t.detach().contiguous(), nh, s)
-            return self.proj(out)
+            out = ops.swin_window_attention_f32(_lin(self.qkv, x), pad.detach(), bias_t.detach().contiguous(), nh, s)
+            return _lin(self.proj, out)
         pb, pr = (w - H % w) % w, (w - W % w) % w
         x = F.pad(x, (0, 0, 0, pr, 0, pb))
         Hp, Wp = H + pb, W + pr
@@ -113,6 +126,8 @@ class _SwinBlock(nn.Module):
             from .. import ops                      # inference: LayerNorm / residual add + LayerNorm in one pass (B2)
             h = ops.add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)[1]
             x, h = ops.add_layernorm(x, self.attn(h), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            if x.dtype == torch.float32:
+                return x + _lin(self.mlp[3], _lin(self.mlp[0], h, gelu=True))
             return x + self.mlp(h)
         x = x + self.attn(self.norm1(x))
         return x + self.mlp(self.norm2(x))
@@ -144,7 +159,7 @@ class _PatchMerging(nn.Module):
         H, W = x.shape[1], x.shape[2]
         x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat((x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]), dim=-1)
-        return self.reduction(self.norm(x))
+        return _lin(self.reduction, self.norm(x))
 
 
 class _PatchEmbedNHWC(PatchEmbed):

@@ -144,6 +144,8 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const float *__res
                 const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 float v = acc[a][b][r] + bv;
                 if (ACT == 1) v = v * (1.0f / (1.0f + __expf(-1.702f * v)));
+            if (ACT == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                if (ACT == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                 if (m < M) C[(size_t)m * N + n] = v;
             }
     }
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
         auto finish = [&](float v, int b) {
             v += bv[b];
             if (ACT == 1) v = v * (1.0f / (1.0f + __expf(-1.702f * v)));
+            if (ACT == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             return v;
         };
         if (m0 + G2_BM <= M) {
@@ -471,7 +474,7 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
                                   float *C, void *stream)
 {
     ORYON_CHECK_ARG(A && W_hi && W_lo && C && M >= 0 && K > 0 && N > 0);
-    ORYON_CHECK_ARG(K % GX_BK == 0 && N % GX_BN == 0 && (act == 0 || act == 1));
+    ORYON_CHECK_ARG(K % GX_BK == 0 && N % GX_BN == 0 && act >= 0 && act <= 2);
     if (M == 0) return ORYON_OK;
     static const int variant = getenv("ORYON_GEMM_X3_VARIANT") ? atoi(getenv("ORYON_GEMM_X3_VARIANT")) : 2;      // dev: 1 = small-tile kernel
     if (variant != 1 && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)) {
@@ -489,15 +492,16 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
         if (grid > n_slots) grid = n_slots;
         hipStream_t st2 = as_stream(stream);
         const __half *wh2 = static_cast<const __half *>(W_hi), *wl2 = static_cast<const __half *>(W_lo);
-        if (act == 1) {
-            allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<1>), 2 * G2_STAGE);
-            hipLaunchKernelGGL((linear_f16x3_stream_kernel<1>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2, bias, N, C, tiles_m,
-                               tiles_n, sup_n, sup_rows, sup_cols, n_slots);
-        } else {
-            allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<0>), 2 * G2_STAGE);
-            hipLaunchKernelGGL((linear_f16x3_stream_kernel<0>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2, bias, N, C, tiles_m,
-                               tiles_n, sup_n, sup_rows, sup_cols, n_slots);
-        }
+#define ORYON_LAUNCH_STREAM(ACT)                                                                                                    \
+    do {                                                                                                                            \
+        allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<ACT>), 2 * G2_STAGE);                           \
+        hipLaunchKernelGGL((linear_f16x3_stream_kernel<ACT>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2, bias, N, C, \
+                           tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots);                                                   \
+    } while (0)
+        if (act == 2) ORYON_LAUNCH_STREAM(2);
+        else if (act == 1) ORYON_LAUNCH_STREAM(1);
+        else ORYON_LAUNCH_STREAM(0);
+#undef ORYON_LAUNCH_STREAM
         ORYON_CHECK_LAUNCH();
         return ORYON_OK;
     }
@@ -510,7 +514,9 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
     const dim3 grid(supers * 64);
     hipStream_t st = as_stream(stream);
     const __half *wh = static_cast<const __half *>(W_hi), *wl = static_cast<const __half *>(W_lo);
-    if (act == 1)
+    if (act == 2)
+        hipLaunchKernelGGL((linear_f16x3_kernel<2>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols);
+    else if (act == 1)
         hipLaunchKernelGGL((linear_f16x3_kernel<1>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols);
     else
         hipLaunchKernelGGL((linear_f16x3_kernel<0>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols);

@@ -520,17 +520,19 @@ def linear_f16x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 @_on_tensor_device
-def linear_f16x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, quick_gelu: bool = False) -> torch.Tensor:
+def linear_f16x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, quick_gelu: bool = False,
+                 gelu: bool = False) -> torch.Tensor:
     """act(x @ weight.T + bias) for fp32 x [..., K], weight [N, K] on the fp16 matrix pipe with error-compensated operands (B4):
-    fp32-grade results (~1e-6 relative) at ~3x the fp32-MFMA rate.  Inference only."""
+    fp32-grade results (~1e-6 relative) at ~3x the fp32-MFMA rate.  act: QuickGELU (CLIP) or erf-GELU (Swin) or none.  Inference only."""
     dev = _lib.require_gpu(x.device)
+    assert not (quick_gelu and gelu)
     K, N = weight.shape[1], weight.shape[0]
     x2 = x.reshape(-1, K).contiguous()
     hi, lo = _split_weight_f16x3(weight)
     out = torch.empty((x2.shape[0], N), dtype=torch.float32, device=dev)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
-    check(lib().oryon_linear_f16x3(ptr(x2), x2.shape[0], K, ptr(hi), ptr(lo), ptr(b), N, 1 if quick_gelu else 0, ptr(out), stream_ptr(dev)),
-          "oryon_linear_f16x3")
+    check(lib().oryon_linear_f16x3(ptr(x2), x2.shape[0], K, ptr(hi), ptr(lo), ptr(b), N, 2 if gelu else (1 if quick_gelu else 0), ptr(out),
+                                   stream_ptr(dev)), "oryon_linear_f16x3")
     return out.view(*x.shape[:-1], N)
 
 
