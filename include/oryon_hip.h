@@ -318,7 +318,7 @@ int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const floa
  *     with every product accumulated as Ahi*Whi + Ahi*Wlo + Alo*Whi on the fp16 matrix pipe (fp32 accumulate): ~2^-22 relative, i.e.
  *     fp32-grade results at ~3x the fp32-MFMA rate.  act: 0 = none, 1 = QuickGELU x*sigmoid(1.702x) (CLIP), 2 = GELU x*Phi(x) with erf (Swin's nn.GELU), fused
  *     into the epilogue.
- *     K % 32 == 0, N % 256 == 0, |values| < 65504. */
+ *     K % 32 == 0, N % 256 == 0 (N % 128 == 0 when K >= 64), N * K < 2^30, |values| < 65504. */
 int oryon_split_f16x3(const float *x, int64_t n, void *hi_f16, void *lo_f16, void *stream);
 int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,
                        void *stream);

@@ -144,7 +144,6 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const float *__res
                 const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 float v = acc[a][b][r] + bv;
                 if (ACT == 1) v = v * (1.0f / (1.0f + __expf(-1.702f * v)));
-            if (ACT == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                 if (ACT == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                 if (m < M) C[(size_t)m * N + n] = v;
             }
@@ -227,7 +226,10 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
             const int row = a_row0 + 64 * i;
             a_src[i] = (unsigned)((row < a_rows ? row : a_rows - 1) * K + a_c4 * 4);      // float index inside the tile's rows: < 256 K
         }
-        w_mat = reinterpret_cast<const char *>(wave_u < 4 ? Whi : Wlo) + ((size_t)(ln0 + w_piece0 * 16) * K) * 2;
+        // N % 128 == 0: the last column tile may be half wide; the waves whose 64 weight rows fall past N re-read the tile's first rows
+        // (their products land in accumulators that are never stored)
+        const int w_row = ln0 + w_piece0 * 16 < N ? ln0 + w_piece0 * 16 : ln0;
+        w_mat = reinterpret_cast<const char *>(wave_u < 4 ? Whi : Wlo) + ((size_t)w_row * K) * 2;
     };
     set_load_tile(m0, n0);
     const unsigned a_dst = (unsigned)(a_row0 * 64 + ((((a_c4 >> 1) ^ ((a_row0 >> 2) & 3)) << 4) | ((a_c4 & 1) << 3)));   // + 4096 i
@@ -399,8 +401,9 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
         // Full tiles (all but the last row of tiles) store without a branch: with per-row predicates the compiler puts an
         // s_waitcnt vmcnt(0) in front of every store and the 128 stores of a wave complete one round trip at a time.
         float bv[4];
+        const bool cols_in = n0 + wn * 128 < N;                      // wave-uniform (N % 128 == 0)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) bv[b] = bias ? bias[n0 + wn * 128 + b * 32 + l31] : 0.0f;
+        for (int b = 0; b < 4; ++b) bv[b] = bias && cols_in ? bias[n0 + wn * 128 + b * 32 + l31] : 0.0f;
         const int mrow = m0 + wm * 64 + 4 * kh;
         float *ctile = C + (size_t)mrow * N + n0 + wn * 128 + l31;
         auto finish = [&](float v, int b) {
@@ -409,7 +412,8 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
             if (ACT == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             return v;
         };
-        if (m0 + G2_BM <= M) {
+        if (!cols_in) {
+        } else if (m0 + G2_BM <= M) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -474,11 +478,12 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
                                   float *C, void *stream)
 {
     ORYON_CHECK_ARG(A && W_hi && W_lo && C && M >= 0 && K > 0 && N > 0);
-    ORYON_CHECK_ARG(K % GX_BK == 0 && N % GX_BN == 0 && act >= 0 && act <= 2);
+    ORYON_CHECK_ARG(K % GX_BK == 0 && act >= 0 && act <= 2);
+    ORYON_CHECK_ARG(N % GX_BN == 0 || (N % 128 == 0 && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)));   // half-wide last column tile: stream kernel only
     if (M == 0) return ORYON_OK;
     static const int variant = getenv("ORYON_GEMM_X3_VARIANT") ? atoi(getenv("ORYON_GEMM_X3_VARIANT")) : 2;      // dev: 1 = small-tile kernel
-    if (variant != 1 && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)) {
-        const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = N / G2_BN;
+    if ((variant != 1 || N % GX_BN != 0) && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)) {
+        const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
         const int sup_n = (tiles_n + 7) / 8;
         const int sup_cols = (tiles_n + sup_n - 1) / sup_n;
         const int sup_rows = 64 / sup_cols;

@@ -516,7 +516,8 @@ def _split_weight_f16x3(weight: torch.Tensor):
 
 def linear_f16x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and not torch.is_grad_enabled()
-            and weight.dim() == 2 and weight.shape[1] % 32 == 0 and weight.shape[0] % 256 == 0 and x.shape[-1] == weight.shape[1])
+            and weight.dim() == 2 and weight.shape[1] % 32 == 0 and x.shape[-1] == weight.shape[1] and weight.numel() < 2 ** 30
+            and (weight.shape[0] % 256 == 0 or (weight.shape[0] % 128 == 0 and weight.shape[1] >= 64)))
 
 
 @_on_tensor_device

@@ -222,20 +222,24 @@ def test_fp16x3_linear_and_clip_tower_match_fp32():
     dev = "cuda"
     torch.set_grad_enabled(False)                # inference-only kernel: the dispatch refuses to run under autograd
     g = torch.Generator(device=dev).manual_seed(1)
-    for M, K, N, gelu in ((577 * 3, 1024, 3072, False), (1000, 1024, 4096, True), (130, 4096, 1024, False), (1, 64, 256, False)):
+    for M, K, N, gelu in ((577 * 3, 1024, 3072, False), (1000, 1024, 4096, True), (130, 4096, 1024, False), (1, 64, 256, False),
+                          (1500, 128, 384, "erf"), (700, 512, 128, False), (300, 32, 256, "erf")):   # half-wide last tile; K = 32 kernel
         x = torch.randn(M, K, generator=g, device=dev) * 3.0
         w = torch.randn(N, K, generator=g, device=dev) * K ** -0.5
         b = torch.randn(N, generator=g, device=dev)
         assert ops.linear_f16x3_supported(x, w)
         ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
         f32 = torch.nn.functional.linear(x, w, b)
-        if gelu:
+        if gelu == "erf":
+            ref, f32 = torch.nn.functional.gelu(ref), torch.nn.functional.gelu(f32)
+        elif gelu:
             ref, f32 = ref * torch.sigmoid(1.702 * ref), f32 * torch.sigmoid(1.702 * f32)
-        got = ops.linear_f16x3(x, w, b, quick_gelu=gelu)
+        got = ops.linear_f16x3(x, w, b, quick_gelu=gelu is True, gelu=gelu == "erf")
         scale = float(ref.abs().max())
         e_x3, e_32 = float((got.double() - ref).abs().max()) / scale, float((f32.double() - ref).abs().max()) / scale
         assert e_x3 < 5e-6 and e_x3 <= 2.0 * e_32 + 1e-7, (M, K, N, e_x3, e_32)
     assert not ops.linear_f16x3_supported(torch.zeros(4, 100, device=dev), torch.zeros(256, 100, device=dev))    # K % 32
+    assert not ops.linear_f16x3_supported(torch.zeros(4, 32, device=dev), torch.zeros(128, 32, device=dev))      # N % 256 when K < 64
     cfg = CLIPConfig.vit_l14_336()
     cfg.v_layers, cfg.t_layers = 3, 1
     torch.manual_seed(0)
