@@ -160,10 +160,8 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
     key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
     xs = {"anchor": {"rgb": rgb_a}, "query": {"rgb": rgb_q}, "prompt_tokens": toks}
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if backbone_dtype == "bf16" else torch.autocast("cuda", enabled=False)
-    from oryon_amd.backbone import clip as clip_mod
-    clip_mod.FP16X3_LINEAR = backbone_dtype == "fp16x3"       # fp32 tensors, linears on the fp16 pipe with split operands (B4)
-    from oryon_amd.backbone import swin as swin_mod
-    swin_mod.FUSED_F32_ATTENTION = backbone_dtype == "fp16x3"  # ... and the Swin window attention as one fp32 kernel (B3 on fp32 tensors)
+    from oryon_amd.backbone import enable_fp16x3
+    enable_fp16x3(backbone_dtype == "fp16x3")                 # fp32 tensors; linears / attention on the fp16 pipe with split operands (B2-B5)
     if backbone_dtype == "bf16w":
         model = model.to(torch.bfloat16)
         xs["anchor"]["rgb"], xs["query"]["rgb"] = rgb_a.to(torch.bfloat16), rgb_q.to(torch.bfloat16)
@@ -225,7 +223,9 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
         return None
     # ~0.39 TFLOP per ViT-L/14@336 image, 2 images per pair; fusion + decoder alone: 2.4 + 3.3 GFLOP per image
     flops_backbone = B * 2 * (5.7e9 if decode_only else 0.39e12)
-    peak = PEAK_FP32_MFMA_TFLOPS if backbone_dtype in ("fp32", "fp16x3") else PEAK_F16_MFMA_TFLOPS
+    # fp16x3: every fp32 multiply-add is three fp16 MFMA multiply-adds, so the fp32-equivalent rate is priced against a third of the
+    # dense fp16 peak (the towers' linears, attention and the Swin linears run there; the convolutions still run on the fp32 pipe)
+    peak = {"fp32": PEAK_FP32_MFMA_TFLOPS, "fp16x3": PEAK_F16_MFMA_TFLOPS / 3.0}.get(backbone_dtype, PEAK_F16_MFMA_TFLOPS)
     achieved = flops_backbone / (bb_ms * 1e-3) / 1e12
     return {
         "metric": ("image-pairs/sec (decode+match+reg): fusion + decoder on cached CLIP / Swin encodings (-> C=32 @192x192), then match + pose"
@@ -235,13 +235,16 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
         "value": total * steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "backbone_ms_per_step": bb_ms, "pairs_per_gpu": B, "pairs_ok": pairs_ok,
         "dtype": {"fp32": "f32 (PyTorch-ROCm fp32 GEMMs / convolutions, TF32-style shortcuts off)",
-                  "fp16x3": "f32 tensors; CLIP linears as error-compensated fp16x3 MFMA GEMMs (oryon_linear_f16x3: ~1e-6 relative, fp32-grade), "
-                            "everything else PyTorch-ROCm fp32",
+                  "fp16x3": "f32 tensors; CLIP / Swin linears and the CLIP attention as error-compensated fp16x3 MFMA kernels (oryon_linear_f16x3, "
+                            "oryon_mha_f16x3: ~1e-6 relative, fp32-grade), fused fp32 LayerNorm / window attention, convolutions PyTorch-ROCm fp32",
                   "bf16": "bf16 backbone GEMMs (autocast), f32 match+pose",
                   "bf16w": "bf16 backbone (weights + activations), f32 match+pose"}[backbone_dtype],
         "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
         "prompt_cache": "80-template text tower evaluated once (identical prompt set), as in eval of one object class",
-        "roofline": {"bound": "mfma", "kernel": "backbone GEMMs / convolutions (hipBLASLt / MIOpen through PyTorch-ROCm)",
+        "roofline": {"bound": "mfma",
+                     "kernel": ("backbone GEMMs: oryon_linear_f16x3 / oryon_mha_f16x3 (fp32-equivalent FLOP/s against a third of the dense fp16 "
+                                "peak) + MIOpen convolutions" if backbone_dtype == "fp16x3" else
+                                "backbone GEMMs / convolutions (hipBLASLt / MIOpen through PyTorch-ROCm)"),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None},
     }
 

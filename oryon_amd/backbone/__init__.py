@@ -1,0 +1,11 @@
+"""Frozen feature towers of Oryon.forward (CLIP ViT-L/14@336 image + text, Swin-B guidance): plain PyTorch modules with the reference's
+state-dict names, plus the HIP inference paths behind module switches."""
+
+
+def enable_fp16x3(flag: bool = True) -> None:
+    """fp32-grade fast inference path of both towers: linears and the CLIP attention as error-compensated fp16x3 MFMA kernels (B4, B5),
+    Swin window attention and residual-add + LayerNorm as single fp32 kernels (B3, B2).  Off by default: torch fp32 everywhere.
+    Results stay within ~1e-5 of the fp32 evaluation (tests/test_backbone_pins.py); takes effect under torch.no_grad() on CUDA only."""
+    from . import clip, swin
+    clip.FP16X3_LINEAR = bool(flag)
+    swin.FUSED_F32_ATTENTION = bool(flag)
