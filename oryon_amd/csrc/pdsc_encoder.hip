@@ -375,6 +375,18 @@ __device__ __forceinline__ void split_half(float x, _Float16 &hi, _Float16 &lo)
     lo = (_Float16)(x - (float)hi);
 }
 
+// Two values at a time: packed conversions (v_cvt_pk_f16_f32 on gfx950, round-to-nearest-even) - same results as split_half.
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 xf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const xf32x2 v = {a, b};
+    const xf16x2 h = __builtin_convertvector(v, xf16x2);
+    const xf16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, xf32x2), xf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__restrict__ QKV, const float *__restrict__ sc,
                                                                  const int32_t *__restrict__ n_rows, int n_cap,
@@ -412,8 +424,7 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
 #pragma unroll
         for (int i = 0; i < KF4; ++i) {
             const int e = t + 256 * i, row = e / (C / 4), c4 = e % (C / 4);
-            const bool in = j0 + row < n_cap;
-            kv[i] = in ? *reinterpret_cast<const float4 *>(base + (size_t)(j0 + row) * 3 * C + C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            kv[i] = *reinterpret_cast<const float4 *>(base + (size_t)(j0 + row) * 3 * C + C + 4 * c4);   // n_cap % ATT_KT == 0: the tile is allocated
         }
 #pragma unroll
         for (int o = 0; o < VOCT; ++o) {
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int key = j0 + kb * 32 + 16 * t2 + 8 * (e >> 2) + 4 * h + (e & 3);
-                vv[o * 8 + e] = key < n_cap ? base[(size_t)key * 3 * C + 2 * C + vch] : 0.0f;
+                vv[o * 8 + e] = base[(size_t)key * 3 * C + 2 * C + vch];
             }
         }
     };
@@ -436,20 +447,22 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
 #pragma unroll
         for (int i = 0; i < KF4; ++i) {
             const int e = t + 256 * i, row = e / (C / 4), c4 = e % (C / 4);
-            union { _Float16 h[4]; uint2 u; } ph, pl;
-            split_half(kv[i].x, ph.h[0], pl.h[0]); split_half(kv[i].y, ph.h[1], pl.h[1]);
-            split_half(kv[i].z, ph.h[2], pl.h[2]); split_half(kv[i].w, ph.h[3], pl.h[3]);
-            *reinterpret_cast<uint2 *>(Kh + row * KLD + 4 * c4) = ph.u;
-            *reinterpret_cast<uint2 *>(Kl + row * KLD + 4 * c4) = pl.u;
+            uint2 ph, pl;
+            split_pair(kv[i].x, kv[i].y, ph.x, pl.x);
+            split_pair(kv[i].z, kv[i].w, ph.y, pl.y);
+            *reinterpret_cast<uint2 *>(Kh + row * KLD + 4 * c4) = ph;
+            *reinterpret_cast<uint2 *>(Kl + row * KLD + 4 * c4) = pl;
         }
 #pragma unroll
         for (int o = 0; o < VOCT; ++o) {
             const int oct = vgrp + GROUPS * o;
-            union { _Float16 h[8]; uint4 u; } ph, pl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) split_half(vv[o * 8 + e], ph.h[e], pl.h[e]);
-            *reinterpret_cast<uint4 *>(Vh + ((size_t)oct * C + vch) * 8) = ph.u;
-            *reinterpret_cast<uint4 *>(Vl + ((size_t)oct * C + vch) * 8) = pl.u;
+            uint4 ph, pl;
+            split_pair(vv[o * 8 + 0], vv[o * 8 + 1], ph.x, pl.x);
+            split_pair(vv[o * 8 + 2], vv[o * 8 + 3], ph.y, pl.y);
+            split_pair(vv[o * 8 + 4], vv[o * 8 + 5], ph.z, pl.z);
+            split_pair(vv[o * 8 + 6], vv[o * 8 + 7], ph.w, pl.w);
+            *reinterpret_cast<uint4 *>(Vh + ((size_t)oct * C + vch) * 8) = ph;
+            *reinterpret_cast<uint4 *>(Vl + ((size_t)oct * C + vch) * 8) = pl;
         }
     };
 
@@ -490,16 +503,32 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
-#pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
+        // One wave per SIMD: nobody hides an LDS read that is waited for right after its issue, and that is how the compiler orders
+        // this loop when left alone (ds_read -> s_waitcnt lgkmcnt(0) -> 1-2 MFMAs, 32 times per tile).  The fragments of k16 step
+        // s_+1 are therefore requested before the MFMAs of step s_, and sched_barrier keeps it that way.
+        xhalf8 kf[2][2][2];                           // [buffer][key block][hi | lo]
+        auto read_k = [&](int s_, int buf) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const xhalf8 ah = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
-                const xhalf8 al = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s_], s[kb], 0, 0, 0);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s_], s[kb], 0, 0, 0);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s_], s[kb], 0, 0, 0);
+                kf[buf][kb][0] = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+                kf[buf][kb][1] = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
             }
+        };
+        read_k(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int buf = s_ & 1;
+            if (s_ + 1 < NS) read_k(s_ + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // the two key blocks alternate: back-to-back MFMAs are independent; per accumulator the order stays hi*hi, hi*lo, lo*hi
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][0][0], qh[s_], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][1][0], qh[s_], s[1], 0, 0, 0);
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][0][0], ql[s_], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][1][0], ql[s_], s[1], 0, 0, 0);
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][0][1], qh[s_], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][1][1], qh[s_], s[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         float m_tile = -INFINITY;
 #pragma unroll
@@ -522,13 +551,16 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __expf(s[kb][r] - m_new);     // v_exp_f32 path: ~1e-6 relative, VALU issue is what bounds this kernel
-                l_tile += p;
-                _Float16 h_, l_;
-                split_half(p, h_, l_);
-                ph[kb][r >> 3][r & 7] = h_;
-                pl[kb][r >> 3][r & 7] = l_;
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __expf(s[kb][r] - m_new);    // v_exp_f32 path: ~1e-6 relative, VALU issue is what bounds this kernel
+                const float p1 = __expf(s[kb][r + 1] - m_new);
+                l_tile += p0;
+                l_tile += p1;
+                unsigned uh, ul;
+                split_pair(p0, p1, uh, ul);
+                const xf16x2 h2 = __builtin_bit_cast(xf16x2, uh), l2 = __builtin_bit_cast(xf16x2, ul);
+                ph[kb][r >> 3][r & 7] = h2[0]; ph[kb][r >> 3][(r & 7) + 1] = h2[1];
+                pl[kb][r >> 3][r & 7] = l2[0]; pl[kb][r >> 3][(r & 7) + 1] = l2[1];
             }
         l_run = l_run * alpha + l_tile;
         m_run = m_new;
@@ -536,21 +568,31 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
-        // O^T += V^T P^T
+        // O^T += V^T P^T, the V fragments of key octet pair o+1 requested before the MFMAs of pair o (as above)
+        xhalf8 vf[2][CB][2];                          // [buffer][channel block][hi | lo]
+        auto read_v = [&](int o, int buf) {           // o = kb * 2 + t2
+            const int oct = o * 2 + hi;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                const int oct = (kb * 2 + t2) * 2 + hi;
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const xhalf8 vh = *reinterpret_cast<const xhalf8 *>(Vh + ((size_t)oct * C + cb * 32 + l31) * 8);
-                    const xhalf8 vl = *reinterpret_cast<const xhalf8 *>(Vl + ((size_t)oct * C + cb * 32 + l31) * 8);
-                    acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kb][t2], acc_o[cb], 0, 0, 0);
-                    acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][t2], acc_o[cb], 0, 0, 0);
-                    acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kb][t2], acc_o[cb], 0, 0, 0);
-                }
+            for (int cb = 0; cb < CB; ++cb) {
+                vf[buf][cb][0] = *reinterpret_cast<const xhalf8 *>(Vh + ((size_t)oct * C + cb * 32 + l31) * 8);
+                vf[buf][cb][1] = *reinterpret_cast<const xhalf8 *>(Vl + ((size_t)oct * C + cb * 32 + l31) * 8);
             }
+        };
+        read_v(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int buf = o & 1, kb = o >> 1, t2 = o & 1;
+            if (o + 1 < 4) read_v(o + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[buf][cb][0], ph[kb][t2], acc_o[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[buf][cb][0], pl[kb][t2], acc_o[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[buf][cb][1], ph[kb][t2], acc_o[cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     const float l_all = l_run + __shfl_xor(l_run, 32);
     if (KS > 1) {
