@@ -784,6 +784,7 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
     const int qt_begin = split * qt_per;
     const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const unsigned hi_mask = 0u - (unsigned)hi;
     const char *qp = reinterpret_cast<const char *>(q8) + (size_t)p * cap_q * RB;
     const float2 *qs = reinterpret_cast<const float2 *>(q_scale + (size_t)p * (cap_q / 16));
 
@@ -899,7 +900,13 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
             }
 #pragma unroll
             for (int ab = 0; ab < NAB; ++ab) prev[ab] = acc[ab];
-            prev_sc = hi ? sc2[qb].y : sc2[qb].x;
+            // lane half hi picks .x / .y with bit masks: written as `hi ? .y : .x` the compiler indexes the float2 array dynamically,
+            // moves it to LDS (one 32-byte slot per thread) and reads it back with 8-way bank-conflicting ds_read_b32 - 1.1e8
+            // SQ_LDS_BANK_CONFLICT cycles per launch in the round-1 / early round-2 counters
+            {
+                const unsigned ux = __builtin_bit_cast(unsigned, sc2[qb].x), uy = __builtin_bit_cast(unsigned, sc2[qb].y);
+                prev_sc = __builtin_bit_cast(float, (ux & ~hi_mask) | (uy & hi_mask));
+            }
             prev_sid = (qt * NQB + qb) * 2 + hi;
         }
         if (!(VAR & 2)) {

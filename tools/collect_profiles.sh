@@ -2,6 +2,7 @@
 # Collect the rocprofv3 evidence that profiles/ holds, on the GPU box:  bash tools/collect_profiles.sh <out_dir>
 #   1. kernel-trace of `python bench.py` (default workload)                     -> <out>/kernel_stats.md + the printed JSON line
 #   2. separate --pmc passes (no trace domains besides --kernel-trace), restricted to the heavy kernels -> <out>/pmc_counters.md
+#   3. full (feat+match+pose) stage on the fp16x3 path: kernel trace + matrix-pipe counters -> <out>/full_stage_*.md
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$R/gpurun_out/profiles}
@@ -29,4 +30,15 @@ RX='screen_v2_kernel|gather_q8_v3|pdsc_attention|match_decide|match_resolve|pdsc
   { echo; echo "## FETCH_SIZE calibration: 1 GiB (1048576 KiB) read once by each kernel"; echo
     python $R/tools/rocpd_summary.py $P/c_results.db | sed -n '/## PMC counters/,$p' | tail -n +3; } >> "$OUT/pmc_counters.md"
 }
+# 3. the widened stage set on the fp32-grade fp16x3 path: kernel trace of one full (feat+match+pose) stage run and the matrix-pipe
+#    counters of its GEMM / attention kernels
+D=/tmp/prof_full; rm -rf $D
+rocprofv3 --kernel-trace --stats -d $D -o full -- python $R/bench.py --stages full --backbone-dtype fp16x3 --steps 2 --warmup 1 > /tmp/full.log 2>&1
+python $R/tools/rocpd_summary.py $D/full_results.db --exclude "naive_conv|Im2d2Col|Col2Im2d" > "$OUT/full_stage_kernel_stats.md"   # MIOpen find-mode trial launches
+{
+  echo "# rocprofv3 PMC pass: bench.py --stages full --backbone-dtype fp16x3 --steps 1 --warmup 0, kernels /linear_f16x3_stream|mha_x3/"
+  P=/tmp/prof_pmc_full; rm -rf $P
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --kernel-include-regex "linear_f16x3_stream|mha_x3" -d $P -o p -- python $R/bench.py --stages full --backbone-dtype fp16x3 --steps 1 --warmup 0 > /tmp/pmc_full.log 2>&1
+  echo; python $R/tools/rocpd_summary.py $P/p_results.db | sed -n '/## PMC counters/,$p' | tail -n +3
+} > "$OUT/full_stage_pmc.md"
 ls -la "$OUT"

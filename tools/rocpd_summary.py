@@ -3,20 +3,27 @@
 (the same content as `--stats` CSV output): calls, total / average / min / max duration, share.
 Optionally also dumps PMC counter sums per kernel.
 
-    python tools/rocpd_summary.py gpurun_out/prof/bench_results.db > profiles/r01_bench_kernel_stats.md
+    python tools/rocpd_summary.py gpurun_out/prof/bench_results.db [--exclude REGEX] > profiles/r01_bench_kernel_stats.md
 """
+import re
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, exclude=None):
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
     rows = c.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                      f"from kernels group by {name_col} order by 3 desc").fetchall()
+    dropped = 0.0
+    if exclude:
+        dropped = sum(r[2] for r in rows if re.search(exclude, r[0])) / 1e6
+        rows = [r for r in rows if not re.search(exclude, r[0])]
     total = sum(r[2] for r in rows) or 1
     print(f"# rocprofv3 kernel-trace summary of `{path.split('/')[-1]}`\n")
+    if exclude:
+        print(f"(kernels matching /{exclude}/ left out: {dropped:.1f} ms in total - one-off library auto-tuning launches of the warm-up pass)\n")
     print("| kernel | calls | total ms | avg us | min us | max us | % of GPU time |")
     print("|---|---:|---:|---:|---:|---:|---:|")
     for n, k, tot, avg, mn, mx in rows:
@@ -37,4 +44,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "--exclude" else None)
