@@ -712,6 +712,151 @@ __global__ __launch_bounds__(256) void pdsc_linear_x3_kernel(const float *__rest
     }
 }
 
+// fc_message of one NonLocal layer as ONE kernel (PointDSC.py:27-45: conv C->C/2 + BN + ReLU, conv C/2->C/2 + BN + ReLU, conv C/2->C,
+// + the residual; C = 128): feat = feat1 + W3 relu(W2 relu(W1 msg + b1) + b2) + b3.  Three dependent launches of tiny GEMMs (29 us per layer:
+// launch latency and five HBM round trips of [rows, 64..128] activations) become one.
+// The chain runs TRANSPOSED, Y^T = W X^T: the weights are the MFMA's A operand (rows = output channels), the activations its B operand
+// (columns = points), so an accumulator register holds (point = lane % 32, channel = crow(r, lane / 32)) - and the 8 registers 8j .. 8j+7
+// of a lane are exactly one B-operand fragment of the NEXT layer, provided that layer's weights list their input channels in that register
+// order.  oryon_pointdsc_finalize stores the three matrices that way (pre-split into fp16 hi / lo, rows swizzled: PDSC_MLP_* image), so the
+// intermediate activations never leave the registers: bias + ReLU + split, next MFMA.  A wave owns 32 points and all channels; a workgroup
+// (4 waves, 128 points) copies the 80 KB weight image into LDS once (LDS-DMA) while its waves fetch and split their input rows.
+__global__ __launch_bounds__(256) void pdsc_mlp3_x3_kernel(const float *__restrict__ msg, const float *__restrict__ resid,
+                                                            const char *__restrict__ img, const float *__restrict__ b1,
+                                                            const float *__restrict__ b2, const float *__restrict__ b3,
+                                                            const int32_t *__restrict__ n_rows, int n_cap, float *__restrict__ out)
+{
+    constexpr int C = 128;
+    extern __shared__ __attribute__((aligned(1024))) char mlp_lds[];
+    const int b = blockIdx.y, q0 = blockIdx.x * 128;
+    if (q0 >= n_rows[b]) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // weight image -> LDS: 80 pieces of 1 KB, 20 per wave, lane-linear
+#pragma unroll
+    for (int j = 0; j < PDSC_MLP_IMG_BYTES / 4096; ++j) {
+        const int piece = wave_u * (PDSC_MLP_IMG_BYTES / 4096) + j;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(mlp_lds + piece * 1024), 16, 0, 0);
+    }
+    // this lane's point: channels 16 s + 8 hi .. + 7 of k-step s, split into B-operand fragments
+    const size_t prow = ((size_t)b * n_cap + q0 + wave * 32 + l31) * C;
+    xhalf8 xh[8], xl[8];
+    {
+        const float4 *xp = reinterpret_cast<const float4 *>(msg + prow);
+        float4 raw[16];
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) { raw[2 * s_] = xp[4 * s_ + 2 * hi]; raw[2 * s_ + 1] = xp[4 * s_ + 2 * hi + 1]; }
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            uint4 uh, ul;
+            split_pair(raw[2 * s_].x, raw[2 * s_].y, uh.x, ul.x);
+            split_pair(raw[2 * s_].z, raw[2 * s_].w, uh.y, ul.y);
+            split_pair(raw[2 * s_ + 1].x, raw[2 * s_ + 1].y, uh.z, ul.z);
+            split_pair(raw[2 * s_ + 1].z, raw[2 * s_ + 1].w, uh.w, ul.w);
+            xh[s_] = __builtin_bit_cast(xhalf8, uh);
+            xl[s_] = __builtin_bit_cast(xhalf8, ul);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // A fragments: 256-byte rows (W1) slot ^ (row & 15), 128-byte rows (W2, W3) slot ^ ((row >> 1) & 7)
+    auto w1_frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(mlp_lds + base + o * 256 + (((2 * s_ + hi) ^ (o & 15)) << 4));
+    };
+    auto w23_frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(mlp_lds + base + o * 128 + (((2 * s_ + hi) ^ ((o >> 1) & 7)) << 4));
+    };
+    // bias + ReLU + split of two 32-channel accumulator blocks -> the 4 B fragments (k-steps) of the next layer
+    auto next_operand = [&](const f32x16 (&acc)[2], const float *bias, xhalf8 (&oh)[4], xhalf8 (&ol)[4]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {                 // registers 8 j + 4 g2 .. + 3: channels rb*32 + 8 (2 j + g2) + 4 hi + 0..3
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + rb * 32 + 8 * (2 * j + g2) + 4 * hi);
+                    const int r0 = 8 * j + 4 * g2;
+                    const float v0 = fmaxf(acc[rb][r0] + bv.x, 0.0f), v1 = fmaxf(acc[rb][r0 + 1] + bv.y, 0.0f);
+                    const float v2 = fmaxf(acc[rb][r0 + 2] + bv.z, 0.0f), v3 = fmaxf(acc[rb][r0 + 3] + bv.w, 0.0f);
+                    split_pair(v0, v1, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v2, v3, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                oh[rb * 2 + j] = __builtin_bit_cast(xhalf8, uh);
+                ol[rb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+    };
+    // Two 32-channel output blocks (rb0, rb0 + 1) over NS k-steps: the four weight fragments of step s+1 are requested before the six
+    // MFMAs of step s (left alone the compiler reads each fragment right before its first use: one exposed LDS latency per fragment).
+    // The two accumulators alternate, per accumulator the order is hi*hi, hi*lo, lo*hi.
+    auto two_blocks = [&](auto &&frag, int base_h, int base_l, int rb0, int NS, const xhalf8 *bh, const xhalf8 *bl, f32x16 (&acc)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        xhalf8 w[2][2][2];                            // [buffer][block][hi | lo]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { w[0][i][0] = frag(base_h, rb0 + i, 0); w[0][i][1] = frag(base_l, rb0 + i, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            if (s_ < NS) {
+                const int cur = s_ & 1;
+                if (s_ + 1 < NS) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { w[cur ^ 1][i][0] = frag(base_h, rb0 + i, s_ + 1); w[cur ^ 1][i][1] = frag(base_l, rb0 + i, s_ + 1); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bh[s_], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bh[s_], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bl[s_], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bl[s_], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][1], bh[s_], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][1], bh[s_], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // layer 1: [64, 128] x [128, points]
+    f32x16 a1[2];
+    two_blocks(w1_frag, PDSC_MLP_W1H, PDSC_MLP_W1L, 0, 8, xh, xl, a1);
+    xhalf8 h1h[4], h1l[4];
+    next_operand(a1, b1, h1h, h1l);
+    // layer 2: [64, 64] x [64, points]
+    f32x16 a2[2];
+    two_blocks(w23_frag, PDSC_MLP_W2H, PDSC_MLP_W2L, 0, 4, h1h, h1l, a2);
+    xhalf8 h2h[4], h2l[4];
+    next_operand(a2, b2, h2h, h2l);
+    // layer 3: [128, 64] x [64, points], + bias + residual, stored as float4 groups (channels rb*32 + 8 g + 4 hi + 0..3 of the lane's point)
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        float4 rv[2][4];                              // the residual rows travel under the MFMAs
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rv[i][g] = *reinterpret_cast<const float4 *>(resid + prow + (2 * rp + i) * 32 + 8 * g + 4 * hi);
+        f32x16 a3[2];
+        two_blocks(w23_frag, PDSC_MLP_W3H, PDSC_MLP_W3L, 2 * rp, 4, h2h, h2l, a3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = (2 * rp + i) * 32 + 8 * g + 4 * hi;
+                const float4 bv = *reinterpret_cast<const float4 *>(b3 + c);
+                float4 o;
+                o.x = a3[i][4 * g + 0] + bv.x + rv[i][g].x;
+                o.y = a3[i][4 * g + 1] + bv.y + rv[i][g].y;
+                o.z = a3[i][4 * g + 2] + bv.z + rv[i][g].z;
+                o.w = a3[i][4 * g + 3] + bv.w + rv[i][g].w;
+                *reinterpret_cast<float4 *>(out + prow + c) = o;
+            }
+    }
+}
+
 // Combine the key-split partials: msg = sum_s e^{m_s - m} O_s / sum_s e^{m_s - m} l_s,  m = max_s m_s.
 __global__ __launch_bounds__(256) void pdsc_attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
                                                                     const int32_t *__restrict__ n_rows, int n_cap, int C, int KS,
@@ -829,6 +974,14 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
                                n_rows, n_cap, C, KS, B, ws.msg);
         if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
         // fc_message: C -> C/2 -> C/2 -> C, residual onto the PointCN output
+        static const bool fused_mlp = !getenv("ORYON_PDSC_FUSED_MLP") || atoi(getenv("ORYON_PDSC_FUSED_MLP")) != 0;   // dev: 0 = three launches
+        if (C == 128 && x3 && fused_mlp && L.mlp_img) {
+            allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_mlp3_x3_kernel), PDSC_MLP_IMG_BYTES);
+            hipLaunchKernelGGL(pdsc_mlp3_x3_kernel, dim3(n_cap / 128, B), dim3(256), PDSC_MLP_IMG_BYTES, st, ws.msg, ws.feat1, L.mlp_img, L.b_m1,
+                               L.b_m2, L.b_m3, n_rows, n_cap, ws.feat);
+            if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
+            continue;
+        }
         rc = launch_linear(true, false, ws.msg, C, fb, L.w_m1, L.b_m1, nullptr, 0, 0, ws.h1, H, hb, C, H, B, n_cap, n_rows, st);
         if (rc) return rc;
         rc = launch_linear(true, false, ws.h1, H, hb, L.w_m2, L.b_m2, nullptr, 0, 0, ws.h2, H, hb, H, H, B, n_cap, n_rows, st);

@@ -12,6 +12,7 @@ struct oryon_pointdsc {
     oryon_pointdsc_config_t cfg;
     std::map<std::string, std::vector<float>> host;   // raw tensors by reference name
     float *dev_blob = nullptr;
+    char *dev_mlp = nullptr;            // [num_layers][PDSC_MLP_IMG_BYTES] (C == 128)
     float *seed_scratch = nullptr;      // oryon_pointdsc_seeds (stage API, no workspace argument): grown on demand
     size_t seed_scratch_floats = 0;
     PdscModel model;
@@ -144,6 +145,7 @@ extern "C" void oryon_pointdsc_destroy(oryon_pointdsc_t *h)
 {
     if (!h) return;
     if (h->dev_blob) (void)hipFree(h->dev_blob);
+    if (h->dev_mlp) (void)hipFree(h->dev_mlp);
     if (h->seed_scratch) (void)hipFree(h->seed_scratch);
     delete h;
 }
@@ -235,6 +237,38 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
     ORYON_CHECK_HIP(hipMalloc(&h->dev_blob, total * sizeof(float)));
     ORYON_CHECK_HIP(hipMemcpyAsync(h->dev_blob, blob.data(), total * sizeof(float), hipMemcpyHostToDevice, as_stream(stream)));
     ORYON_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    // fc_message weights once more, pre-split into fp16 hi / lo and laid out as the fused kernel's LDS image
+    if (h->dev_mlp) { (void)hipFree(h->dev_mlp); h->dev_mlp = nullptr; }
+    if (C == 128) {
+        std::vector<char> img((size_t)L * PDSC_MLP_IMG_BYTES, 0);
+        auto put_half = [](char *dst_hi, char *dst_lo, size_t byte, float x) {
+            const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+            memcpy(dst_hi + byte, &hi, 2);
+            memcpy(dst_lo + byte, &lo, 2);
+        };
+        // k-slot (16-byte unit) q = 2 * step + half, element e of a PERMUTED K axis: the channel an accumulator register holds
+        auto perm_src = [](int q, int e) { const int s2 = q >> 1, hi = q & 1, rb = s2 >> 1, j = s2 & 1; return rb * 32 + (e & 3) + 8 * (2 * j + (e >> 2)) + 4 * hi; };
+        for (int l = 0; l < L; ++l) {
+            char *im = img.data() + (size_t)l * PDSC_MLP_IMG_BYTES;
+            // the BN-folded matrices sit in the fp32 blob: w_m1 [H,C], w_m2 [H,H], w_m3 [C,H]
+            const size_t base = 2 + (size_t)l * 10;                  // offs index of this layer's w_pcn
+            const float *w1 = blob.data() + offs[base + 4], *w2 = blob.data() + offs[base + 6], *w3 = blob.data() + offs[base + 8];
+            for (int o = 0; o < H; ++o)
+                for (int k = 0; k < C; ++k)                          // natural K order, 256-byte rows, slot ^ (row & 15)
+                    put_half(im + PDSC_MLP_W1H, im + PDSC_MLP_W1L, (size_t)o * 256 + (size_t)(((k >> 3) ^ (o & 15)) << 4) + (k & 7) * 2, w1[(size_t)o * C + k]);
+            for (int o = 0; o < H; ++o)
+                for (int q = 0; q < 8; ++q)
+                    for (int e = 0; e < 8; ++e)                      // permuted K order, 128-byte rows, slot ^ ((row >> 1) & 7)
+                        put_half(im + PDSC_MLP_W2H, im + PDSC_MLP_W2L, (size_t)o * 128 + (size_t)((q ^ ((o >> 1) & 7)) << 4) + e * 2, w2[(size_t)o * H + perm_src(q, e)]);
+            for (int o = 0; o < C; ++o)
+                for (int q = 0; q < 8; ++q)
+                    for (int e = 0; e < 8; ++e)
+                        put_half(im + PDSC_MLP_W3H, im + PDSC_MLP_W3L, (size_t)o * 128 + (size_t)((q ^ ((o >> 1) & 7)) << 4) + e * 2, w3[(size_t)o * H + perm_src(q, e)]);
+        }
+        ORYON_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&h->dev_mlp), img.size()));
+        ORYON_CHECK_HIP(hipMemcpyAsync(h->dev_mlp, img.data(), img.size(), hipMemcpyHostToDevice, as_stream(stream)));
+        ORYON_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    }
     const float *d = h->dev_blob;
     size_t i = 0;
     PdscModel &M = h->model;
@@ -248,6 +282,7 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
         Ly.w_m1 = d + offs[i++]; Ly.b_m1 = d + offs[i++];
         Ly.w_m2 = d + offs[i++]; Ly.b_m2 = d + offs[i++];
         Ly.w_m3 = d + offs[i++]; Ly.b_m3 = d + offs[i++];
+        Ly.mlp_img = h->dev_mlp ? h->dev_mlp + (size_t)l * PDSC_MLP_IMG_BYTES : nullptr;
     }
     M.w_c1 = d + offs[i++]; M.b_c1 = d + offs[i++];
     M.w_c2 = d + offs[i++]; M.b_c2 = d + offs[i++];
