@@ -15,12 +15,15 @@ struct PdscLayer {
     const float *w_m2, *b_m2;     // [C/2,C/2] BN-folded
     const float *w_m3, *b_m3;     // [C,C/2]
     const char *mlp_img;          // fc_message weights as the LDS image of pdsc_mlp3_x3_kernel (C == 128 only, else nullptr)
+    const char *pq_img;           // PointCN + q|k|v weights as the four 64 KB LDS chunks of pdsc_pcn_qkv_x3_kernel (C == 128 only)
 };
 
 // LDS image of one layer's fc_message weights for pdsc_mlp3_x3_kernel (C = 128, H = 64): six fp16 matrices, rows swizzled for
 // conflict-free ds_read_b128, the K axis of the 2nd / 3rd matrix permuted into MFMA accumulator-register order (pdsc_encoder.hip).
 constexpr int PDSC_MLP_W1H = 0, PDSC_MLP_W1L = 16384, PDSC_MLP_W2H = 32768, PDSC_MLP_W2L = 40960, PDSC_MLP_W3H = 49152,
               PDSC_MLP_W3L = 65536, PDSC_MLP_IMG_BYTES = 81920;
+// pdsc_pcn_qkv_x3_kernel: four chunks (PointCN, q, k, v) of [hi: 128 rows x 256 B | lo: the same], slot ^ (row & 15); q|k|v K axis permuted
+constexpr int PDSC_PQ_CHUNK_BYTES = 65536, PDSC_PQ_IMG_BYTES = 4 * PDSC_PQ_CHUNK_BYTES;
 
 struct PdscModel {
     oryon_pointdsc_config_t cfg;

@@ -857,6 +857,142 @@ __global__ __launch_bounds__(256) void pdsc_mlp3_x3_kernel(const float *__restri
     }
 }
 
+// PointCN + q|k|v of one layer as ONE kernel, same transposed register chain as pdsc_mlp3_x3_kernel:
+//   feat1 = relu(Wp feat + bp)  (stored: it is the residual of the layer's fc_message)      qkv = Wq feat1 + bq
+// The weights do not fit LDS together (4 x 64 KB: PointCN, q, k, v - hi and lo halves of a 128 x 128 matrix each), so they stream through
+// two 64 KB areas: PointCN | q are requested up front, k replaces PointCN once every wave has finished layer 1, v replaces q.
+__global__ __launch_bounds__(256) void pdsc_pcn_qkv_x3_kernel(const float *__restrict__ feat, const char *__restrict__ img,
+                                                               const float *__restrict__ bp, const float *__restrict__ bq,
+                                                               const int32_t *__restrict__ n_rows, int n_cap, float *__restrict__ feat1,
+                                                               float *__restrict__ qkv)
+{
+    constexpr int C = 128, HALF = PDSC_PQ_CHUNK_BYTES / 2;
+    extern __shared__ __attribute__((aligned(1024))) char pq_lds[];
+    const int b = blockIdx.y, q0 = blockIdx.x * 128;
+    if (q0 >= n_rows[b]) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_chunk = [&](int chunk, int area) {                       // 64 pieces of 1 KB, 16 per wave
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int piece = wave_u * 16 + j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (size_t)chunk * PDSC_PQ_CHUNK_BYTES + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(pq_lds + area * PDSC_PQ_CHUNK_BYTES + piece * 1024), 16, 0, 0);
+        }
+    };
+    dma_chunk(0, 0);
+    dma_chunk(1, 1);
+    const size_t prow = (size_t)b * n_cap + q0 + wave * 32 + l31;
+    xhalf8 xh[8], xl[8];
+    {
+        const float4 *xp = reinterpret_cast<const float4 *>(feat + prow * C);
+        float4 raw[16];
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) { raw[2 * s_] = xp[4 * s_ + 2 * hi]; raw[2 * s_ + 1] = xp[4 * s_ + 2 * hi + 1]; }
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            uint4 uh, ul;
+            split_pair(raw[2 * s_].x, raw[2 * s_].y, uh.x, ul.x);
+            split_pair(raw[2 * s_].z, raw[2 * s_].w, uh.y, ul.y);
+            split_pair(raw[2 * s_ + 1].x, raw[2 * s_ + 1].y, uh.z, ul.z);
+            split_pair(raw[2 * s_ + 1].z, raw[2 * s_ + 1].w, uh.w, ul.w);
+            xh[s_] = __builtin_bit_cast(xhalf8, uh);
+            xl[s_] = __builtin_bit_cast(xhalf8, ul);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(pq_lds + base + o * 256 + (((2 * s_ + hi) ^ (o & 15)) << 4));
+    };
+    // two 32-channel output blocks over the 8 k-steps, fragments of step s+1 requested before the MFMAs of step s (see pdsc_mlp3_x3_kernel)
+    auto two_blocks = [&](int area, int rb0, const xhalf8 *bh, const xhalf8 *bl, f32x16 (&acc)[2]) {
+        const int base_h = area * PDSC_PQ_CHUNK_BYTES, base_l = base_h + HALF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        xhalf8 w[2][2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { w[0][i][0] = frag(base_h, rb0 + i, 0); w[0][i][1] = frag(base_l, rb0 + i, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const int cur = s_ & 1;
+            if (s_ + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { w[cur ^ 1][i][0] = frag(base_h, rb0 + i, s_ + 1); w[cur ^ 1][i][1] = frag(base_l, rb0 + i, s_ + 1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bh[s_], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bh[s_], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bl[s_], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bl[s_], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][1], bh[s_], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][1], bh[s_], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // layer 1 (PointCN, area 0): bias + ReLU, stored as feat1 and kept as the 8 B fragments of layer 2
+    xhalf8 fh[8], fl[8];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        f32x16 acc[2];
+        two_blocks(0, 2 * rp, xh, xl, acc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rb = 2 * rp + i;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int c = rb * 32 + 8 * (2 * j + g2) + 4 * hi, r0 = 8 * j + 4 * g2;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bp + c);
+                    float4 v;
+                    v.x = fmaxf(acc[i][r0] + bv.x, 0.0f); v.y = fmaxf(acc[i][r0 + 1] + bv.y, 0.0f);
+                    v.z = fmaxf(acc[i][r0 + 2] + bv.z, 0.0f); v.w = fmaxf(acc[i][r0 + 3] + bv.w, 0.0f);
+                    *reinterpret_cast<float4 *>(feat1 + prow * C + c) = v;
+                    split_pair(v.x, v.y, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v.z, v.w, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                fh[rb * 2 + j] = __builtin_bit_cast(xhalf8, uh);
+                fl[rb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+        }
+    }
+    // q from area 1 while k lands in area 0, k from area 0 while v lands in area 1, v from area 1
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const int area = (part + 1) & 1;
+        if (part > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this part's chunk has landed (requested one part ago)
+        if (part < 2) {
+            __syncthreads();                                                     // every wave is done with the other area; part's chunk visible
+            dma_chunk(part + 2, area ^ 1);
+        } else {
+            __syncthreads();
+        }
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            f32x16 acc[2];
+            two_blocks(area, 2 * rp, fh, fl, acc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = part * C + (2 * rp + i) * 32 + 8 * g + 4 * hi;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bq + c);
+                    float4 o;
+                    o.x = acc[i][4 * g + 0] + bv.x; o.y = acc[i][4 * g + 1] + bv.y;
+                    o.z = acc[i][4 * g + 2] + bv.z; o.w = acc[i][4 * g + 3] + bv.w;
+                    *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;
+                }
+        }
+    }
+}
+
 // Combine the key-split partials: msg = sum_s e^{m_s - m} O_s / sum_s e^{m_s - m} l_s,  m = max_s m_s.
 __global__ __launch_bounds__(256) void pdsc_attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
                                                                     const int32_t *__restrict__ n_rows, int n_cap, int C, int KS,
@@ -952,15 +1088,24 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
     hipLaunchKernelGGL(pdsc_sc_kernel, dim3(n_cap / 128, n_cap / ATT_KT, B), dim3(256), 0, st, src, tgt, n_rows, n_cap, inv_sigma2, ws.sc);
     for (int l = 0; l < M.cfg.num_layers; ++l) {
         const PdscLayer &L = M.layers[l];
-        // PointCN: conv + BN + ReLU (BN folded)
-        rc = launch_linear(true, false, ws.feat, C, fb, L.w_pcn, L.b_pcn, nullptr, 0, 0, ws.feat1, C, fb, C, C, B, n_cap, n_rows, st);
-        if (rc) return rc;
-        // q | k | v projections as one GEMM with N = 3C
-        rc = launch_linear(false, false, ws.feat1, C, fb, L.w_qkv, L.b_qkv, nullptr, 0, 0, ws.qkv, 3 * C, qb, C, 3 * C, B, n_cap, n_rows, st);
-        if (rc) return rc;
+        static const bool x3 = getenv("ORYON_PDSC_FP32_MFMA") == nullptr;     // fp16x3 unless the pure-fp32 kernels are asked for
+        static const bool fused_pq = !getenv("ORYON_PDSC_FUSED_PQ") || atoi(getenv("ORYON_PDSC_FUSED_PQ")) != 0;       // dev: 0 = two launches
+        if (C == 128 && x3 && fused_pq && L.pq_img) {
+            // PointCN (conv + BN + ReLU, BN folded) and the q | k | v projections in one launch
+            allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_pcn_qkv_x3_kernel), 2 * PDSC_PQ_CHUNK_BYTES);
+            hipLaunchKernelGGL(pdsc_pcn_qkv_x3_kernel, dim3(n_cap / 128, B), dim3(256), 2 * PDSC_PQ_CHUNK_BYTES, st, ws.feat, L.pq_img, L.b_pcn,
+                               L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv);
+            if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
+        } else {
+            // PointCN: conv + BN + ReLU (BN folded)
+            rc = launch_linear(true, false, ws.feat, C, fb, L.w_pcn, L.b_pcn, nullptr, 0, 0, ws.feat1, C, fb, C, C, B, n_cap, n_rows, st);
+            if (rc) return rc;
+            // q | k | v projections as one GEMM with N = 3C
+            rc = launch_linear(false, false, ws.feat1, C, fb, L.w_qkv, L.b_qkv, nullptr, 0, 0, ws.qkv, 3 * C, qb, C, 3 * C, B, n_cap, n_rows, st);
+            if (rc) return rc;
+        }
         const int KS = ws.att_splits;
         dim3 ag(n_cap / ATT_Q, KS, B);
-        static const bool x3 = getenv("ORYON_PDSC_FP32_MFMA") == nullptr;     // fp16x3 unless the pure-fp32 kernels are asked for
         if (C == 128 && x3)
             hipLaunchKernelGGL((pdsc_attention_x3_kernel<128>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         else if (C == 128)

@@ -13,6 +13,7 @@ struct oryon_pointdsc {
     std::map<std::string, std::vector<float>> host;   // raw tensors by reference name
     float *dev_blob = nullptr;
     char *dev_mlp = nullptr;            // [num_layers][PDSC_MLP_IMG_BYTES] (C == 128)
+    char *dev_pq = nullptr;             // [num_layers][PDSC_PQ_IMG_BYTES] (C == 128)
     float *seed_scratch = nullptr;      // oryon_pointdsc_seeds (stage API, no workspace argument): grown on demand
     size_t seed_scratch_floats = 0;
     PdscModel model;
@@ -146,6 +147,7 @@ extern "C" void oryon_pointdsc_destroy(oryon_pointdsc_t *h)
     if (!h) return;
     if (h->dev_blob) (void)hipFree(h->dev_blob);
     if (h->dev_mlp) (void)hipFree(h->dev_mlp);
+    if (h->dev_pq) (void)hipFree(h->dev_pq);
     if (h->seed_scratch) (void)hipFree(h->seed_scratch);
     delete h;
 }
@@ -239,6 +241,7 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
     ORYON_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
     // fc_message weights once more, pre-split into fp16 hi / lo and laid out as the fused kernel's LDS image
     if (h->dev_mlp) { (void)hipFree(h->dev_mlp); h->dev_mlp = nullptr; }
+    if (h->dev_pq) { (void)hipFree(h->dev_pq); h->dev_pq = nullptr; }
     if (C == 128) {
         std::vector<char> img((size_t)L * PDSC_MLP_IMG_BYTES, 0);
         auto put_half = [](char *dst_hi, char *dst_lo, size_t byte, float x) {
@@ -268,6 +271,28 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
         ORYON_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&h->dev_mlp), img.size()));
         ORYON_CHECK_HIP(hipMemcpyAsync(h->dev_mlp, img.data(), img.size(), hipMemcpyHostToDevice, as_stream(stream)));
         ORYON_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+        // PointCN (natural K: its input comes from memory) and q | k | v (K in accumulator-register order) for pdsc_pcn_qkv_x3_kernel
+        std::vector<char> pq((size_t)L * PDSC_PQ_IMG_BYTES, 0);
+        for (int l = 0; l < L; ++l) {
+            char *im = pq.data() + (size_t)l * PDSC_PQ_IMG_BYTES;
+            const size_t base = 2 + (size_t)l * 10;
+            const float *wp = blob.data() + offs[base + 0], *wq = blob.data() + offs[base + 2];
+            for (int o = 0; o < C; ++o)
+                for (int k = 0; k < C; ++k)
+                    put_half(im, im + PDSC_PQ_CHUNK_BYTES / 2, (size_t)o * 256 + (size_t)(((k >> 3) ^ (o & 15)) << 4) + (k & 7) * 2, wp[(size_t)o * C + k]);
+            for (int part = 0; part < 3; ++part) {
+                char *ch = im + (size_t)(1 + part) * PDSC_PQ_CHUNK_BYTES;
+                for (int o = 0; o < C; ++o)
+                    for (int q = 0; q < 16; ++q)
+                        for (int e = 0; e < 8; ++e)
+                            put_half(ch, ch + PDSC_PQ_CHUNK_BYTES / 2, (size_t)o * 256 + (size_t)((q ^ (o & 15)) << 4) + e * 2,
+                                     wq[((size_t)part * C + o) * C + perm_src(q, e)]);
+            }
+        }
+        if (h->dev_pq) { (void)hipFree(h->dev_pq); h->dev_pq = nullptr; }
+        ORYON_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&h->dev_pq), pq.size()));
+        ORYON_CHECK_HIP(hipMemcpyAsync(h->dev_pq, pq.data(), pq.size(), hipMemcpyHostToDevice, as_stream(stream)));
+        ORYON_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
     }
     const float *d = h->dev_blob;
     size_t i = 0;
@@ -283,6 +308,7 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
         Ly.w_m2 = d + offs[i++]; Ly.b_m2 = d + offs[i++];
         Ly.w_m3 = d + offs[i++]; Ly.b_m3 = d + offs[i++];
         Ly.mlp_img = h->dev_mlp ? h->dev_mlp + (size_t)l * PDSC_MLP_IMG_BYTES : nullptr;
+        Ly.pq_img = h->dev_pq ? h->dev_pq + (size_t)l * PDSC_PQ_IMG_BYTES : nullptr;
     }
     M.w_c1 = d + offs[i++]; M.b_c1 = d + offs[i++];
     M.w_c2 = d + offs[i++]; M.b_c2 = d + offs[i++];
