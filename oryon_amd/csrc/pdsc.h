@@ -24,6 +24,8 @@ constexpr int PDSC_MLP_W1H = 0, PDSC_MLP_W1L = 16384, PDSC_MLP_W2H = 32768, PDSC
               PDSC_MLP_W3L = 65536, PDSC_MLP_IMG_BYTES = 81920;
 // pdsc_pcn_qkv_x3_kernel: four chunks (PointCN, q, k, v) of [hi: 128 rows x 256 B | lo: the same], slot ^ (row & 15); q|k|v K axis permuted
 constexpr int PDSC_PQ_CHUNK_BYTES = 65536, PDSC_PQ_IMG_BYTES = 4 * PDSC_PQ_CHUNK_BYTES;
+// K / V image of one 64-key tile (C = 128): Kh | Kl as [64 keys][136 halves] (16-byte row pad), Vh | Vl as [8 octets][128 channels][8 keys]
+constexpr int PDSC_KV_KL = 17408, PDSC_KV_VH = 34816, PDSC_KV_VL = 51200, PDSC_KV_TILE_BYTES = 67584;
 
 struct PdscModel {
     oryon_pointdsc_config_t cfg;
@@ -40,6 +42,7 @@ struct PdscWorkspace {
     float *feat1;     // [B,n_cap,C]
     float *qkv;       // [B,n_cap,3C]
     float *msg;       // [B,n_cap,C]
+    char *kv_img;     // [B,n_cap/64,PDSC_KV_TILE_BYTES] K / V of every 64-key tile as the attention kernel's LDS image (C == 128; else unused)
     float *sc;        // [B,n_cap/32,n_cap/64,8,64,4] spatial-consistency tiles in attention-register layout
     float *att_o;     // [att_splits,B,n_cap,C]   key-split attention partials (att_splits > 1 only)
     float *att_ml;    // [att_splits,B,n_cap,2]   running max, exp-sum

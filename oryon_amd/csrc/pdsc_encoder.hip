@@ -624,6 +624,198 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
         }
 }
 
+// The same kernel fed by pdsc_pcn_qkv_x3_kernel's K / V tile images (C = 128, no key split across workgroups): K / V of a tile arrive
+// pre-split and in LDS layout, 66 pieces of 1 KB by LDS-DMA - no staging registers, no conversion work (the fp32-fed kernel splits the same
+// K / V in each of a pair's four query-block workgroups) - and the next tile lands in a second buffer while this one is multiplied: one
+// barrier per tile instead of two.
+template <int C>
+__global__ __launch_bounds__(256) void pdsc_attention_x3_img_kernel(const float *__restrict__ QKV, const char *__restrict__ kv_img,
+                                                                     const float *__restrict__ sc, const int32_t *__restrict__ n_rows,
+                                                                     int n_cap, float inv_sqrt_c, float *__restrict__ msg)
+{
+    static_assert(C == 128, "tile image geometry");
+    constexpr int CB = C / 32;
+    constexpr int NS = C / 16;                    // k16 steps of the first product
+    constexpr int KLD = C + 8;                    // halves per K row
+    extern __shared__ __attribute__((aligned(1024))) char att_lds[];            // two tile images
+    const int b = blockIdx.z;
+    const int n = n_rows[b];
+    const int q0 = blockIdx.x * ATT_Q;
+    if (q0 >= n) return;
+    const int j_begin = 0, j_end = n;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int qrow = q0 + wave * 32 + l31;
+    const float *base = QKV + (size_t)b * n_cap * 3 * C;
+    const char *img = kv_img + (size_t)b * (n_cap / ATT_KT) * PDSC_KV_TILE_BYTES;
+    const float4 *sc_q = reinterpret_cast<const float4 *>(sc) + (((size_t)b * (n_cap / 32) + (q0 / 32 + wave)) * (n_cap / ATT_KT)) * 8 * 64 + lane;
+    const bool q_live = q0 + wave * 32 < n;
+    float4 scv[8];
+    auto dma_tile = [&](int j0, int buf) {
+        const char *src = img + (size_t)(j0 / ATT_KT) * PDSC_KV_TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 17; ++j) {
+            const int piece = wave_u * 17 + j;
+            if (piece < PDSC_KV_TILE_BYTES / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(att_lds + buf * PDSC_KV_TILE_BYTES + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto fetch_sc = [&](int j0) {
+        const float4 *sp = sc_q + (size_t)(j0 / ATT_KT) * 8 * 64;
+#pragma unroll
+        for (int v4 = 0; v4 < 8; ++v4) scv[v4] = q_live ? sp[(size_t)v4 * 64] : make_float4(-1.f, -1.f, -1.f, -1.f);
+    };
+
+    // Q^T as B operand: lane (query l31, half hi), k16 step s -> channels 16s + 8hi .. +7, split once
+    xhalf8 qh[NS], ql[NS];
+    {
+        const float4 *qv = reinterpret_cast<const float4 *>(base + (size_t)qrow * 3 * C);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const float4 a = qv[4 * s_ + 2 * hi], c = qv[4 * s_ + 2 * hi + 1];
+            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h_, l_;
+                split_half(x[e], h_, l_);
+                qh[s_][e] = h_;
+                ql[s_][e] = l_;
+            }
+        }
+    }
+    f32x16 acc_o[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    dma_tile(0, 0);
+    fetch_sc(0);
+    int buf = 0;
+    for (int j0 = j_begin; j0 < j_end; j0 += ATT_KT, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this tile's pieces (and SC values) have landed
+        __syncthreads();                                                 // ... everybody's; and the other buffer is no longer read
+        if (j0 + ATT_KT < j_end) dma_tile(j0 + ATT_KT, buf ^ 1);
+        const _Float16 *Kh = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES);
+        const _Float16 *Kl = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_KL);
+        const _Float16 *Vh = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_VH);
+        const _Float16 *Vl = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_VL);
+
+        // S^T = K Q^T, three fp16 products per k16 step and key block
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+        // One wave per SIMD: nobody hides an LDS read that is waited for right after its issue, and that is how the compiler orders
+        // this loop when left alone (ds_read -> s_waitcnt lgkmcnt(0) -> 1-2 MFMAs, 32 times per tile).  The fragments of k16 step
+        // s_+1 are therefore requested before the MFMAs of step s_, and sched_barrier keeps it that way.
+        xhalf8 kf[2][2][2];                           // [buffer][key block][hi | lo]
+        auto read_k = [&](int s_, int buf) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                kf[buf][kb][0] = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+                kf[buf][kb][1] = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+            }
+        };
+        read_k(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int buf = s_ & 1;
+            if (s_ + 1 < NS) read_k(s_ + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // the two key blocks alternate: back-to-back MFMAs are independent; per accumulator the order stays hi*hi, hi*lo, lo*hi
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][0][0], qh[s_], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][1][0], qh[s_], s[1], 0, 0, 0);
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][0][0], ql[s_], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][1][0], ql[s_], s[1], 0, 0, 0);
+            s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][0][1], qh[s_], s[0], 0, 0, 0);
+            s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[buf][1][1], qh[s_], s[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 q4 = scv[kb * 4 + (r >> 2)];
+                const float scq = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+                float v = scq * (s[kb][r] * inv_sqrt_c);
+                v = (scq >= 0.0f) ? v : -INFINITY;
+                s[kb][r] = v;
+                m_tile = fmaxf(m_tile, v);
+            }
+        if (j0 + ATT_KT < j_end) fetch_sc(j0 + ATT_KT);
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = __expf(m_run - m_new);
+        float l_tile = 0.0f;
+        xhalf8 ph[2][2], pl[2][2];                  // [kb][t2]: keys crow(8*t2 + e, hi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __expf(s[kb][r] - m_new);    // v_exp_f32 path: ~1e-6 relative, VALU issue is what bounds this kernel
+                const float p1 = __expf(s[kb][r + 1] - m_new);
+                l_tile += p0;
+                l_tile += p1;
+                unsigned uh, ul;
+                split_pair(p0, p1, uh, ul);
+                const xf16x2 h2 = __builtin_bit_cast(xf16x2, uh), l2 = __builtin_bit_cast(xf16x2, ul);
+                ph[kb][r >> 3][r & 7] = h2[0]; ph[kb][r >> 3][(r & 7) + 1] = h2[1];
+                pl[kb][r >> 3][r & 7] = l2[0]; pl[kb][r >> 3][(r & 7) + 1] = l2[1];
+            }
+        l_run = l_run * alpha + l_tile;
+        m_run = m_new;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
+        // O^T += V^T P^T.  ONE fragment buffer, channel-block-major: the three MFMAs of block cb are followed by the read of cb's fragments
+        // for the next octet pair, which then has the nine MFMAs of the other blocks to arrive (a second buffer costs 32 registers this
+        // kernel does not have: every value beyond 256 is parked in AGPRs and copied back, ~100 v_accvgpr moves per tile)
+        xhalf8 vf[CB][2];
+        auto read_v1 = [&](int o, int cb) {
+            const int oct = o * 2 + hi;
+            vf[cb][0] = *reinterpret_cast<const xhalf8 *>(Vh + ((size_t)oct * C + cb * 32 + l31) * 8);
+            vf[cb][1] = *reinterpret_cast<const xhalf8 *>(Vl + ((size_t)oct * C + cb * 32 + l31) * 8);
+        };
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) read_v1(0, cb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int kb = o >> 1, t2 = o & 1;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[cb][0], ph[kb][t2], acc_o[cb], 0, 0, 0);
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[cb][0], pl[kb][t2], acc_o[cb], 0, 0, 0);
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[cb][1], ph[kb][t2], acc_o[cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (o + 1 < 4) read_v1(o + 1, cb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const float l_all = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.0f / l_all;
+    float *mo = msg + ((size_t)b * n_cap + qrow) * C;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = acc_o[cb][4 * g + 0] * inv_l;
+            v.y = acc_o[cb][4 * g + 1] * inv_l;
+            v.z = acc_o[cb][4 * g + 2] * inv_l;
+            v.w = acc_o[cb][4 * g + 3] * inv_l;
+            *reinterpret_cast<float4 *>(mo + cb * 32 + 8 * g + 4 * hi) = v;
+        }
+}
+
 // fp16x3 version of pdsc_linear_kernel (same tile, same epilogue) for K % 32 == 0: X and W tiles are split into hi/lo halves
 // while they are staged (8-byte loads, 4-byte LDS stores; rows 80 bytes apart: the ds_read_b128 of a 16-lane group is
 // conflict-free), 12 fp16 MFMAs per k-tile and wave instead of 32 fp32 ones.
@@ -864,7 +1056,7 @@ __global__ __launch_bounds__(256) void pdsc_mlp3_x3_kernel(const float *__restri
 __global__ __launch_bounds__(256) void pdsc_pcn_qkv_x3_kernel(const float *__restrict__ feat, const char *__restrict__ img,
                                                                const float *__restrict__ bp, const float *__restrict__ bq,
                                                                const int32_t *__restrict__ n_rows, int n_cap, float *__restrict__ feat1,
-                                                               float *__restrict__ qkv)
+                                                               float *__restrict__ qkv, char *__restrict__ kv_img)
 {
     constexpr int C = 128, HALF = PDSC_PQ_CHUNK_BYTES / 2;
     extern __shared__ __attribute__((aligned(1024))) char pq_lds[];
@@ -907,7 +1099,9 @@ __global__ __launch_bounds__(256) void pdsc_pcn_qkv_x3_kernel(const float *__res
         return *reinterpret_cast<const xhalf8 *>(pq_lds + base + o * 256 + (((2 * s_ + hi) ^ (o & 15)) << 4));
     };
     // two 32-channel output blocks over the 8 k-steps, fragments of step s+1 requested before the MFMAs of step s (see pdsc_mlp3_x3_kernel)
-    auto two_blocks = [&](int area, int rb0, const xhalf8 *bh, const xhalf8 *bl, f32x16 (&acc)[2]) {
+    // swap = false: weights are the A operand (accumulator: lane = point, registers = channels); swap = true: the activations are (lane =
+    // channel, registers = points crow(r, hi)) - the same fragments either way, the 32x32x16 A and B register layouts are mirror images
+    auto two_blocks = [&](int area, int rb0, const xhalf8 *bh, const xhalf8 *bl, f32x16 (&acc)[2], bool swap) {
         const int base_h = area * PDSC_PQ_CHUNK_BYTES, base_l = base_h + HALF;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -925,12 +1119,21 @@ __global__ __launch_bounds__(256) void pdsc_pcn_qkv_x3_kernel(const float *__res
                 for (int i = 0; i < 2; ++i) { w[cur ^ 1][i][0] = frag(base_h, rb0 + i, s_ + 1); w[cur ^ 1][i][1] = frag(base_l, rb0 + i, s_ + 1); }
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bh[s_], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bh[s_], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bl[s_], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bl[s_], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][1], bh[s_], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][1], bh[s_], acc[1], 0, 0, 0);
+            if (!swap) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bh[s_], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bh[s_], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bl[s_], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bl[s_], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][1], bh[s_], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][1], bh[s_], acc[1], 0, 0, 0);
+            } else {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][0][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][1][0], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s_], w[cur][0][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s_], w[cur][1][0], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][0][1], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][1][1], acc[1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -939,7 +1142,7 @@ __global__ __launch_bounds__(256) void pdsc_pcn_qkv_x3_kernel(const float *__res
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp) {
         f32x16 acc[2];
-        two_blocks(0, 2 * rp, xh, xl, acc);
+        two_blocks(0, 2 * rp, xh, xl, acc, false);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int rb = 2 * rp + i;
@@ -974,21 +1177,56 @@ __global__ __launch_bounds__(256) void pdsc_pcn_qkv_x3_kernel(const float *__res
         } else {
             __syncthreads();
         }
+        // q (and k, v without an image buffer): fp32 rows of the q|k|v array.  With `kv_img`: k and v leave as the attention kernel's LDS
+        // tile image, already split into fp16 hi / lo - k rows [key][136 halves] from the transposed product (lane = key: 8-byte pieces),
+        // v from the un-transposed one (lane = channel, registers 8 t2 .. 8 t2 + 7 = the 8 keys of octet (kb, t2, hi): 16-byte pieces).
+        const int p_pair = q0 + wave * 32;                           // first point of this wave inside its pair
+        char *tile = kv_img ? kv_img + ((size_t)b * (n_cap / 64) + (p_pair >> 6)) * PDSC_KV_TILE_BYTES : nullptr;
+        const bool as_v = kv_img && part == 2;
 #pragma unroll
         for (int rp = 0; rp < 2; ++rp) {
             f32x16 acc[2];
-            two_blocks(area, 2 * rp, fh, fl, acc);
+            two_blocks(area, 2 * rp, fh, fl, acc, as_v);
+            if (as_v) {
+                const int kb = (p_pair >> 5) & 1;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    const int ch = (2 * rp + i) * 32 + l31;
+                    const float bv = bq[2 * C + ch];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = part * C + (2 * rp + i) * 32 + 8 * g + 4 * hi;
-                    const float4 bv = *reinterpret_cast<const float4 *>(bq + c);
-                    float4 o;
-                    o.x = acc[i][4 * g + 0] + bv.x; o.y = acc[i][4 * g + 1] + bv.y;
-                    o.z = acc[i][4 * g + 2] + bv.z; o.w = acc[i][4 * g + 3] + bv.w;
-                    *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        uint4 uh, ul;
+                        split_pair(acc[i][8 * t2 + 0] + bv, acc[i][8 * t2 + 1] + bv, uh.x, ul.x);
+                        split_pair(acc[i][8 * t2 + 2] + bv, acc[i][8 * t2 + 3] + bv, uh.y, ul.y);
+                        split_pair(acc[i][8 * t2 + 4] + bv, acc[i][8 * t2 + 5] + bv, uh.z, ul.z);
+                        split_pair(acc[i][8 * t2 + 6] + bv, acc[i][8 * t2 + 7] + bv, uh.w, ul.w);
+                        const int oct = (kb * 2 + t2) * 2 + hi;
+                        *reinterpret_cast<uint4 *>(tile + PDSC_KV_VH + ((size_t)oct * C + ch) * 16) = uh;
+                        *reinterpret_cast<uint4 *>(tile + PDSC_KV_VL + ((size_t)oct * C + ch) * 16) = ul;
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cc = (2 * rp + i) * 32 + 8 * g + 4 * hi, c = part * C + cc;
+                        const float4 bv = *reinterpret_cast<const float4 *>(bq + c);
+                        float4 o;
+                        o.x = acc[i][4 * g + 0] + bv.x; o.y = acc[i][4 * g + 1] + bv.y;
+                        o.z = acc[i][4 * g + 2] + bv.z; o.w = acc[i][4 * g + 3] + bv.w;
+                        if (kv_img && part == 1) {
+                            uint2 uh, ul;
+                            split_pair(o.x, o.y, uh.x, ul.x);
+                            split_pair(o.z, o.w, uh.y, ul.y);
+                            const size_t off = (size_t)((p_pair & 63) + l31) * 272 + cc * 2;
+                            *reinterpret_cast<uint2 *>(tile + off) = uh;
+                            *reinterpret_cast<uint2 *>(tile + PDSC_KV_KL + off) = ul;
+                        } else {
+                            *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;
+                        }
+                    }
+            }
         }
     }
 }
@@ -1090,11 +1328,14 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         const PdscLayer &L = M.layers[l];
         static const bool x3 = getenv("ORYON_PDSC_FP32_MFMA") == nullptr;     // fp16x3 unless the pure-fp32 kernels are asked for
         static const bool fused_pq = !getenv("ORYON_PDSC_FUSED_PQ") || atoi(getenv("ORYON_PDSC_FUSED_PQ")) != 0;       // dev: 0 = two launches
+        static const bool att_img = !getenv("ORYON_PDSC_ATT_IMG") || atoi(getenv("ORYON_PDSC_ATT_IMG")) != 0;           // dev: 0 = fp32 K / V
+        bool use_img = false;
         if (C == 128 && x3 && fused_pq && L.pq_img) {
             // PointCN (conv + BN + ReLU, BN folded) and the q | k | v projections in one launch
             allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_pcn_qkv_x3_kernel), 2 * PDSC_PQ_CHUNK_BYTES);
+            use_img = ws.att_splits == 1 && ws.kv_img != nullptr && att_img;
             hipLaunchKernelGGL(pdsc_pcn_qkv_x3_kernel, dim3(n_cap / 128, B), dim3(256), 2 * PDSC_PQ_CHUNK_BYTES, st, ws.feat, L.pq_img, L.b_pcn,
-                               L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv);
+                               L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, use_img ? ws.kv_img : nullptr);
             if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
         } else {
             // PointCN: conv + BN + ReLU (BN folded)
@@ -1106,7 +1347,11 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         }
         const int KS = ws.att_splits;
         dim3 ag(n_cap / ATT_Q, KS, B);
-        if (C == 128 && x3)
+        if (C == 128 && x3 && use_img) {
+            allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_attention_x3_img_kernel<128>), 2 * PDSC_KV_TILE_BYTES);
+            hipLaunchKernelGGL((pdsc_attention_x3_img_kernel<128>), ag, dim3(256), 2 * PDSC_KV_TILE_BYTES, st, ws.qkv, ws.kv_img, ws.sc, n_rows,
+                               n_cap, inv_sqrt_c, ws.msg);
+        } else if (C == 128 && x3)
             hipLaunchKernelGGL((pdsc_attention_x3_kernel<128>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         else if (C == 128)
             hipLaunchKernelGGL((pdsc_attention_kernel<128>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);

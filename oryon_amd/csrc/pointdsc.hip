@@ -49,6 +49,7 @@ size_t carve(const oryon_pointdsc_config_t &cfg, int B, int n_cap, void *ws_ptr,
     w.feat1 = c.take<float>(rows * C);
     w.qkv = c.take<float>(rows * 3 * C);
     w.msg = c.take<float>(rows * C);
+    w.kv_img = c.take<char>(C == 128 ? rows / 64 * PDSC_KV_TILE_BYTES : 0);
     w.sc = c.take<float>(rows * n_cap);
     w.att_splits = pdsc_attention_splits(B, n_cap);
     w.att_o = c.take<float>(w.att_splits > 1 ? rows * C * w.att_splits : 0);
