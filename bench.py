@@ -517,7 +517,8 @@ def main():
         inputs["feat_q"].copy_(torch.einsum("bck,khw->bchw", basis, coef))
         inputs["feat_q"].add_(0.02 * torch.randn(inputs["feat_q"].shape, generator=gen, device=dev))
         inputs["feat_a"].copy_(inputs["feat_q"]).add_(0.01 * torch.randn(inputs["feat_a"].shape, generator=gen, device=dev))
-        run_steps(3)                                  # lets the engine's asynchronous back-off settle
+        engine.collect_i8_stats = True                # report the int8 stage's undecided fraction on these inputs (asynchronous, no sync)
+        run_steps(3)                                  # lets the asynchronous statistics arrive
         barrier()
         t0 = time.perf_counter()
         hout, _, hstatus = run_steps(5)

@@ -245,7 +245,7 @@ int oryon_select_corrs(const int32_t *roi_a, const int32_t *roi_q, int roi_strid
  * corrs [B, n_cap, 4] int32; n_corr [B] or NULL (then n_cap rows each); depth_* [B,H*,W*] fp32 millimetres;
  * cam_* [B,9] fp32 (row-major K, already rounded from the reference's fp64); status [B] may be NULL
  * (pairs whose status != ORYON_PAIR_OK are skipped and get n_out = 0).
- * pcd_a/pcd_q [B, n_cap, 3] fp32 metres, compacted over valid rows in order; n_out [B]. */
+ * pcd_a/pcd_q [B, n_cap, 3] fp32 metres, compacted over valid rows in order, rows >= n_out zeroed; n_out [B]. */
 int oryon_lift_pairs(const int32_t *corrs, const int32_t *n_corr, int B, int n_cap, int FH, int FW,
                      const float *depth_a, int HA, int WA, const float *depth_q, int HQ, int WQ,
                      const float *cam_a, const float *cam_q, const int32_t *status, float *pcd_a, float *pcd_q,

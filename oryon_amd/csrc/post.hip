@@ -146,8 +146,14 @@ __global__ __launch_bounds__(512) void lift_pairs_kernel(
 {
     __shared__ int s_wave[8];
     const int p = blockIdx.x;
+    float *oa = pcd_a + (size_t)p * n_cap * 3, *oq = pcd_q + (size_t)p * n_cap * 3;
+    // rows past the lifted count are zero (the callers hand over uninitialised buffers: no separate fill launches)
+    auto zero_from = [&](int first) {
+        for (int e = first * 3 + (int)threadIdx.x; e < n_cap * 3; e += (int)blockDim.x) { oa[e] = 0.0f; oq[e] = 0.0f; }
+    };
     if (status && status[p] != ORYON_PAIR_OK) {
         if (threadIdx.x == 0) n_out[p] = 0;
+        zero_from(0);
         return;
     }
     const int n = n_corr ? n_corr[p] : n_cap;
@@ -155,7 +161,6 @@ __global__ __launch_bounds__(512) void lift_pairs_kernel(
     const float *da = depth_a + (size_t)p * HA * WA, *dq = depth_q + (size_t)p * HQ * WQ;
     const float fxa = cam_a[p * 9 + 0], cxa = cam_a[p * 9 + 2], fya = cam_a[p * 9 + 4], cya = cam_a[p * 9 + 5];
     const float fxq = cam_q[p * 9 + 0], cxq = cam_q[p * 9 + 2], fyq = cam_q[p * 9 + 4], cyq = cam_q[p * 9 + 5];
-    float *oa = pcd_a + (size_t)p * n_cap * 3, *oq = pcd_q + (size_t)p * n_cap * 3;
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += blockDim.x) {
         const int i = i0 + threadIdx.x;
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(512) void lift_pairs_kernel(
         base += tot;
     }
     if (threadIdx.x == 0) n_out[p] = base;
+    zero_from(base);
 }
 
 // lift_pcd proper (utils/pcd.py:44-74): selected pixels of one depth map -> [n,3] millimetres.

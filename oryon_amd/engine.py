@@ -70,6 +70,7 @@ class MatchPoseEngine:
         # (round 2: the lazy tail resolves ambiguous anchors with an exact scan of the sampled rows only, which is cheaper than the fp16
         # route on every distribution tried, so the back-off is off by default - thresholds >= 1 never trigger)
         self.i8_max_undecided = 2.0
+        self.collect_i8_stats = False       # measurement aid: keep `_i8_frac` up to date even though the back-off is off
         self.i8_retry_every = 16
         self._i8_pending = None        # (pinned [2] int64 tensor, event)
         self._i8_host = None           # pinned buffer, allocated once
@@ -186,7 +187,9 @@ class MatchPoseEngine:
                 corrs, n_valid, n_sel, status, min_dist, argmin, valid = ops.match_corrs_i8(
                     a_hat, a8, a_sc, feat_q, roi_a, roi_q, q_norm, q8, q_sc, q_eps, n_a, n_q, cfg.dist_th, FW, cfg.n_corrs, cfg.seed,
                     pair_key, corr_rows=self.n_cap, force_eager=keep, n_undecided=n_und, round_f16=cfg.half_descriptors)
-            if self._i8_pending is None:
+            # statistics for the back-off (skip the int8 stage while most anchors come back undecided): only collected when the
+            # back-off can trigger at all (i8_max_undecided < 1; off by default - the lazy tail handles such inputs on the device)
+            if self._i8_pending is None and (self.i8_max_undecided < 1.0 or self.collect_i8_stats):
                 if self._i8_host is None:
                     self._i8_host = torch.empty((2, B), dtype=torch.int32, pin_memory=True)
                     self._i8_dev = torch.empty((2, B), dtype=torch.int32, device=dev)

@@ -432,8 +432,8 @@ def lift_pairs(corrs: torch.Tensor, n_corr: Optional[torch.Tensor], feat_hw, dep
     B, n_cap = corrs.shape[0], corrs.shape[1]
     assert corrs.dtype == torch.int32 and depth_a.dtype == torch.float32 and depth_q.dtype == torch.float32
     assert cam_a.dtype == torch.float32 and cam_a.shape == (B, 9) and cam_q.shape == (B, 9)
-    pa = torch.zeros((B, n_cap, 3), dtype=torch.float32, device=dev)
-    pq = torch.zeros((B, n_cap, 3), dtype=torch.float32, device=dev)
+    pa = torch.empty((B, n_cap, 3), dtype=torch.float32, device=dev)      # the kernel zeroes the rows past the lifted count
+    pq = torch.empty((B, n_cap, 3), dtype=torch.float32, device=dev)
     n_out = torch.empty((B,), dtype=torch.int32, device=dev)
     check(lib().oryon_lift_pairs(ptr(corrs), ptr(n_corr), B, n_cap, int(feat_hw[0]), int(feat_hw[1]),
                                  ptr(depth_a.contiguous()), depth_a.shape[1], depth_a.shape[2],
