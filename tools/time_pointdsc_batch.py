@@ -5,7 +5,7 @@ from bench import build_solver
 dev = torch.device("cuda", 0)
 solver = build_solver(dev)
 g = torch.Generator(device=dev).manual_seed(0)
-for B in (32, 64, 128, 256):
+for B in ([int(a) for a in sys.argv[1:]] or [32, 64, 128, 256]):
     src = torch.rand(B, 512, 3, generator=g, device=dev)
     tgt = src + 0.01 * torch.randn(B, 512, 3, generator=g, device=dev)
     n = torch.full((B,), 500, dtype=torch.int32, device=dev)
