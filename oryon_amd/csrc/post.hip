@@ -30,6 +30,31 @@ __device__ __forceinline__ int block_rank_sel(bool flag, int *s_wave, int &total
     return base + before;
 }
 
+// Ordered block scan of per-thread COUNTS (exclusive offset of this thread, chunk total through `total`): lets a thread own several
+// consecutive entries per scan step - these one-workgroup-per-pair kernels are bound by the latency of their scan steps.
+__device__ __forceinline__ int block_scan_counts_sel(int cnt, int *s_wave, int &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        incl += (lane >= o) ? v : 0;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) {
+        const int c = s_wave[w];
+        base += (w < wave) ? c : 0;
+        tot += c;
+    }
+    total = tot;
+    return base + incl - cnt;
+}
+
 // One workgroup per pair.  scratch[p, :] receives the ordered list of valid anchor rows.
 __global__ __launch_bounds__(SEL_THREADS) void select_corrs_kernel(
     const int32_t *__restrict__ roi_a, const int32_t *__restrict__ roi_q, int stride_a, int stride_q,
@@ -55,12 +80,16 @@ __global__ __launch_bounds__(SEL_THREADS) void select_corrs_kernel(
     const int32_t *am = argmin + (size_t)p * cap_a;
     int32_t *list = scratch + (size_t)p * cap_a;
     int nv = 0;
-    for (int i0 = 0; i0 < na; i0 += SEL_THREADS) {
-        const int i = i0 + threadIdx.x;
-        const bool f = i < na && v[i] != 0;
+    for (int i0 = 0; i0 < na; i0 += SEL_THREADS * 8) {              // eight consecutive rows per thread and scan step
+        const int i = i0 + (int)threadIdx.x * 8;
+        unsigned bits = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bits |= (i + e < na && v[i + e] != 0 ? 1u : 0u) << e;
         int tot;
-        const int r = block_rank_sel(f, s_wave, tot);
-        if (f) list[nv + r] = i;
+        int o = nv + block_scan_counts_sel(__popc(bits), s_wave, tot);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (bits & (1u << e)) list[o++] = i + e;
         nv += tot;
     }
     __syncthreads();
@@ -121,16 +150,26 @@ __global__ __launch_bounds__(SEL_THREADS) void select_corrs_kernel(
     const unsigned Tk = s_prefix;
     const int ties_to_take = (int)s_remaining;
     int kept = 0, ties_seen = 0;
-    for (int i0 = 0; i0 < nv; i0 += SEL_THREADS) {
-        const int i = i0 + threadIdx.x;
-        const bool in = i < nv;
-        const unsigned k = in ? rng_u32(seed, key, 1u, (uint32_t)i) : 0xFFFFFFFFu;
-        const bool tie = in && k == Tk;
+    for (int i0 = 0; i0 < nv; i0 += SEL_THREADS * 8) {
+        const int i = i0 + (int)threadIdx.x * 8;
+        unsigned below = 0u, tie = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = i + e < nv;
+            const unsigned k = in ? rng_u32(seed, key, 1u, (uint32_t)(i + e)) : 0xFFFFFFFFu;
+            below |= (in && k < Tk ? 1u : 0u) << e;
+            tie |= (in && k == Tk ? 1u : 0u) << e;
+        }
         int tie_total, keep_total;
-        const int tie_rank = block_rank_sel(tie, s_wave, tie_total);
-        const bool keep = in && (k < Tk || (tie && ties_seen + tie_rank < ties_to_take));
-        const int pos = block_rank_sel(keep, s_wave, keep_total);
-        if (keep) emit(kept + pos, list[i]);
+        int tie_rank = ties_seen + block_scan_counts_sel(__popc(tie), s_wave, tie_total);
+        unsigned keep = below;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (tie & (1u << e)) { if (tie_rank < ties_to_take) keep |= 1u << e; ++tie_rank; }
+        int pos = kept + block_scan_counts_sel(__popc(keep), s_wave, keep_total);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (keep & (1u << e)) emit(pos++, list[i + e]);
         kept += keep_total;
         ties_seen += tie_total;
     }
