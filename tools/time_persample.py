@@ -17,3 +17,4 @@ for it in range(3):
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); pipe.test_step(batch, 0); torch.cuda.synchronize(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(16)
