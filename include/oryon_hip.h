@@ -205,8 +205,9 @@ int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8, const floa
  * fp32 scan K1 on a compacted list of just those rows - before the sampling if their validity is open, after it (sampled rows only)
  * if the bound already proves them valid - against fp32 query rows materialised for that pair inside the call.  force_eager != 0
  * sends every pair through the complete tail of oryon_match_screened8_raw instead (all of min_dist / argmin exact).  corrs / n_valid / n_sel / status are exactly what oryon_select_corrs returns on the outputs of
- * oryon_match_screened8_raw.  valid [B,cap_a] is exact on every row; min_dist / argmin are exact on sampled rows and on every row of
- * an eager pair, and hold the screening estimate / 0 elsewhere. */
+ * oryon_match_screened8_raw.  valid [B,cap_a] is exact on every row; argmin is exact on sampled rows and on every row of an eager
+ * pair; min_dist is exact on every row of an eager pair and on the sampled / resolved rows that needed an fp32 comparison (more than one
+ * candidate inside the int8 margin, or validity open); elsewhere both hold the screening estimate / 0. */
 size_t oryon_match_corrs_i8_workspace_bytes(int B, int C, int cap_a, int cap_q, int corr_rows);
 int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW, int layout,
                          const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q, const float *q_norm,

@@ -1538,7 +1538,7 @@ __global__ __launch_bounds__(256) void match_list_sampled_amb_kernel(int cap_a, 
 // Exact resolution of ONE unambiguous anchor by one wave: candidates = rows of the winning 16-row slice within the int8 margin of its
 // maximum (re-scored from the int8 rows, as match_decide_kernel does), then the canonical fp32 chain per candidate on x_k / d read
 // from the raw map (as match_rescore_raw_kernel does).  Returns (distance, first index of the minimum) in lane 0.
-template <bool NHWC>
+template <bool NHWC, bool NEED_DIST = true>
 __device__ __forceinline__ void resolve_anchor(int p, int a, const float *__restrict__ a_hat, const int8_t *__restrict__ a8,
                                                const int8_t *__restrict__ q8, const float *__restrict__ q_scale8,
                                                const float *__restrict__ a_scale8, const float *__restrict__ feat_q, int C_true, int HW,
@@ -1569,6 +1569,13 @@ __device__ __forceinline__ void resolve_anchor(int p, int a, const float *__rest
     const float s8 = (float)idot * q_scale8[(size_t)p * (cap_q / 16) + sid] * sa;
     const bool hit = (seg == 0) && (q < nq) && (s8 >= m1 - margin);
     unsigned long long hits = __ballot(hit);
+    if (!NEED_DIST && __popcll(hits) == 1) {
+        // a single row inside the int8 margin IS the argmin (every other row is provably farther): no fp32 work, and none of the 256
+        // scattered 4-byte reads of its raw descriptor (the NCHW gather is what bounds this kernel: one 64-byte sector per channel)
+        j_out = __shfl(q, __ffsll((long long)hits) - 1);
+        d_out = __builtin_nanf("");
+        return;
+    }
     // anchor row (k-permuted: position 8g + 4h + j holds k = 8g + 2j + h) -> natural order in LDS
     float *A = lds, *Q = lds + Cp;
     for (int pos = lane; pos < Cp; pos += 64) {
@@ -1665,9 +1672,12 @@ __global__ __launch_bounds__(256) void match_resolve_selected_kernel(
     if (state[arow] == LZ_RESOLVED) {
         j = argmin[arow];
     } else {
-        resolve_anchor<NHWC>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q, n_q[p],
-                             m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, round_f16, d, j);
-        if (lane == 0) { min_dist[arow] = d; argmin[arow] = j; }        // same value from every slot that drew this row
+        resolve_anchor<NHWC, false>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q,
+                                    n_q[p], m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, round_f16, d, j);
+        if (lane == 0) {                                                // same values from every slot that drew this row
+            argmin[arow] = j;
+            if (d == d) min_dist[arow] = d;                             // NaN: single candidate, the distance was never needed
+        }
     }
     if (lane == 0) {
         j = (j < 0 || j >= n_q[p]) ? 0 : j;                            // cannot happen for a row that passed the validity cut
