@@ -314,7 +314,11 @@ def main():
                          "shapes), then match + pose - a separate stage set, never mixed into the headline")
     ap.add_argument("--backbone-dtype", choices=["fp32", "fp16x3", "bf16", "bf16w"], default="fp32",
                     help="fp32 | bf16 (autocast over fp32 weights) | bf16w (weights converted to bf16 once)")
-    ap.add_argument("--overlap-gather", action="store_true", help="K0 gather of step k+1 on its own stream under the screening of step k")
+    ap.add_argument("--no-overlap-gather", dest="overlap_gather", action="store_false",
+                    help="keep the K0 gather of step k+1 on the main stream (default: on its own stream, under the screening / registration of "
+                         "step k; the inputs are resident before the timed region)")
+    ap.add_argument("--overlap-gather", dest="overlap_gather", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(overlap_gather=True)
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not overlap the registration of step k with the matching of step k+1 (second HIP stream)")
     ap.add_argument("--match-mode", choices=["screened", "screened16", "exact"], default="screened",
@@ -466,7 +470,9 @@ def main():
                 "match_mode": a.match_mode + (" (int8-MFMA pre-screen, fp16-MFMA screening of the undecided anchors, exact fp32 re-scoring: outputs identical to the fp32 scan)" if use_i8 else " (fp16-MFMA screening, exact fp32 re-scoring: outputs identical to the fp32 scan)" if screened else ""),
                 "sample_first": a.sample_first or None,
                 "pairs_per_gpu": B, "global_pairs": total, "parallelism": f"pairs sharded over {world} GPU(s), all_gather of poses",
-                "pipelining": "none" if a.no_overlap else "registration of step k on a second HIP stream under the matching of step k+1",
+                "pipelining": ("none" if a.no_overlap else "registration of step k on a second HIP stream under the matching of step k+1"
+                               + ("; K0 (ROI + gather) of step k+1 on a third stream under the screening / registration of step k"
+                                  if a.overlap_gather else "")),
                 "pairs_ok": int(ok.sum()), "max_rot_err_vs_gt": float(rot_err.max()) if rot_err.numel() else None,
                 "max_trans_err_m_vs_gt": float(trans_err.max()) if trans_err.numel() else None,
             },
@@ -517,6 +523,7 @@ def main():
         inputs["feat_q"].copy_(torch.einsum("bck,khw->bchw", basis, coef))
         inputs["feat_q"].add_(0.02 * torch.randn(inputs["feat_q"].shape, generator=gen, device=dev))
         inputs["feat_a"].copy_(inputs["feat_q"]).add_(0.01 * torch.randn(inputs["feat_a"].shape, generator=gen, device=dev))
+        torch.cuda.synchronize()                      # the gather stream reads the maps as soon as a step is submitted: finish rewriting them first
         engine.collect_i8_stats = True                # report the int8 stage's undecided fraction on these inputs (asynchronous, no sync)
         run_steps(3)                                  # lets the asynchronous statistics arrive
         barrier()

@@ -138,7 +138,7 @@ class MatchPoseEngine:
         else:
             cap_a = ops.round_up(FH * FW, ops.ROW_PAD)
         cap_q = ops.round_up(FH * FW, ops.ROW_PAD)
-        a16 = q16 = a8 = q8 = a_sc = q_sc = q_eps = q_norm = q_hat = None
+        a16 = q16 = a8 = q8 = a_sc = q_sc = q_eps = q_norm = q_hat = roi_a1 = n_a1 = None
         stage1 = use_i8 and cfg.sample_first > 0 and not keep
         if use_i8:
             # K0v3: anchors -> fp32 + int8 rows, queries -> int8 rows + row norms only (the re-scoring pass reads its few candidates
@@ -165,7 +165,9 @@ class MatchPoseEngine:
             gathered.record(self._gather_stream)
             gctx.__exit__(None, None, None)
             main.wait_event(gathered)
-            for t_ in (roi_a, roi_q, n_a, n_q, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, q_norm):
+            # EVERY tensor allocated under the gather stream and read on the main stream: without the record the allocator would hand
+            # its memory to the next batch's gather (which runs ahead) while this batch's matcher still reads it
+            for t_ in (roi_a, roi_q, n_a, n_q, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, q_norm, roi_a1, n_a1):
                 if t_ is not None:
                     t_.record_stream(main)
         if use_i8:

@@ -185,6 +185,54 @@ def test_engine_overlap_stream_gives_identical_results():
     assert torch.equal(o0["status"], r0["status"]) and torch.equal(o1["status"], r1["status"])
 
 
+def test_engine_gather_stream_gives_identical_results():
+    """overlap_gather (K0 of the next batch on its own stream, under the screening / registration of the current one) + overlap_registration
+    over four back-to-back batches at the int8 route's size (C = 256), inputs handed over both as resident and behind a producer event:
+    every pose / status / count equals the plain engine's, bit for bit."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    from oryon_amd.synth import make_pair
+    dev = "cuda"
+    H, C = 64, 256
+    pairs = [make_pair(i, H, H, C, device=dev) for i in range(50, 58)]
+    st = lambda k, sl: torch.stack([p[k] for p in pairs[sl]])
+    solver = _solver()
+    args = lambda sl: (st("feat_a", sl), st("feat_q", sl), st("mask_a", sl), st("mask_q", sl), st("depth_a", sl), st("depth_q", sl),
+                       st("camera", sl).to(dev), st("camera", sl).to(dev))
+    slices = [slice(0, 2), slice(2, 4), slice(4, 6), slice(6, 8)]
+    ref = MatchPoseEngine(solver, MatchPoseConfig())
+    want = [ref.run(*args(sl), torch.arange(sl.start, sl.stop, device=dev)) for sl in slices]
+    eng = MatchPoseEngine(solver, MatchPoseConfig(), overlap_registration=True, overlap_gather=True)
+    ins = [args(sl) for sl in slices]
+    torch.cuda.synchronize()
+    outs = []
+    for i, sl in enumerate(slices):
+        if i % 2 == 0:
+            outs.append(eng.run(*ins[i], torch.arange(sl.start, sl.stop, device=dev), inputs_resident=True))
+        else:
+            ev = torch.cuda.Event()
+            ev.record()                                   # "the producer finished these maps here"
+            outs.append(eng.run(*ins[i], torch.arange(sl.start, sl.stop, device=dev), inputs_event=ev))
+    for o in outs:
+        eng.finish(o)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        for k in ("pose", "status", "n_valid", "n_lifted"):
+            assert torch.equal(o[k], w[k]), k
+    # the sample-first schedule allocates more under the gather stream (the first-stage ROI): same check, many batches in flight
+    cfg = MatchPoseConfig(sample_first=256)
+    ref = MatchPoseEngine(solver, cfg)
+    want = [ref.run(*ins[i % 4], torch.arange(8 * i, 8 * i + 2, device=dev)) for i in range(12)]
+    eng = MatchPoseEngine(solver, cfg, overlap_registration=True, overlap_gather=True)
+    torch.cuda.synchronize()
+    outs = [eng.run(*ins[i % 4], torch.arange(8 * i, 8 * i + 2, device=dev), inputs_resident=True) for i in range(12)]
+    for o in outs:
+        eng.finish(o)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        for k in ("pose", "status", "n_lifted"):
+            assert torch.equal(o[k], w[k]), k
+
+
 def test_cfg4_sized_pair_recovers_ground_truth():
     """BASELINE cfg4 geometry (384x384 maps, C=512) for one rank's worth of two pairs: the pose must match the generator's."""
     from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
