@@ -751,8 +751,10 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_kernel
 //   * 4 accumulators are live instead of 8, which pays for a double-buffered A operand (the 8 ds_read_b128 of query block qb+1
 //     also issue under qb's MFMAs).
 // sched_group_barrier pins the interleave (1 MFMA : 2 VALU : <=1 LDS read) in the emitted code.
-template <int CP, int VAR = 0>     // VAR != 0: timing ablations only (ORYON_SCREEN8_ABLATE): 1 no epilogue, 2 no DMA / barrier, 8 DMA spread over two blocks
-__global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_kernel(
+// WAVES = 8: 512 anchors per workgroup - the eight waves share ONE query-tile stream (half the L2 -> LDS bytes, DMA issues and LDS footprint per
+// anchor of two 4-wave workgroups on a CU); T is then the number of 512-anchor panels.
+template <int CP, int VAR = 0, int WAVES = 4>     // VAR != 0: timing ablations only (ORYON_SCREEN8_ABLATE): 1 no epilogue, 2 no DMA / barrier, 8 DMA spread over two blocks
+__global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_i8_screen_v2_kernel(
     const int8_t *__restrict__ a8, const int8_t *__restrict__ q8, const float *__restrict__ q_scale, int B, int cap_a, int cap_q,
     const int32_t *__restrict__ n_a, const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max,
     int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
     constexpr int TILE_BYTES = screen8_tile_bytes(CP);
     constexpr int ROWS = 128, NQB = 4, NAB = 2;
     constexpr int NKS = CP / 32;
-    constexpr int NI = TILE_BYTES / 4096;
+    constexpr int NI = TILE_BYTES / (1024 * WAVES);
     constexpr int LPR = RB / 256;
     char *smem;
     if constexpr (2 * TILE_BYTES > 65536) {
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
     const int panel = slot % T;
     const int p = unit / S, split = unit % S;
     const int na = n_a[p], nq = n_q[p];
-    const int a0 = panel * MT16;
+    const int a0 = panel * (64 * WAVES);
     if (a0 >= na) return;
     const int nqt = (nq + ROWS - 1) / ROWS;
     const int qt_per = (nqt + S - 1) / S;
@@ -791,7 +793,8 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
     i32x4 breg[NAB][NKS];
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
-        const char *arow = reinterpret_cast<const char *>(a8) + ((size_t)p * cap_a + a0 + wave * 64 + ab * 32 + l31) * RB + 16 * hi;
+        const int arow_i = a0 + wave * 64 + ab * 32 + l31;              // WAVES = 8: the last panel may reach past cap_a (a multiple of 256)
+        const char *arow = reinterpret_cast<const char *>(a8) + ((size_t)p * cap_a + (arow_i < cap_a ? arow_i : cap_a - 1)) * RB + 16 * hi;
 #pragma unroll
         for (int s = 0; s < NKS; ++s) breg[ab][s] = *reinterpret_cast<const i32x4 *>(arow + 32 * s);
     }
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(256, CP == 512 ? 1 : 2) void match_i8_screen_v2_ker
         const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
         const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
         const int a = a0 + wave * 64 + ab * 32 + l31;
-        if (hi == 0) {
+        if (hi == 0 && a < cap_a) {
             const size_t o = ((size_t)p * S + split) * cap_a + a;
             ws_max[o] = m1;
             ws_i1[o] = i1;
@@ -1209,6 +1212,13 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
 #define ABL(V) case V: hipLaunchKernelGGL((match_i8_screen_v2_kernel<256, V>), dim3(groups), dim3(256), 0, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, ws_max, ws_i1, ws_m2); break
         switch (ablate) { ABL(1); ABL(2); ABL(3); default: ABL(8); }
 #undef ABL
+        return;
+    }
+    static const int waves = getenv("ORYON_SCREEN8_WAVES") ? atoi(getenv("ORYON_SCREEN8_WAVES")) : 4;
+    if (waves == 8 && CP == 256) {
+        const int T8 = (cap_a + 511) / 512;
+        hipLaunchKernelGGL((match_i8_screen_v2_kernel<256, 0, 8>), dim3(groups / T * T8), dim3(512), 0, st, a8, q8, q_scale, B, cap_a, cap_q, n_a,
+                           n_q, T8, S, ws_max, ws_i1, ws_m2);
         return;
     }
     if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_i8_screen_v2_kernel<CP>), (int)dyn);
