@@ -565,3 +565,37 @@ def test_lazy_corrs_full_size_and_c512():
     p = [make_pair(i, 64, 64, 400, device=dev) for i in (0, 1)]                    # C = 400 -> C_pad 512
     _lazy_vs_eager(st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), 512, 0.25)
     _lazy_vs_eager(st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), 512, 0.4, max_corrs=64)
+
+
+def test_lazy_corrs_exact_ties_and_single_candidates():
+    """The sampled-row shortcut (a single row inside the int8 margin is the argmin, no fp32 re-scoring) next to the cases that must NOT take
+    it: query maps with exact duplicates of the matched pixel in the same 16-row slice, in another slice of the same 128-row tile and far
+    away (ties resolve to the first index), and near-duplicates (1e-3 noise).  Lazy == eager == exact scan, bit for bit."""
+    dev = "cuda"
+    C, H = 256, 48
+    g = torch.Generator(device=dev).manual_seed(33)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+    fqs, fas = [], []
+    for kind in range(4):
+        fq = rn(C, H, H)
+        fa = fq.flip(-1) + 0.05 * rn(C, H, H)
+        flat = fq.view(C, -1)
+        src = torch.arange(0, H * H, 7, device=dev)
+        if kind == 0:
+            dst = src + 1                                  # duplicate right next to the original: same slice
+        elif kind == 1:
+            dst = src + 40                                 # another slice of the same tile (mostly)
+        elif kind == 2:
+            dst = (src + 1171) % (H * H)                   # far away
+        else:
+            dst = src + 2
+        keep = dst < H * H
+        src, dst = src[keep], dst[keep]
+        flat[:, dst] = flat[:, src] if kind < 3 else flat[:, src] + 1e-3 * rn(C, src.numel())
+        fqs.append(fq)
+        fas.append(fa)
+    fa, fq = torch.stack(fas), torch.stack(fqs)
+    ma = torch.ones((4, H, H), dtype=torch.int32, device=dev)
+    mq = torch.ones((4, H, H), dtype=torch.int32, device=dev)
+    (corrs, n_valid, n_sel, status, md, am, va), und, va0, na = _lazy_vs_eager(fa, fq, ma, mq, 256, 0.25)
+    assert status.tolist() == [0, 0, 0, 0] and min(n_valid.tolist()) > 1500
