@@ -490,3 +490,40 @@ def test_engine_sample_first_schedule():
         T = out["pose"][b].cpu()
         if b != 3:
             assert float((T[:3, :3] - gt[:3, :3]).abs().max()) < 1e-2 and float((T[:3, 3] - gt[:3, 3]).abs().max()) < 5e-3
+
+
+def test_registration_is_bit_stable_beside_another_registration():
+    """Two solver instances on two streams, the same 64 x 500 correspondences: every pose of the first equals its serial result bit for
+    bit while the second one's encoder (fp16x3 MFMA kernels) and whole registration run beside it.  With packed fp32 VALU ops in the build
+    this fails within a few iterations (a wave's v_pk_*_f32 results go wrong in lanes 48-63 next to another kernel's double-rate MFMAs,
+    DESIGN.md "Concurrency and the packed-fp32 finding"); the library is built without them (csrc/Makefile NOPK)."""
+    from oryon_amd.pointdsc import PointDSC
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1234)                     # the released 3DMatch geometry: 12 layers x 128 channels (the fp16x3 MFMA kernels' case)
+    m = PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, sigma_d=0.1, k=40, nms_radius=0.1).to(dev).eval()
+    noise = PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, sigma_d=0.1, k=40, nms_radius=0.1).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    B = 64
+    src = torch.rand(B, 512, 3, generator=g, device=dev)
+    tgt = src + 0.01 * torch.randn(B, 512, 3, generator=g, device=dev)
+    n = torch.full((B,), 500, dtype=torch.int32, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    feat, conf = [x.clone() for x in m.encode(src, tgt, n)]
+    seeds, ns = m.pick_seeds_batched(src, conf, n)
+    sT, _, best = m.hypotheses(src, tgt, feat, n, seeds, ns)
+    T0 = sT[torch.arange(B, device=dev), best.long()].contiguous()
+    want_refine = m.refine(src, tgt, n, T0).clone()
+    want_pose = m.register(src, tgt, n, status)[0].clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for it in range(25):
+        with torch.cuda.stream(sb):
+            for _ in range(2):
+                noise.encode(src, tgt, n)
+            noise.register(src, tgt, n, status)
+        with torch.cuda.stream(sa):
+            refined = [m.refine(src, tgt, n, T0) for _ in range(20)]
+            poses = [m.register(src, tgt, n, status)[0] for _ in range(2)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, want_refine) for o in refined), f"refine differs beside another registration (iteration {it})"
+        assert all(torch.equal(o, want_pose) for o in poses), f"register differs beside another registration (iteration {it})"
