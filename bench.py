@@ -429,7 +429,7 @@ def main():
     if rank == 0:
         cp = 32 if C <= 32 else 64 if C <= 64 else 128 if C <= 128 else 256 if C <= 256 else (C + 31) // 32 * 32
         if use_i8:
-            kernel, peak = f"match_i8_screen_kernel<{cp}> (int8-MFMA pre-screen of K1s8)", PEAK_I8_MFMA_TOPS
+            kernel, peak = f"match_i8_screen_v2_kernel<{cp}, 0, 4> (int8-MFMA pre-screen of K1s8)", PEAK_I8_MFMA_TOPS
         elif screened:
             kernel, peak = f"match_f16_screen_kernel<{max(cp, 128)},2> (fp16-MFMA screening pass of K1s)", PEAK_F16_MFMA_TFLOPS
         elif cp <= 256:
