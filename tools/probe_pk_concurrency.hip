@@ -10,7 +10,8 @@
 //     beside three DEPENDENT v_mfma_f32_32x32x16_f16 per step (acc -> acc -> acc), registers only ...... 21
 //     beside LDS reads + hi/lo split + three dependent f16 MFMAs (the fp16x3 kernels' shape) ........... 305-324
 // i.e. the trigger on the other side is a chain of accumulate-dependent double-rate MFMAs; nothing in the victim is needed beyond
-// v_pk_{mul,fma,add}_f32.  The library is therefore built without packed fp32 ops (oryon_amd/csrc/Makefile NOPK).
+// v_pk_{mul,fma,add}_f32.  A second victim with the other multi-element instruction classes the library still contains
+// (v_cvt_pk_f16_f32 splits, v_dot4 int8 chains, fp64 FMA chains) runs in the same iterations and never differs (0 of 2000 on every line).  The library is therefore built without packed fp32 ops (oryon_amd/csrc/Makefile NOPK).
 //   hipcc -O3 --offload-arch=gfx950 tools/probe_pk_concurrency.hip -o /tmp/probe_pk && /tmp/probe_pk
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -58,6 +59,35 @@ __global__ __launch_bounds__(256) void victim(const float *__restrict__ T_in, co
         }
     out[(size_t)b * 256 + t] = acc_pk;
     out[(size_t)gridDim.x * 256 + (size_t)b * 256 + t] = acc_s;
+}
+
+// the other multi-element instruction classes the library's code objects still contain (v_cvt_pk_f16_f32, v_dot4c_i32_i8) and its fp64 chains:
+// out[0] = sum of the hi/lo fp16 split residuals, out[1] = an int8 dot-product chain, out[2] = an fp64 FMA chain
+__global__ __launch_bounds__(256) void victim_other(const float *__restrict__ src, int n, int rounds, float *__restrict__ out)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *sp = src + (size_t)b * n * 3;
+    float acc_cvt = 0.f;
+    int acc_dot = 0;
+    double acc_d = 0.0;
+    for (int r = 0; r < rounds; ++r)
+        for (int j = t; j < n; j += 256) {
+            const float x = sp[3 * j], y = sp[3 * j + 1], z = sp[3 * j + 2];
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 v = {x, y};
+            const h2 hi = __builtin_convertvector(v, h2);                   // v_cvt_pk_f16_f32
+            const f2 lo = v - __builtin_convertvector(hi, f2);
+            const h2 lo_h = __builtin_convertvector(lo, h2);
+            acc_cvt += (float)hi[0] + (float)hi[1] + 1024.f * ((float)lo_h[0] + (float)lo_h[1]);
+            const int pa = __builtin_bit_cast(int, x) ^ (j * 0x01010101), pb = __builtin_bit_cast(int, z) + r;
+            acc_dot = __builtin_amdgcn_sdot4(pa, pb, acc_dot, false);       // v_dot4_i32_i8 / v_dot4c_i32_i8
+            acc_d = __builtin_fma((double)x, (double)y, acc_d) + (double)z * 0.5;
+        }
+    const size_t N = (size_t)gridDim.x * 256;
+    out[(size_t)b * 256 + t] = acc_cvt;
+    out[N + (size_t)b * 256 + t] = (float)acc_dot;
+    out[2 * N + (size_t)b * 256 + t] = (float)acc_d;
 }
 
 template <int KIND> __global__ __launch_bounds__(256) void aggressor(int iters, float *sink)
@@ -167,14 +197,18 @@ int main()
     CK(hipMemcpy(dt, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
     hipStream_t sa, sb;
     CK(hipStreamCreate(&sa)); CK(hipStreamCreate(&sb));
-    std::vector<float> ref(NV), got(NV);
+    std::vector<float> ref(NV), got(NV), ref2(3 * B * 256), got2(3 * B * 256);
+    float *dout2;
+    CK(hipMalloc(&dout2, ref2.size() * 4));
+    hipLaunchKernelGGL(victim_other, dim3(B), dim3(256), 0, sa, ds, n, rounds, dout2);
+    CK(hipMemcpyAsync(ref2.data(), dout2, ref2.size() * 4, hipMemcpyDeviceToHost, sa));
     hipLaunchKernelGGL(victim, dim3(B), dim3(256), 0, sa, dT, ds, dt, n, rounds, dout);
     CK(hipMemcpyAsync(ref.data(), dout, (size_t)NV * 4, hipMemcpyDeviceToHost, sa));
     CK(hipStreamSynchronize(sa));
     const char *names[9] = {"nothing", "v_mfma_f32_32x32x16_f16", "v_mfma_i32_32x32x32_i8", "v_mfma_f32_32x32x2_f32", "LDS + split + 3 f16 MFMAs", "LDS + split + 1 f16 MFMA",
                             "3 dependent f16 MFMAs only", "LDS + split, no MFMA", "LDS + cvt + 3 f16 MFMAs"};
     for (int kind = -1; kind < 8; ++kind) {
-        int bad_pk = 0, bad_s = 0, launches = 0, lane_hist[4] = {0, 0, 0, 0};
+        int bad_pk = 0, bad_s = 0, bad_other = 0, launches = 0, lane_hist[4] = {0, 0, 0, 0};
         for (int it = 0; it < 200; ++it) {
             if (kind == 0) hipLaunchKernelGGL(aggressor<0>, dim3(2048), dim3(256), 0, sb, 4000, dsink);
             if (kind == 1) hipLaunchKernelGGL(aggressor<1>, dim3(2048), dim3(256), 0, sb, 4000, dsink);
@@ -195,11 +229,15 @@ int main()
                 for (int i = NV / 2; i < NV; ++i)
                     if (memcmp(&got[i], &ref[i], 4)) b2 = true;
                 bad_pk += b1; bad_s += b2;
+                hipLaunchKernelGGL(victim_other, dim3(B), dim3(256), 0, sa, ds, n, rounds, dout2);
+                CK(hipMemcpyAsync(got2.data(), dout2, got2.size() * 4, hipMemcpyDeviceToHost, sa));
+                CK(hipStreamSynchronize(sa));
+                bad_other += memcmp(got2.data(), ref2.data(), got2.size() * 4) != 0;
             }
             CK(hipStreamSynchronize(sb));
         }
-        printf("victim beside %-28s: %4d of %d launches differ in the compiler's (packed) result, %d in the single-op result; wrong lanes by quarter 0-15/16-31/32-47/48-63: %d/%d/%d/%d\n",
-               names[kind + 1], bad_pk, launches, bad_s, lane_hist[0], lane_hist[1], lane_hist[2], lane_hist[3]);
+        printf("victim beside %-28s: %4d of %d launches differ in the compiler's (packed) result, %d in the single-op result, %d in the cvt_pk / dot4 / fp64 victim; wrong lanes by quarter 0-15/16-31/32-47/48-63: %d/%d/%d/%d\n",
+               names[kind + 1], bad_pk, launches, bad_s, bad_other, lane_hist[0], lane_hist[1], lane_hist[2], lane_hist[3]);
     }
     return 0;
 }
