@@ -631,16 +631,22 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_kernel(const float *__r
 template <int C>
 __global__ __launch_bounds__(256) void pdsc_attention_x3_img_kernel(const float *__restrict__ QKV, const char *__restrict__ kv_img,
                                                                      const float *__restrict__ sc, const int32_t *__restrict__ n_rows,
-                                                                     int n_cap, float inv_sqrt_c, float *__restrict__ msg)
+                                                                     int n_cap, float inv_sqrt_c, float *__restrict__ msg, int n_pairs)
 {
     static_assert(C == 128, "tile image geometry");
     constexpr int CB = C / 32;
     constexpr int NS = C / 16;                    // k16 steps of the first product
     constexpr int KLD = C + 8;                    // halves per K row
     extern __shared__ __attribute__((aligned(1024))) char att_lds[];            // two tile images
-    const int b = blockIdx.z;
+    // XCD-aware block map: the query blocks of one pair read the same K / V tile images, so they go to ONE XCD (linear block id mod 8) and
+    // share the images through its L2 (with the plain (query block, pair) grid a pair's four blocks landed on four XCDs and each fetched
+    // the pair's 540 KB of images for itself).  The grid's z extent is B rounded up to a multiple of 8.
+    const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int b = (lin / 8 / (int)gridDim.x) * 8 + (lin & 7);
+    const int qblk = (lin / 8) % (int)gridDim.x;
+    if (b >= n_pairs) return;
     const int n = n_rows[b];
-    const int q0 = blockIdx.x * ATT_Q;
+    const int q0 = qblk * ATT_Q;
     if (q0 >= n) return;
     const int j_begin = 0, j_end = n;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -1349,8 +1355,8 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         dim3 ag(n_cap / ATT_Q, KS, B);
         if (C == 128 && x3 && use_img) {
             allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_attention_x3_img_kernel<128>), 2 * PDSC_KV_TILE_BYTES);
-            hipLaunchKernelGGL((pdsc_attention_x3_img_kernel<128>), ag, dim3(256), 2 * PDSC_KV_TILE_BYTES, st, ws.qkv, ws.kv_img, ws.sc, n_rows,
-                               n_cap, inv_sqrt_c, ws.msg);
+            hipLaunchKernelGGL((pdsc_attention_x3_img_kernel<128>), dim3(n_cap / ATT_Q, 1, (B + 7) / 8 * 8), dim3(256), 2 * PDSC_KV_TILE_BYTES, st,
+                               ws.qkv, ws.kv_img, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, B);
         } else if (C == 128 && x3)
             hipLaunchKernelGGL((pdsc_attention_x3_kernel<128>), ag, dim3(256), 0, st, ws.qkv, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, KS, ws.att_o, ws.att_ml);
         else if (C == 128)
