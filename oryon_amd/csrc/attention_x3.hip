@@ -26,14 +26,20 @@ __device__ __forceinline__ void mha_split(float x, _Float16 &hi, _Float16 &lo)
     lo = (_Float16)(x - (float)hi);
 }
 
-__global__ __launch_bounds__(256) void mha_x3_kernel(const float *__restrict__ qkv, int L, int Dm, float scale, float *__restrict__ out)
+__global__ __launch_bounds__(256) void mha_x3_kernel(const float *__restrict__ qkv, int L, int Dm, float scale, float *__restrict__ out, int n_qblk,
+                                                     int heads, int n_units)
 {
     constexpr int C = MHA_D, CB = C / 32, NS = C / 16;
     constexpr int KF4 = MHA_KT * (C / 4) / 256;          // 4 float4 of K per thread and tile
     constexpr int VPT = MHA_KT * C / 256, VOCT = VPT / 8, GROUPS = 256 / C;
     __shared__ __attribute__((aligned(16))) _Float16 Kh[MHA_KT * MHA_KLD], Kl[MHA_KT * MHA_KLD];
     __shared__ __attribute__((aligned(16))) _Float16 Vh[MHA_KT * C], Vl[MHA_KT * C];
-    const int img = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * MHA_Q;
+    // XCD-aware block map (1-D grid): the query blocks of one (image, head) read the same K / V rows, so they get linear ids that are equal
+    // mod 8 - one XCD, one L2 - instead of landing on n_qblk different XCDs that each fetch the 295 KB of K / V for themselves
+    const int lin = blockIdx.x;
+    const int unit = (lin / 8 / n_qblk) * 8 + (lin & 7);
+    if (unit >= n_units) return;
+    const int img = unit / heads, head = unit % heads, q0 = ((lin / 8) % n_qblk) * MHA_Q;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const size_t rs = (size_t)3 * Dm;                    // row stride of qkv
     const float *base = qkv + (size_t)img * L * rs + head * C;
@@ -202,8 +208,9 @@ extern "C" int oryon_mha_f16x3(const float *qkv, int N, int L, int heads, int he
     ORYON_CHECK_ARG(qkv && out && N >= 0 && L > 0 && heads > 0 && head_dim == MHA_D);
     ORYON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0);
     if (N == 0) return ORYON_OK;
-    hipLaunchKernelGGL(mha_x3_kernel, dim3((L + MHA_Q - 1) / MHA_Q, heads, N), dim3(256), 0, as_stream(stream), qkv, L, heads * head_dim,
-                       0.125f, out);
+    const int n_qblk = (L + MHA_Q - 1) / MHA_Q, n_units = heads * N;
+    hipLaunchKernelGGL(mha_x3_kernel, dim3(n_qblk * ((n_units + 7) / 8 * 8)), dim3(256), 0, as_stream(stream), qkv, L, heads * head_dim, 0.125f, out,
+                       n_qblk, heads, n_units);
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }
