@@ -145,11 +145,14 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
                                                                const int32_t *__restrict__ n_seeds, int S_cap, int k_cfg,
                                                                float inv_sigma2, float inv_sigma_d2,
                                                                int32_t *__restrict__ knn_out, float *__restrict__ M_out,
-                                                               const float *__restrict__ dist_pre /* [B,S_cap,n_cap] or NULL */)
+                                                               const float *__restrict__ dist_pre /* [B,S_cap,n_cap] or NULL */, int n_batch)
 {
     extern __shared__ float sm[];
-    const int b = blockIdx.y, s = blockIdx.x;
-    if (s >= n_seeds[b]) return;
+    // XCD-aware block map: the seeds of one pair gather rows of the same feature matrix (256 KB at n = 500, C = 128), so they run on one XCD
+    // (linear block id mod 8) and share it through that L2.  gridDim.y is the pair count rounded up to a multiple of 8.
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int b = (lin / 8 / (int)gridDim.x) * 8 + (lin & 7), s = (lin / 8) % (int)gridDim.x;
+    if (b >= n_batch || s >= n_seeds[b]) return;
     const int n = n_rows[b];
     const int k = k_cfg < n - 1 ? k_cfg : n - 1;
     int P = 256;                            // sort size: power of two >= n
@@ -510,8 +513,8 @@ int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float
                            n_cap, seeds, n_seeds, S_cap, ws.seed_dist);
         dist_pre = ws.seed_dist;
     }
-    hipLaunchKernelGGL(pdsc_knn_matrix_kernel, dim3(S_cap, B), dim3(256), sh1, st, feat_n, src, tgt, n_rows, n_cap, C, seeds,
-                       n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, dist_pre);
+    hipLaunchKernelGGL(pdsc_knn_matrix_kernel, dim3(S_cap, (B + 7) / 8 * 8), dim3(256), sh1, st, feat_n, src, tgt, n_rows, n_cap, C, seeds,
+                       n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, dist_pre, B);
     if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
     const int nit = M.cfg.num_iterations < HYP_MAX_IT ? M.cfg.num_iterations : HYP_MAX_IT;
     hipLaunchKernelGGL(pdsc_power_kernel, dim3(S_cap, B), dim3(64), 0, st, n_rows, n_seeds, S_cap, k, nit, ws.Mmat, ws.v_hist, ws.close_hist);
