@@ -326,6 +326,12 @@ def main():
     ap.add_argument("--sample-first", type=int, default=0,
                     help="MatchPoseConfig.sample_first: the matcher runs on a random subset of this many anchors per pair first (identically "
                          "distributed correspondences; pairs that come up short are redone on all anchors).  0 = off (default, the headline)")
+    ap.add_argument("--reps", type=int, default=7,
+                    help="repetitions of the timed window of --steps steps (each bracketed by barrier + synchronize); `value` / `ms_per_step` are "
+                         "the MEDIAN window, every window is listed in `timing.windows_ms_per_step`")
+    ap.add_argument("--engine", choices=["native", "python"], default="native",
+                    help="native: one C-ABI call per step (oryon_engine_submit: engine-owned streams / events, persistent arena, no torch "
+                         "allocation per step); python: the per-call schedule of oryon_amd/engine.py (torch streams, ~40 torch allocations per step)")
     ap.add_argument("--no-stage-sets", action="store_true",
                     help="skip the 'decode+match+pose' and 'full' stage sets that the default run measures after the headline")
     ap.add_argument("--collation-selftest", action="store_true",
@@ -363,13 +369,22 @@ def main():
         inputs["feat_q"] = inputs["feat_q"].contiguous(memory_format=torch.channels_last)
     engine = MatchPoseEngine(build_solver(dev), MatchPoseConfig(dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1,
                                                                 match_mode=a.match_mode, sample_first=a.sample_first),
-                             overlap_registration=not a.no_overlap, overlap_gather=a.overlap_gather and not a.no_overlap)
+                             overlap_registration=not a.no_overlap, overlap_gather=a.overlap_gather and not a.no_overlap,
+                             native=a.engine == "native", result_views=True)
+    engine.native_timing = True           # HIP events around the three sections and the screening kernel of every native step
     key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
     total = B * world
+    # the C ABI's input types, made once: fp32 [B,9] intrinsics (the reference's float64 [B,3,3] rounded, as pipeline.py:434-435 + lift_pcd do)
+    inputs["cam"] = inputs["cam"].reshape(B, 9).to(torch.float32).contiguous()
+    host = {"submit_s": 0.0, "submits": 0}
 
     def submit(keep=False):
-        return engine.run(inputs["feat_a"], inputs["feat_q"], inputs["mask_a"], inputs["mask_q"], inputs["depth_a"],
-                          inputs["depth_q"], inputs["cam"], inputs["cam"], key, keep=keep, inputs_resident=True)
+        t_ = time.perf_counter()
+        out = engine.run(inputs["feat_a"], inputs["feat_q"], inputs["mask_a"], inputs["mask_q"], inputs["depth_a"],
+                         inputs["depth_q"], inputs["cam"], inputs["cam"], key, keep=keep, inputs_resident=True)
+        host["submit_s"] += time.perf_counter() - t_
+        host["submits"] += 1
+        return out
 
     def collect(out):
         engine.finish(out)
@@ -403,22 +418,53 @@ def main():
     barrier()
     screened = a.match_mode in ("screened", "screened16") and 64 < C <= 512
     use_i8 = screened and a.match_mode == "screened" and C > 128
-    with MatchTimer("match_corrs_i8" if use_i8 else "match_screened" if screened else "match") as mt:
-        t0 = time.perf_counter()
-        out, pose, status = run_steps(a.steps)
+    want_native = use_i8 and a.engine == "native" and not a.sample_first
+    if want_native and engine._native is None:
+        run_steps(1)                      # --warmup 0: the first step builds the engine (arena, streams); not a timed step
         barrier()
-        elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    native = engine._native if want_native else None
+
+    def alloc_counters():
+        ms = torch.cuda.memory_stats(dev)
+        return ms.get("num_device_alloc", 0), ms.get("allocation.all.allocated", 0), ms.get("num_alloc_retries", 0)
+
+    # R repetitions of the timed window: EXACTLY --steps steps between two barrier + synchronize brackets, max over ranks; the
+    # headline is the median window.  Every window also records where the host was (time inside the submit calls), what the
+    # caching allocator did (hipMalloc calls / torch allocations inside the window) and, from the native engine's HIP events, how
+    # long each of the three streams was busy per step - so a reader can tell a host-bound or allocator-bound window from a GPU-bound one.
+    windows, sections = [], []
+    with MatchTimer("match_corrs_i8" if use_i8 else "match_screened" if screened else "match") as mt:
+        for _ in range(max(1, a.reps)):
+            a0 = alloc_counters()
+            h0 = (host["submit_s"], host["submits"], native.host_stats()[1] if native else 0.0)
+            first_step = native.steps if native else 0
+            barrier()
+            t0 = time.perf_counter()
+            out, pose, status = run_steps(a.steps)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            a1 = alloc_counters()
+            w = {"ms_per_step": float(el.item()) / a.steps * 1e3,
+                 "host_submit_ms_per_step": (host["submit_s"] - h0[0]) / max(1, host["submits"] - h0[1]) * 1e3,
+                 "device_allocs": a1[0] - a0[0], "torch_allocs_per_step": (a1[1] - a0[1]) / a.steps, "alloc_retries": a1[2] - a0[2]}
+            if native:
+                w["host_submit_ms_per_step_c_abi"] = (native.host_stats()[1] - h0[2]) / a.steps
+                sections += [native.timing(k) for k in range(max(first_step, native.steps - 64), native.steps)]
+            windows.append(w)
+    med = lambda xs: sorted(xs)[len(xs) // 2] if xs else None
+    ms_med = med([w["ms_per_step"] for w in windows])
+    elapsed = ms_med * 1e-3 * a.steps
 
     # result sanity + algorithmic work of the dominant kernel (this rank's launch)
     out, pose, status = step(keep=True)
     torch.cuda.synchronize()
     n_a, n_q = out["n_a"].double(), out["n_q"].double()
     flops = float((2.0 * n_a * n_q * C).sum())
-    match_ms = mt.mean_ms()
+    match_ms = med([t["screen_kernel_ms"] for t in sections]) if sections else mt.mean_ms()
+    match_ms_mean = sum(t["screen_kernel_ms"] for t in sections) / len(sections) if sections else match_ms
     ok = status[:total] == 0
     gt = inputs["pose_gt"].to(torch.float32)
     mine = out["pose"].cpu()
@@ -436,7 +482,11 @@ def main():
             kernel, peak = f"match_f32_regb_kernel<{cp}>", PEAK_FP32_MFMA_TFLOPS
         else:
             kernel, peak = "match_f32_kernel (LDS-staged, wide descriptors)", PEAK_FP32_MFMA_TFLOPS
-        launch_ms = match_ms
+        from oryon_amd._lib import lib as _L
+        dispatched = _L().oryon_dominant_kernel().decode()          # what the library actually launched between the events
+        if dispatched:
+            kernel = dispatched + kernel[kernel.index(" ("):] if " (" in kernel else dispatched
+        launch_ms = match_ms_mean                                   # average launch duration over the timed windows (HIP events)
         achieved = flops / (launch_ms * 1e-3) / 1e12
         # the other roofline of SURVEY.md 8(d): operand bytes the kernel has to read once (rows actually used, in the kernel's
         # operand type) + its per-anchor outputs, against the 8 TB/s HBM peak - far from binding for ROIs of this size
@@ -447,7 +497,7 @@ def main():
         # rocprofv3 --pmc passes of this exact workload AND this exact kernel source - the record carries the sha256 of the kernel's
         # source file, and a mismatch (the kernel changed since the counters were collected) reports null instead of a stale number
         traffic, traffic_src = None, "no PMC record for this workload"
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if use_i8 and (B, H, C) == (64, 224, 256) and a.layout == "nchw" and os.path.exists(tpath):
             import hashlib
             with open(tpath) as fh:
@@ -455,13 +505,30 @@ def main():
             with open(os.path.join(ROOT, "oryon_amd", "csrc", "match16.hip"), "rb") as fh:
                 sha = hashlib.sha256(fh.read()).hexdigest()
             if tj.get("kernel_source_sha256") == sha:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source", "profiles/r02_pmc_counters.md")
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source", "profiles/r03_pmc_counters.md")
             else:
-                traffic_src = "profiles/r02_traffic.json is stale (match16.hip changed since the PMC passes): not reported"
+                traffic_src = "profiles/r03_traffic.json is stale (match16.hip changed since the PMC passes): not reported"
         rec = {
             "metric": METRIC, "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timing": {
+                "statistic": f"median of {len(windows)} windows of {a.steps} steps, each bracketed by barrier + torch.cuda.synchronize, max over ranks",
+                "windows_ms_per_step": [round(w["ms_per_step"], 4) for w in windows],
+                "engine": ("native: one oryon_engine_submit per step (engine-owned HIP streams / events, persistent arena)" if native else
+                           "python: per-call schedule (torch streams, torch allocations per step)"),
+                "host_submit_ms_per_step": med([w["host_submit_ms_per_step"] for w in windows]),
+                "host_submit_ms_per_step_c_abi": med([w["host_submit_ms_per_step_c_abi"] for w in windows]) if native else None,
+                "torch_allocs_per_step": [round(w["torch_allocs_per_step"], 2) for w in windows],
+                "device_allocs_in_window": [w["device_allocs"] for w in windows],
+                "alloc_retries_in_window": [w["alloc_retries"] for w in windows],
+                "stream_busy_ms_per_step": ({k: med([t[k] for t in sections]) for k in ("gather_ms", "match_ms", "screen_kernel_ms", "registration_ms")}
+                                            if sections else None),
+                "step_timeline_ms": ({k: med([t[k] for t in sections]) for k in ("match_start", "match_end", "registration_start", "registration_end")}
+                                     if sections else None),
+                "step_latency_ms": med([t["registration_end"] for t in sections]) if sections else None,
+                "timed_steps_with_events": len(sections),
+            },
             "config": {
                 "workload": f"{'cfg2' if (H, C) == (224, 256) else 'cfg4 geometry' if (H, C) == (384, 512) else 'custom'}: Batch={B} synthetic {H}x{H} pairs per GPU, C={C} fp32 descriptors given (HIP matcher + lift + "
                             f"PointDSC 12x128), N1<=5000, n_corrs=500",

@@ -45,6 +45,8 @@ const char *oryon_last_error(void);
  * stream immediately before / after the DOMINANT kernel launch of the next oryon_match_f32 / oryon_match_screened call
  * made by this thread (match_f32_regb_kernel, resp. the match_f16_screen_kernel screening pass), then forgotten. */
 int oryon_profile_events(void *start_event, void *stop_event);
+/* Name (template arguments included) of the kernel the events above bracketed most recently; "" before the first armed call. */
+const char *oryon_dominant_kernel(void);
 /* ORYON_OK iff device `device` exists and is gfx950. */
 int oryon_device_check(int device);
 
@@ -312,6 +314,64 @@ int oryon_pointdsc_hypotheses(oryon_pointdsc_t *handle, const float *src, const 
                               int32_t *best, void *stream);
 int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const float *tgt, const int32_t *n, int B,
                           int n_cap, const float *T_in, float *T_out, uint8_t *labels, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The whole batched step as ONE call (round 3): what the per-sample loop of FPM_Pipeline.test_step does for every pair of a batch
+ * (pipeline.py:313-355: is_detection_valid -> get_featmap_corrs [utils/pcd.py:177-216] -> get_pose [pipeline.py:429-472:
+ * scale / validate / lift, get_pointdsc_pose]), for B pairs, enqueued from C++ on streams and events the engine owns, over a
+ * persistent arena the caller hands over once.  oryon_engine_submit issues, without allocating or synchronising,
+ *     gather stream : oryon_roi_compact x2, oryon_roi_subsample, oryon_gather_q8 x2                       (K0)
+ *     match stream  : oryon_match_corrs_i8, oryon_lift_pairs                                               (K1s8 + K1b, K2)
+ *     reg stream    : oryon_pointdsc_register                                                              (K3-K10)
+ * with exactly the arguments oryon_amd/engine.py passes to those entry points, so results are identical bit for bit.  The K0
+ * outputs alternate between two buffer sets, everything else a step produces between n_slots result slots, registrations between
+ * two streams: K0 of step k+1 and the registrations of steps k-1, k-2 overlap the matching of step k.
+ * Route: the int8-screened matcher (128 < C <= 512, 0 < dist_th <= 0.5); other routes stay with the per-call entry points.
+ *
+ * overlap: 0 = everything on the caller's stream (no engine streams), 1 = match on an engine stream, registration on one stream
+ *          per slot, 2 = additionally K0 on its own stream (n_slots >= 2 for overlap >= 1).
+ * Per-pair results live in the arena: oryon_engine_buffer gives offset / size of a slot's named buffer ("pose" [B,16] fp32,
+ *          "status_out" [B] i32, "n_valid", "n_lift", "n_a", "n_q", "n_und" [B] i32, "corrs" [B,n_cap,4] i32, "pcd_a", "pcd_q"
+ *          [B,n_cap,3] fp32, "roi_a", "roi_q" [B,FH*FW] i32, "min_dist", "argmin", "valid" [B,cap_a], ...); a slot's buffers are valid
+ *          from oryon_engine_wait(slot) until the n_slots-th next submit.
+ * oryon_engine_submit returns the slot index (>= 0) or a negative error.  inputs_resident != 0: the inputs were complete before
+ *          the call (nothing pending on caller_stream produces them), so K0 need not wait for the caller's stream.  The caller
+ *          must not overwrite the inputs before oryon_engine_wait(slot, stream) has been passed on the stream that overwrites them.
+ * Measurement: oryon_engine_set_timing(1) brackets the three sections and the screening kernel of every step with HIP events;
+ *          oryon_engine_timing(step) (step = 0-based index of the submit, one of the last 64) -> {gather, match+lift, screening
+ *          kernel, registration} durations in ms and the start / end of the match and registration sections relative to the start
+ *          of the gather (valid once the step has completed).
+ *          oryon_engine_host_stats: host time spent inside oryon_engine_submit. */
+typedef struct oryon_engine oryon_engine_t;
+typedef struct {
+    int B, C, FH, FW;        /* pairs per step; descriptor maps [B,C,FH,FW] */
+    int HA, WA, HQ, WQ;      /* depth maps [B,HA,WA] / [B,HQ,WQ] fp32 millimetres */
+    int layout;              /* ORYON_LAYOUT_NCHW | ORYON_LAYOUT_NHWC */
+    float dist_th;           /* test.dist_th (0.25) */
+    int n_corrs;             /* test.n_corrs (500) */
+    int src_sampling;        /* test.src_sampling (5000); 0 = keep every ROI pixel */
+    uint64_t seed;
+    int round_f16;           /* the reference's half-descriptor branch (utils/pcd.py:195-197) */
+    int n_slots;             /* result slots: a step's results stay readable until the n_slots-th next submit (4) */
+    int overlap;             /* see above (2) */
+} oryon_engine_config_t;
+size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver);
+int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,
+                        size_t arena_bytes);
+void oryon_engine_destroy(oryon_engine_t *handle);
+int oryon_engine_buffer(const oryon_engine_t *handle, int slot, const char *name, size_t *offset, size_t *bytes);
+int oryon_engine_geometry(const oryon_engine_t *handle, int *cap_a, int *cap_q, int *c_pad, int *n_cap);
+/* feat_* [B,C,FH,FW] fp32 in cfg.layout; mask_* [B,FH*FW] int32 (== 1 selects); depth_* fp32; cam_* [B,9] fp32; pair_key [B] int64 or NULL */
+int oryon_engine_submit(oryon_engine_t *handle, const float *feat_a, const float *feat_q, const int32_t *mask_a, const int32_t *mask_q,
+                        const float *depth_a, const float *depth_q, const float *cam_a, const float *cam_q, const int64_t *pair_key,
+                        int force_eager, int inputs_resident, void *caller_stream);
+int oryon_engine_wait(oryon_engine_t *handle, int slot, void *caller_stream);
+int oryon_engine_set_timing(oryon_engine_t *handle, int enable);
+int oryon_engine_timing(oryon_engine_t *handle, int64_t step, float *out8);
+/* ms from timing event `event_a` of step `step_a` to event `event_b` of step `step_b` (events per step: 0/1 gather begin / end,
+ * 2/3 match + lift begin / end, 4/5 screening kernel begin / end, 6/7 registration begin / end): timelines across steps. */
+int oryon_engine_elapsed(oryon_engine_t *handle, int64_t step_a, int event_a, int64_t step_b, int event_b, float *ms);
+int oryon_engine_host_stats(const oryon_engine_t *handle, int64_t *n_submit, double *submit_ms_total, double *submit_ms_last);
 
 /* B4  error-compensated fp16x3 linear layer for the frozen fp32 towers (CLIP ViT-L/14@336, Swin) of Oryon.forward
  *     (net.py:142-167, models/vlm.py:43-61; the reference evaluates them with fp32 torch linears):

@@ -19,6 +19,12 @@ class OryonError(RuntimeError):
     pass
 
 
+class EngineConfig(ctypes.Structure):
+    _fields_ = [("B", c_int), ("C", c_int), ("FH", c_int), ("FW", c_int), ("HA", c_int), ("WA", c_int), ("HQ", c_int), ("WQ", c_int),
+                ("layout", c_int), ("dist_th", c_float), ("n_corrs", c_int), ("src_sampling", c_int), ("seed", c_uint64),
+                ("round_f16", c_int), ("n_slots", c_int), ("overlap", c_int)]
+
+
 class PointDSCConfig(ctypes.Structure):
     _fields_ = [("in_dim", c_int), ("num_layers", c_int), ("num_channels", c_int), ("num_iterations", c_int),
                 ("ratio", c_float), ("inlier_threshold", c_float), ("sigma_d", c_float), ("k", c_int),
@@ -31,6 +37,7 @@ _PROTOS = {
     "oryon_last_error": (c_char_p, []),
     "oryon_device_check": (c_int, [c_int]),
     "oryon_profile_events": (c_int, [_P, _P]),
+    "oryon_dominant_kernel": (c_char_p, []),
     "oryon_quick_gelu_bf16": (c_int, [_P, _P, ctypes.c_int64, _P]),
     "oryon_add_layernorm_bf16": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int, c_float, _P, _P, _P]),
     "oryon_add_layernorm_f32": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int, c_float, _P, _P, _P]),
@@ -72,6 +79,17 @@ _PROTOS = {
     "oryon_linear_f16x3": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
     "oryon_mha_f16x3": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "oryon_pose_metrics": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "oryon_engine_arena_bytes": (c_size_t, [POINTER(EngineConfig), c_void_p]),
+    "oryon_engine_create": (c_int, [POINTER(c_void_p), POINTER(EngineConfig), c_void_p, _P, c_size_t]),
+    "oryon_engine_destroy": (None, [c_void_p]),
+    "oryon_engine_buffer": (c_int, [c_void_p, c_int, c_char_p, POINTER(c_size_t), POINTER(c_size_t)]),
+    "oryon_engine_geometry": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "oryon_engine_submit": (c_int, [c_void_p, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "oryon_engine_wait": (c_int, [c_void_p, c_int, _P]),
+    "oryon_engine_set_timing": (c_int, [c_void_p, c_int]),
+    "oryon_engine_timing": (c_int, [c_void_p, c_int64, POINTER(c_float)]),
+    "oryon_engine_elapsed": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, POINTER(c_float)]),
+    "oryon_engine_host_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "oryon_pointdsc_create": (c_int, [POINTER(c_void_p), POINTER(PointDSCConfig)]),
     "oryon_pointdsc_destroy": (None, [c_void_p]),
     "oryon_pointdsc_load_param": (c_int, [c_void_p, c_char_p, _P, c_int64]),

@@ -13,7 +13,8 @@ namespace oryon {
 
 void set_error(const char *fmt, ...);
 // measurement hook (oryon_profile_events): HIP events recorded around the dominant kernel launch of the next matcher call
-void profile_begin(hipStream_t st);
+// kernel_name (a string literal): what oryon_dominant_kernel() reports for the launch the events bracket
+void profile_begin(hipStream_t st, const char *kernel_name = nullptr);
 void profile_end(hipStream_t st);
 
 #define ORYON_CHECK_ARG(cond)                                                           \

@@ -1,0 +1,408 @@
+// oryon_engine: the whole batched match -> lift -> registration step enqueued from C++ (round 3).
+//
+// Replaces the body of the per-sample loop of FPM_Pipeline.test_step (pipeline.py:313-355) for B pairs, like
+// oryon_amd/engine.py did with ~40 torch allocations, ~15 ctypes calls and per-step torch stream / event objects.  Here one call
+// enqueues everything:
+//
+//     gather stream G : K0   roi_compact x2 -> roi_subsample -> gather_q8 (queries) -> gather_q8 (anchors)
+//     match  stream M : K1s8 oryon_match_corrs_i8 (int8 screen, lazy tail, sampling)  -> K2 oryon_lift_pairs
+//     reg    stream R : K3-K10 oryon_pointdsc_register                                  (one stream per slot)
+//
+// on streams and events the engine owns, over a persistent arena carved once (no allocation, no torch object, no Python per
+// launch).  The K0 outputs alternate between two buffer sets and everything a step hands on or hands back (ROI lists, matcher
+// outputs, lifted points, the registration workspace, poses) between n_slots (4) result slots, so K0 of step k+1 and the
+// registrations of steps k-1, k-2 (two registration streams) run beside the matching of step k and no matcher ever waits for a
+// registration to release its buffers - the same software pipeline the Python engine built out of torch streams and fresh tensors.  Results are bit for bit those of the Python engine (same
+// entry points, same arguments): tests/test_gpu_native_engine.py.
+#include <stdlib.h>
+#include <chrono>
+#include <new>
+#include <vector>
+#include "common.h"
+
+using namespace oryon;
+
+namespace {
+constexpr int MAX_SLOTS = 8;
+constexpr int G_SLOTS = 2;             // K0 output sets (the rows the screening kernel reads)
+constexpr int MAX_REG_STREAMS = 4;
+constexpr int TIMING_RING = 64;        // timing-event sets: the sections of the last 64 steps can be read back
+constexpr int ROW_PAD = 256;
+
+inline size_t up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+struct GatherBuf {
+    int8_t *a8, *q8;
+    float *a_sc, *q_sc, *a_eps, *q_eps, *a_norm, *q_norm, *a_hat;
+};
+
+struct SlotBuf {
+    int32_t *roi_a, *roi_q, *n_a, *n_q;
+    float *min_dist;
+    int32_t *argmin;
+    uint8_t *valid;
+    int32_t *corrs, *n_valid, *n_sel, *status, *n_und;
+    float *pcd_a, *pcd_q;
+    int32_t *n_lift;
+    float *pose;
+    int32_t *status_out;
+    void *pdsc_ws;
+    size_t base, bytes;                        // offset of the slot in the arena
+};
+
+struct Named {
+    const char *name;
+    size_t off, bytes;
+};
+
+struct Layout {
+    GatherBuf gbuf[G_SLOTS];
+    SlotBuf slot[MAX_SLOTS];
+    std::vector<Named> names[MAX_SLOTS];
+    void *match_ws;
+    size_t match_ws_bytes, pdsc_ws_bytes, bytes;
+    int cap_a, cap_q, c_pad, n_cap;
+};
+}  // namespace
+
+struct oryon_engine {
+    oryon_engine_config_t cfg;
+    oryon_pointdsc_t *solver;
+    char *arena;
+    Layout L;
+    int device;
+    hipStream_t sg, sm, sr[MAX_REG_STREAMS];
+    int n_reg_streams;
+    // ordering events (timing disabled), one set per result slot
+    hipEvent_t ev_inputs[MAX_SLOTS], ev_gathered[MAX_SLOTS], ev_matched[MAX_SLOTS], ev_done[MAX_SLOTS];
+    // timing events: gather section, match section, screening kernel, registration section
+    hipEvent_t tev[TIMING_RING][8];           // per step: gather begin / end, match begin / end, screen begin / end, registration begin / end
+    bool timed[TIMING_RING];
+    bool used[MAX_SLOTS];
+    bool timing;
+    int64_t n_submit;
+    double host_ns_total, host_ns_last;
+};
+
+namespace {
+// carve the arena (base == nullptr: sizes only)
+int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver, char *base, Layout &L)
+{
+    const int HW = c.FH * c.FW;
+    L.c_pad = c.C <= 256 ? 256 : 512;
+    const int keep = c.src_sampling > 0 ? (c.src_sampling < HW ? c.src_sampling : HW) : HW;
+    L.cap_a = (int)up((size_t)keep, ROW_PAD);
+    L.cap_q = (int)up((size_t)HW, ROW_PAD);
+    L.n_cap = (int)up((size_t)c.n_corrs, 128);
+    const size_t B = (size_t)c.B;
+    L.match_ws_bytes = oryon_match_corrs_i8_workspace_bytes(c.B, L.c_pad, L.cap_a, L.cap_q, L.n_cap);
+    L.pdsc_ws_bytes = oryon_pointdsc_workspace_bytes(solver, c.B, L.n_cap);
+    if (!L.match_ws_bytes || !L.pdsc_ws_bytes) return ORYON_ERR_INVALID_ARG;
+    size_t off = 0;
+    for (int g = 0; g < G_SLOTS; ++g) {
+        GatherBuf &b = L.gbuf[g];
+        auto take = [&](size_t n) {
+            const size_t o = off;
+            off = up(off + n, 256);
+            return base ? base + o : nullptr;
+        };
+#define TAKE(field, type, count) b.field = reinterpret_cast<type *>(take((size_t)(count) * sizeof(type)))
+        TAKE(a8, int8_t, B * L.cap_a * L.c_pad);
+        TAKE(q8, int8_t, B * L.cap_q * L.c_pad);
+        TAKE(a_sc, float, B * (L.cap_a / 16));
+        TAKE(q_sc, float, B * (L.cap_q / 16));
+        TAKE(a_eps, float, B);
+        TAKE(q_eps, float, B);
+        TAKE(a_norm, float, B * L.cap_a);
+        TAKE(q_norm, float, B * L.cap_q);
+        TAKE(a_hat, float, B * L.cap_a * L.c_pad);
+#undef TAKE
+    }
+    for (int s = 0; s < c.n_slots; ++s) {
+        SlotBuf &b = L.slot[s];
+        L.names[s].clear();
+        b.base = off;
+        auto take = [&](const char *name, size_t n) {
+            const size_t o = off;
+            off = up(off + n, 256);
+            L.names[s].push_back({name, o, n});
+            return base ? base + o : nullptr;
+        };
+#define TAKE(field, type, count) b.field = reinterpret_cast<type *>(take(#field, (size_t)(count) * sizeof(type)))
+        TAKE(roi_a, int32_t, B * HW);
+        TAKE(roi_q, int32_t, B * HW);
+        TAKE(n_a, int32_t, B);
+        TAKE(n_q, int32_t, B);
+        TAKE(min_dist, float, B * L.cap_a);
+        TAKE(argmin, int32_t, B * L.cap_a);
+        TAKE(valid, uint8_t, B * L.cap_a);
+        TAKE(corrs, int32_t, B * L.n_cap * 4);
+        TAKE(n_valid, int32_t, B);
+        TAKE(n_sel, int32_t, B);
+        TAKE(status, int32_t, B);
+        TAKE(n_und, int32_t, B);
+        TAKE(pcd_a, float, B * L.n_cap * 3);
+        TAKE(pcd_q, float, B * L.n_cap * 3);
+        TAKE(n_lift, int32_t, B);
+        TAKE(pose, float, B * 16);
+        TAKE(status_out, int32_t, B);
+#undef TAKE
+        b.pdsc_ws = take("pdsc_ws", L.pdsc_ws_bytes);
+        b.bytes = off - b.base;
+    }
+    L.match_ws = base ? base + off : nullptr;
+    off = up(off + L.match_ws_bytes, 256);
+    L.bytes = off;
+    return ORYON_OK;
+}
+
+int check_cfg(const oryon_engine_config_t *c)
+{
+    ORYON_CHECK_ARG(c && c->B > 0 && c->C > 128 && c->C <= 512 && c->FH > 0 && c->FW > 0);
+    ORYON_CHECK_ARG(c->HA > 0 && c->WA > 0 && c->HQ > 0 && c->WQ > 0 && c->n_corrs > 0 && c->src_sampling >= 0);
+    ORYON_CHECK_ARG(c->dist_th > 0.0f && c->dist_th <= 0.5f && c->n_slots >= 1 && c->n_slots <= MAX_SLOTS);
+    ORYON_CHECK_ARG(c->layout == ORYON_LAYOUT_NCHW || c->layout == ORYON_LAYOUT_NHWC);
+    ORYON_CHECK_ARG(c->overlap >= 0 && c->overlap <= 2 && (c->overlap == 0 || c->n_slots >= 2));      // results of step k live until submit k + n_slots
+    ORYON_CHECK_ARG((size_t)c->C * (size_t)c->FH * (size_t)c->FW * 4u < (1ull << 32));
+    return ORYON_OK;
+}
+}  // namespace
+
+extern "C" size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver)
+{
+    if (check_cfg(cfg) || !solver) return 0;
+    Layout L;
+    if (carve_engine(*cfg, solver, nullptr, L)) return 0;
+    return L.bytes;
+}
+
+extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,
+                                   size_t arena_bytes)
+{
+    ORYON_CHECK_ARG(handle && solver && arena);
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    oryon_engine *e = new (std::nothrow) oryon_engine();
+    ORYON_CHECK_ARG(e != nullptr);
+    e->cfg = *cfg;
+    e->solver = solver;
+    e->arena = static_cast<char *>(arena);
+    if ((rc = carve_engine(*cfg, solver, e->arena, e->L))) { delete e; set_error("oryon_engine_create: cannot size the workspaces (solver finalized?)"); return rc; }
+    if (arena_bytes < e->L.bytes) {
+        set_error("oryon_engine_create: arena too small (%zu < %zu)", arena_bytes, e->L.bytes);
+        delete e;
+        return ORYON_ERR_WORKSPACE;
+    }
+    (void)hipGetDevice(&e->device);
+    e->sg = e->sm = nullptr;
+    e->timing = false;
+    e->n_submit = 0;
+    e->host_ns_total = e->host_ns_last = 0.0;
+    hipError_t err = hipSuccess;
+    auto ok = [&](hipError_t x) { if (err == hipSuccess) err = x; };
+    if (cfg->overlap >= 1) ok(hipStreamCreateWithFlags(&e->sm, hipStreamNonBlocking));
+    if (cfg->overlap >= 2) ok(hipStreamCreateWithFlags(&e->sg, hipStreamNonBlocking));
+    for (int s = 0; s < MAX_REG_STREAMS; ++s) e->sr[s] = nullptr;
+    e->n_reg_streams = getenv("ORYON_ENGINE_REG_STREAMS") ? atoi(getenv("ORYON_ENGINE_REG_STREAMS")) : 2;
+    if (e->n_reg_streams < 1 || e->n_reg_streams > MAX_REG_STREAMS) e->n_reg_streams = 2;
+    for (int s = 0; s < MAX_SLOTS; ++s) {
+        e->used[s] = false;
+        e->ev_inputs[s] = e->ev_gathered[s] = e->ev_matched[s] = e->ev_done[s] = nullptr;
+    }
+    for (int r = 0; r < TIMING_RING; ++r) {
+        e->timed[r] = false;
+        for (int i = 0; i < 8; ++i) e->tev[r][i] = nullptr;
+    }
+    for (int s = 0; s < e->n_reg_streams; ++s)
+        if (cfg->overlap >= 1) ok(hipStreamCreateWithFlags(&e->sr[s], hipStreamNonBlocking));
+    for (int s = 0; s < cfg->n_slots; ++s) {
+        for (hipEvent_t *ev : {&e->ev_inputs[s], &e->ev_gathered[s], &e->ev_matched[s], &e->ev_done[s]})
+            ok(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
+    for (int r = 0; r < TIMING_RING; ++r)
+        for (int i = 0; i < 8; ++i) ok(hipEventCreate(&e->tev[r][i]));
+    if (err != hipSuccess) {
+        set_error("oryon_engine_create: stream / event creation failed: %s", hipGetErrorString(err));
+        oryon_engine_destroy(e);
+        return ORYON_ERR_HIP;
+    }
+    *handle = e;
+    return ORYON_OK;
+}
+
+extern "C" void oryon_engine_destroy(oryon_engine_t *e)
+{
+    if (!e) return;
+    for (int s = 0; s < MAX_REG_STREAMS; ++s)
+        if (e->sr[s]) { (void)hipStreamSynchronize(e->sr[s]); (void)hipStreamDestroy(e->sr[s]); }
+    for (int s = 0; s < MAX_SLOTS; ++s) {
+        for (hipEvent_t ev : {e->ev_inputs[s], e->ev_gathered[s], e->ev_matched[s], e->ev_done[s]})
+            if (ev) (void)hipEventDestroy(ev);
+    }
+    for (int r = 0; r < TIMING_RING; ++r)
+        for (int i = 0; i < 8; ++i)
+            if (e->tev[r][i]) (void)hipEventDestroy(e->tev[r][i]);
+    if (e->sm) { (void)hipStreamSynchronize(e->sm); (void)hipStreamDestroy(e->sm); }
+    if (e->sg) { (void)hipStreamSynchronize(e->sg); (void)hipStreamDestroy(e->sg); }
+    delete e;
+}
+
+extern "C" int oryon_engine_set_timing(oryon_engine_t *e, int enable)
+{
+    ORYON_CHECK_ARG(e);
+    e->timing = enable != 0;
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_buffer(const oryon_engine_t *e, int slot, const char *name, size_t *offset, size_t *bytes)
+{
+    ORYON_CHECK_ARG(e && name && offset && bytes && slot >= 0 && slot < e->cfg.n_slots);
+    for (const Named &n : e->L.names[slot])
+        if (strcmp(n.name, name) == 0) {
+            *offset = n.off;
+            *bytes = n.bytes;
+            return ORYON_OK;
+        }
+    set_error("oryon_engine_buffer: no buffer named '%s'", name);
+    return ORYON_ERR_INVALID_ARG;
+}
+
+extern "C" int oryon_engine_geometry(const oryon_engine_t *e, int *cap_a, int *cap_q, int *c_pad, int *n_cap)
+{
+    ORYON_CHECK_ARG(e);
+    if (cap_a) *cap_a = e->L.cap_a;
+    if (cap_q) *cap_q = e->L.cap_q;
+    if (c_pad) *c_pad = e->L.c_pad;
+    if (n_cap) *n_cap = e->L.n_cap;
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const float *feat_q, const int32_t *mask_a, const int32_t *mask_q,
+                                   const float *depth_a, const float *depth_q, const float *cam_a, const float *cam_q,
+                                   const int64_t *pair_key, int force_eager, int inputs_resident, void *caller_stream)
+{
+    ORYON_CHECK_ARG(e && feat_a && feat_q && mask_a && mask_q && depth_a && depth_q && cam_a && cam_q);
+    const auto t_host0 = std::chrono::steady_clock::now();
+    const oryon_engine_config_t &c = e->cfg;
+    const int slot = (int)(e->n_submit % c.n_slots);
+    SlotBuf &b = e->L.slot[slot];
+    GatherBuf &g = e->L.gbuf[e->n_submit % G_SLOTS];
+    hipStream_t caller = as_stream(caller_stream);
+    hipStream_t sm = c.overlap >= 1 ? e->sm : caller;
+    hipStream_t sg = c.overlap >= 2 ? e->sg : sm;
+    hipStream_t sr = c.overlap >= 1 ? e->sr[e->n_submit % e->n_reg_streams] : caller;
+    const int HW = c.FH * c.FW, B = c.B;
+    const bool timing = e->timing;
+    hipEvent_t *tev = e->tev[e->n_submit % TIMING_RING];
+    e->timed[e->n_submit % TIMING_RING] = timing;
+    int rc;
+    // ---- ordering in: the engine's streams start after the caller's inputs exist; a result slot is re-used only after the step
+    // that last used it has completed (its registration wrote the slot's pose: everything before it is done as well); a K0 buffer
+    // set only after the matcher of the step before last has read it
+    if (c.overlap >= 1) {
+        // the registration of this step overwrites the slot's pose / status_out: it is ordered after whatever the caller had queued
+        // before this call (its reads of the slot's previous results).  The gather / match streams wait for the caller's stream only
+        // when the inputs are not known to be complete already (inputs_resident): that wait is what keeps K0 of step k+1 from running
+        // under the matching of step k when the caller's stream is itself waiting for step k-1.
+        ORYON_CHECK_HIP(hipEventRecord(e->ev_inputs[slot], caller));
+        ORYON_CHECK_HIP(hipStreamWaitEvent(sr, e->ev_inputs[slot], 0));
+        if (!inputs_resident) {
+            ORYON_CHECK_HIP(hipStreamWaitEvent(sg, e->ev_inputs[slot], 0));
+            if (sm != sg) ORYON_CHECK_HIP(hipStreamWaitEvent(sm, e->ev_inputs[slot], 0));
+        }
+        if (e->used[slot]) {
+            // the step that used this result slot (k - n_slots): K0 overwrites its ROI lists, the matcher what its registration read
+            ORYON_CHECK_HIP(hipStreamWaitEvent(sg, e->ev_done[slot], 0));
+            if (sm != sg) ORYON_CHECK_HIP(hipStreamWaitEvent(sm, e->ev_done[slot], 0));
+        }
+        if (sg != sm && e->n_submit >= G_SLOTS)       // K0 overwrites the rows the matcher of step k - 2 read
+            ORYON_CHECK_HIP(hipStreamWaitEvent(sg, e->ev_matched[(e->n_submit - G_SLOTS) % c.n_slots], 0));
+    }
+    // ---- K0 on the gather stream
+    if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[0], sg));
+    if ((rc = oryon_roi_compact(mask_a, B, HW, b.roi_a, b.n_a, sg))) return rc;
+    if ((rc = oryon_roi_compact(mask_q, B, HW, b.roi_q, b.n_q, sg))) return rc;
+    if (c.src_sampling > 0 && (rc = oryon_roi_subsample(b.roi_a, b.n_a, B, HW, c.src_sampling, c.seed, pair_key, sg))) return rc;
+    if ((rc = oryon_gather_q8(feat_q, B, c.C, HW, c.layout, b.roi_q, HW, b.n_q, e->L.cap_q, e->L.c_pad, g.q8, g.q_sc, g.q_eps, g.q_norm,
+                              nullptr, c.round_f16, sg))) return rc;
+    if ((rc = oryon_gather_q8(feat_a, B, c.C, HW, c.layout, b.roi_a, HW, b.n_a, e->L.cap_a, e->L.c_pad, g.a8, g.a_sc, g.a_eps, g.a_norm,
+                              g.a_hat, c.round_f16, sg))) return rc;
+    if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[1], sg));
+    if (sg != sm) {
+        ORYON_CHECK_HIP(hipEventRecord(e->ev_gathered[slot], sg));
+        ORYON_CHECK_HIP(hipStreamWaitEvent(sm, e->ev_gathered[slot], 0));
+    }
+    // ---- K1s8 + K1b + K2 on the match stream (one shared workspace: matcher calls are serial on this stream)
+    if (timing) {
+        ORYON_CHECK_HIP(hipEventRecord(tev[2], sm));
+        (void)oryon_profile_events(tev[4], tev[5]);
+    }
+    // corrs rows beyond max_corrs are never written by the sampler and K2 only reads n_sel rows: no zero-fill needed
+    if ((rc = oryon_match_corrs_i8(g.a_hat, g.a8, g.a_sc, feat_q, c.C, HW, c.layout, b.roi_a, HW, b.roi_q, HW, g.q_norm, g.q8, g.q_sc, g.q_eps,
+                                   B, e->L.c_pad, e->L.cap_a, e->L.cap_q, b.n_a, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key,
+                                   force_eager, b.min_dist, b.argmin, b.valid, b.corrs, b.n_valid, b.n_sel, b.status, b.n_und, c.round_f16,
+                                   e->L.match_ws, e->L.match_ws_bytes, sm))) return rc;
+    if ((rc = oryon_lift_pairs(b.corrs, b.n_sel, B, e->L.n_cap, c.FH, c.FW, depth_a, c.HA, c.WA, depth_q, c.HQ, c.WQ, cam_a, cam_q, b.status,
+                               b.pcd_a, b.pcd_q, b.n_lift, sm))) return rc;
+    if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[3], sm));
+    if (c.overlap >= 1) {
+        ORYON_CHECK_HIP(hipEventRecord(e->ev_matched[slot], sm));
+        ORYON_CHECK_HIP(hipStreamWaitEvent(sr, e->ev_matched[slot], 0));
+    }
+    // ---- K3-K10 on the slot's registration stream
+    if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[6], sr));
+    if ((rc = oryon_pointdsc_register(e->solver, b.pcd_a, b.pcd_q, b.n_lift, B, e->L.n_cap, b.status, b.pdsc_ws, e->L.pdsc_ws_bytes, b.pose,
+                                      nullptr, b.status_out, sr))) return rc;
+    if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[7], sr));
+    if (c.overlap >= 1) ORYON_CHECK_HIP(hipEventRecord(e->ev_done[slot], sr));
+    e->used[slot] = true;
+    e->n_submit += 1;
+    e->host_ns_last = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t_host0).count();
+    e->host_ns_total += e->host_ns_last;
+    return slot;
+}
+
+extern "C" int oryon_engine_wait(oryon_engine_t *e, int slot, void *caller_stream)
+{
+    ORYON_CHECK_ARG(e && slot >= 0 && slot < e->cfg.n_slots && e->used[slot]);
+    if (e->cfg.overlap >= 1) ORYON_CHECK_HIP(hipStreamWaitEvent(as_stream(caller_stream), e->ev_done[slot], 0));
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_host_stats(const oryon_engine_t *e, int64_t *n_submit, double *submit_ms_total, double *submit_ms_last)
+{
+    ORYON_CHECK_ARG(e);
+    if (n_submit) *n_submit = e->n_submit;
+    if (submit_ms_total) *submit_ms_total = e->host_ns_total * 1e-6;
+    if (submit_ms_last) *submit_ms_last = e->host_ns_last * 1e-6;
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_timing(oryon_engine_t *e, int64_t step, float *out8)
+{
+    ORYON_CHECK_ARG(e && out8 && step >= 0 && step < e->n_submit && step >= e->n_submit - TIMING_RING);
+    if (!e->timed[step % TIMING_RING]) { set_error("oryon_engine_timing: step %lld was submitted with timing off (oryon_engine_set_timing)", (long long)step); return ORYON_ERR_STATE; }
+    hipEvent_t *t = e->tev[step % TIMING_RING];
+    // durations of the three sections + the screening kernel, and the sections' start / end relative to the start of the gather
+    const int q[8][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {0, 2}, {0, 3}, {0, 6}, {0, 7}};
+    for (int i = 0; i < 8; ++i) {
+        const hipError_t err = hipEventElapsedTime(&out8[i], t[q[i][0]], t[q[i][1]]);
+        if (err != hipSuccess) {
+            set_error("oryon_engine_timing: %s (step still running?)", hipGetErrorString(err));
+            return ORYON_ERR_STATE;
+        }
+    }
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_elapsed(oryon_engine_t *e, int64_t step_a, int event_a, int64_t step_b, int event_b, float *ms)
+{
+    ORYON_CHECK_ARG(e && ms && event_a >= 0 && event_a < 8 && event_b >= 0 && event_b < 8);
+    for (int64_t st : {step_a, step_b}) {
+        ORYON_CHECK_ARG(st >= 0 && st < e->n_submit && st >= e->n_submit - TIMING_RING);
+        if (!e->timed[st % TIMING_RING]) { set_error("oryon_engine_elapsed: step %lld was submitted with timing off", (long long)st); return ORYON_ERR_STATE; }
+    }
+    const hipError_t err = hipEventElapsedTime(ms, e->tev[step_a % TIMING_RING][event_a], e->tev[step_b % TIMING_RING][event_b]);
+    if (err != hipSuccess) { set_error("oryon_engine_elapsed: %s (step still running?)", hipGetErrorString(err)); return ORYON_ERR_STATE; }
+    return ORYON_OK;
+}

@@ -489,7 +489,8 @@ extern "C" int oryon_match_f32(const float *a_hat, const float *q_hat, int B, in
 #define LAUNCH_REGB(CPV)                                                                                                  \
     hipLaunchKernelGGL((match_f32_regb_kernel<CPV>), dim3(groups_regb), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, cap_a, cap_q, \
                        n_a, n_q, threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx, nullptr, nullptr)
-    profile_begin(st);
+    profile_begin(st, C == 32 ? "match_f32_regb_kernel<32>" : C == 64 ? "match_f32_regb_kernel<64>" : C == 128 ? "match_f32_regb_kernel<128>" :
+                      C == 256 ? "match_f32_regb_kernel<256>" : "match_f32_kernel (LDS-staged, wide descriptors)");
     if (C == 32) LAUNCH_REGB(32);
     else if (C == 64) LAUNCH_REGB(64);
     else if (C == 128) LAUNCH_REGB(128);

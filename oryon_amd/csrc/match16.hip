@@ -1131,7 +1131,7 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
     } else {
         // single screening pass keeping (max, argmax, second max) per anchor; anchors whose runner-up is within MARGIN of the
         // maximum (duplicates, smooth descriptor fields) go through a second, compacted candidate pass
-        profile_begin(st);
+        profile_begin(st, C == 256 ? "match_f16_screen_kernel<256, 2>" : C == 512 ? "match_f16_screen_kernel<512, 2>" : "match_f16_screen_kernel<128, 2>");
         if (C == 256) LAUNCH16(256, 2); else if (C == 512) LAUNCH16(512, 2); else LAUNCH16(128, 2);
         profile_end(st);
         ORYON_CHECK_LAUNCH();
@@ -1195,6 +1195,19 @@ Screen8Ws carve_screen8(void *base, int B, int C, int cap_a, int cap_q, int S)
     return w;
 }
 
+// the kernel launch_screen8<CP> dispatches under the current development switches (for oryon_dominant_kernel)
+template <int CP>
+const char *screen8_name()
+{
+    const int variant = getenv("ORYON_SCREEN8_VARIANT") ? atoi(getenv("ORYON_SCREEN8_VARIANT")) : 2;
+    const int ablate = getenv("ORYON_SCREEN8_ABLATE") ? atoi(getenv("ORYON_SCREEN8_ABLATE")) : 0;
+    const int waves = getenv("ORYON_SCREEN8_WAVES") ? atoi(getenv("ORYON_SCREEN8_WAVES")) : 4;
+    if (variant == 1) return CP == 256 ? "match_i8_screen_kernel<256>" : "match_i8_screen_kernel<512>";
+    if (ablate && CP == 256) return "match_i8_screen_v2_kernel<256, ABLATED> (timing ablation: results are wrong)";
+    if (waves == 8 && CP == 256) return "match_i8_screen_v2_kernel<256, 0, 8>";
+    return CP == 256 ? "match_i8_screen_v2_kernel<256, 0, 4>" : "match_i8_screen_v2_kernel<512, 0, 4>";
+}
+
 template <int CP>
 void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *q8, const float *q_scale, int B, int cap_a, int cap_q,
                     const int32_t *n_a, const int32_t *n_q, int T, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
@@ -1255,7 +1268,7 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
     const float cut0 = 1.0f - 2.0f * threshold;
     const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    profile_begin(st);
+    profile_begin(st, C == 256 ? screen8_name<256>() : screen8_name<512>());
     if (C == 256) launch_screen8<256>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     profile_end(st);
@@ -1358,7 +1371,7 @@ extern "C" int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8,
     const float cut0 = 1.0f - 2.0f * threshold;
     const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    profile_begin(st);
+    profile_begin(st, C == 256 ? screen8_name<256>() : screen8_name<512>());
     if (C == 256) launch_screen8<256>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     profile_end(st);
@@ -1802,7 +1815,7 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     const float cut0 = 1.0f - 2.0f * threshold;
     const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    profile_begin(st);
+    profile_begin(st, C == 256 ? screen8_name<256>() : screen8_name<512>());
     if (C == 256) launch_screen8<256>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     profile_end(st);

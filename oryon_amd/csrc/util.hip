@@ -15,13 +15,21 @@ void set_error(const char *fmt, ...)
 
 namespace oryon {
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-void profile_begin(hipStream_t st) { if (g_ev_start) (void)hipEventRecord(g_ev_start, st); }
+static const char *g_dominant = "";
+void profile_begin(hipStream_t st, const char *kernel_name)
+{
+    if (!g_ev_start) return;
+    (void)hipEventRecord(g_ev_start, st);
+    if (kernel_name) g_dominant = kernel_name;          // the kernel these events bracket
+}
 void profile_end(hipStream_t st)
 {
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
     g_ev_start = g_ev_stop = nullptr;
 }
 }  // namespace oryon
+
+extern "C" const char *oryon_dominant_kernel(void) { return oryon::g_dominant; }
 
 extern "C" int oryon_profile_events(void *start_event, void *stop_event)
 {

@@ -13,13 +13,15 @@ Differences from the drop-in per-sample facade (oryon_amd.pcd / oryon_amd.pointd
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 from torch import Tensor
 
 from . import _lib, ops
+from ._lib import check, lib
 from .pointdsc import PointDSC
 
 PAIR_OK, PAIR_NO_MASK, PAIR_NO_CORR = 0, 1, 2
@@ -48,10 +50,118 @@ class MatchPoseConfig:
     sample_first: int = 0
 
 
+class NativeStep:
+    """`oryon_engine_*` of the C ABI (csrc/engine.hip): the whole step - K0 on a gather stream, K1s8 + K1b + K2 on a match stream,
+    K3-K10 on a registration stream per slot - enqueued by ONE C call over a persistent arena.  Nothing is allocated per step and no
+    torch stream / event object is created; the arena is one torch uint8 tensor (torch is the memory plumbing), the slot buffers the
+    results come back in are views of it.  A slot's views stay valid until the `n_slots`-th (4th) next submit."""
+
+    _SLOT_VIEWS = {  # name -> (dtype, shape builder)
+        "pose": (torch.float32, lambda g: (g["B"], 4, 4)), "status_out": (torch.int32, lambda g: (g["B"],)),
+        "n_valid": (torch.int32, lambda g: (g["B"],)), "n_lift": (torch.int32, lambda g: (g["B"],)),
+        "n_a": (torch.int32, lambda g: (g["B"],)), "n_q": (torch.int32, lambda g: (g["B"],)), "n_und": (torch.int32, lambda g: (g["B"],)),
+        "n_sel": (torch.int32, lambda g: (g["B"],)), "status": (torch.int32, lambda g: (g["B"],)),
+        "roi_a": (torch.int32, lambda g: (g["B"], g["HW"])), "roi_q": (torch.int32, lambda g: (g["B"], g["HW"])),
+        "min_dist": (torch.float32, lambda g: (g["B"], g["cap_a"])), "argmin": (torch.int32, lambda g: (g["B"], g["cap_a"])),
+        "valid": (torch.uint8, lambda g: (g["B"], g["cap_a"])), "corrs": (torch.int32, lambda g: (g["B"], g["n_cap"], 4)),
+        "pcd_a": (torch.float32, lambda g: (g["B"], g["n_cap"], 3)), "pcd_q": (torch.float32, lambda g: (g["B"], g["n_cap"], 3)),
+    }
+
+    def __init__(self, solver: PointDSC, cfg: "MatchPoseConfig", key: Tuple, dev: torch.device, overlap: int, n_slots: int = 4):
+        B, C, FH, FW, HA, WA, HQ, WQ, layout = key
+        self.key, self.dev = key, dev
+        solver._ensure_handle(dev)
+        self._solver = solver                                   # keeps the C handle alive
+        self.ecfg = _lib.EngineConfig(B=B, C=C, FH=FH, FW=FW, HA=HA, WA=WA, HQ=HQ, WQ=WQ, layout=layout, dist_th=cfg.dist_th,
+                                      n_corrs=cfg.n_corrs, src_sampling=int(cfg.src_sampling or 0), seed=int(cfg.seed) & (2**64 - 1),
+                                      round_f16=int(cfg.half_descriptors), n_slots=n_slots, overlap=overlap)
+        self.cfg_sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap)
+        need = lib().oryon_engine_arena_bytes(ctypes.byref(self.ecfg), solver._handle)
+        if need == 0:
+            raise _lib.OryonError(f"oryon_engine_arena_bytes: {lib().oryon_last_error().decode()}")
+        with torch.cuda.device(dev):
+            self.arena = torch.empty((need,), dtype=torch.uint8, device=dev)
+            self._h = ctypes.c_void_p()
+            check(lib().oryon_engine_create(ctypes.byref(self._h), ctypes.byref(self.ecfg), solver._handle, self.arena.data_ptr(), need),
+                  "oryon_engine_create")
+        ca, cq, cp, nc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().oryon_engine_geometry(self._h, ctypes.byref(ca), ctypes.byref(cq), ctypes.byref(cp), ctypes.byref(nc)))
+        self.geo = dict(B=B, HW=FH * FW, cap_a=ca.value, cap_q=cq.value, c_pad=cp.value, n_cap=nc.value)
+        self.n_slots = n_slots
+        self.steps = 0                                          # submits so far; step k used slot k % n_slots
+        self._views = [dict() for _ in range(n_slots)]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                torch.cuda.synchronize(self.dev)
+                lib().oryon_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def view(self, slot: int, name: str) -> Tensor:
+        v = self._views[slot].get(name)
+        if v is None:
+            off, nbytes = ctypes.c_size_t(), ctypes.c_size_t()
+            check(lib().oryon_engine_buffer(self._h, slot, name.encode(), ctypes.byref(off), ctypes.byref(nbytes)), "oryon_engine_buffer")
+            dtype, shape = self._SLOT_VIEWS[name]
+            v = self.arena[off.value: off.value + nbytes.value].view(dtype).view(shape(self.geo))
+            self._views[slot][name] = v
+        return v
+
+    def set_timing(self, on: bool) -> None:
+        check(lib().oryon_engine_set_timing(self._h, int(on)))
+
+    def timing(self, step: int) -> Dict[str, float]:
+        """ms: durations of the gather / match+lift / screening-kernel / registration sections of submit number `step` (0-based, one
+        of the last 64) and the sections' positions relative to the start of its gather (the step must have completed)."""
+        out = (ctypes.c_float * 8)()
+        check(lib().oryon_engine_timing(self._h, int(step), out), "oryon_engine_timing")
+        names = ("gather_ms", "match_ms", "screen_kernel_ms", "registration_ms", "match_start", "match_end", "registration_start",
+                 "registration_end")
+        return dict(zip(names, (float(x) for x in out)))
+
+    def elapsed(self, step_a: int, event_a: int, step_b: int, event_b: int) -> float:
+        """ms between two timing events (0/1 gather, 2/3 match + lift, 4/5 screening kernel, 6/7 registration: begin / end) of two steps."""
+        ms = ctypes.c_float()
+        check(lib().oryon_engine_elapsed(self._h, int(step_a), event_a, int(step_b), event_b, ctypes.byref(ms)), "oryon_engine_elapsed")
+        return float(ms.value)
+
+    def host_stats(self) -> Tuple[int, float, float]:
+        n, tot, last = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        check(lib().oryon_engine_host_stats(self._h, ctypes.byref(n), ctypes.byref(tot), ctypes.byref(last)))
+        return n.value, tot.value, last.value
+
+    def submit(self, feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, force_eager: bool, inputs_resident: bool) -> int:
+        with torch.cuda.device(self.dev):
+            slot = lib().oryon_engine_submit(self._h, feat_a.data_ptr(), feat_q.data_ptr(), mask_a.data_ptr(), mask_q.data_ptr(),
+                                             depth_a.data_ptr(), depth_q.data_ptr(), cam_a.data_ptr(), cam_q.data_ptr(),
+                                             None if pair_key is None else pair_key.data_ptr(), int(force_eager), int(inputs_resident),
+                                             torch.cuda.current_stream(self.dev).cuda_stream)
+        if slot < 0:
+            check(slot, "oryon_engine_submit")
+        self.steps += 1
+        return slot
+
+    def next_slot(self) -> int:
+        return self.steps % self.n_slots
+
+    def wait(self, slot: int) -> None:
+        check(lib().oryon_engine_wait(self._h, slot, torch.cuda.current_stream(self.dev).cuda_stream), "oryon_engine_wait")
+
+
 class MatchPoseEngine:
     def __init__(self, solver: PointDSC, cfg: Optional[MatchPoseConfig] = None, overlap_registration: bool = False,
-                 overlap_gather: bool = False):
-        """overlap_registration: run the registration stage (K3-K10: many small, latency-bound launches) on a second HIP
+                 overlap_gather: bool = False, native: bool = True, result_views: bool = False):
+        """result_views: `finish` leaves the native step's results as views of its slot buffers
+        instead of copying pose / status / counts (four tiny tensors) out of the arena: the allocation-free mode of bench.py
+        (valid until the fourth-next `run`).
+        native: on the int8-screened route (the default for 128 < C <= 512) the whole step is enqueued by ONE call of the C ABI's
+        step engine (`oryon_engine_submit`, csrc/engine.hip) over a persistent arena - no torch allocation, stream or event per step;
+        the returned tensors are views of the slot buffers and stay valid until the fourth-next `run`.  False keeps the per-call
+        schedule below (same entry points, same results bit for bit); other routes always take it.
+        overlap_registration: run the registration stage (K3-K10: many small, latency-bound launches) on a second HIP
         stream so that it overlaps with the matching stage of the NEXT batch submitted by the caller; `run` then returns
         immediately after queueing and `finish(out)` makes the caller's stream wait for the poses.
         overlap_gather: additionally run K0 (ROI + gather/normalise: HBM-bound) on its own stream, so that the gather of
@@ -61,6 +171,11 @@ class MatchPoseEngine:
         self.n_cap = ops.round_up(self.cfg.n_corrs, 128)
         self.overlap = overlap_registration
         self.overlap_gather = overlap_gather
+        self.native = native
+        self.result_views = result_views
+        self._native: Optional[NativeStep] = None
+        self._inflight: Dict[int, Dict[str, Tensor]] = {}       # slot -> result dict of the native step that last used it
+        self.native_timing = False          # bracket the sections of every native step with HIP events (NativeStep.timing)
         self._reg_stream = None
         self.reg_streams = 2
         self._gather_stream = None
@@ -79,12 +194,108 @@ class MatchPoseEngine:
 
     def finish(self, out: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Order the caller's current stream after the registration of `out` (no-op without overlap)."""
+        slot = out.pop("_native_slot", None)
+        if slot is not None:
+            self._native.wait(slot)
+            out.pop("_inputs", None)
+            if self.collect_i8_stats and self._i8_pending is None:
+                self._queue_i8_stats(self._native.view(slot, "n_und"), self._native.view(slot, "n_a"))
+            if not self.result_views:
+                for k, v in list(out.items()):           # the slot buffers are re-used n_slots steps later: hand out copies
+                    if isinstance(v, Tensor):
+                        out[k] = v.clone()
+            if self._inflight.get(slot) is out:
+                del self._inflight[slot]
+            return out
         ev = out.pop("_done", None)
         if ev is not None:
             cur = torch.cuda.current_stream(out["pose"].device)
             cur.wait_event(ev)
             for k in ("pose", "status"):
                 out[k].record_stream(cur)
+        return out
+
+    def _queue_i8_stats(self, n_und: Tensor, n_a: Tensor) -> None:
+        """Asynchronous read-back of (undecided anchors, anchors) per pair on the current stream: pinned buffer + event, never a sync."""
+        B, dev = n_a.shape[0], n_a.device
+        if self._i8_host is None:
+            self._i8_host = torch.empty((2, B), dtype=torch.int32, pin_memory=True)
+            self._i8_dev = torch.empty((2, B), dtype=torch.int32, device=dev)
+        if self._i8_host.shape[1] == B:
+            # two device-to-device copies into one staging tensor + one async D2H: no torch arithmetic in the step
+            self._i8_dev[0].copy_(n_und)
+            self._i8_dev[1].copy_(n_a)
+            self._i8_host.copy_(self._i8_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._i8_pending = (self._i8_host, ev)
+
+    def _collect_inflight(self, slot: Optional[int] = None) -> None:
+        """Native steps whose results the caller has not collected yet and whose slot (all slots: None) is about to be re-used:
+        `finish` them now, handing out copies."""
+        for s_ in ([slot] if slot is not None else list(self._inflight)):
+            stale = self._inflight.pop(s_, None)
+            if stale is not None and "_native_slot" in stale:
+                views, self.result_views = self.result_views, False
+                try:
+                    self.finish(stale)
+                finally:
+                    self.result_views = views
+
+    def _run_native(self, feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, keep, inputs_event, inputs_resident, dev):
+        """The step through `oryon_engine_submit`.  Inputs are handed over as they are when they already have the C ABI's types
+        (fp32 maps in NCHW or channels_last storage, int32 masks, fp32 depth, fp32 [B,9] intrinsics); anything else is converted on the
+        caller's stream first (a torch allocation: keep the inputs in those types to stay allocation-free)."""
+        cfg = self.cfg
+        B, C, FH, FW = feat_a.shape
+        converted = False
+
+        def as_type(t, dtype, shape=None):
+            nonlocal converted
+            if shape is not None:
+                t = t.reshape(shape)
+            if t.dtype != dtype or not t.is_contiguous():
+                converted = True
+                t = t.to(dtype).contiguous()
+            return t
+
+        feat_a, lay_a = ops.map_layout(feat_a)
+        feat_q, lay_q = ops.map_layout(feat_q)
+        if lay_a != lay_q:
+            feat_q, lay_q = feat_q.contiguous(memory_format=torch.channels_last if lay_a == ops.LAYOUT_NHWC else torch.contiguous_format), lay_a
+            converted = True
+        assert feat_a.dtype == torch.float32 and feat_q.dtype == torch.float32
+        mask_a, mask_q = as_type(mask_a, torch.int32, (B, FH * FW)), as_type(mask_q, torch.int32, (B, FH * FW))
+        depth_a, depth_q = as_type(depth_a, torch.float32), as_type(depth_q, torch.float32)
+        cam_a, cam_q = as_type(cam_a, torch.float32, (B, 9)), as_type(cam_q, torch.float32, (B, 9))
+        key = (B, C, FH, FW, depth_a.shape[1], depth_a.shape[2], depth_q.shape[1], depth_q.shape[2], lay_a)
+        overlap = 2 if (self.overlap and self.overlap_gather) else (1 if self.overlap else 0)
+        sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap)
+        nat = self._native
+        if nat is None or nat.key != key or nat.cfg_sig != sig or nat.dev != dev:
+            self._collect_inflight()                  # results still living in the old arena
+            self._native = None                       # release the previous arena before sizing the new one
+            del nat
+            nat = self._native = NativeStep(self.solver, cfg, key, dev, overlap)
+            nat.set_timing(self.native_timing)
+        if inputs_event is not None:
+            torch.cuda.current_stream(dev).wait_event(inputs_event)
+            inputs_resident = False
+        # the slot this step takes still holds the results of a step the caller has not collected: collect them now (copies)
+        self._collect_inflight(nat.next_slot())
+        slot = nat.submit(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, keep,
+                          inputs_resident and not converted)
+        # the engine's streams read the inputs asynchronously: the result dict keeps them alive until `finish` has ordered the caller's
+        # stream after the step (an input freed earlier could be handed to a new tensor and overwritten while the step still reads it)
+        out = dict(pose=nat.view(slot, "pose"), status=nat.view(slot, "status_out"), n_valid=nat.view(slot, "n_valid"),
+                   n_lifted=nat.view(slot, "n_lift"), _native_slot=slot,
+                   _inputs=(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key))
+        if keep:
+            for k in ("roi_a", "roi_q", "n_a", "n_q", "min_dist", "argmin", "valid", "corrs", "pcd_a", "pcd_q"):
+                out[k] = nat.view(slot, k)
+        self._inflight[slot] = out
+        if not self.overlap:
+            self.finish(out)                          # serial schedule: everything ran on the caller's stream already
         return out
 
     @torch.no_grad()
@@ -94,13 +305,11 @@ class MatchPoseEngine:
         """feat_* [B,C,FH,FW] fp32, mask_* [B,FH,FW] int (==1 selects), depth_* [B,H,W] fp32 mm, cam_* [B,3,3] or [B,9].
         Returns pose [B,4,4] fp32 (identity on failure), status [B] int32, n_valid [B], n_lifted [B].
         With overlap_gather the gather stream starts after `inputs_event` (the producer's event), or immediately when
-        `inputs_resident` says the inputs were complete before this call; by default it waits for everything queued on the
-        caller's stream so far (always correct, but then it cannot overlap the previous batch's matching)."""
+        `inputs_resident` says the inputs (ALL of them, `pair_key` included) were complete before this call; by default it waits for
+        everything queued on the caller's stream so far (always correct, but then it cannot overlap the previous batch's matching)."""
         dev = _lib.require_gpu(feat_a.device)
         cfg = self.cfg
         B, C, FH, FW = feat_a.shape
-        if pair_key is None:
-            pair_key = torch.arange(B, dtype=torch.int64, device=dev)
         main = torch.cuda.current_stream(dev)
         # the screens' validity cut is 1 - 2*dist_th: thresholds above 0.5 (or non-positive) take the exact scan
         screened = cfg.match_mode in ("screened", "screened16") and 64 < C <= 512 and 0.0 < cfg.dist_th <= 0.5
@@ -116,9 +325,11 @@ class MatchPoseEngine:
                     use_i8 = False
                 else:
                     self._i8_skipped, self._i8_frac = 0, 0.0
-        if cfg.half_descriptors and not use_i8:
-            # every route but the int8 one takes pre-rounded maps (one extra pass; K0v3 rounds on the way in)
-            feat_a, feat_q = ops.round_to_f16(feat_a), ops.round_to_f16(feat_q)
+        if use_i8 and self.native and cfg.sample_first <= 0:
+            return self._run_native(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, keep, inputs_event,
+                                    inputs_resident, dev)
+        if pair_key is None:
+            pair_key = torch.arange(B, dtype=torch.int64, device=dev)
         if self.overlap_gather:
             if self._gather_stream is None:
                 self._gather_stream = torch.cuda.Stream(device=dev)
@@ -129,6 +340,10 @@ class MatchPoseEngine:
             gctx.__enter__()
             if inputs_event is not None:
                 self._gather_stream.wait_event(inputs_event)
+        if cfg.half_descriptors and not use_i8:
+            # every route but the int8 one takes pre-rounded maps (one extra pass; K0v3 rounds on the way in).  The rounding runs on
+            # the stream that consumes it (the gather stream when there is one, after its wait for the inputs)
+            feat_a, feat_q = ops.round_to_f16(feat_a), ops.round_to_f16(feat_q)
         # two launches on the callers' tensors instead of a torch.cat + one launch: no torch arithmetic inside the step
         roi_a, n_a = ops.roi_compact(mask_a.reshape(B, FH, FW))
         roi_q, n_q = ops.roi_compact(mask_q.reshape(B, FH, FW))
@@ -167,7 +382,8 @@ class MatchPoseEngine:
             main.wait_event(gathered)
             # EVERY tensor allocated under the gather stream and read on the main stream: without the record the allocator would hand
             # its memory to the next batch's gather (which runs ahead) while this batch's matcher still reads it
-            for t_ in (roi_a, roi_q, n_a, n_q, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, q_norm, roi_a1, n_a1):
+            rounded = (feat_a, feat_q) if cfg.half_descriptors and not use_i8 else ()
+            for t_ in (roi_a, roi_q, n_a, n_q, a_hat, q_hat, a16, q16, a8, q8, a_sc, q_sc, q_eps, q_norm, roi_a1, n_a1) + rounded:
                 if t_ is not None:
                     t_.record_stream(main)
         if use_i8:
@@ -192,17 +408,7 @@ class MatchPoseEngine:
             # statistics for the back-off (skip the int8 stage while most anchors come back undecided): only collected when the
             # back-off can trigger at all (i8_max_undecided < 1; off by default - the lazy tail handles such inputs on the device)
             if self._i8_pending is None and (self.i8_max_undecided < 1.0 or self.collect_i8_stats):
-                if self._i8_host is None:
-                    self._i8_host = torch.empty((2, B), dtype=torch.int32, pin_memory=True)
-                    self._i8_dev = torch.empty((2, B), dtype=torch.int32, device=dev)
-                if self._i8_host.shape[1] == B:
-                    # two device-to-device copies into one staging tensor + one async D2H: no torch arithmetic in the step
-                    self._i8_dev[0].copy_(n_und)
-                    self._i8_dev[1].copy_(n_a)
-                    self._i8_host.copy_(self._i8_dev, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(dev))
-                    self._i8_pending = (self._i8_host, ev)
+                self._queue_i8_stats(n_und, n_a)
         else:
             if screened:
                 min_dist, argmin, valid = ops.match_screened(a_hat, q_hat, a16, q16, n_a, n_q, cfg.dist_th)

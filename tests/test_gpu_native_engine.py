@@ -1,0 +1,162 @@
+"""The C ABI's step engine (oryon_engine_*, csrc/engine.hip) against the per-call schedule of oryon_amd/engine.py: the same entry
+points with the same arguments, so every result must be identical BIT FOR BIT - whatever the overlap mode, however many steps
+are in flight, whatever the caller does with the slot views.  Replaces the per-sample loop of pipeline.py:313-355."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(layers=2, ch=32):
+    from oracle import oryon_oracle as orc
+    from oryon_amd.pointdsc import PointDSC
+    m = PointDSC(in_dim=6, num_layers=layers, num_channels=ch, num_iterations=10, ratio=0.1, sigma_d=0.1, k=40, nms_radius=0.1)
+    m.load_state_dict(orc.analytic_pointdsc_params(layers, ch), strict=True)
+    return m.cuda().eval()
+
+
+def _inputs(first, n, H, C, dev="cuda", nhwc=False):
+    from oryon_amd.synth import make_pair
+    pairs = [make_pair(first + i, H, H, C, device=dev) for i in range(n)]
+    st = lambda k: torch.stack([p[k] for p in pairs])
+    fa, fq = st("feat_a"), st("feat_q")
+    if nhwc:
+        fa, fq = fa.contiguous(memory_format=torch.channels_last), fq.contiguous(memory_format=torch.channels_last)
+    cam = st("camera").to(dev)
+    return (fa, fq, st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"), cam, cam)
+
+
+KEEP_KEYS = ("pose", "status", "n_valid", "n_lifted", "n_a", "n_q", "roi_a", "roi_q", "corrs", "pcd_a", "pcd_q", "valid")
+
+
+@pytest.mark.parametrize("H,C,nhwc", [(56, 256, False), (48, 160, False), (40, 512, False), (56, 256, True)])
+def test_native_step_equals_python_schedule(H, C, nhwc):
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    solver = _solver()
+    ins = _inputs(100, 3, H, C, nhwc=nhwc)
+    key = torch.arange(7, 10, device="cuda")
+    for keep in (False, True):
+        a = MatchPoseEngine(solver, MatchPoseConfig(), native=False).run(*ins, key, keep=keep)
+        b = MatchPoseEngine(solver, MatchPoseConfig(), native=True).run(*ins, key, keep=keep)
+        torch.cuda.synchronize()
+        assert b["status"].tolist() == [0, 0, 0]
+        for k in (KEEP_KEYS if keep else KEEP_KEYS[:4]):
+            if k in ("roi_a", "roi_q"):          # entries beyond the count are scratch
+                n = a["n_a" if k == "roi_a" else "n_q"].tolist()
+                for i, ni in enumerate(n):
+                    assert torch.equal(a[k][i, :ni], b[k][i, :ni]), k
+            elif k in ("corrs", "pcd_a", "pcd_q"):
+                assert torch.equal(a[k][:, :500], b[k][:, :500]), k
+            elif k == "valid":
+                for i, ni in enumerate(a["n_a"].tolist()):
+                    assert torch.equal(a[k][i, :ni], b[k][i, :ni]), k
+            else:
+                assert torch.equal(a[k], b[k]), k
+
+
+def test_native_half_descriptors_and_failures():
+    """round_f16 route + pairs without a mask / without correspondences: status codes and identity poses as pipeline.py:335-350."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    solver = _solver()
+    fa, fq, ma, mq, da, dq, cam, _ = _inputs(200, 4, 48, 256)
+    ma = ma.clone(); fq = fq.clone()
+    ma[1] = 0                                         # no anchor mask -> NO_MASK
+    fq[2] = torch.randn_like(fq[2])                   # unrelated query descriptors -> NO_CORR
+    cfg = MatchPoseConfig(half_descriptors=True)
+    a = MatchPoseEngine(solver, cfg, native=False).run(fa, fq, ma, mq, da, dq, cam, cam)
+    b = MatchPoseEngine(solver, cfg, native=True).run(fa, fq, ma, mq, da, dq, cam, cam)
+    torch.cuda.synchronize()
+    assert b["status"].tolist() == [0, 1, 2, 0]
+    eye = torch.eye(4, device="cuda")
+    assert torch.equal(b["pose"][1], eye) and torch.equal(b["pose"][2], eye)
+    for k in ("pose", "status", "n_valid", "n_lifted"):
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("overlap", [(False, False), (True, False), (True, True)])
+def test_native_pipelined_many_steps_in_flight(overlap):
+    """12 steps submitted back to back before anything is collected (more than the two slots hold: the engine collects a slot's
+    results itself before re-using it), inputs alternately resident / behind an event / plain: all equal the serial python schedule."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    solver = _solver()
+    sets = [_inputs(300 + 2 * i, 2, 64, 256) for i in range(4)]
+    keys = [torch.arange(8 * i, 8 * i + 2, device="cuda") for i in range(12)]     # inputs_resident covers the keys too: made up front
+    ref = MatchPoseEngine(solver, MatchPoseConfig(), native=False)
+    want = [ref.run(*sets[i % 4], keys[i]) for i in range(12)]
+    torch.cuda.synchronize()
+    eng = MatchPoseEngine(solver, MatchPoseConfig(), overlap_registration=overlap[0], overlap_gather=overlap[1], native=True)
+    outs = []
+    for i in range(12):
+        kw = {}
+        if i % 3 == 0:
+            kw["inputs_resident"] = True
+        elif i % 3 == 1:
+            ev = torch.cuda.Event()
+            ev.record()
+            kw["inputs_event"] = ev
+        outs.append(eng.run(*sets[i % 4], keys[i] if i % 3 == 0 else keys[i].clone(), **kw))
+    for o in outs:
+        eng.finish(o)
+    torch.cuda.synchronize()
+    for i, (o, w) in enumerate(zip(outs, want)):
+        for k in ("pose", "status", "n_valid", "n_lifted"):
+            assert torch.equal(o[k], w[k]), (i, k)
+
+
+def test_native_result_views_and_timing():
+    """result_views=True hands out views of the slot buffers (no allocation); the engine's HIP-event timing and host statistics."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    solver = _solver()
+    ins = list(_inputs(400, 2, 64, 256))
+    ins[6] = ins[7] = ins[6].reshape(2, 9).float().contiguous()       # the C ABI's own input types: nothing to convert per step
+    ref = MatchPoseEngine(solver, MatchPoseConfig(), native=False).run(*ins)
+    eng = MatchPoseEngine(solver, MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=True, result_views=True)
+    eng.native_timing = True
+    o0 = eng.finish(eng.run(*ins, inputs_resident=True))
+    o1 = eng.finish(eng.run(*ins, inputs_resident=True))
+    torch.cuda.synchronize()
+    nat = eng._native
+    assert o0["pose"].data_ptr() == nat.view(0, "pose").data_ptr() and o1["pose"].data_ptr() == nat.view(1, "pose").data_ptr()
+    assert torch.equal(o0["pose"], ref["pose"]) and torch.equal(o1["pose"], ref["pose"])
+    before = torch.cuda.memory_stats()["allocation.all.allocated"]
+    for _ in range(6):
+        o = eng.finish(eng.run(*ins, inputs_resident=True))
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_stats()["allocation.all.allocated"] == before, "the native step allocated through torch"
+    assert torch.equal(o["pose"], ref["pose"])
+    t = nat.timing(nat.steps - 1)
+    assert 0 < t["screen_kernel_ms"] <= t["match_ms"] and t["gather_ms"] > 0 and t["registration_ms"] > 0
+    assert t["registration_end"] >= t["match_end"] >= t["match_start"] >= 0
+    n, tot, last = nat.host_stats()
+    assert n == 8 and 0 < last < 50 and tot >= last
+    from oryon_amd._lib import lib
+    assert lib().oryon_dominant_kernel().decode().startswith("match_i8_screen")
+
+
+def test_engine_c_abi_argument_checks():
+    """Bad configurations / arenas are refused with an error code and a message, never a crash."""
+    from oryon_amd import _lib
+    from oryon_amd._lib import lib
+    solver = _solver()
+    solver._ensure_handle(torch.device("cuda", 0))
+    cfg = _lib.EngineConfig(B=2, C=32, FH=16, FW=16, HA=16, WA=16, HQ=16, WQ=16, layout=0, dist_th=0.25, n_corrs=500, src_sampling=5000,
+                            seed=1, round_f16=0, n_slots=2, overlap=2)
+    assert lib().oryon_engine_arena_bytes(ctypes.byref(cfg), solver._handle) == 0          # C <= 128 is not the int8 route
+    cfg.C = 256
+    need = lib().oryon_engine_arena_bytes(ctypes.byref(cfg), solver._handle)
+    assert need > 0
+    arena = torch.empty((need,), dtype=torch.uint8, device="cuda")
+    h = ctypes.c_void_p()
+    assert lib().oryon_engine_create(ctypes.byref(h), ctypes.byref(cfg), solver._handle, arena.data_ptr(), need - 1) == -3
+    assert b"arena too small" in lib().oryon_last_error()
+    cfg.n_slots = 1
+    assert lib().oryon_engine_create(ctypes.byref(h), ctypes.byref(cfg), solver._handle, arena.data_ptr(), need) == -1
+    cfg.n_slots = 2
+    assert lib().oryon_engine_create(ctypes.byref(h), ctypes.byref(cfg), solver._handle, arena.data_ptr(), need) == 0
+    off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib().oryon_engine_buffer(h, 0, b"pose", ctypes.byref(off), ctypes.byref(nb)) == 0 and nb.value == 2 * 64
+    assert lib().oryon_engine_buffer(h, 0, b"nope", ctypes.byref(off), ctypes.byref(nb)) == -1
+    assert lib().oryon_engine_wait(h, 0, None) == -1                                          # nothing submitted to that slot yet
+    lib().oryon_engine_destroy(h)

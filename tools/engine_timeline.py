@@ -1,0 +1,48 @@
+"""Per-step timeline of the native step engine on the cfg2 workload (HIP events of oryon_engine_set_timing): for the last 12 steps of
+a 20-step window the absolute start / end of the gather, match and registration sections (ms since the first event), so that
+bubbles between sections and the overlap between steps can be read off.  `python tools/engine_timeline.py [steps]`."""
+import os
+import sys
+import ctypes
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda", 0)
+B, H, C = 64, 224, 256
+inp = bench.make_inputs(B, H, C, 0, dev)
+inp["cam"] = inp["cam"].reshape(B, 9).float().contiguous()
+eng = MatchPoseEngine(bench.build_solver(dev), MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=True, result_views=True)
+eng.native_timing = True
+key = torch.arange(B, device=dev)
+
+
+def run(n):
+    prev = None
+    for _ in range(n):
+        cur = eng.run(inp["feat_a"], inp["feat_q"], inp["mask_a"], inp["mask_q"], inp["depth_a"], inp["depth_q"], inp["cam"], inp["cam"], key,
+                      inputs_resident=True)
+        if prev is not None:
+            eng.finish(prev)
+        prev = cur
+    eng.finish(prev)
+
+
+run(5)
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+run(steps)
+torch.cuda.synchronize()
+print(f"{(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step")
+nat = eng._native
+first = nat.steps - min(steps, 14)
+print("absolute ms since the gather start of step", first, ": step  G[begin end]  M[begin end] (screen begin end)  R[begin end]")
+for k in range(first, nat.steps):
+    ts = [nat.elapsed(first, 0, k, ev) for ev in range(8)]
+    print(f"{k:4d}  G[{ts[0]:7.2f} {ts[1]:7.2f}]  M[{ts[2]:7.2f} {ts[3]:7.2f}] ({ts[4]:7.2f} {ts[5]:7.2f})  R[{ts[6]:7.2f} {ts[7]:7.2f}]")
