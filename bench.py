@@ -17,8 +17,11 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# five HIP streams (the caller's + the engine's four) need more than the runtime's default of four hardware queues - see oryon_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -341,7 +341,10 @@ int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const floa
  *          oryon_engine_timing(step) (step = 0-based index of the submit, one of the last 64) -> {gather, match+lift, screening
  *          kernel, registration} durations in ms and the start / end of the match and registration sections relative to the start
  *          of the gather (valid once the step has completed).
- *          oryon_engine_host_stats: host time spent inside oryon_engine_submit. */
+ *          oryon_engine_host_stats: host time spent inside oryon_engine_submit.
+ * Hardware queues: with overlap == 2 the engine owns four streams; the HIP runtime maps all streams of the process onto
+ *          GPU_MAX_HW_QUEUES (default 4) hardware queues, and streams that share one execute in submission order.  Run the host
+ *          process with GPU_MAX_HW_QUEUES >= 6 (the Python package sets 8 at import) or the two registration streams serialise. */
 typedef struct oryon_engine oryon_engine_t;
 typedef struct {
     int B, C, FH, FW;        /* pairs per step; descriptor maps [B,C,FH,FW] */
@@ -352,8 +355,11 @@ typedef struct {
     int src_sampling;        /* test.src_sampling (5000); 0 = keep every ROI pixel */
     uint64_t seed;
     int round_f16;           /* the reference's half-descriptor branch (utils/pcd.py:195-197) */
-    int n_slots;             /* result slots: a step's results stay readable until the n_slots-th next submit (4) */
+    int n_slots;             /* result slots: a step's results stay readable until the n_slots-th next submit (6; <= 8) */
     int overlap;             /* see above (2) */
+    int gather_sets;         /* K0 output sets: K0 may run this many steps ahead of the matcher minus one (3; <= 4, <= n_slots) */
+    int reg_streams;         /* registration streams the steps alternate over (2; <= 4) */
+    int reg_lag;             /* > 0: the matcher of step k waits for the registration of step k - reg_lag (< n_slots); 0 = never (default) */
 } oryon_engine_config_t;
 size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver);
 int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,

@@ -24,7 +24,7 @@ using namespace oryon;
 
 namespace {
 constexpr int MAX_SLOTS = 8;
-constexpr int G_SLOTS = 2;             // K0 output sets (the rows the screening kernel reads)
+constexpr int MAX_G_SLOTS = 4;         // K0 output sets (the rows the screening kernel reads): cfg.gather_sets of them
 constexpr int MAX_REG_STREAMS = 4;
 constexpr int TIMING_RING = 64;        // timing-event sets: the sections of the last 64 steps can be read back
 constexpr int ROW_PAD = 256;
@@ -56,7 +56,7 @@ struct Named {
 };
 
 struct Layout {
-    GatherBuf gbuf[G_SLOTS];
+    GatherBuf gbuf[MAX_G_SLOTS];
     SlotBuf slot[MAX_SLOTS];
     std::vector<Named> names[MAX_SLOTS];
     void *match_ws;
@@ -99,7 +99,7 @@ int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver,
     L.pdsc_ws_bytes = oryon_pointdsc_workspace_bytes(solver, c.B, L.n_cap);
     if (!L.match_ws_bytes || !L.pdsc_ws_bytes) return ORYON_ERR_INVALID_ARG;
     size_t off = 0;
-    for (int g = 0; g < G_SLOTS; ++g) {
+    for (int g = 0; g < c.gather_sets; ++g) {
         GatherBuf &b = L.gbuf[g];
         auto take = [&](size_t n) {
             const size_t o = off;
@@ -161,6 +161,8 @@ int check_cfg(const oryon_engine_config_t *c)
     ORYON_CHECK_ARG(c && c->B > 0 && c->C > 128 && c->C <= 512 && c->FH > 0 && c->FW > 0);
     ORYON_CHECK_ARG(c->HA > 0 && c->WA > 0 && c->HQ > 0 && c->WQ > 0 && c->n_corrs > 0 && c->src_sampling >= 0);
     ORYON_CHECK_ARG(c->dist_th > 0.0f && c->dist_th <= 0.5f && c->n_slots >= 1 && c->n_slots <= MAX_SLOTS);
+    ORYON_CHECK_ARG(c->gather_sets >= 1 && c->gather_sets <= MAX_G_SLOTS && c->gather_sets <= c->n_slots);
+    ORYON_CHECK_ARG(c->reg_streams >= 1 && c->reg_streams <= MAX_REG_STREAMS && c->reg_lag >= 0 && c->reg_lag < c->n_slots);
     ORYON_CHECK_ARG(c->layout == ORYON_LAYOUT_NCHW || c->layout == ORYON_LAYOUT_NHWC);
     ORYON_CHECK_ARG(c->overlap >= 0 && c->overlap <= 2 && (c->overlap == 0 || c->n_slots >= 2));      // results of step k live until submit k + n_slots
     ORYON_CHECK_ARG((size_t)c->C * (size_t)c->FH * (size_t)c->FW * 4u < (1ull << 32));
@@ -203,8 +205,7 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     if (cfg->overlap >= 1) ok(hipStreamCreateWithFlags(&e->sm, hipStreamNonBlocking));
     if (cfg->overlap >= 2) ok(hipStreamCreateWithFlags(&e->sg, hipStreamNonBlocking));
     for (int s = 0; s < MAX_REG_STREAMS; ++s) e->sr[s] = nullptr;
-    e->n_reg_streams = getenv("ORYON_ENGINE_REG_STREAMS") ? atoi(getenv("ORYON_ENGINE_REG_STREAMS")) : 2;
-    if (e->n_reg_streams < 1 || e->n_reg_streams > MAX_REG_STREAMS) e->n_reg_streams = 2;
+    e->n_reg_streams = cfg->reg_streams;
     for (int s = 0; s < MAX_SLOTS; ++s) {
         e->used[s] = false;
         e->ev_inputs[s] = e->ev_gathered[s] = e->ev_matched[s] = e->ev_done[s] = nullptr;
@@ -286,7 +287,7 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
     const oryon_engine_config_t &c = e->cfg;
     const int slot = (int)(e->n_submit % c.n_slots);
     SlotBuf &b = e->L.slot[slot];
-    GatherBuf &g = e->L.gbuf[e->n_submit % G_SLOTS];
+    GatherBuf &g = e->L.gbuf[e->n_submit % c.gather_sets];
     hipStream_t caller = as_stream(caller_stream);
     hipStream_t sm = c.overlap >= 1 ? e->sm : caller;
     hipStream_t sg = c.overlap >= 2 ? e->sg : sm;
@@ -315,8 +316,12 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
             ORYON_CHECK_HIP(hipStreamWaitEvent(sg, e->ev_done[slot], 0));
             if (sm != sg) ORYON_CHECK_HIP(hipStreamWaitEvent(sm, e->ev_done[slot], 0));
         }
-        if (sg != sm && e->n_submit >= G_SLOTS)       // K0 overwrites the rows the matcher of step k - 2 read
-            ORYON_CHECK_HIP(hipStreamWaitEvent(sg, e->ev_matched[(e->n_submit - G_SLOTS) % c.n_slots], 0));
+        // optional throttle (off by default: measured slower, DESIGN.md "step engine"): the matcher of step k starts only after the
+        // registration of step k - reg_lag has finished
+        if (c.reg_lag > 0 && e->n_submit >= c.reg_lag)
+            ORYON_CHECK_HIP(hipStreamWaitEvent(sm, e->ev_done[(e->n_submit - c.reg_lag) % c.n_slots], 0));
+        if (sg != sm && e->n_submit >= c.gather_sets)       // K0 overwrites the rows the matcher of step k - gather_sets read
+            ORYON_CHECK_HIP(hipStreamWaitEvent(sg, e->ev_matched[(e->n_submit - c.gather_sets) % c.n_slots], 0));
     }
     // ---- K0 on the gather stream
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[0], sg));

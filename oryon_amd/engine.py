@@ -54,7 +54,7 @@ class NativeStep:
     """`oryon_engine_*` of the C ABI (csrc/engine.hip): the whole step - K0 on a gather stream, K1s8 + K1b + K2 on a match stream,
     K3-K10 on a registration stream per slot - enqueued by ONE C call over a persistent arena.  Nothing is allocated per step and no
     torch stream / event object is created; the arena is one torch uint8 tensor (torch is the memory plumbing), the slot buffers the
-    results come back in are views of it.  A slot's views stay valid until the `n_slots`-th (4th) next submit."""
+    results come back in are views of it.  A slot's views stay valid until the `n_slots`-th (6th) next submit."""
 
     _SLOT_VIEWS = {  # name -> (dtype, shape builder)
         "pose": (torch.float32, lambda g: (g["B"], 4, 4)), "status_out": (torch.int32, lambda g: (g["B"],)),
@@ -67,14 +67,17 @@ class NativeStep:
         "pcd_a": (torch.float32, lambda g: (g["B"], g["n_cap"], 3)), "pcd_q": (torch.float32, lambda g: (g["B"], g["n_cap"], 3)),
     }
 
-    def __init__(self, solver: PointDSC, cfg: "MatchPoseConfig", key: Tuple, dev: torch.device, overlap: int, n_slots: int = 4):
+    def __init__(self, solver: PointDSC, cfg: "MatchPoseConfig", key: Tuple, dev: torch.device, overlap: int, n_slots: int = 6,
+                 gather_sets: int = 3, reg_streams: int = 2, reg_lag: int = 0):
         B, C, FH, FW, HA, WA, HQ, WQ, layout = key
         self.key, self.dev = key, dev
         solver._ensure_handle(dev)
         self._solver = solver                                   # keeps the C handle alive
         self.ecfg = _lib.EngineConfig(B=B, C=C, FH=FH, FW=FW, HA=HA, WA=WA, HQ=HQ, WQ=WQ, layout=layout, dist_th=cfg.dist_th,
                                       n_corrs=cfg.n_corrs, src_sampling=int(cfg.src_sampling or 0), seed=int(cfg.seed) & (2**64 - 1),
-                                      round_f16=int(cfg.half_descriptors), n_slots=n_slots, overlap=overlap)
+                                      round_f16=int(cfg.half_descriptors), n_slots=n_slots, overlap=overlap,
+                                      gather_sets=min(gather_sets, n_slots), reg_streams=reg_streams,
+                                      reg_lag=reg_lag if overlap else 0)
         self.cfg_sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap)
         need = lib().oryon_engine_arena_bytes(ctypes.byref(self.ecfg), solver._handle)
         if need == 0:
@@ -156,10 +159,10 @@ class MatchPoseEngine:
                  overlap_gather: bool = False, native: bool = True, result_views: bool = False):
         """result_views: `finish` leaves the native step's results as views of its slot buffers
         instead of copying pose / status / counts (four tiny tensors) out of the arena: the allocation-free mode of bench.py
-        (valid until the fourth-next `run`).
+        (valid until the sixth-next `run`).
         native: on the int8-screened route (the default for 128 < C <= 512) the whole step is enqueued by ONE call of the C ABI's
         step engine (`oryon_engine_submit`, csrc/engine.hip) over a persistent arena - no torch allocation, stream or event per step;
-        the returned tensors are views of the slot buffers and stay valid until the fourth-next `run`.  False keeps the per-call
+        the returned tensors are views of the slot buffers and stay valid until the sixth-next `run`.  False keeps the per-call
         schedule below (same entry points, same results bit for bit); other routes always take it.
         overlap_registration: run the registration stage (K3-K10: many small, latency-bound launches) on a second HIP
         stream so that it overlaps with the matching stage of the NEXT batch submitted by the caller; `run` then returns
@@ -175,6 +178,7 @@ class MatchPoseEngine:
         self.result_views = result_views
         self._native: Optional[NativeStep] = None
         self._inflight: Dict[int, Dict[str, Tensor]] = {}       # slot -> result dict of the native step that last used it
+        self.native_geometry = dict(n_slots=6, gather_sets=3, reg_streams=2, reg_lag=0)      # NativeStep's pipeline depth (see oryon_engine_config_t)
         self.native_timing = False          # bracket the sections of every native step with HIP events (NativeStep.timing)
         self._reg_stream = None
         self.reg_streams = 2
@@ -214,6 +218,18 @@ class MatchPoseEngine:
             for k in ("pose", "status"):
                 out[k].record_stream(cur)
         return out
+
+    def _py_mark(self, idx: int, stream) -> None:
+        """Dev aid (tools/engine_timeline.py): with `py_timeline` set to a list, the per-call schedule records a timing event at the
+        section boundaries of every step (same indices as oryon_engine_elapsed: 0/1 gather, 2/3 match + lift, 6/7 registration)."""
+        tl = getattr(self, "py_timeline", None)
+        if tl is None:
+            return
+        if idx == 0:
+            tl.append({})
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        tl[-1][idx] = ev
 
     def _queue_i8_stats(self, n_und: Tensor, n_a: Tensor) -> None:
         """Asynchronous read-back of (undecided anchors, anchors) per pair on the current stream: pinned buffer + event, never a sync."""
@@ -276,7 +292,7 @@ class MatchPoseEngine:
             self._collect_inflight()                  # results still living in the old arena
             self._native = None                       # release the previous arena before sizing the new one
             del nat
-            nat = self._native = NativeStep(self.solver, cfg, key, dev, overlap)
+            nat = self._native = NativeStep(self.solver, cfg, key, dev, overlap, **self.native_geometry)
             nat.set_timing(self.native_timing)
         if inputs_event is not None:
             torch.cuda.current_stream(dev).wait_event(inputs_event)
@@ -338,6 +354,7 @@ class MatchPoseEngine:
                 inputs_event.record(main)
             gctx = torch.cuda.stream(self._gather_stream)
             gctx.__enter__()
+            self._py_mark(0, self._gather_stream)
             if inputs_event is not None:
                 self._gather_stream.wait_event(inputs_event)
         if cfg.half_descriptors and not use_i8:
@@ -377,9 +394,11 @@ class MatchPoseEngine:
             q_hat = ops.gather_normalise(feat_q.contiguous(), roi_q, n_q, cap_q)
         if self.overlap_gather:
             gathered = torch.cuda.Event()
+            self._py_mark(1, self._gather_stream)
             gathered.record(self._gather_stream)
             gctx.__exit__(None, None, None)
             main.wait_event(gathered)
+            self._py_mark(2, main)
             # EVERY tensor allocated under the gather stream and read on the main stream: without the record the allocator would hand
             # its memory to the next batch's gather (which runs ahead) while this batch's matcher still reads it
             rounded = (feat_a, feat_q) if cfg.half_descriptors and not use_i8 else ()
@@ -429,12 +448,15 @@ class MatchPoseEngine:
             self._reg_turn += 1
             rs = self._reg_stream[slot]
             ready = torch.cuda.Event()
+            self._py_mark(3, main)
             ready.record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(rs):
                 rs.wait_event(ready)
                 for t_ in (pcd_a, pcd_q, n_lift, status):
                     t_.record_stream(rs)
+                self._py_mark(6, rs)
                 pose, _, status_out = self.solver.register(pcd_a, pcd_q, n_lift, status, ws_slot=slot)
+                self._py_mark(7, rs)
                 done = torch.cuda.Event()
                 done.record(rs)
         else:

@@ -18,13 +18,26 @@ B, H, C = 64, 224, 256
 inp = bench.make_inputs(B, H, C, 0, dev)
 inp["cam"] = inp["cam"].reshape(B, 9).float().contiguous()
 eng = MatchPoseEngine(bench.build_solver(dev), MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=True, result_views=True)
-eng.native_timing = True
+eng.native_timing = not os.environ.get("ENG_NO_TIMING")
+for k_ in ("n_slots", "gather_sets", "reg_streams", "reg_lag"):
+    if os.environ.get("ENG_" + k_.upper()):
+        eng.native_geometry[k_] = int(os.environ["ENG_" + k_.upper()])
+if os.environ.get("ENG_PYTHON"):
+    eng = MatchPoseEngine(bench.build_solver(dev), MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=False)
+    eng.py_timeline = []
 key = torch.arange(B, device=dev)
 
 
+PACE = float(os.environ.get("ENG_PACE_MS", "0")) * 1e-3
+
+
 def run(n):
+    import time as _t
     prev = None
     for _ in range(n):
+        t_ = _t.perf_counter()
+        while PACE and _t.perf_counter() - t_ < PACE:
+            pass
         cur = eng.run(inp["feat_a"], inp["feat_q"], inp["mask_a"], inp["mask_q"], inp["depth_a"], inp["depth_q"], inp["cam"], inp["cam"], key,
                       inputs_resident=True)
         if prev is not None:
@@ -41,6 +54,15 @@ run(steps)
 torch.cuda.synchronize()
 print(f"{(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step")
 nat = eng._native
+if nat is None and getattr(eng, "py_timeline", None):
+    tl = eng.py_timeline[-min(steps, 14):]
+    base = tl[0][0]
+    print("python schedule, absolute ms since the gather start of the first listed step:  G[begin end]  M[begin end]  R[begin end]")
+    for i, t in enumerate(tl):
+        e = {k: base.elapsed_time(v) for k, v in t.items()}
+        print(f"{i:4d}  G[{e[0]:7.2f} {e[1]:7.2f}]  M[{e[2]:7.2f} {e[3]:7.2f}]  R[{e[6]:7.2f} {e[7]:7.2f}]")
+if nat is None or not eng.native_timing:
+    raise SystemExit(0)
 first = nat.steps - min(steps, 14)
 print("absolute ms since the gather start of step", first, ": step  G[begin end]  M[begin end] (screen begin end)  R[begin end]")
 for k in range(first, nat.steps):
