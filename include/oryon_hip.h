@@ -404,6 +404,22 @@ int oryon_mha_f16x3(const float *qkv, int N, int L, int heads, int head_dim, flo
 int oryon_pose_metrics(const float *pred_pose, const float *gt_pose, int B, const float *model_pts, const int32_t *pts_offset, int n_models,
                        int max_pts, const int32_t *model_of_pair, float *workspace, float *out, void *stream);
 
+/* f3  the BOP errors the reference's evaluator reports next to ADD(-S): MSSD (maximum symmetry-aware surface distance, millimetres)
+ *     and MSPD (maximum symmetry-aware projection distance, pixels) for a batch of pairs.
+ *     Replaces utils/evaluator.py:258-275 (both poses rounded to FLOAT16, translation = half(t) * 1000 in half arithmetic) +
+ *     bop_toolkit_lib/pose_error.py:370-427 (my_mssd, my_mspd: float64 arithmetic on the rounded poses).
+ * pred_pose / gt_pose [B,16] float64 row-major 4x4 (metres; float64 so that the half rounding sees the caller's values, whatever their
+ * type); K [B,9] float64 (the query camera); model_pts_mm [sum M, 3] float64 MILLIMETRES (what the evaluator holds) with pts_offset
+ * [n_models+1]; syms [sum S, 12] float64 = the models' symmetry sets as row-major 3x4 [R|t] (bop_toolkit_lib/misc.py:43-90,
+ * format_sym_set :402-411; the identity included) with sym_offset [n_models+1]; max_syms = largest set; model_of_pair [B] or NULL.
+ * max_points: 3 = what the reference computes (its np_transform, pose_error.py:339-352, slices `pts[:, :3]` on the POINT axis of a
+ * [1,N,3] array, so my_mssd / my_mspd see the first three model points only); 0 = every point (the BOP definition).
+ * workspace: oryon_pose_bop_workspace_bytes(B, max_syms).  out [B,2] float64 = (MSSD error, MSPD error). */
+size_t oryon_pose_bop_workspace_bytes(int B, int max_syms);
+int oryon_pose_bop_errors(const double *pred_pose, const double *gt_pose, const double *K, int B, const double *model_pts_mm,
+                          const int32_t *pts_offset, const double *syms, const int32_t *sym_offset, int n_models, int max_syms,
+                          const int32_t *model_of_pair, int max_points, double *workspace, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,8 @@ _PROTOS = {
     "oryon_linear_f16x3": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
     "oryon_mha_f16x3": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "oryon_pose_metrics": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "oryon_pose_bop_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "oryon_pose_bop_errors": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P]),
     "oryon_engine_arena_bytes": (c_size_t, [POINTER(EngineConfig), c_void_p]),
     "oryon_engine_create": (c_int, [POINTER(c_void_p), POINTER(EngineConfig), c_void_p, _P, c_size_t]),
     "oryon_engine_destroy": (None, [c_void_p]),

@@ -255,8 +255,8 @@ class FixedSplit:
 
     # ------------------------------------------------------------------ object models (evaluation)
     def object_info(self, obj_key) -> Dict:
-        """{'pts' [N,3] millimetres, 'diameter' (BOP, mm), 'symmetric' bool}: what the evaluator's ADD(-S) branch needs
-        (utils/evaluator.py:246-256: symmetric <=> the BOP symmetry set has more than the identity)."""
+        """{'pts' [N,3] millimetres, 'diameter' (BOP, mm), 'syms' [S,3,4] the BOP symmetry set, 'symmetric' bool}: what the evaluator
+        needs (utils/evaluator.py:246-275: ADD-S iff the symmetry set has more than the identity; MSSD / MSPD minimise over it)."""
         if obj_key not in self._models:
             if self.kind == "nocs":
                 d = join(self.base, "obj_models", "real_test")
@@ -269,6 +269,9 @@ class FixedSplit:
                 with open(join(d, "models_info.json")) as f:
                     info = json.load(f)[str(int(obj_key))]
                 pts = read_ply_vertices(join(d, f"obj_{int(obj_key):06d}.ply"))
-            sym = bool(info.get("symmetries_discrete")) or bool(info.get("symmetries_continuous"))
-            self._models[obj_key] = {"pts": pts, "diameter": float(info["diameter"]), "symmetric": sym}
+            from .evaluation import format_sym_set, get_symmetry_transformations
+            # the symmetry set the reference's evaluator holds (utils/data/nocs.py:139, utils/data/toyl.py:233: max_sym_disc_step=0.05)
+            syms = format_sym_set(get_symmetry_transformations(info, max_sym_disc_step=0.05))
+            self._models[obj_key] = {"pts": np.asarray(pts, dtype=np.float64), "diameter": float(info["diameter"]), "syms": syms,
+                                     "symmetric": syms.shape[0] > 1}
         return self._models[obj_key]

@@ -487,8 +487,34 @@ def pose_metrics(pred_pose: torch.Tensor, gt_pose: torch.Tensor, model_pts: torc
     ws = torch.empty((B, 2), dtype=torch.float32, device=dev)
     out = torch.empty((B, 4), dtype=torch.float32, device=dev)
     mop = None if model_of_pair is None else model_of_pair.to(dev, torch.int32).contiguous()
-    check(lib().oryon_pose_metrics(ptr(pred), ptr(gt), B, ptr(pts), ptr(pts_offset.to(dev, torch.int32).contiguous()), n_models, max(1, max_pts),
+    off_dev = pts_offset.to(dev, torch.int32).contiguous()
+    check(lib().oryon_pose_metrics(ptr(pred), ptr(gt), B, ptr(pts), ptr(off_dev), n_models, max(1, max_pts),
                                    ptr(mop), ptr(ws), ptr(out), stream_ptr(dev)), "oryon_pose_metrics")
+    return out
+
+
+@_on_tensor_device
+def pose_bop_errors(pred_pose: torch.Tensor, gt_pose: torch.Tensor, K: torch.Tensor, model_pts_mm: torch.Tensor, pts_offset: torch.Tensor,
+                    syms: torch.Tensor, sym_offset: torch.Tensor, model_of_pair: Optional[torch.Tensor] = None,
+                    max_points: int = 3) -> torch.Tensor:
+    """MSSD (mm) and MSPD (px) of a batch of pairs on the device -> [B,2] float64 (utils/evaluator.py:258-275 +
+    bop_toolkit_lib/pose_error.py:370-427).  pred / gt [B,4,4] metres, K [B,3,3]; model_pts_mm [sum M,3] millimetres with pts_offset
+    [n+1]; syms [sum S,3,4] with sym_offset [n+1]; everything is handed over as float64 (the poses are rounded to float16 inside).
+    max_points = 3 is the reference's behaviour (first three model points only, see include/oryon_hip.h); 0 = all points."""
+    dev = _lib.require_gpu(pred_pose.device if pred_pose.is_cuda else model_pts_mm.device)
+    B = pred_pose.shape[0]
+    f64 = lambda t, shape: t.to(dev, torch.float64).reshape(shape).contiguous()
+    pred, gt, Kc = f64(pred_pose, (B, 16)), f64(gt_pose, (B, 16)), f64(K, (B, 9))
+    pts, sy = f64(model_pts_mm, (-1, 3)), f64(syms, (-1, 12))
+    po, so = pts_offset.to(torch.int32).cpu(), sym_offset.to(torch.int32).cpu()
+    n_models = po.numel() - 1
+    max_syms = int((so[1:] - so[:-1]).max())
+    ws = torch.empty((max(1, lib().oryon_pose_bop_workspace_bytes(B, max_syms) // 8),), dtype=torch.float64, device=dev)
+    out = torch.empty((B, 2), dtype=torch.float64, device=dev)
+    mop = None if model_of_pair is None else model_of_pair.to(dev, torch.int32).contiguous()
+    po_d, so_d = po.to(dev), so.to(dev)               # named: a temporary would be freed (and its block re-used) before the launch
+    check(lib().oryon_pose_bop_errors(ptr(pred), ptr(gt), ptr(Kc), B, ptr(pts), ptr(po_d), ptr(sy), ptr(so_d), n_models, max_syms,
+                                      ptr(mop), int(max_points), ptr(ws), ptr(out), stream_ptr(dev)), "oryon_pose_bop_errors")
     return out
 
 

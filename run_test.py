@@ -118,7 +118,9 @@ def run_real(a) -> dict:
                                                                src_sampling=args.test.src_sampling, seed=a.seed, half_descriptors=True))
     collate = DeviceCollate(args.dataset.max_corrs, args.dataset.img_size, dev)
     n = len(split) if a.pairs <= 0 else min(a.pairs, len(split))
-    rows, t0 = [], time.perf_counter()
+    from oryon_amd.evaluation import Evaluator, evaluate_batch
+    evaluator = None
+    n_rows, t0 = 0, time.perf_counter()
     for first in range(0, n, a.batch):
         idx = list(range(first, min(first + a.batch, n)))
         batch = collate([split[i] for i in idx])
@@ -137,34 +139,44 @@ def run_real(a) -> dict:
                 ia = float(iou[0][i]) if iou is not None else 1.0
                 iq = float(iou[1][i]) if iou is not None else 1.0
                 pipe.add_pred_pose(batch["anchor"]["instance_id"][i], batch["query"]["instance_id"][i], ia, iq, pose_rel[i].numpy())
-        # evaluation on the device (f3): pred_q = pose_rel @ anchor.pose (pipeline.py:320), ADD / ADD-S with the float16 model transform,
-        # rotation / translation errors - one call per batch over the concatenated object models
-        anchor_pose = batch["anchor"]["pose"].to(dev, torch.float32)
-        pred_q = torch.bmm(pose_rel.to(dev), anchor_pose)
-        keys = list(dict.fromkeys(batch["cls_id"]))
-        objs = [split.object_info(k) for k in keys]
-        pts = torch.cat([torch.from_numpy(o["pts"] / 1000.0).float() for o in objs]).to(dev)
-        off = torch.tensor(np.concatenate(([0], np.cumsum([o["pts"].shape[0] for o in objs]))), dtype=torch.int32)
-        which = torch.tensor([keys.index(k) for k in batch["cls_id"]], dtype=torch.int32)
-        met = ops.pose_metrics(pred_q, batch["query"]["pose"].to(dev, torch.float32), pts, off, which).cpu().numpy()
-        for i in range(len(idx)):
-            obj = objs[keys.index(batch["cls_id"][i])]
-            rows.append(dict(instance=batch["instance_id"][i], status=int(status[i]), add_s=float(met[i, 1] if obj["symmetric"] else met[i, 0]),
-                             add_diam=extent_diameter(obj["pts"]) / 1000.0, rot_deg=float(met[i, 2]), trans_cm=float(met[i, 3])))
+        # evaluation (f3), registered exactly as the reference's test loop does (pipeline.py:313-350, utils/evaluator.py:206-338): pairs
+        # that failed (no mask / no correspondences) are automatic failures with every score 0, the others are scored on
+        # pred_q = pose_rel @ anchor.pose with the errors computed on the device (ADD / ADD-S with the float16 model transform,
+        # rotation / translation errors, MSSD / MSPD on float16-rounded poses)
+        objects = {k: split.object_info(k) for k in dict.fromkeys(batch["cls_id"])}
+        if evaluator is None:                 # mask IoUs exist on the batched path with predicted masks only
+            evaluator = Evaluator(exp_tag=f"{a.dataset}_{a.split}_{a.mask}", compute_iou=iou is not None)
+        evaluate_batch(evaluator, pred_pose_rel=pose_rel.numpy(), anchor_pose=batch["anchor"]["pose"].cpu().numpy(),
+                       gt_pose=batch["query"]["pose"].cpu().numpy(), K=batch["query"]["camera"].cpu().numpy().reshape(-1, 3, 3),
+                       status=[int(s_) for s_ in status], cls_ids=list(batch["cls_id"]), instance_ids=list(batch["instance_id"]),
+                       objects=objects, iou_a=None if iou is None else iou[0].numpy(), iou_q=None if iou is None else iou[1].numpy(),
+                       device=dev)
+        n_rows += len(idx)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "w") as f:
         f.writelines(pipe.pred_lines)
-    add_ok = [float(r["add_s"] <= 0.1 * r["add_diam"]) for r in rows]
+    means = evaluator.get_means()
+    metric_file = os.path.splitext(a.out)[0] + ".json"           # what scripts/evaluation/compute_metrics.py:52,116-118 writes next to the CSV
+    with open(metric_file, "w") as f:
+        evaluator.save(f)
+    latex = evaluator.get_latex_str()
+    for line in evaluator.test_summary():                        # per-class rows (utils/evaluator.py:340-358)
+        print(line)
+    print(latex, end="")
     summary = {
-        "dataset": a.dataset, "split": a.split, "obj": a.obj, "mask": a.mask, "pairs": len(rows),
-        "failures": sum(1 for r in rows if r["status"] != 0), "ADD(S)-0.1d": float(np.mean(add_ok)) if rows else None,
-        "R_error_deg_mean": float(np.mean([r["rot_deg"] for r in rows])) if rows else None,
-        "T_error_cm_mean": float(np.mean([r["trans_cm"] for r in rows])) if rows else None,
-        "pairs_per_s": len(rows) / wall if wall > 0 else None, "wall_s": round(wall, 3), "csv": a.out, "weights": loaded,
+        "dataset": a.dataset, "split": a.split, "obj": a.obj, "mask": a.mask, "pairs": n_rows,
+        "Missing segm": int(sum(evaluator.counts["Missing segm"])), "Failed pose": int(sum(evaluator.counts["Failed pose"])),
+        "Zero pose": int(sum(evaluator.counts["Zero pose"])),
+        "ADD(S)-0.1d": means.get("ADD(S)-0.1d"), "MSSD": means.get("MSSD"), "MSPD": means.get("MSPD"),
+        "R_error_deg_mean": means.get("R error"), "T_error_cm_mean": means.get("T error"),
+        "recalls": {k: v for k, v in means.items() if k.startswith("Recall")}, "Mean IoU": means.get("Mean IoU"),
+        "latex_row": latex.strip(), "metrics_json": metric_file,
+        "pairs_per_s": n_rows / wall if wall > 0 else None, "wall_s": round(wall, 3), "csv": a.out, "weights": loaded,
         "half_descriptors": bool(a.half_descriptors),
-        "not_computed": "VSD / MSSD / MSPD / AR (BOP toolkit + OpenGL renderer; SURVEY.md 2.1 out of scope)",
+        "not_computed": "VSD / AR (OpenGL renderer of the BOP toolkit; SURVEY.md 2.1 out of scope): the LaTeX row carries '-' there, as the "
+                        "reference's own compute_vsd=False format does",
     }
     print(json.dumps(summary))
     return summary

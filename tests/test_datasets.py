@@ -178,6 +178,11 @@ def test_run_test_real_asset_mode_on_fabricated_tree(tmp_path):
     lines = open(out).read().strip().split("\n")
     assert len(lines) == 2 and len(lines[0].split(",")) == 5 and len(lines[0].split(",")[2].split(" ")) == 12
     assert summary["ADD(S)-0.1d"] is not None and summary["R_error_deg_mean"] is not None
+    # MSSD / MSPD, the failure bookkeeping and the table row of the reference's evaluator (utils/evaluator.py:206-338, :420-440)
+    assert 0.0 <= summary["MSSD"] <= 1.0 and 0.0 <= summary["MSPD"] <= 1.0 and summary["latex_row"].count("&") == 6
+    assert summary["Missing segm"] + summary["Failed pose"] >= 0 and os.path.exists(summary["metrics_json"])
+    saved = __import__("json").load(open(summary["metrics_json"]))
+    assert len(saved["MSSD"]) == 2 and len(saved["Missing segm"]) == 2 and len(saved["instance_id"]) == 2
 
 
 @pytest.mark.gpu

@@ -16,6 +16,7 @@ Reference entry points executed here:
                               cal_leading_eigenvector, post_refinement, forward)
   utils/pointdsc/init.py      get_pointdsc_pose
 """
+import json
 import os
 import sys
 import types
@@ -413,6 +414,88 @@ def gen_metrics():
     save("g7_metrics", pcd=pcd, pred=pred, gt=gt, add=add, adds=adds, theta=theta, shift=shift, mask1=m1, mask2=m2, iou=iou)
 
 
+
+def gen_bop_metrics():
+    """G9: the reference's Evaluator (utils/evaluator.py, compute_vsd=False) run for real on fabricated objects and poses:
+    register_test (ADD(S)-0.1d, MSSD, MSPD, R / T errors, recalls, zero-pose and failed-pose bookkeeping), register_test_failure,
+    get_means / get_latex_str, plus the raw my_mssd / my_mspd errors (bop_toolkit_lib/pose_error.py) and the symmetry sets of
+    bop_toolkit_lib/misc.get_symmetry_transformations for an asymmetric, a discretely and a continuously symmetric model."""
+    from utils.evaluator import Evaluator                                             # reference
+    from bop_toolkit_lib.misc import get_symmetry_transformations, format_sym_set    # reference
+    from bop_toolkit_lib.pose_error import my_mssd, my_mspd                           # reference
+    from utils.pcd import get_diameter                                                # reference
+    g = torch.Generator().manual_seed(91)
+    infos = {
+        "box": {"diameter": 180.0},
+        "brick": {"diameter": 210.0, "symmetries_discrete": [[-1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]]},
+        "can": {"diameter": 150.0, "symmetries_continuous": [{"axis": [0, 0, 1], "offset": [0, 0, 0]}],
+                "symmetries_discrete": [[1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1]]},
+    }
+    models, diams, symms = {}, {}, {}
+    for i, (name, info) in enumerate(infos.items()):
+        pts = (torch.rand(300 + 57 * i, 3, generator=g, dtype=torch.float64).numpy() - 0.5) * np.array([120.0, 90.0, 60.0 + 30 * i])
+        if name == "can":                                     # a body of revolution about z
+            r = np.hypot(pts[:, 0], pts[:, 1]).clip(1e-3)
+            pts[:, :2] *= (45.0 / r)[:, None]
+        models[name] = {"pts": pts}
+        diams[name] = info["diameter"]
+        symms[name] = get_symmetry_transformations(info, max_sym_disc_step=0.05)
+    ev = Evaluator("g9", compute_vsd=False, compute_iou=True)
+    ev.add_object_info(models, diams, symms)
+    ev.init_test()
+    K = np.array([[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]])
+    names = list(infos)
+    n = 12
+    cls = [names[i % 3] for i in range(n)]
+    gt = np.tile(np.eye(4), (n, 1, 1))
+    anchor = np.tile(np.eye(4), (n, 1, 1))
+    rel = np.tile(np.eye(4), (n, 1, 1))
+    for i in range(n):
+        gt[i, :3, :3] = _rand_rot(g).numpy()
+        gt[i, :3, 3] = torch.randn(3, generator=g).numpy() * 0.08 + np.array([0.02, -0.03, 0.9])
+        anchor[i, :3, :3] = _rand_rot(g).numpy()
+        anchor[i, :3, 3] = torch.randn(3, generator=g).numpy() * 0.08 + np.array([0.0, 0.0, 0.8])
+        err = np.eye(4)
+        ang = [0.0, 0.01, 0.03, 0.08, 0.2, 0.6][i % 6]
+        axis = torch.randn(3, generator=g).numpy()
+        axis /= np.linalg.norm(axis)
+        Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        err[:3, :3] = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        err[:3, 3] = torch.randn(3, generator=g).numpy() * [0.0, 0.002, 0.006, 0.02, 0.05, 0.1][i % 6]
+        rel[i] = err @ gt[i] @ np.linalg.inv(anchor[i])       # pred_q = rel @ anchor = err @ gt
+    rel[7] = np.eye(4)                                         # "failed pose": the identity came back
+    rel[10] = 0.0                                              # "zero pose" (utils/evaluator.py:229-231)
+    rel32, anchor32, gt_t = rel.astype(np.float32), anchor.astype(np.float32), gt.copy()
+    mssd_raw, mspd_raw = np.zeros(n), np.zeros(n)
+    failures = {3}
+    for i in range(n):
+        iou_a, iou_q = torch.tensor([0.5 + 0.04 * i]), torch.tensor([0.9 - 0.05 * i])
+        if i in failures:
+            ev.register_test_failure({"iou_a": iou_a, "iou_q": iou_q, "cls_id": [cls[i]], "instance_id": [f"inst{i}"]})
+            continue
+        pred_rel = torch.tensor(rel32[i])
+        pred_q = pred_rel @ torch.tensor(anchor32[i])         # pipeline.py:320 (fp32)
+        ev.register_test({"iou_a": iou_a, "iou_q": iou_q, "gt_pose": torch.tensor(gt_t[i]).unsqueeze(0), "pred_pose": pred_q.unsqueeze(0),
+                          "pred_pose_rel": pred_rel.unsqueeze(0), "cls_id": [cls[i]], "camera": [K.copy()], "depth": [np.zeros((2, 2))],
+                          "instance_id": [f"inst{i}"]})
+        pq = pred_q.numpy().copy()
+        if np.count_nonzero(rel32[i]) <= 1:
+            pq = np.eye(4, dtype=np.float32)
+        p16, g16 = pq.astype(np.float16), gt_t[i].astype(np.float16)
+        sy = format_sym_set(symms[cls[i]])
+        mssd_raw[i] = my_mssd(p16[:3, :3], np.expand_dims(p16[:3, 3], 1) * 1000, g16[:3, :3], np.expand_dims(g16[:3, 3], 1) * 1000,
+                              models[cls[i]]["pts"], sy)
+        mspd_raw[i] = my_mspd(p16[:3, :3], np.expand_dims(p16[:3, 3], 1) * 1000, g16[:3, :3], np.expand_dims(g16[:3, 3], 1) * 1000,
+                              K, models[cls[i]]["pts"], sy)
+    means = ev.get_means()
+    out = {f"metric_{k}": np.asarray(v, dtype=np.float64) for k, v in ev.metrics.items() if k not in ("cls_id", "instance_id")}
+    out.update({f"count_{k}": np.asarray(v) for k, v in ev.counts.items()})
+    save("g9_bop_metrics", K=K, gt=gt_t, anchor=anchor32, rel=rel32, cls=np.array(cls), failures=np.array(sorted(failures)),
+         mssd_raw=mssd_raw, mspd_raw=mspd_raw, latex=np.array(ev.get_latex_str()), mean_names=np.array(list(means)),
+         mean_values=np.array([means[k] for k in means]), add_diam=np.array([get_diameter(models[c]["pts"]) / 1000.0 for c in names]),
+         info_json=np.array(json.dumps(infos)), model_names=np.array(names),
+         **{f"pts_{k}": v["pts"] for k, v in models.items()}, **{f"syms_{k}": format_sym_set(v) for k, v in symms.items()}, **out)
+
 def gen_data():
     """G8: raw samples -> utils/data/common.preprocess_item -> utils/augmentations.resize -> datasets.CollateWrapper, all
     REFERENCE code.  The modules import with permissive stubs for packages that are imported but never called on this path
@@ -466,7 +549,7 @@ def gen_data():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone", "metrics", "data"]
+    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone", "metrics", "bop", "data"]
     if "data" in which:
         gen_data()
     if "matcher" in which:
@@ -485,3 +568,5 @@ if __name__ == "__main__":
         gen_backbone()
     if "metrics" in which:
         gen_metrics()
+    if "bop" in which:
+        gen_bop_metrics()
