@@ -450,7 +450,7 @@ def main():
             if world > 1:
                 dist.all_reduce(el, op=dist.ReduceOp.MAX)
             a1 = alloc_counters()
-            w = {"ms_per_step": float(el.item()) / a.steps * 1e3,
+            w = {"ms_per_step": float(el.item()) / a.steps * 1e3, "ms_per_step_rank": elapsed / a.steps * 1e3,
                  "host_submit_ms_per_step": (host["submit_s"] - h0[0]) / max(1, host["submits"] - h0[1]) * 1e3,
                  "device_allocs": a1[0] - a0[0], "torch_allocs_per_step": (a1[1] - a0[1]) / a.steps, "alloc_retries": a1[2] - a0[2]}
             if native:
@@ -474,6 +474,29 @@ def main():
     st_local = out["status"].cpu() == 0
     rot_err = (mine[:, :3, :3] - gt[:, :3, :3]).abs().amax(dim=(1, 2))[st_local]
     trans_err = (mine[:, :3, 3] - gt[:, :3, 3]).abs().amax(dim=1)[st_local]
+
+    # collated result of the last complete step (identical on every rank): a checksum of the pose bytes in global pair order, so that a
+    # sharded run can be compared bit for bit with a single-GPU run over the same global pairs (tests/test_gpu_bench_contract.py)
+    import hashlib
+    pose_sha = hashlib.sha256(pose[:total].contiguous().cpu().numpy().tobytes() + status[:total].contiguous().cpu().numpy().tobytes()).hexdigest()
+    multi = None
+    if world > 1:
+        # the only collective of the path: one all_gather of [B_r,17] fp32 per step (pose + status), timed on its own with HIP events;
+        # and every rank's own throughput over the median window
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gather_poses(out["pose"], out["status"], total)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(20):
+            gather_poses(out["pose"], out["status"], total)
+        ev1.record()
+        torch.cuda.synchronize()
+        mine_ms = torch.tensor([med([w["ms_per_step_rank"] for w in windows])], dtype=torch.float64, device=dev)
+        all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
+        dist.all_gather(all_ms, mine_ms)
+        multi = {"backend": "nccl (RCCL over xGMI)", "rccl_ranks": world, "all_gather_us": ev0.elapsed_time(ev1) / 20 * 1e3,
+                 "all_gather_bytes_per_rank": B * 17 * 4, "per_rank_pairs_per_s": [B * 1e3 / float(t.item()) for t in all_ms],
+                 "collectives_per_step": 1}
 
     if rank == 0:
         cp = 32 if C <= 32 else 64 if C <= 64 else 128 if C <= 128 else 256 if C <= 256 else (C + 31) // 32 * 32
@@ -515,6 +538,7 @@ def main():
             "metric": METRIC, "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "multi_gpu": multi,
             "timing": {
                 "statistic": f"median of {len(windows)} windows of {a.steps} steps, each bracketed by barrier + torch.cuda.synchronize, max over ranks",
                 "windows_ms_per_step": [round(w["ms_per_step"], 4) for w in windows],
@@ -543,6 +567,7 @@ def main():
                 "pipelining": ("none" if a.no_overlap else "registration of step k on a second HIP stream under the matching of step k+1"
                                + ("; K0 (ROI + gather) of step k+1 on a third stream under the screening / registration of step k"
                                   if a.overlap_gather else "")),
+                "pose_sha256": pose_sha, "first_pair": 0,
                 "pairs_ok": int(ok.sum()), "max_rot_err_vs_gt": float(rot_err.max()) if rot_err.numel() else None,
                 "max_trans_err_m_vs_gt": float(trans_err.max()) if trans_err.numel() else None,
             },

@@ -2,7 +2,12 @@
 <|endoftext|> specials, context 77) - the role of models/tokenizer.py:64-151 in the reference, which is itself a copy
 of the published openai/CLIP tokenizer.  The merge table (`bpe_simple_vocab_16e6.txt.gz`) is not part of the
 reference tree; give its path to use real prompts.  Synthetic runs feed token ids directly (`Oryon.forward` accepts a
-LongTensor [B, 80, 77] under xs['prompt_tokens']).  Untested against the reference (vocabulary unavailable)."""
+LongTensor [B, 80, 77] under xs['prompt_tokens']).
+Pinned to the reference's tokenizer on a fabricated merge table (tests/golden/g10_tokenizer.npz, tests/test_backbone.py): same ids
+for templates, punctuation, HTML entities, blanks, case, non-ASCII bytes and over-long prompts (plain truncation to the context
+length WITHOUT re-inserting the end token, models/tokenizer.py:141-143).  One step of the reference is not reproduced: `ftfy.fix_text`
+(models/tokenizer.py:52, mojibake repair; the package is not available here) - a no-op on the datasets' plain-ASCII object names
+and templates, a divergence on text with broken encodings."""
 from __future__ import annotations
 
 import gzip
@@ -77,9 +82,6 @@ class SimpleTokenizer:
         sot, eot = self.encoder["<|startoftext|>"], self.encoder["<|endoftext|>"]
         out = torch.zeros(len(texts), L, dtype=torch.long)
         for i, t in enumerate(texts):
-            ids = [sot] + self.encode(t) + [eot]
-            if len(ids) > L:
-                ids = ids[:L]
-                ids[-1] = eot
+            ids = ([sot] + self.encode(t) + [eot])[:L]          # the reference truncates and does not restore the end token
             out[i, :len(ids)] = torch.tensor(ids)
         return out

@@ -222,6 +222,10 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     }
     for (int r = 0; r < TIMING_RING; ++r)
         for (int i = 0; i < 8; ++i) ok(hipEventCreate(&e->tev[r][i]));
+    // rows of `corrs` beyond n_corrs are never written by the sampler: zero them once, so that the slot reads like the freshly zeroed
+    // tensor the per-call schedule hands out
+    for (int s = 0; s < cfg->n_slots; ++s)
+        ok(hipMemset(e->L.slot[s].corrs, 0, (size_t)cfg->B * e->L.n_cap * 4 * sizeof(int32_t)));
     if (err != hipSuccess) {
         set_error("oryon_engine_create: stream / event creation failed: %s", hipGetErrorString(err));
         oryon_engine_destroy(e);

@@ -84,6 +84,23 @@ def read_ply_vertices(path: str) -> np.ndarray:
         return out
 
 
+def unique_matches(matches: torch.Tensor) -> torch.Tensor:
+    """Distinct rows of an [N,4] match list as float (utils/misc.py:146-164).  The reference builds them through a Python set of
+    strings, so its row ORDER changes from process to process (string hashing); here the distinct rows come in lexicographic order."""
+    return torch.unique(matches.to(torch.int), dim=0).to(torch.float)
+
+
+def sample_correspondences(corrs: torch.Tensor, max_corrs: int) -> torch.Tensor:
+    """datasets.py:116-136 (test-time branch): distinct matches, then exactly max_corrs of them drawn from the global torch generator
+    (torch.multinomial over a uniform weight vector, with replacement only when fewer exist - utils/misc.py:242-254).  Equal to the
+    reference in distribution; row-for-row equality is not defined (see unique_matches)."""
+    if corrs.shape[0] == 0:
+        return torch.zeros((0, 4))
+    u = unique_matches(corrs.clone())
+    w = torch.ones(u.shape[0], dtype=torch.float64)
+    return u[torch.multinomial(w, max_corrs, replacement=max_corrs > u.shape[0])]
+
+
 def extent_diameter(pts: np.ndarray) -> float:
     """The ADD diameter of the reference: largest side of the axis-aligned bounding box (utils/pcd.py:16-20), not the BOP diameter."""
     xyz = pts[:, :3]
@@ -205,6 +222,8 @@ class FixedSplit:
             pose[:3, :3] = np.asarray(g["cam_R_m2c"], dtype=np.float64).reshape(3, 3)
             pose[:3, 3] = np.asarray(g["cam_t_m2c"], dtype=np.float64) / 1000.0
             names = self.obj_names[str(int(cls_id))]
+            for v in meta.values():                                           # toyl.py:125-130: the per-image dict is keyed by the object
+                v.clear()                                                     # id, so of several annotations of one object the LAST wins
             meta["cls_ids"].append(int(cls_id))
             meta["mask_ids"].append(i + 1)                                    # toyl.py:123: masks are numbered by annotation order
             meta["cls_names"].append(names[0])
@@ -249,7 +268,7 @@ class FixedSplit:
         item_q = preprocess_item(self.get_item(sq, iq, obj_key))
         prompt = self.prompts_for(item_a)
         corrs = torch.as_tensor(self.corrs[index])
-        sampled = corrs[: self.max_corrs] if corrs.shape[0] >= self.max_corrs else corrs      # GT corrs are only consumed by the training loss
+        sampled = sample_correspondences(corrs, self.max_corrs)               # consumed by the training loss / FMR only, not by the pose path
         valid = check_validity(item_a) and check_validity(item_q) and corrs.shape[0] > 0
         return item_a, item_q, prompt, sampled, corrs, self.poses[index], obj_key, instance_id, valid
 

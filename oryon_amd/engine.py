@@ -202,7 +202,7 @@ class MatchPoseEngine:
         if slot is not None:
             self._native.wait(slot)
             out.pop("_inputs", None)
-            if self.collect_i8_stats and self._i8_pending is None:
+            if (self.collect_i8_stats or self.i8_max_undecided < 1.0) and self._i8_pending is None:
                 self._queue_i8_stats(self._native.view(slot, "n_und"), self._native.view(slot, "n_a"))
             if not self.result_views:
                 for k, v in list(out.items()):           # the slot buffers are re-used n_slots steps later: hand out copies

@@ -322,7 +322,18 @@ def gather_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_c
     return out8, scale, eps, norm, out32
 
 
-_raw_ws = {}
+import threading
+
+_raw_ws = {}                      # (device, stream) -> cached matcher workspace (holds room for the rarely used fp32 fall-back rows)
+_raw_ws_lock = threading.Lock()   # the C entry points issue ~15 dependent launches on the workspace and ctypes releases the GIL: two host
+                                  # threads that launch on ONE stream must not interleave their sequences on the shared buffer
+
+
+def release_workspaces() -> None:
+    """Drop the cached matcher workspaces (they pin the largest size ever requested per (device, stream) for the life of the process)."""
+    with _raw_ws_lock:
+        _raw_ws.clear()
+
 
 
 @_on_tensor_device
@@ -342,14 +353,15 @@ def match_screened8_raw(a_hat, a8, a_scale, feat_q, roi_q, q_norm, q8, q_scale, 
     # the workspace holds room for the (rarely used) fp32 fall-back rows of every pair: cached per (device, stream) instead of
     # being re-requested from the allocator on every call
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _raw_ws.get(key)
-    if ws is None or ws.numel() < wsb:
-        ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
-        _raw_ws[key] = ws
-    check(lib().oryon_match_screened8_raw(ptr(a_hat), ptr(a8), ptr(a_scale), feat_q.data_ptr(), C_true, HW, layout, ptr(roi_q),
-                                          roi_q.shape[1], ptr(q_norm), ptr(q8), ptr(q_scale), ptr(q_eps), B, Cp, cap_a, cap_q, ptr(n_a),
-                                          ptr(n_q), float(threshold), ptr(min_dist), ptr(argmin), ptr(valid), ptr(n_undecided),
-                                          int(bool(round_f16)), ptr(ws), ws.numel(), stream_ptr(dev)), "oryon_match_screened8_raw")
+    with _raw_ws_lock:
+        ws = _raw_ws.get(key)
+        if ws is None or ws.numel() < wsb:
+            ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+            _raw_ws[key] = ws
+        check(lib().oryon_match_screened8_raw(ptr(a_hat), ptr(a8), ptr(a_scale), feat_q.data_ptr(), C_true, HW, layout, ptr(roi_q),
+                                              roi_q.shape[1], ptr(q_norm), ptr(q8), ptr(q_scale), ptr(q_eps), B, Cp, cap_a, cap_q, ptr(n_a),
+                                              ptr(n_q), float(threshold), ptr(min_dist), ptr(argmin), ptr(valid), ptr(n_undecided),
+                                              int(bool(round_f16)), ptr(ws), ws.numel(), stream_ptr(dev)), "oryon_match_screened8_raw")
     return min_dist, argmin, valid
 
 
@@ -374,10 +386,19 @@ def match_corrs_i8(a_hat, a8, a_scale, feat_q, roi_a, roi_q, q_norm, q8, q_scale
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     wsb = lib().oryon_match_corrs_i8_workspace_bytes(B, Cp, cap_a, cap_q, corr_rows)
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _raw_ws.get(key)
-    if ws is None or ws.numel() < wsb:
-        ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
-        _raw_ws[key] = ws
+    with _raw_ws_lock:
+        ws = _raw_ws.get(key)
+        if ws is None or ws.numel() < wsb:
+            ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+            _raw_ws[key] = ws
+        return _match_corrs_i8_locked(a_hat, a8, a_scale, feat_q, C_true, HW, layout, roi_a, roi_q, q_norm, q8, q_scale, q_eps, B, Cp, cap_a,
+                                      cap_q, n_a, n_q, threshold, W, max_corrs, corr_rows, seed, pair_key, force_eager, min_dist, argmin, valid,
+                                      corrs, n_valid, n_sel, status, n_undecided, round_f16, ws, dev)
+
+
+def _match_corrs_i8_locked(a_hat, a8, a_scale, feat_q, C_true, HW, layout, roi_a, roi_q, q_norm, q8, q_scale, q_eps, B, Cp, cap_a, cap_q, n_a,
+                           n_q, threshold, W, max_corrs, corr_rows, seed, pair_key, force_eager, min_dist, argmin, valid, corrs, n_valid, n_sel,
+                           status, n_undecided, round_f16, ws, dev):
     check(lib().oryon_match_corrs_i8(ptr(a_hat), ptr(a8), ptr(a_scale), feat_q.data_ptr(), C_true, HW, layout, ptr(roi_a), roi_a.shape[1],
                                      ptr(roi_q), roi_q.shape[1], ptr(q_norm), ptr(q8), ptr(q_scale), ptr(q_eps), B, Cp, cap_a, cap_q,
                                      ptr(n_a), ptr(n_q), float(threshold), int(W), int(max_corrs), corr_rows, int(seed) & (2**64 - 1),
@@ -519,6 +540,12 @@ def pose_bop_errors(pred_pose: torch.Tensor, gt_pose: torch.Tensor, K: torch.Ten
 
 
 _x3_weights = {}
+# Validation mode of the fp16x3 path (backbone.enable_fp16x3(True, guard=True)): every call first checks max|activation| against the
+# float16 range (one reduction + a host sync per linear - for a first run with a real checkpoint, not for throughput) and evaluates
+# that layer with torch's fp32 linear when the split would overflow; weights are checked once, when they are split.
+X3_GUARD = False
+X3_LIMIT = 60000.0            # below float16's 65504 with room for the rounding of `hi`
+x3_guard_fallbacks = 0        # layers evaluated by torch because an operand left the float16 range (guard mode)
 
 
 def _split_weight_f16x3(weight: torch.Tensor):
@@ -530,6 +557,9 @@ def _split_weight_f16x3(weight: torch.Tensor):
         hit = None
     if hit is None:
         w = weight.detach().to(torch.float32).contiguous()
+        if X3_GUARD and float(w.abs().amax()) >= X3_LIMIT:
+            raise _lib.OryonError(f"fp16x3 linear: a weight of magnitude {float(w.abs().amax()):.3g} does not fit the float16 split "
+                                  "(|w| must stay below 65504): evaluate this model with backbone.enable_fp16x3(False)")
         hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
         lo = torch.empty(w.shape, dtype=torch.float16, device=w.device)
         check(lib().oryon_split_f16x3(ptr(w), w.numel(), ptr(hi), ptr(lo), stream_ptr(w.device)), "oryon_split_f16x3")
@@ -550,11 +580,19 @@ def linear_f16x3_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
 def linear_f16x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, quick_gelu: bool = False,
                  gelu: bool = False) -> torch.Tensor:
     """act(x @ weight.T + bias) for fp32 x [..., K], weight [N, K] on the fp16 matrix pipe with error-compensated operands (B4):
-    fp32-grade results (~1e-6 relative) at ~3x the fp32-MFMA rate.  act: QuickGELU (CLIP) or erf-GELU (Swin) or none.  Inference only."""
+    fp32-grade results (~1e-6 relative) at ~3x the fp32-MFMA rate.  act: QuickGELU (CLIP) or erf-GELU (Swin) or none.  Inference only.
+    Range: |x|, |w| < 65504 or the split overflows silently to inf (X3_GUARD checks it, see above); an operand below 2^-3 in magnitude
+    has its low half in float16's subnormal range, i.e. an ABSOLUTE split error of up to 2^-25 instead of the relative 2^-22."""
     dev = _lib.require_gpu(x.device)
     assert not (quick_gelu and gelu)
     K, N = weight.shape[1], weight.shape[0]
     x2 = x.reshape(-1, K).contiguous()
+    if X3_GUARD and not bool(torch.isfinite(x2).all() & (x2.abs().amax() < X3_LIMIT)):
+        global x3_guard_fallbacks
+        x3_guard_fallbacks += 1
+        y = torch.nn.functional.linear(x2, weight, bias)
+        y = y * torch.sigmoid(1.702 * y) if quick_gelu else (torch.nn.functional.gelu(y) if gelu else y)
+        return y.view(*x.shape[:-1], N)
     hi, lo = _split_weight_f16x3(weight)
     out = torch.empty((x2.shape[0], N), dtype=torch.float32, device=dev)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()

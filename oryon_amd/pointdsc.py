@@ -235,7 +235,8 @@ class PointDSC(nn.Module):
     # ---- reference-shaped forward -------------------------------------------------------------
     def forward(self, data: Dict) -> Dict:
         """data: corr_pos [bs,n,6], src_keypts/tgt_keypts [bs,n,3], 'testing' key required.  Returns final_trans [bs,4,4],
-        final_labels [bs,n] float, M None.
+        final_labels [bs,n] float, M None (as the reference's inference branch; data['return_M'] = True adds the feature-similarity
+        matrix of its training branch, PointDSC.py:158-163).
         The device encoder builds its input as cat(src,tgt) - mean over the rows (what utils/pointdsc/init.py:18-19 passes as
         corr_pos); a caller-supplied corr_pos that is anything else cannot be honoured and raises instead of being silently
         replaced."""
@@ -259,7 +260,15 @@ class PointDSC(nn.Module):
         tp[:, :n] = tgt.float()
         nn_ = torch.full((bs,), n, dtype=torch.int32, device=dev)
         T, labels, _ = self.register(sp, tp, nn_, want_labels=True)
-        return {"final_trans": T, "final_labels": labels[:, :n].float(), "M": None}
+        M = None                                   # the reference's inference branch returns None here too (PointDSC.py:158-165)
+        if data.get("return_M"):
+            # on request: the feature-similarity matrix the reference builds on its training / validation branch
+            # (PointDSC.py:158-163), from the device encoder's features - clamp(1 - (1 - f_i . f_j) / sigma^2, 0, 1), zero diagonal
+            feat, _ = self.encode(sp, tp, nn_)
+            f = torch.nn.functional.normalize(feat[:, :n], p=2, dim=-1)
+            M = torch.clamp(1 - (1 - f @ f.transpose(1, 2)) / float(self.sigma) ** 2, min=0, max=1)
+            M[:, torch.arange(n), torch.arange(n)] = 0
+        return {"final_trans": T, "final_labels": labels[:, :n].float(), "M": M}
 
 
 def get_pointdsc_pose(pointdsc_model: nn.Module, pcd1: Tensor, pcd2: Tensor, device: str) -> Tensor:

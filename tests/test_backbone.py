@@ -184,3 +184,16 @@ def test_oryon_forward_contract_tiny_clip():
     assert net.fusion.training and not net.vlm.training          # CLIP never leaves eval mode (net.py:78-89, vlm.py:30-34)
     with pytest.raises(RuntimeError):
         net.vlm.encode_prompt([["mug"] + ["a photo of a mug"] * 80])   # string prompts need the BPE vocabulary file
+
+
+def test_tokenizer_matches_reference_on_fabricated_merge_table():
+    """Token ids of the reference's SimpleTokenizer (models/tokenizer.py:64-151, ftfy stubbed with the identity) for the prompts of
+    tests/golden/g10_tokenizer.npz, on the fabricated merge table shipped beside it."""
+    from oryon_amd.backbone.tokenizer import SimpleTokenizer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g10_tokenizer.npz"))
+    tok = SimpleTokenizer(os.path.join(os.path.dirname(__file__), "golden", "bpe_fabricated.txt.gz"))
+    ids = tok(g["texts"].tolist())
+    assert tuple(ids.shape) == tuple(g["ids"].shape) == (len(g["texts"]), 77)
+    assert np.array_equal(ids.numpy(), g["ids"])
+    assert int((g["ids"][:, -1] != 0).sum()) == 1                      # the over-long prompt fills the context (no end token restored)
+    assert tok("a photo of a mug.").shape == (1, 77)

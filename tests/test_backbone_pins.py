@@ -320,3 +320,32 @@ def test_add_layernorm_f32_matches_fp64():
             assert torch.equal(s, s_ref)
             e, e32 = float((h.double() - h_ref).abs().max()), float((h_32.double() - h_ref).abs().max())
             assert e < 5e-6 and e <= 2.0 * e32 + 1e-7, (rows, D, e, e32)
+
+
+@pytest.mark.gpu
+def test_fp16x3_guard_catches_operands_outside_the_float16_range():
+    """enable_fp16x3(True, guard=True): an activation beyond float16's range would split into inf silently; the guard evaluates that
+    layer with torch's fp32 linear instead (counted), in-range layers still take the kernel; an out-of-range weight is refused."""
+    from oryon_amd import ops
+    from oryon_amd.backbone import enable_fp16x3
+    torch.manual_seed(0)
+    w = torch.randn(256, 128, device="cuda") * 0.05
+    b = torch.randn(256, device="cuda")
+    x = torch.randn(4, 64, 128, device="cuda")
+    with torch.no_grad():
+        ref = torch.nn.functional.linear(x, w, b)
+        enable_fp16x3(True, guard=True)
+        try:
+            before = ops.x3_guard_fallbacks
+            y = ops.linear_f16x3(x, w, b)
+            assert ops.x3_guard_fallbacks == before and float((y - ref).abs().max()) < 1e-5
+            x_big = x.clone()
+            x_big[0, 0, 0] = 7.0e4
+            unguarded_ref = torch.nn.functional.linear(x_big, w, b)
+            y2 = ops.linear_f16x3(x_big, w, b)
+            assert ops.x3_guard_fallbacks == before + 1 and torch.isfinite(y2).all() and torch.equal(y2, unguarded_ref)
+            with pytest.raises(Exception, match="does not fit the float16 split"):
+                ops.linear_f16x3(x, w * 1.0e7, b)
+        finally:
+            enable_fp16x3(False)
+    assert ops.X3_GUARD is False

@@ -38,3 +38,32 @@ def test_other_matcher_modes_report_their_own_kernel():
     for mode, kern in (("screened16", "match_f16_screen_kernel"), ("exact", "match_f32_regb_kernel")):
         rec = _run("--steps", "1", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--match-mode", mode)
         assert kern in rec["roofline"]["kernel"] and rec["config"]["pairs_ok"] == 4 and "cpu_baseline" not in rec
+
+
+def test_two_gpu_run_over_rccl_equals_single_gpu_bit_for_bit():
+    """The N > 1 path on real hardware (skipped on 1-GPU boxes): `bench.py --gpus 2` launches its two ranks (one process per GPU,
+    torch.distributed backend nccl = RCCL), each matches + registers its own pairs, one all_gather collates the poses.  The collated
+    poses / status of the 2 x 8 global pairs must equal a single-GPU run over the same 16 pairs bit for bit (checksum over the pose
+    and status bytes in global pair order), and the line carries the multi-GPU fields."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL)")
+    common = ("--steps", "3", "--warmup", "1", "--reps", "2", "--size", "96", "--no-cpu-baseline", "--no-stage-sets")
+    two = _run("--gpus", "2", "--batch", "8", *common)
+    one = _run("--gpus", "1", "--batch", "16", *common)
+    assert two["n_gpus"] == 2 and two["config"]["global_pairs"] == 16 and two["config"]["pairs_ok"] == 16
+    assert two["config"]["pose_sha256"] == one["config"]["pose_sha256"]
+    m = two["multi_gpu"]
+    assert m["rccl_ranks"] == 2 and m["all_gather_us"] > 0 and len(m["per_rank_pairs_per_s"]) == 2 and m["collectives_per_step"] == 1
+    assert one["multi_gpu"] is None and two["scaling"] == "weak"
+    assert abs(two["value"] - 16 * 1e3 / two["ms_per_step"]) < 1e-6 * two["value"]
+
+
+def test_line_carries_timing_diagnostics():
+    rec = _run("--steps", "3", "--warmup", "1", "--batch", "8", "--reps", "3", "--no-cpu-baseline", "--no-stage-sets")
+    t = rec["timing"]
+    assert len(t["windows_ms_per_step"]) == 3 and abs(rec["ms_per_step"] - sorted(t["windows_ms_per_step"])[1]) < 1e-3
+    assert t["host_submit_ms_per_step"] > 0 and t["host_submit_ms_per_step_c_abi"] > 0
+    assert all(d == 0 for d in t["device_allocs_in_window"]) and max(t["torch_allocs_per_step"]) < 1.0
+    assert set(t["stream_busy_ms_per_step"]) == {"gather_ms", "match_ms", "screen_kernel_ms", "registration_ms"}
+    assert rec["roofline"]["kernel"].startswith("match_i8_screen_v2_kernel<256, 0, 4>") and len(rec["config"]["pose_sha256"]) == 64

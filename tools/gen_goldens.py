@@ -496,6 +496,61 @@ def gen_bop_metrics():
          info_json=np.array(json.dumps(infos)), model_names=np.array(names),
          **{f"pts_{k}": v["pts"] for k, v in models.items()}, **{f"syms_{k}": format_sym_set(v) for k, v in symms.items()}, **out)
 
+
+def gen_tokenizer():
+    """G10: the reference's SimpleTokenizer (models/tokenizer.py:64-151) run on a FABRICATED merge table (a few hundred merges learnt
+    here from the prompt corpus by plain BPE counting - the published 16e6 vocabulary file is not in the tree) and a set of prompts:
+    templates, punctuation, digits, apostrophes, HTML entities, runs of blanks, upper case, non-ASCII bytes, and one prompt longer
+    than the 77-token context.  `ftfy` is absent; its fix_text is stubbed with the identity, so the golden pins everything of the
+    reference's encode path except ftfy's mojibake repair (a no-op on the datasets' plain-ASCII object names and templates)."""
+    import gzip
+    import collections
+    ft = types.ModuleType("ftfy")
+    ft.fix_text = lambda t: t
+    sys.modules["ftfy"] = ft
+    from models.tokenizer import SimpleTokenizer, bytes_to_unicode                    # reference
+    names = ["mug", "laptop", "camera", "bowl", "can", "bottle", "toy car", "power drill", "rubber duck", "cereal box"]
+    templates = ["a photo of a {}.", "a bad photo of the {}.", "a close-up photo of a {}.", "itap of my {}.", "a rendering of a {}.",
+                 "a {} in a video game.", "art of the {}.", "a black and white photo of the {}.", "the origami {}.", "a low resolution photo of the {}."]
+    corpus = [t.format(n) for n in names for t in templates]
+    b2u = bytes_to_unicode()
+    words = collections.Counter()
+    import regex as re
+    pat = re.compile(r"""'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+""", re.IGNORECASE)
+    for line in corpus:
+        for tok in re.findall(pat, line.lower()):
+            u = "".join(b2u[b] for b in tok.encode("utf-8"))
+            words[tuple(u[:-1]) + (u[-1] + "</w>",)] += 1
+    merges = []
+    for _ in range(400):
+        pairs = collections.Counter()
+        for w, c in words.items():
+            for a, b in zip(w, w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda p_: pairs[p_])
+        merges.append(best)
+        new = collections.Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i < len(w) - 1 and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1]); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            new[tuple(out)] += c
+        words = new
+    bpe_path = os.path.join(OUT, "bpe_fabricated.txt.gz")
+    with gzip.open(bpe_path, "wb") as f:
+        f.write(("#version: fabricated for tests (not the CLIP vocabulary)\n" + "\n".join(" ".join(m) for m in merges) + "\n").encode("utf-8"))
+    tok = SimpleTokenizer(bpe_path)
+    texts = corpus[::7] + ["A  Photo   of  THE Mug!!", "it's the robot's toy-car (no. 42)", "caf\u00e9 &amp; cr\u00e8me &lt;bowl&gt;", "x",
+                           "  leading and trailing blanks  ", "a photo of a " + " ".join(["very"] * 90) + " long prompt", "3d rendering, 100% real?"]
+    ids = torch.stack([tok(t) for t in texts])
+    print(f"fabricated BPE table: {len(merges)} merges, {len(texts)} prompts, longest {int((ids != 0).sum(1).max())} tokens")
+    save("g10_tokenizer", texts=np.array(texts), ids=ids.numpy(), n_merges=len(merges))
+
 def gen_data():
     """G8: raw samples -> utils/data/common.preprocess_item -> utils/augmentations.resize -> datasets.CollateWrapper, all
     REFERENCE code.  The modules import with permissive stubs for packages that are imported but never called on this path
@@ -549,7 +604,7 @@ def gen_data():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone", "metrics", "bop", "data"]
+    which = sys.argv[1:] or ["matcher", "lift", "kabsch", "pointdsc", "e2e", "backbone", "metrics", "bop", "tokenizer", "data"]
     if "data" in which:
         gen_data()
     if "matcher" in which:
@@ -570,3 +625,5 @@ if __name__ == "__main__":
         gen_metrics()
     if "bop" in which:
         gen_bop_metrics()
+    if "tokenizer" in which:
+        gen_tokenizer()
