@@ -1201,7 +1201,7 @@ const char *screen8_name()
 {
     const int variant = getenv("ORYON_SCREEN8_VARIANT") ? atoi(getenv("ORYON_SCREEN8_VARIANT")) : 2;
     const int ablate = getenv("ORYON_SCREEN8_ABLATE") ? atoi(getenv("ORYON_SCREEN8_ABLATE")) : 0;
-    const int waves = getenv("ORYON_SCREEN8_WAVES") ? atoi(getenv("ORYON_SCREEN8_WAVES")) : 4;
+    const int waves = getenv("ORYON_SCREEN8_WAVES") ? atoi(getenv("ORYON_SCREEN8_WAVES")) : 8;
     if (variant == 1) return CP == 256 ? "match_i8_screen_kernel<256>" : "match_i8_screen_kernel<512>";
     if (ablate && CP == 256) return "match_i8_screen_v2_kernel<256, ABLATED> (timing ablation: results are wrong)";
     if (waves == 8 && CP == 256) return "match_i8_screen_v2_kernel<256, 0, 8>";
@@ -1227,7 +1227,7 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
 #undef ABL
         return;
     }
-    static const int waves = getenv("ORYON_SCREEN8_WAVES") ? atoi(getenv("ORYON_SCREEN8_WAVES")) : 4;
+    static const int waves = getenv("ORYON_SCREEN8_WAVES") ? atoi(getenv("ORYON_SCREEN8_WAVES")) : 8;
     if (waves == 8 && CP == 256) {
         const int T8 = (cap_a + 511) / 512;
         hipLaunchKernelGGL((match_i8_screen_v2_kernel<256, 0, 8>), dim3(groups / T * T8), dim3(512), 0, st, a8, q8, q_scale, B, cap_a, cap_q, n_a,

@@ -66,4 +66,4 @@ def test_line_carries_timing_diagnostics():
     assert t["host_submit_ms_per_step"] > 0 and t["host_submit_ms_per_step_c_abi"] > 0
     assert all(d == 0 for d in t["device_allocs_in_window"]) and max(t["torch_allocs_per_step"]) < 1.0
     assert set(t["stream_busy_ms_per_step"]) == {"gather_ms", "match_ms", "screen_kernel_ms", "registration_ms"}
-    assert rec["roofline"]["kernel"].startswith("match_i8_screen_v2_kernel<256, 0, 4>") and len(rec["config"]["pose_sha256"]) == 64
+    assert rec["roofline"]["kernel"].startswith("match_i8_screen_v2_kernel<256, 0, 8>") and rec["roofline"]["unshared"]["frac"] > 0 and len(rec["config"]["pose_sha256"]) == 64

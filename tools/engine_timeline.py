@@ -17,7 +17,8 @@ dev = torch.device("cuda", 0)
 B, H, C = 64, 224, 256
 inp = bench.make_inputs(B, H, C, 0, dev)
 inp["cam"] = inp["cam"].reshape(B, 9).float().contiguous()
-eng = MatchPoseEngine(bench.build_solver(dev), MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=True, result_views=True)
+ser = bool(os.environ.get("ENG_SERIAL"))
+eng = MatchPoseEngine(bench.build_solver(dev), MatchPoseConfig(), overlap_registration=not ser, overlap_gather=not ser, native=True, result_views=True)
 eng.native_timing = not os.environ.get("ENG_NO_TIMING")
 for k_ in ("n_slots", "gather_sets", "reg_streams", "reg_lag"):
     if os.environ.get("ENG_" + k_.upper()):
@@ -26,6 +27,16 @@ if os.environ.get("ENG_PYTHON"):
     eng = MatchPoseEngine(bench.build_solver(dev), MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=False)
     eng.py_timeline = []
 key = torch.arange(B, device=dev)
+if os.environ.get("ENG_HARD"):
+    # bench.py's `hard_descriptors` inputs: smooth rank-8 fields + noise (every anchor ambiguous for the int8 stage)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, H, device=dev), indexing="ij")
+    coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy), torch.sin(7 * yy), torch.cos(5 * xx)])
+    basis = torch.randn((B, C, coef.shape[0]), generator=gen, device=dev)
+    inp["feat_q"].copy_(torch.einsum("bck,khw->bchw", basis, coef))
+    inp["feat_q"].add_(0.02 * torch.randn(inp["feat_q"].shape, generator=gen, device=dev))
+    inp["feat_a"].copy_(inp["feat_q"]).add_(0.01 * torch.randn(inp["feat_a"].shape, generator=gen, device=dev))
+    torch.cuda.synchronize()
 
 
 PACE = float(os.environ.get("ENG_PACE_MS", "0")) * 1e-3
