@@ -35,6 +35,7 @@ from oryon_amd.synth import make_pair  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # same table, "Peak BF16/FP16 MFMA" dense
 PEAK_I8_MFMA_TOPS = 5000.0         # dense INT8 = 2x the 16-bit rate (same table: FP8 ~5 PF dense; i8 32x32x32 measured 4.4 POP/s)
+PEAK_FP6_MFMA_TFLOPS = 10000.0     # same table, "Peak FP6/FP4 MFMA ~10 PF dense" (MX block-scaled only; 32x32x64 measured 8.9 PF/s)
 PEAK_HBM_BYTES = 8.0e12            # same guide: HBM3E 8 TB/s
 METRIC = "image-pairs/sec end-to-end (feat+match+reg) @224², C=256; ADD(-S) parity"
 
@@ -335,6 +336,8 @@ def main():
     ap.add_argument("--engine", choices=["native", "python"], default="native",
                     help="native: one C-ABI call per step (oryon_engine_submit: engine-owned streams / events, persistent arena, no torch "
                          "allocation per step); python: the per-call schedule of oryon_amd/engine.py (torch streams, ~40 torch allocations per step)")
+    ap.add_argument("--screen", choices=["mx6", "int8"], default="mx6",
+                    help="screening operands of the native engine's lazy matcher: MX-fp6 (v_mfma_scale_f32_32x32x64_f8f6f4, default) or int8")
     ap.add_argument("--no-stage-sets", action="store_true",
                     help="skip the 'decode+match+pose' and 'full' stage sets that the default run measures after the headline")
     ap.add_argument("--collation-selftest", action="store_true",
@@ -375,6 +378,7 @@ def main():
                              overlap_registration=not a.no_overlap, overlap_gather=a.overlap_gather and not a.no_overlap,
                              native=a.engine == "native", result_views=True)
     engine.native_timing = True           # HIP events around the three sections and the screening kernel of every native step
+    engine.native_geometry["screen"] = 1 if a.screen == "mx6" else 0
     key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
     total = B * world
     # the C ABI's input types, made once: fp32 [B,9] intrinsics (the reference's float64 [B,3,3] rounded, as pipeline.py:434-435 + lift_pcd do)
@@ -506,6 +510,7 @@ def main():
     if native is not None:
         ser = MatchPoseEngine(engine.solver, engine.cfg, overlap_registration=False, overlap_gather=False, native=True, result_views=True)
         ser.native_timing = True
+        ser.native_geometry["screen"] = engine.native_geometry["screen"]
         for _ in range(6):
             ser.run(inputs["feat_a"], inputs["feat_q"], inputs["mask_a"], inputs["mask_q"], inputs["depth_a"], inputs["depth_q"],
                     inputs["cam"], inputs["cam"], key, inputs_resident=True)
@@ -527,7 +532,11 @@ def main():
             kernel, peak = "match_f32_kernel (LDS-staged, wide descriptors)", PEAK_FP32_MFMA_TFLOPS
         from oryon_amd._lib import lib as _L
         dispatched = _L().oryon_dominant_kernel().decode()          # what the library actually launched between the events
-        if dispatched:
+        op = "int8 multiply-accumulate, 2 ops each, i32 accumulate" if use_i8 else "floating-point fma, 2 flops each"
+        if "mx6" in dispatched:
+            kernel, peak = dispatched + " (MX-fp6 MFMA screen of the lazy matcher: v_mfma_scale_f32_32x32x64_f8f6f4, e2m3 operands)", PEAK_FP6_MFMA_TFLOPS
+            op = "fp6 (e2m3, block-scaled) multiply-accumulate, 2 flops each, f32 accumulate"
+        elif dispatched:
             kernel = dispatched + kernel[kernel.index(" ("):] if " (" in kernel else dispatched
         launch_ms = match_ms_mean                                   # average launch duration over the timed windows (HIP events)
         achieved = flops / (launch_ms * 1e-3) / 1e12
@@ -578,7 +587,7 @@ def main():
                             f"PointDSC 12x128), N1<=5000, n_corrs=500",
                 "stages": "match+lift+registration (descriptor maps resident in HBM; backbone not in the timed region)",
                 "descriptor_layout": "NCHW contiguous fp32 (as Oryon.forward returns them)" if a.layout == "nchw" else "channels_last (NHWC storage) fp32",
-                "match_mode": a.match_mode + (" (int8-MFMA pre-screen, fp16-MFMA screening of the undecided anchors, exact fp32 re-scoring: outputs identical to the fp32 scan)" if use_i8 else " (fp16-MFMA screening, exact fp32 re-scoring: outputs identical to the fp32 scan)" if screened else ""),
+                "match_mode": a.match_mode + ((" (MX-fp6 MFMA screen with a proven bound, exact fp32 re-scoring of the sampled anchors' candidates; anchors the bound cannot settle are resolved exactly: outputs identical to the fp32 scan)" if native is not None and engine.native_geometry.get("screen", 0) == 1 else " (int8-MFMA pre-screen, fp16-MFMA screening of the undecided anchors, exact fp32 re-scoring: outputs identical to the fp32 scan)") if use_i8 else " (fp16-MFMA screening, exact fp32 re-scoring: outputs identical to the fp32 scan)" if screened else ""),
                 "sample_first": a.sample_first or None,
                 "pairs_per_gpu": B, "global_pairs": total, "parallelism": f"pairs sharded over {world} GPU(s), all_gather of poses",
                 "pipelining": ("none" if a.no_overlap else "registration of step k on a second HIP stream under the matching of step k+1"
@@ -590,7 +599,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "op": "int8 multiply-accumulate, 2 ops each, i32 accumulate" if use_i8 else "floating-point fma, 2 flops each",
+                "unit": "TFLOP/s", "op": op,
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "flops_per_launch": flops, "avg_launch_ms": launch_ms,
                 "algorithmic_bytes_per_launch": alg_bytes, "hbm_frac": hbm_frac,

@@ -219,6 +219,27 @@ int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, const float *a_
                          int32_t *n_valid, int32_t *n_sel, int32_t *status, int32_t *n_undecided, int round_f16, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* K0 + K1s6 (round 3): the same lazy matcher with an MX-fp6 screen in place of the int8 one.  Replaces the same reference lines
+ * (utils/pcd.py:192-193, :28-29, :202-214); the results are those of oryon_match_corrs_i8 bit for bit (every decision the screen takes is
+ * backed by a proven bound, everything else is resolved exactly), only the dominant kernel changes: v_mfma_scale_f32_32x32x64_f8f6f4
+ * multiplies 64 channels per instruction at the int8 instruction's rate.
+ *     oryon_gather_mx6 writes, per ROI row and 32-channel block, one 32-byte slot: bytes 0-23 = 32 fp6 (e2m3) codes of x^ / 2^e (element t
+ *     at bits [6t, 6t+6)), byte 24 = e + 127 (E8M0), bytes 25-31 = 0 - rows of C_pad bytes, like the int8 rows; the block exponent puts the
+ *     block's largest magnitude into (3.75, 7.5].  err_max [n_maps] receives the largest MEASURED quantisation error |x^ - dequant|_2 over
+ *     the map's live rows; row_norm / out_f32 as oryon_gather_q8.
+ *     oryon_match_corrs_mx6 = oryon_match_corrs_i8 on such operands (lazy route only): |s6 - a^.q^| <= |ea| + |eq| + |ea||eq| + 1.2e-4 with
+ *     ea / eq the pair's a_err_max / q_err_max decides validity and unambiguity; the winning slice's 16 rows are re-scored from the mx6
+ *     slots, candidates inside the margin of the slice maximum go to the exact fp32 chain on the raw map.  Workspace:
+ *     oryon_match_corrs_i8_workspace_bytes. */
+int oryon_gather_mx6(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
+                     int rows_cap, int C_pad, uint8_t *out_mx6, float *err_max, float *row_norm, float *out_f32, int round_f16, void *stream);
+int oryon_match_corrs_mx6(const float *a_hat, const uint8_t *a_mx6, const float *a_err_max, const float *feat_q, int C_true, int HW, int layout,
+                          const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q, const float *q_norm,
+                          const uint8_t *q_mx6, const float *q_err_max, int B, int C, int cap_a, int cap_q, const int32_t *n_a,
+                          const int32_t *n_q, float threshold, int W, int max_corrs, int corr_rows, uint64_t seed, const int64_t *pair_key,
+                          float *min_dist, int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
+                          int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream);
+
 /* "Sample first" (optional engine schedule, off by default).  Only max_corrs correspondences per pair leave the matcher
  * (utils/pcd.py:205-214), drawn uniformly from the valid anchor rows - so a uniformly random first-stage subset of the anchors that
  * already holds >= max_corrs valid rows yields an identically distributed sample.  The engine runs the matcher on such a subset;
@@ -360,6 +381,8 @@ typedef struct {
     int gather_sets;         /* K0 output sets: K0 may run this many steps ahead of the matcher minus one (3; <= 4, <= n_slots) */
     int reg_streams;         /* registration streams the steps alternate over (2; <= 4) */
     int reg_lag;             /* > 0: the matcher of step k waits for the registration of step k - reg_lag (< n_slots); 0 = never (default) */
+    int screen;              /* 0 = int8 screen (oryon_gather_q8 + oryon_match_corrs_i8), 1 = MX-fp6 screen (oryon_gather_mx6 +
+                                oryon_match_corrs_mx6; steps submitted with force_eager take the int8 route) */
 } oryon_engine_config_t;
 size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver);
 int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,

@@ -163,7 +163,7 @@ int check_cfg(const oryon_engine_config_t *c)
     ORYON_CHECK_ARG(c->dist_th > 0.0f && c->dist_th <= 0.5f && c->n_slots >= 1 && c->n_slots <= MAX_SLOTS);
     ORYON_CHECK_ARG(c->gather_sets >= 1 && c->gather_sets <= MAX_G_SLOTS && c->gather_sets <= c->n_slots);
     ORYON_CHECK_ARG(c->reg_streams >= 1 && c->reg_streams <= MAX_REG_STREAMS && c->reg_lag >= 0 && c->reg_lag < c->n_slots);
-    ORYON_CHECK_ARG(c->layout == ORYON_LAYOUT_NCHW || c->layout == ORYON_LAYOUT_NHWC);
+    ORYON_CHECK_ARG((c->layout == ORYON_LAYOUT_NCHW || c->layout == ORYON_LAYOUT_NHWC) && (c->screen == 0 || c->screen == 1));
     ORYON_CHECK_ARG(c->overlap >= 0 && c->overlap <= 2 && (c->overlap == 0 || c->n_slots >= 2));      // results of step k live until submit k + n_slots
     ORYON_CHECK_ARG((size_t)c->C * (size_t)c->FH * (size_t)c->FW * 4u < (1ull << 32));
     return ORYON_OK;
@@ -332,10 +332,19 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
     if ((rc = oryon_roi_compact(mask_a, B, HW, b.roi_a, b.n_a, sg))) return rc;
     if ((rc = oryon_roi_compact(mask_q, B, HW, b.roi_q, b.n_q, sg))) return rc;
     if (c.src_sampling > 0 && (rc = oryon_roi_subsample(b.roi_a, b.n_a, B, HW, c.src_sampling, c.seed, pair_key, sg))) return rc;
+    const bool mx6 = c.screen == 1 && !force_eager;           // the eager route (complete min_dist / argmin arrays) keeps the int8 operands
+    if (mx6) {
+        // the row buffers hold 32-byte mx6 slots instead of int8 rows (same size); the per-map error norms go where eps_max went
+        if ((rc = oryon_gather_mx6(feat_q, B, c.C, HW, c.layout, b.roi_q, HW, b.n_q, e->L.cap_q, e->L.c_pad, reinterpret_cast<uint8_t *>(g.q8),
+                                   g.q_eps, g.q_norm, nullptr, c.round_f16, sg))) return rc;
+        if ((rc = oryon_gather_mx6(feat_a, B, c.C, HW, c.layout, b.roi_a, HW, b.n_a, e->L.cap_a, e->L.c_pad, reinterpret_cast<uint8_t *>(g.a8),
+                                   g.a_eps, g.a_norm, g.a_hat, c.round_f16, sg))) return rc;
+    } else {
     if ((rc = oryon_gather_q8(feat_q, B, c.C, HW, c.layout, b.roi_q, HW, b.n_q, e->L.cap_q, e->L.c_pad, g.q8, g.q_sc, g.q_eps, g.q_norm,
                               nullptr, c.round_f16, sg))) return rc;
     if ((rc = oryon_gather_q8(feat_a, B, c.C, HW, c.layout, b.roi_a, HW, b.n_a, e->L.cap_a, e->L.c_pad, g.a8, g.a_sc, g.a_eps, g.a_norm,
                               g.a_hat, c.round_f16, sg))) return rc;
+    }
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[1], sg));
     if (sg != sm) {
         ORYON_CHECK_HIP(hipEventRecord(e->ev_gathered[slot], sg));
@@ -347,6 +356,13 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
         (void)oryon_profile_events(tev[4], tev[5]);
     }
     // corrs rows beyond max_corrs are never written by the sampler and K2 only reads n_sel rows: no zero-fill needed
+    if (mx6) {
+        if ((rc = oryon_match_corrs_mx6(g.a_hat, reinterpret_cast<const uint8_t *>(g.a8), g.a_eps, feat_q, c.C, HW, c.layout, b.roi_a, HW, b.roi_q,
+                                        HW, g.q_norm, reinterpret_cast<const uint8_t *>(g.q8), g.q_eps, B, e->L.c_pad, e->L.cap_a, e->L.cap_q,
+                                        b.n_a, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key, b.min_dist, b.argmin, b.valid,
+                                        b.corrs, b.n_valid, b.n_sel, b.status, b.n_und, c.round_f16, e->L.match_ws, e->L.match_ws_bytes, sm)))
+            return rc;
+    } else
     if ((rc = oryon_match_corrs_i8(g.a_hat, g.a8, g.a_sc, feat_q, c.C, HW, c.layout, b.roi_a, HW, b.roi_q, HW, g.q_norm, g.q8, g.q_sc, g.q_eps,
                                    B, e->L.c_pad, e->L.cap_a, e->L.cap_q, b.n_a, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key,
                                    force_eager, b.min_dist, b.argmin, b.valid, b.corrs, b.n_valid, b.n_sel, b.status, b.n_und, c.round_f16,

@@ -40,11 +40,28 @@ constexpr int G8_STAGE_BYTES = 16384;          // per wave
         asm volatile("" ::: "memory");      \
     } while (0)
 
+typedef float f32x16g __attribute__((ext_vector_type(16)));
+typedef float f32x32g __attribute__((ext_vector_type(32)));
+typedef unsigned u32x6g __attribute__((ext_vector_type(6)));
+
+template <int N, int FMT>
+struct RowRegs {
+    float v[N];
+    __device__ __forceinline__ float get(int k) const { return v[k]; }
+    __device__ __forceinline__ void set(int k, float x) { v[k] = x; }
+};
 template <int N>
-__device__ __forceinline__ float chain_sq(const float (&v)[N], float acc)
+struct RowRegs<N, 1> {
+    f32x16g t[N / 16];
+    __device__ __forceinline__ float get(int k) const { return t[((k >> 5) << 1) | (k & 1)][(k & 31) >> 1]; }
+    __device__ __forceinline__ void set(int k, float x) { t[((k >> 5) << 1) | (k & 1)][(k & 31) >> 1] = x; }
+};
+
+template <int N, class RR>
+__device__ __forceinline__ float chain_sq(const RR &r, float acc)
 {
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc = __fmaf_rn(v[i], v[i], acc);
+    for (int i = 0; i < N; ++i) acc = __fmaf_rn(r.get(i), r.get(i), acc);
     return acc;
 }
 
@@ -56,7 +73,15 @@ __device__ __forceinline__ unsigned stage_addr(int t, int s, int RB)
     return (unsigned)(t * RB + (s & ~(L - 1)) * 16 + (((s & (L - 1)) ^ (t & (L - 1))) << 4));
 }
 
-template <int CP, int LPR, bool NHWC>
+// FMT = 1 (round 3): MX-fp6 screening operands instead of int8 rows, same row size.  A row's 32-channel block b becomes one 32-byte
+// slot: 24 bytes = 32 fp6 e2m3 codes (element t at bits [6t, 6t+6)), byte 24 = the block's E8M0 exponent (value 2^(e-127)), rest 0 -
+// exactly what a lane of v_mfma_scale_f32_32x32x64_f8f6f4 consumes for its (row, 32 k) share (tools/probe_mfma_mx.hip).  The block
+// exponent puts the block's largest |x^| into (3.75, 7.5]; codes come from v_cvt_scalef32_2xpk16_fp6_f32 (RN-even, saturating; its
+// two 16-float operands interleave: result element 2i = a[i], 2i+1 = b[i] - tools/probe_cvt_fp6.hip), the decoded values from
+// v_cvt_scalef32_pk32_f32_fp6, so the row's quantisation error e = x^ - dequant is MEASURED: eps_max[m] receives the largest
+// |e|_2 over the map's live rows (float bits, atomic max) - the bound of the mx6 screen is |s6 - a^.q^| <= |ea| + |eq| + |ea||eq|.
+// `scale` is not written in this mode.
+template <int CP, int LPR, bool NHWC, int FMT = 0>
 __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_kernel(
     const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride,
     const int32_t *__restrict__ count, const int32_t *__restrict__ map_enable, int rows_cap, int n_maps, int chunk_tiles,
@@ -92,14 +117,19 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
     const int pix = live ? roi[(size_t)m * roi_stride + my_row] : 0;
     const bool tile_full = (row0 + ROWS <= n) && (C == CP);   // wave-uniform
 
-    float v[KPL];
+    // the row's raw values.  FMT = 0: a plain register array.  FMT = 1: sixteen-float register tuples, tuple 2b = the even and tuple
+    // 2b + 1 the odd channels of block b - the operand pairs of the fp6 conversion instruction, which takes 16 CONTIGUOUS registers
+    // each (built from a scalar array the tuples have to be copied together while all 256 values are live: ~100 scratch spills)
+    RowRegs<KPL, FMT> R;
+#define VG(k) R.get(k)
+#define VS(k, x) R.set(k, x)
     if constexpr (!NHWC) {
         // channel-planar map: value (k, pix) at feat[m][k][pix]
         const char *fb = reinterpret_cast<const char *>(feat + (size_t)m * C * HW);
         const unsigned voff = (unsigned)pix * 4u + (unsigned)seg * (unsigned)KPL * (unsigned)HW * 4u;
         if (tile_full) {
 #pragma unroll
-            for (int i = 0; i < KPL; ++i) v[i] = *reinterpret_cast<const float *>(fb + (size_t)i * HW * 4 + voff);
+            for (int i = 0; i < KPL; ++i) VS(i, *reinterpret_cast<const float *>(fb + (size_t)i * HW * 4 + voff));
         } else {
             // ragged tile (last rows of a map, or C < CP): every lane loads from a clamped, valid address; dead rows / channels are
             // zeroed afterwards.  The bounds go through opaque copies so that the compiler neither shares the 256 plane addresses
@@ -110,12 +140,12 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
             for (int i = 0; i < KPL; ++i) {
                 int k = seg * KPL + i;
                 k = k < c_b ? k : c_b - 1;
-                v[i] = *reinterpret_cast<const float *>(fb + (size_t)k * hw_b * 4 + (unsigned)pix * 4u);
+                VS(i, *reinterpret_cast<const float *>(fb + (size_t)k * hw_b * 4 + (unsigned)pix * 4u));
             }
             int c_c = C;
             asm volatile("" : "+s"(c_c));
 #pragma unroll
-            for (int i = 0; i < KPL; ++i) v[i] = (live && (seg * KPL + i < c_c)) ? v[i] : 0.0f;
+            for (int i = 0; i < KPL; ++i) VS(i, (live && (seg * KPL + i < c_c)) ? VG(i) : 0.0f);
         }
     } else {
         // channels_last map: value (k, pix) at feat[m][pix][k].  64 channels of the wave's 64 / LPR rows at a time: 4 rows x 256 bytes
@@ -161,7 +191,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const float4 q = *reinterpret_cast<const float4 *>(stage + stage_addr(lane, s, 256));
-                v[64 * c + 4 * s + 0] = q.x; v[64 * c + 4 * s + 1] = q.y; v[64 * c + 4 * s + 2] = q.z; v[64 * c + 4 * s + 3] = q.w;
+                VS(64 * c + 4 * s + 0, q.x); VS(64 * c + 4 * s + 1, q.y); VS(64 * c + 4 * s + 2, q.z); VS(64 * c + 4 * s + 3, q.w);
             }
         }
     }
@@ -170,21 +200,23 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
     // nearest float16 first; everything downstream runs unchanged on the rounded values
     if (round_f16) {
 #pragma unroll
-        for (int i = 0; i < KPL; ++i) v[i] = __half2float(__float2half_rn(v[i]));
+        for (int i = 0; i < KPL; ++i) VS(i, __half2float(__float2half_rn(VG(i))));
     }
 
     // canonical norm: ONE k-ordered fmaf chain per row.  LPR = 2: lanes of segment 1 continue from segment 0's result.
-    float n2 = chain_sq<KPL>(v, 0.0f);
+    float n2 = chain_sq<KPL>(R, 0.0f);
     if constexpr (LPR == 2) {
         const float lo = __shfl(n2, lrow);                    // segment 0's partial chain of the same row
-        const float full = chain_sq<KPL>(v, lo);              // meaningful on segment-1 lanes
+        const float full = chain_sq<KPL>(R, lo);              // meaningful on segment-1 lanes
         n2 = __shfl(full, ROWS + lrow);
     }
     float d = sqrt_rn(n2);
     d = d < 1e-8f ? 1e-8f : d;
+    float rs = 0.0f;
+    if constexpr (FMT == 0) {
     float mx = 0.0f;
 #pragma unroll
-    for (int i = 0; i < KPL; ++i) mx = fmaxf(mx, fabsf(v[i]));
+    for (int i = 0; i < KPL; ++i) mx = fmaxf(mx, fabsf(VG(i)));
     if constexpr (LPR == 2) mx = fmaxf(mx, __shfl_xor(mx, 32));
     float mxs = __fdiv_rn(mx, d);                             // = max_k |x_k / d| (IEEE division is monotone)
     // slice = 16 rows {0-3,8-11,16-19,24-27} + 4h of a 32-row block: the lanes that differ in row bits 0,1,3,4
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
     int E = mxs > 0.0f ? ilogbf(127.0f / mxs) : 30;
     E = E > 30 ? 30 : (E < 0 ? 0 : E);
     const float sc = ldexpf(1.0f, E);
-    const float rs = __fdiv_rn(sc, d);
+    rs = __fdiv_rn(sc, d);
     const int h = (lrow >> 2) & 1;
     if (seg == 0 && (lrow & 27) == 0) scale[(size_t)m * (rows_cap / 16) + (my_row >> 5) * 2 + h] = ldexpf(1.0f, -E);
     {
@@ -205,10 +237,11 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
         for (int off = 32; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
         if (lane == 0 && e > 0.0f) atomicMax(&eps_max[m], __float_as_uint(e));
     }
+    }
     if (seg == 0 && norm) norm[(size_t)m * rows_cap + my_row] = d;
 
+    if constexpr (FMT == 0) {
     // int8 rows: magic-number rounding (RN-even, like rintf) - the low byte of (x*rs + 1.5*2^23) is the two's complement of the integer
-    {
         constexpr int RB8 = KPL;                              // bytes per tile-lane row
 #pragma unroll
         for (int s = 0; s < KPL / 16; ++s) {
@@ -217,7 +250,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
             for (int j = 0; j < 4; ++j) {
                 unsigned b[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b[e] = __float_as_uint(__fmaf_rn(v[16 * s + 4 * j + e], rs, 12582912.0f));
+                for (int e = 0; e < 4; ++e) b[e] = __float_as_uint(__fmaf_rn(VG(16 * s + 4 * j + e), rs, 12582912.0f));
                 const unsigned lo = __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);      // bytes: b0[0], b1[0], 0, 0
                 const unsigned hi2 = __builtin_amdgcn_perm(b[3], b[2], 0x04000c0cu);     // bytes: 0, 0, b2[0], b3[0]
                 w[j] = lo | hi2;
@@ -246,10 +279,10 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     float4 q;
-                    q.x = __fdiv_rn(v[64 * c + 8 * g + 0 + hh], d);
-                    q.y = __fdiv_rn(v[64 * c + 8 * g + 2 + hh], d);
-                    q.z = __fdiv_rn(v[64 * c + 8 * g + 4 + hh], d);
-                    q.w = __fdiv_rn(v[64 * c + 8 * g + 6 + hh], d);
+                    q.x = __fdiv_rn(VG(64 * c + 8 * g + 0 + hh), d);
+                    q.y = __fdiv_rn(VG(64 * c + 8 * g + 2 + hh), d);
+                    q.z = __fdiv_rn(VG(64 * c + 8 * g + 4 + hh), d);
+                    q.w = __fdiv_rn(VG(64 * c + 8 * g + 6 + hh), d);
                     *reinterpret_cast<float4 *>(stage + stage_addr(lane, 2 * g + hh, 256)) = q;
                 }
             WAVE_LDS_ORDER();
@@ -261,6 +294,63 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
             }
         }
     }
+    if constexpr (FMT == 1) {
+        // MX-fp6 slots (see the kernel's header): one 32-channel block = staging slots 2b (code dwords 0-3) and 2b + 1 (code dwords
+        // 4-5, exponent byte, zero)
+        constexpr int RB8 = KPL;
+        float err2 = 0.0f;
+        const float rd = __fdiv_rn(1.0f, d);                             // x * rd = x / d up to 2 ulp: inside the bound's slack
+#pragma unroll
+        for (int b = 0; b < KPL / 32; ++b) {
+            float bm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) bm = fmaxf(bm, fabsf(VG(32 * b + i)));
+            // block exponent e: bm / (d * 2^e) in (3.75, 7.5]; an all-zero block keeps e = -40
+            const float r = __fdiv_rn(bm, d) * (1.0f / 7.5f);
+            int e = r > 0.0f ? ilogbf(r) + 1 : -40;
+            if (r > 0.0f && ldexpf(1.0f, e - 1) >= r) e -= 1;          // r an exact power of two: 2^(e-1) == r is enough
+            e = e < -40 ? -40 : (e > 8 ? 8 : e);
+            // values in code units: x / (d 2^e) (rd 2^-e is exact, a power of two times rd).  The conversions run with the constant
+            // scale 1: a per-lane scale operand gave wrong codes (every row has its own exponent here)
+            const float rde = rd * ldexpf(1.0f, -e);
+            R.t[2 * b] *= rde;                                          // in place: the raw values are not needed any more (out32 is done)
+            R.t[2 * b + 1] *= rde;
+            const f32x16g ev = R.t[2 * b], od = R.t[2 * b + 1];
+            const u32x6g c = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 1.0f);
+            const f32x32g back = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(c, 1.0f);    // the codes' values: what the MFMA multiplies (x 2^e)
+            float be = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float d0 = ev[i] - back[2 * i], d1 = od[i] - back[2 * i + 1];
+                be = __fmaf_rn(d0, d0, be);
+                be = __fmaf_rn(d1, d1, be);
+            }
+            err2 = __fmaf_rn(be, ldexpf(1.0f, 2 * e), err2);
+            *reinterpret_cast<uint4 *>(stage + stage_addr(lane, 2 * b, RB8)) = make_uint4(c[0], c[1], c[2], c[3]);
+            *reinterpret_cast<uint4 *>(stage + stage_addr(lane, 2 * b + 1, RB8)) = make_uint4(c[4], c[5], (unsigned)(e + 127), 0u);
+            // one block at a time: left to itself the scheduler interleaves all eight blocks' conversions (each needs 2 x 16 + 32
+            // contiguous registers) on top of the 256 live raw values and spills ~100 registers to scratch
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // |e|_2 of the row (already in unit terms), rounded up: the fp32 sum of <= 512 squares is within 3e-5 relative (1.00002 after
+        // the square root), + 3e-7 covers x * rd against the canonical x / d
+        if constexpr (LPR == 2) err2 += __shfl_xor(err2, 32);
+        float er = live ? sqrt_rn(err2) * 1.00002f + 3e-7f : 0.0f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) er = fmaxf(er, __shfl_xor(er, off));
+        if (lane == 0 && er > 0.0f) atomicMax(&eps_max[m], __float_as_uint(er));
+        WAVE_LDS_ORDER();
+        constexpr int SPR = RB8 / 16;
+        char *o8 = reinterpret_cast<char *>(out8) + ((size_t)m * rows_cap + row0) * CP;
+#pragma unroll
+        for (int j = 0; j < SPR; ++j) {
+            const int f = j * 64 + lane, t = f / SPR, s = f % SPR;
+            const uint4 q = *reinterpret_cast<const uint4 *>(stage + stage_addr(t, s, RB8));
+            *reinterpret_cast<uint4 *>(o8 + (size_t)(t % ROWS) * CP + (t / ROWS) * KPL + s * 16) = q;
+        }
+    }
+#undef VG
+#undef VS
 }
 
 }  // namespace oryon
@@ -268,7 +358,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
 using namespace oryon;
 
 namespace {
-template <int CP, int LPR, bool NHWC>
+template <int CP, int LPR, bool NHWC, int FMT = 0>
 void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride, const int32_t *count,
                const int32_t *map_enable, int rows_cap, int8_t *out8, float *scale, float *eps, float *norm, float *out32, int round_f16)
 {
@@ -278,7 +368,7 @@ void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, con
     const int chunk_tiles = (T + chunks_per_map - 1) / chunks_per_map;
     const int units = n_maps * chunks_per_map;
     const int groups = ((units + 7) / 8) * 8 * chunk_tiles;
-    auto kern = gather_q8_v3_kernel<CP, LPR, NHWC>;
+    auto kern = gather_q8_v3_kernel<CP, LPR, NHWC, FMT>;
     allow_dynamic_lds(reinterpret_cast<const void *>(kern), 4 * G8_STAGE_BYTES);
     hipLaunchKernelGGL(kern, dim3(groups), dim3(256), 4 * G8_STAGE_BYTES, st, feat, C, HW, roi, roi_stride, count, map_enable, rows_cap,
                        n_maps, chunk_tiles, chunks_per_map, out8, scale, reinterpret_cast<unsigned *>(eps), norm, out32, round_f16);
@@ -290,17 +380,20 @@ namespace oryon {
 // the call must not touch eps_max (fall-back pass)
 int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
                      const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
-                     float *out32, int lanes_per_row, int round_f16, hipStream_t st)
+                     float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt)
 {
     const int lpr = C_pad == 512 ? 2 : (lanes_per_row == 2 ? 2 : 1);
-#define G8(CPV, LPRV)                                                                                                          \
+#define G8(CPV, LPRV, FMTV)                                                                                                    \
     do {                                                                                                                       \
-        if (layout == ORYON_LAYOUT_NHWC) launch_g8<CPV, LPRV, true>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
-        else launch_g8<CPV, LPRV, false>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
+        if (layout == ORYON_LAYOUT_NHWC) launch_g8<CPV, LPRV, true, FMTV>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
+        else launch_g8<CPV, LPRV, false, FMTV>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
     } while (0)
-    if (C_pad == 512) G8(512, 2);
-    else if (lpr == 2) G8(256, 2);
-    else G8(256, 1);
+    if (fmt == 1) {
+        if (C_pad == 512) G8(512, 2, 1);
+        else G8(256, 1, 1);
+    } else if (C_pad == 512) G8(512, 2, 0);
+    else if (lpr == 2) G8(256, 2, 0);
+    else G8(256, 1, 0);
 #undef G8
     return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
 }
@@ -319,7 +412,24 @@ extern "C" int oryon_gather_q8(const float *feat, int n_maps, int C, int HW, int
     ORYON_CHECK_HIP(hipMemsetAsync(eps_max, 0, (size_t)n_maps * sizeof(float), st));
     static const int lpr_env = getenv("ORYON_GATHER8_LPR") ? atoi(getenv("ORYON_GATHER8_LPR")) : 1;
     const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad, out_i8, slice_scale,
-                                    eps_max, row_norm, out_f32, lpr_env, round_f16, st);
+                                    eps_max, row_norm, out_f32, lpr_env, round_f16, st, 0);
     if (rc) { set_error("oryon_gather_q8: launch failed"); return rc; }
+    return ORYON_OK;
+}
+
+extern "C" int oryon_gather_mx6(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride,
+                                const int32_t *count, int rows_cap, int C_pad, uint8_t *out_mx6, float *err_max, float *row_norm,
+                                float *out_f32, int round_f16, void *stream)
+{
+    ORYON_CHECK_ARG(feat && roi && count && out_mx6 && err_max);                               // row_norm, out_f32 may be NULL
+    ORYON_CHECK_ARG(n_maps >= 0 && C > 0 && HW > 0 && roi_stride > 0 && C_pad >= C && (C_pad == 256 || C_pad == 512));
+    ORYON_CHECK_ARG(layout == ORYON_LAYOUT_NCHW || layout == ORYON_LAYOUT_NHWC);
+    ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % 256 == 0 && (size_t)C * (size_t)HW * 4u < (1ull << 32));
+    if (n_maps == 0) return ORYON_OK;
+    hipStream_t st = as_stream(stream);
+    ORYON_CHECK_HIP(hipMemsetAsync(err_max, 0, (size_t)n_maps * sizeof(float), st));
+    const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad,
+                                    reinterpret_cast<int8_t *>(out_mx6), nullptr, err_max, row_norm, out_f32, 1, round_f16, st, 1);
+    if (rc) { set_error("oryon_gather_mx6: launch failed"); return rc; }
     return ORYON_OK;
 }

@@ -940,6 +940,187 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_i8_screen
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ K1s6: MX-fp6 screen (round 3)
+// The same single-pass (m1, slice, m2) screening on v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 (e2m3) operands: 64 channels per
+// instruction at the int8 instruction's issue rate, i.e. twice the multiply-accumulates per matrix-pipe cycle (guide: 8.9 PFLOP/s
+// measured for MX-fp6 32x32x64 against 4.4 POP/s for i8 32x32x32).  Operands are K0's mx6 rows (gather8.hip, FMT = 1): per row and
+// 32-channel block one 32-byte slot = 24 bytes of codes + the block's E8M0 exponent - the share of one lane (row l & 31, block
+// 2 S + (l >> 5) of k-step S), so a lane's A operand is two ds_read_b128 and the hardware applies both exponents: accumulators are
+// the dequantised dot products themselves (no per-slice integer scale).  Row bytes, tile geometry, LDS image, DMA, swizzle, block
+// map, outputs and the meaning of a slice are those of match_i8_screen_v2_kernel.
+//
+// Bound.  With e = x^ - dequant(x^) the MEASURED quantisation error of a row (K0 accumulates |e|_2 per row and keeps the largest per
+// map), s6_ij - a^_i.q^_j = a^_i.eq_j + ea_i.q^_j + ea_i.eq_j, hence by Cauchy-Schwarz on unit rows
+//     |s6_ij - a^_i.q^_j| <= |eq| + |ea| + |ea||eq| (+ 1.2e-4: fp32 accumulation of 256-512 exact products here and in the canonical chain)
+// - a 2-norm bound on errors that really occur (~0.02 per row for e2m3 with a per-block exponent) instead of a worst-case 1-norm one.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+template <int CP, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_screen_kernel(
+    const uint8_t *__restrict__ a6, const uint8_t *__restrict__ q6, int B, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
+    const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
+{
+    constexpr int RB = CP;
+    constexpr int TILE_BYTES = screen8_tile_bytes(CP);
+    constexpr int ROWS = 128, NQB = 4, NAB = 2;
+    constexpr int NKS = CP / 64;                          // k-steps of 64 channels (two 32-channel blocks, one per lane half)
+    constexpr int NI = TILE_BYTES / (1024 * WAVES);
+    constexpr int LPR = RB / 256;
+    char *smem;
+    if constexpr (2 * TILE_BYTES > 65536) {
+        extern __shared__ __attribute__((aligned(256))) char smem_dyn6[];
+        smem = smem_dyn6;
+    } else {
+        __shared__ __attribute__((aligned(256))) char smem_st6[2 * TILE_BYTES];
+        smem = smem_st6;
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = (slot / T) * 8 + xcd;
+    if (unit >= B * S) return;
+    const int panel = slot % T;
+    const int p = unit / S, split = unit % S;
+    const int na = n_a[p], nq = n_q[p];
+    const int a0 = panel * (64 * WAVES);
+    if (a0 >= na) return;
+    const int nqt = (nq + ROWS - 1) / ROWS;
+    const int qt_per = (nqt + S - 1) / S;
+    const int qt_begin = split * qt_per;
+    const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const char *qp = reinterpret_cast<const char *>(q6) + (size_t)p * cap_q * RB;
+
+    // stationary B operand: this wave's 64 anchors, slot (2 S + hi) of every k-step (dwords 0-5 codes, dword 6 = exponent byte)
+    i32x8 breg[NAB][NKS];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const int arow_i = a0 + wave * 64 + ab * 32 + l31;
+        const char *arow = reinterpret_cast<const char *>(a6) + ((size_t)p * cap_a + (arow_i < cap_a ? arow_i : cap_a - 1)) * RB + 32 * hi;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const i32x4 lo = *reinterpret_cast<const i32x4 *>(arow + 64 * s), up = *reinterpret_cast<const i32x4 *>(arow + 64 * s + 16);
+            breg[ab][s] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], 0};
+        }
+    }
+    unsigned dma_off[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        const int row = line / LPR;
+        const int cc = sl ^ (row & 15);
+        dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_one = [&](int qt, int buf, int j) {
+        const char *qb = qp + (size_t)qt * TILE_BYTES;
+        char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    // LDS offsets of the two 16-byte chunks of slot (2 (S & 3) + hi) in the lane's row: chunk index XOR (row & 15) inside a 256-byte line
+    unsigned koff[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) koff[c][e] = (unsigned)(l31 * RB) + ((((unsigned)(4 * c + 2 * hi + e)) ^ (unsigned)(l31 & 15)) << 4);
+    auto rd = [&](int s, int qb, unsigned tile) -> i32x8 {
+        const unsigned base = tile + (unsigned)(qb * 32 * RB + (s >> 2) * 256);
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][0] + base);
+        const i32x4 up = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][1] + base);
+        return i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], 0};
+    };
+
+    float runmax[NAB], run2[NAB];
+    int runidx[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; run2[ab] = -INFINITY; runidx[ab] = 0; }
+    auto reduce_block = [&](const f32x16s &c, int sid, int ab) {
+        const float m0 = fmaxf(fmaxf(c[0], c[1]), c[2]), m1 = fmaxf(fmaxf(c[3], c[4]), c[5]), m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
+        const float m3 = fmaxf(fmaxf(c[9], c[10]), c[11]), m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+        const float x = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
+        const bool improved = x > runmax[ab];
+        run2[ab] = fmaxf(fminf(runmax[ab], x), run2[ab]);
+        runmax[ab] = fmaxf(runmax[ab], x);
+        runidx[ab] = improved ? sid : runidx[ab];
+    };
+    const f32x16s zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    if (qt_end > qt_begin) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) issue_one(qt_begin, 0, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    i32x8 areg[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, 0u);
+    f32x16s prev[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[ab][r] = -3.0e38f;          // the dummy "previous block" before the first one never wins
+    int prev_sid = 0;
+    int buf = 0;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        const unsigned tile = buf * TILE_BYTES;
+        const int qt_next = qt + 1 < qt_end ? qt + 1 : qt;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            f32x16s acc[NAB];
+            if (qb == 0) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) issue_one(qt_next, buf ^ 1, j);
+            }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab)
+                    acc[ab] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(areg[s], breg[ab][s], s == 0 ? zero16 : acc[ab], 2, 2, 0,
+                                                                               areg[s][6], 0, breg[ab][s][6]);
+                if (qb + 1 < NQB) areg[s] = rd(s, qb + 1, tile);
+            }
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sid, ab);
+            // pin the interleave: the previous block's epilogue (~24 VALU) and the next A operand's reads under this block's 2 NKS MFMAs
+#pragma unroll
+            for (int i = 0; i < NKS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 24 / (2 * NKS), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 24 / (2 * NKS), 0);
+                if (qb + 1 < NQB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) prev[ab] = acc[ab];
+            prev_sid = (qt * NQB + qb) * 2 + hi;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
+    }
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sid, ab);
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const float om1 = __shfl_xor(runmax[ab], 32), om2 = __shfl_xor(run2[ab], 32);
+        const int oi1 = __shfl_xor(runidx[ab], 32);
+        const float m1 = fmaxf(runmax[ab], om1);
+        const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
+        const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
+        const int a = a0 + wave * 64 + ab * 32 + l31;
+        if (hi == 0 && a < cap_a) {
+            const size_t o = ((size_t)p * S + split) * cap_a + a;
+            ws_max[o] = m1;
+            ws_i1[o] = i1;
+            ws_m2[o] = m2;
+        }
+    }
+}
+
 // fp32 rows (k permuted inside groups of 8: position 8g+4h+j holds k = 8g+2j+h) -> fp16 rows in natural k order, the values K0's
 // fp16 output would hold.  One lane per group of 8.
 __device__ __forceinline__ uint4 half_group_from_permuted(const float4 lo, const float4 hi4)
@@ -1240,6 +1421,22 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
 }
 }  // namespace
 
+namespace {
+template <int CP>
+void launch_screen_mx6(int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q, const int32_t *n_a,
+                       const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
+{
+    // C_pad 256: 512-anchor panels (8 waves; `groups` was sized for 256-anchor panels, T of them per unit).  C_pad 512: the stationary
+    // operand is 128 registers, so 4 waves per workgroup and one workgroup per CU (512 registers per wave), as the int8 kernel
+    constexpr size_t dyn = 2 * screen8_tile_bytes(CP) > 65536 ? 2 * screen8_tile_bytes(CP) : 0;
+    constexpr int W_ = CP == 512 ? 4 : 8;
+    const int Tw = (cap_a + 64 * W_ - 1) / (64 * W_);
+    if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_mx6_screen_kernel<CP, W_>), (int)dyn);
+    hipLaunchKernelGGL((match_mx6_screen_kernel<CP, W_>), dim3(groups / T * Tw), dim3(64 * W_), dyn, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw, S,
+                       ws_max, ws_i1, ws_m2);
+}
+}  // namespace
+
 extern "C" size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a, int cap_q)
 {
     if (B <= 0 || C <= 0 || cap_a <= 0 || cap_a % MT16 || cap_q <= 0) return 0;
@@ -1304,7 +1501,7 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
 namespace oryon {
 int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
                      const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
-                     float *out32, int lanes_per_row, int round_f16, hipStream_t st);
+                     float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt = 0);
 }
 
 namespace {
@@ -1439,7 +1636,7 @@ constexpr uint8_t LZ_INVALID = 0, LZ_VALID = 1, LZ_UNCERTAIN = 2, LZ_AMB_VALID =
 __global__ __launch_bounds__(256) void match_decide_lite_kernel(
     int cap_a, const int32_t *__restrict__ n_a, int S, const float *__restrict__ ws_m1, const int32_t *__restrict__ ws_i1,
     const float *__restrict__ ws_m2, const float *__restrict__ a_scale8, const float *__restrict__ eps_q8, float cut0, float sqrt_c,
-    float c_true, int force_eager, float *__restrict__ m_final, int32_t *__restrict__ sid_final, float *__restrict__ margin_out,
+    float c_true, int force_eager, int fmt, float *__restrict__ m_final, int32_t *__restrict__ sid_final, float *__restrict__ margin_out,
     uint8_t *__restrict__ state, uint8_t *__restrict__ valid, float *__restrict__ min_dist, int32_t *__restrict__ argmin,
     int32_t *__restrict__ pair_eager, int32_t *__restrict__ n_unc, int32_t *__restrict__ unc_idx, int32_t *__restrict__ n_ambu,
     int32_t *__restrict__ ambu_idx, int32_t *__restrict__ need_f32_lazy, int32_t *__restrict__ n_amb_total)
@@ -1455,11 +1652,19 @@ __global__ __launch_bounds__(256) void match_decide_lite_kernel(
         m2 = fmaxf(fminf(m1, x1), fmaxf(m2, x2));
         if (x1 > m1) { m1 = x1; sid = ws_i1[o]; }
     }
-    const float sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];
-    m1 *= sa;
-    m2 *= sa;
-    const float ea = 0.50003f * sa, eq = 1.00006f * eps_q8[p];
-    const float delta = (ea + eq) * sqrt_c + c_true * ea * eq + 4e-5f;
+    float delta;
+    if (fmt == 1) {
+        // mx6 screen: scores are dequantised dot products; a_scale8 / eps_q8 hold the pair's largest measured row error |e|_2 of the
+        // anchor / query rows (K0, FMT = 1): |s6 - a^.q^| <= |ea| + |eq| + |ea||eq| + fp32 accumulation slack
+        const float ea = a_scale8[p], eq = eps_q8[p];
+        delta = ea + eq + ea * eq + 1.2e-4f;       // + fp32 accumulation of <= 512 products in the MFMA and in the canonical chain (<= 7e-5)
+    } else {
+        const float sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];
+        m1 *= sa;
+        m2 *= sa;
+        const float ea = 0.50003f * sa, eq = 1.00006f * eps_q8[p];
+        delta = (ea + eq) * sqrt_c + c_true * ea * eq + 4e-5f;
+    }
     const bool usable = delta < 0.2f;
     const float margin = usable ? 2.0f * delta + 2e-7f : INFINITY;
     m_final[arow] = m1;
@@ -1561,7 +1766,22 @@ __global__ __launch_bounds__(256) void match_list_sampled_amb_kernel(int cap_a, 
 // Exact resolution of ONE unambiguous anchor by one wave: candidates = rows of the winning 16-row slice within the int8 margin of its
 // maximum (re-scored from the int8 rows, as match_decide_kernel does), then the canonical fp32 chain per candidate on x_k / d read
 // from the raw map (as match_rescore_raw_kernel does).  Returns (distance, first index of the minimum) in lane 0.
-template <bool NHWC, bool NEED_DIST = true>
+typedef float f32x32r __attribute__((ext_vector_type(32)));
+typedef unsigned u32x6r __attribute__((ext_vector_type(6)));
+
+// dequantised dot product of two mx6 slots (32 channels): codes decoded by the conversion instruction (exact: multiples of 1/8 up to
+// 7.5), 32 exact products summed in fp32 (every partial sum is a multiple of 1/64 below 2^11: exact), times both block exponents
+__device__ __forceinline__ float mx6_block_dot(const uint4 a_lo, const uint4 a_up, const uint4 q_lo, const uint4 q_up)
+{
+    const u32x6r ca = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_up.x, a_up.y}, cq = {q_lo.x, q_lo.y, q_lo.z, q_lo.w, q_up.x, q_up.y};
+    const f32x32r fa = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(ca, 1.0f), fq = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(cq, 1.0f);
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sum = __fmaf_rn(fa[i], fq[i], sum);
+    return sum * ldexpf(1.0f, (int)(a_up.z & 255u) + (int)(q_up.z & 255u) - 254);
+}
+
+template <bool NHWC, bool NEED_DIST = true, int FMT = 0>
 __device__ __forceinline__ void resolve_anchor(int p, int a, const float *__restrict__ a_hat, const int8_t *__restrict__ a8,
                                                const int8_t *__restrict__ q8, const float *__restrict__ q_scale8,
                                                const float *__restrict__ a_scale8, const float *__restrict__ feat_q, int C_true, int HW,
@@ -1574,6 +1794,27 @@ __device__ __forceinline__ void resolve_anchor(int p, int a, const float *__rest
     const int half = sid & 1, blk = sid >> 1;
     const int r = lane >> 2, seg = lane & 3;
     const int q = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    bool hit;
+    if constexpr (FMT == 1) {
+        // mx6 rows: the 16 rows of the winning slice re-scored from the very operands the screen multiplied (software sum: the order of
+        // the additions differs from the MFMA's, inside the bound's slack); candidates = rows within the margin of the SLICE maximum
+        // (every exact minimiser lies in this slice and scores at least max - 2 delta)
+        float s6 = 0.0f;
+        if (q < nq) {
+            const uint4 *ar = reinterpret_cast<const uint4 *>(a8 + arow * Cp) + seg * (Cp / 64);
+            const uint4 *qr = reinterpret_cast<const uint4 *>(q8 + ((size_t)p * cap_q + q) * Cp) + seg * (Cp / 64);
+            for (int b = 0; b < Cp / 128; ++b) s6 += mx6_block_dot(ar[2 * b], ar[2 * b + 1], qr[2 * b], qr[2 * b + 1]);
+        }
+        s6 += __shfl_xor(s6, 1);
+        s6 += __shfl_xor(s6, 2);
+        float mx = (q < nq) ? s6 : -INFINITY;
+        mx = fmaxf(mx, __shfl_xor(mx, 4));
+        mx = fmaxf(mx, __shfl_xor(mx, 8));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        hit = (seg == 0) && (q < nq) && (s6 >= mx - margin - 4e-5f);
+        (void)m1;
+    } else {
     const float sa = a_scale8[(size_t)p * (cap_a / 16) + (a >> 5) * 2 + ((a >> 2) & 1)];
     int idot = 0;
     if (q < nq) {
@@ -1590,7 +1831,8 @@ __device__ __forceinline__ void resolve_anchor(int p, int a, const float *__rest
     idot += __shfl_xor(idot, 1);
     idot += __shfl_xor(idot, 2);
     const float s8 = (float)idot * q_scale8[(size_t)p * (cap_q / 16) + sid] * sa;
-    const bool hit = (seg == 0) && (q < nq) && (s8 >= m1 - margin);
+    hit = (seg == 0) && (q < nq) && (s8 >= m1 - margin);
+    }
     unsigned long long hits = __ballot(hit);
     if (!NEED_DIST && __popcll(hits) == 1) {
         // a single row inside the int8 margin IS the argmin (every other row is provably farther): no fp32 work, and none of the 256
@@ -1641,7 +1883,7 @@ __device__ __forceinline__ void resolve_anchor(int p, int a, const float *__rest
 }
 
 // anchors whose VALIDITY the int8 bound could not settle (pairs on the lazy route only): exact distance now, before the sampling
-template <bool NHWC>
+template <bool NHWC, int FMT = 0>
 __global__ __launch_bounds__(256) void match_resolve_uncertain_kernel(
     const float *__restrict__ a_hat, const int8_t *__restrict__ a8, const int8_t *__restrict__ q8, const float *__restrict__ q_scale8,
     const float *__restrict__ a_scale8, const float *__restrict__ feat_q, int C_true, int HW, const int32_t *__restrict__ roi_q,
@@ -1660,7 +1902,7 @@ __global__ __launch_bounds__(256) void match_resolve_uncertain_kernel(
         const size_t arow = (size_t)p * cap_a + a;
         float d;
         int j;
-        resolve_anchor<NHWC>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q, n_q[p],
+        resolve_anchor<NHWC, true, FMT>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q, n_q[p],
                              m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, round_f16, d, j);
         if (lane == 0) {
             min_dist[arow] = d;
@@ -1672,7 +1914,7 @@ __global__ __launch_bounds__(256) void match_resolve_uncertain_kernel(
 }
 
 // the sampled rows of the lazy pairs: exact argmin -> query half of the correspondence
-template <bool NHWC>
+template <bool NHWC, int FMT = 0>
 __global__ __launch_bounds__(256) void match_resolve_selected_kernel(
     const float *__restrict__ a_hat, const int8_t *__restrict__ a8, const int8_t *__restrict__ q8, const float *__restrict__ q_scale8,
     const float *__restrict__ a_scale8, const float *__restrict__ feat_q, int C_true, int HW, const int32_t *__restrict__ roi_q,
@@ -1695,7 +1937,7 @@ __global__ __launch_bounds__(256) void match_resolve_selected_kernel(
     if (state[arow] == LZ_RESOLVED) {
         j = argmin[arow];
     } else {
-        resolve_anchor<NHWC, false>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q,
+        resolve_anchor<NHWC, false, FMT>(p, a, a_hat, a8, q8, q_scale8, a_scale8, feat_q, C_true, HW, roi_q, roi_stride, norm_q, Cp, cap_a, cap_q,
                                     n_q[p], m_final[arow], sid_final[arow], margin_in[arow], lds_res + wave * 2 * Cp, round_f16, d, j);
         if (lane == 0) {                                                // same values from every slot that drew this row
             argmin[arow] = j;
@@ -1784,6 +2026,16 @@ extern "C" size_t oryon_match_corrs_i8_workspace_bytes(int B, int C, int cap_a, 
     return carve_lazy(nullptr, B, C, cap_a, cap_q, pick_split16(B, cap_a / MT16), corr_rows).bytes;
 }
 
+// fmt 0: int8 rows (a_scale / q_scale per 16-row slice, q_eps_max per pair).  fmt 1: mx6 rows in a_i8 / q_i8, a_scale = the largest
+// anchor-row error norm per pair [B], q_eps_max = the largest query-row error norm per pair [B], q_scale unused; lazy route only.
+static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW,
+                                 int layout, const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q,
+                                 const float *q_norm, const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C,
+                                 int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs,
+                                 int corr_rows, uint64_t seed, const int64_t *pair_key, int force_eager, float *min_dist,
+                                 int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
+                                 int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream, int fmt);
+
 extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW,
                                     int layout, const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q,
                                     const float *q_norm, const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C,
@@ -1792,8 +2044,37 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
                                     int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
                                     int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream)
 {
-    ORYON_CHECK_ARG(a_hat && a_i8 && a_scale && feat_q && roi_a && roi_q && q_norm && q_i8 && q_scale && q_eps_max && n_a && n_q);
-    ORYON_CHECK_ARG(min_dist && argmin && valid && corrs && n_valid && n_sel && status);
+    ORYON_CHECK_ARG(a_scale && q_scale);
+    return match_corrs_lazy_impl(a_hat, a_i8, a_scale, feat_q, C_true, HW, layout, roi_a, roi_stride_a, roi_q, roi_stride_q, q_norm, q_i8, q_scale,
+                                 q_eps_max, B, C, cap_a, cap_q, n_a, n_q, threshold, W, max_corrs, corr_rows, seed, pair_key, force_eager, min_dist,
+                                 argmin, valid, corrs, n_valid, n_sel, status, n_undecided, round_f16, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int oryon_match_corrs_mx6(const float *a_hat, const uint8_t *a_mx6, const float *a_err_max, const float *feat_q, int C_true, int HW,
+                                     int layout, const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q,
+                                     const float *q_norm, const uint8_t *q_mx6, const float *q_err_max, int B, int C, int cap_a, int cap_q,
+                                     const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs, int corr_rows,
+                                     uint64_t seed, const int64_t *pair_key, float *min_dist, int32_t *argmin, uint8_t *valid,
+                                     int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status, int32_t *n_undecided, int round_f16,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    ORYON_CHECK_ARG(a_err_max && q_err_max);
+    return match_corrs_lazy_impl(a_hat, reinterpret_cast<const int8_t *>(a_mx6), a_err_max, feat_q, C_true, HW, layout, roi_a, roi_stride_a, roi_q,
+                                 roi_stride_q, q_norm, reinterpret_cast<const int8_t *>(q_mx6), nullptr, q_err_max, B, C, cap_a, cap_q, n_a, n_q,
+                                 threshold, W, max_corrs, corr_rows, seed, pair_key, 0, min_dist, argmin, valid, corrs, n_valid, n_sel, status,
+                                 n_undecided, round_f16, workspace, workspace_bytes, stream, 1);
+}
+
+static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW,
+                                 int layout, const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q,
+                                 const float *q_norm, const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C,
+                                 int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs,
+                                 int corr_rows, uint64_t seed, const int64_t *pair_key, int force_eager, float *min_dist,
+                                 int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
+                                 int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream, int fmt)
+{
+    ORYON_CHECK_ARG(a_hat && a_i8 && a_scale && feat_q && roi_a && roi_q && q_norm && q_i8 && q_eps_max && n_a && n_q);
+    ORYON_CHECK_ARG(min_dist && argmin && valid && corrs && n_valid && n_sel && status && !(fmt == 1 && force_eager));
     ORYON_CHECK_ARG(B >= 0 && (C == 256 || C == 512) && C_true > 0 && C_true <= C && HW > 0 && W > 0 && max_corrs > 0 && corr_rows >= max_corrs);
     ORYON_CHECK_ARG(layout == ORYON_LAYOUT_NCHW || layout == ORYON_LAYOUT_NHWC);
     ORYON_CHECK_ARG(cap_a > 0 && cap_a % MT16 == 0 && cap_q > 0 && cap_q % 256 == 0 && threshold > 0.0f && threshold <= 0.5f);
@@ -1815,14 +2096,22 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     const float cut0 = 1.0f - 2.0f * threshold;
     const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
     const int groups = ((B * S + 7) / 8) * 8 * T;
+    if (fmt == 1) {
+        const uint8_t *a6 = reinterpret_cast<const uint8_t *>(a_i8), *q6 = reinterpret_cast<const uint8_t *>(q_i8);
+        profile_begin(st, C == 256 ? "match_mx6_screen_kernel<256, 8>" : "match_mx6_screen_kernel<512, 4>");
+        if (C == 256) launch_screen_mx6<256>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2);
+        else launch_screen_mx6<512>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2);
+        profile_end(st);
+    } else {
     profile_begin(st, C == 256 ? screen8_name<256>() : screen8_name<512>());
     if (C == 256) launch_screen8<256>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     else launch_screen8<512>(groups, st, a_i8, q_i8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, w.ws_max, w.ws_i1, w.ws_m2);
     profile_end(st);
+    }
     ORYON_CHECK_LAUNCH();
     const float sqrt_c = sqrtf((float)C_true);
     hipLaunchKernelGGL(match_decide_lite_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, n_a, S, w.ws_max, w.ws_i1, w.ws_m2, a_scale,
-                       q_eps_max, cut0, sqrt_c, (float)C_true, force_eager, w.m_final, lw.sid_final, lw.margin, lw.state, valid, min_dist,
+                       q_eps_max, cut0, sqrt_c, (float)C_true, force_eager, fmt, w.m_final, lw.sid_final, lw.margin, lw.state, valid, min_dist,
                        argmin, lw.pair_eager, lw.n_unc, lw.unc_idx, lw.n_ambu, lw.ambu_idx, lw.need_f32_lazy, lw.n_amb_total);
     hipLaunchKernelGGL(match_mask_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_a, lw.pair_eager, lw.n_a_eager, lw.n_a_lazy);
     ORYON_CHECK_LAUNCH();
@@ -1878,12 +2167,15 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
     ORYON_CHECK_LAUNCH();
     // (3) unambiguous anchors whose validity is open: exact distance from the winning slice's candidates
     const size_t lds_res = (size_t)4 * 2 * C * sizeof(float);
-#define RESOLVE_U(NHWCV)                                                                                                       \
-    hipLaunchKernelGGL((match_resolve_uncertain_kernel<NHWCV>), dim3(64, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8, q_scale, a_scale,     \
+#define RESOLVE_U(NHWCV) RESOLVE_U2(NHWCV, 0)
+#define RESOLVE_U2(NHWCV, FMTV)                                                                                                \
+    hipLaunchKernelGGL((match_resolve_uncertain_kernel<NHWCV, FMTV>), dim3(64, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8, q_scale, a_scale,     \
                        feat_q, C_true, HW, roi_q, roi_stride_q, q_norm, C, cap_a, cap_q, n_q, threshold, w.m_final, lw.sid_final, lw.margin,   \
                        lw.n_unc, lw.unc_idx, lw.pair_eager, lw.state, valid, min_dist, argmin, round_f16)
-    if (layout == ORYON_LAYOUT_NHWC) RESOLVE_U(true); else RESOLVE_U(false);
+    if (fmt == 1) { if (layout == ORYON_LAYOUT_NHWC) RESOLVE_U2(true, 1); else RESOLVE_U2(false, 1); }
+    else if (layout == ORYON_LAYOUT_NHWC) RESOLVE_U(true); else RESOLVE_U(false);
 #undef RESOLVE_U
+#undef RESOLVE_U2
     ORYON_CHECK_LAUNCH();
     // (4) the sampling, on the exact valid set
     rc = select_corrs_launch(roi_a, roi_q, roi_stride_a, roi_stride_q, n_a, n_q, argmin, valid, cap_a, B, W, max_corrs, corr_rows, seed,
@@ -1904,12 +2196,15 @@ extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, cons
                        w8.md_c, w8.am_c, w8.va_c, min_dist, argmin, valid, lw.state);
     ORYON_CHECK_LAUNCH();
     // (6) query half of every sampled correspondence: resolved rows read their argmin, the others get it from their winning slice
-#define RESOLVE_S(NHWCV)                                                                                                       \
-    hipLaunchKernelGGL((match_resolve_selected_kernel<NHWCV>), dim3((max_corrs + 3) / 4, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8,       \
+#define RESOLVE_S(NHWCV) RESOLVE_S2(NHWCV, 0)
+#define RESOLVE_S2(NHWCV, FMTV)                                                                                                \
+    hipLaunchKernelGGL((match_resolve_selected_kernel<NHWCV, FMTV>), dim3((max_corrs + 3) / 4, B), dim3(256), lds_res, st, a_hat, a_i8, q_i8,       \
                        q_scale, a_scale, feat_q, C_true, HW, roi_q, roi_stride_q, q_norm, C, cap_a, cap_q, n_q, W, w.m_final, lw.sid_final,    \
                        lw.margin, lw.state, lw.pair_eager, n_sel, lw.sel_rows, corr_rows, min_dist, argmin, corrs, round_f16)
-    if (layout == ORYON_LAYOUT_NHWC) RESOLVE_S(true); else RESOLVE_S(false);
+    if (fmt == 1) { if (layout == ORYON_LAYOUT_NHWC) RESOLVE_S2(true, 1); else RESOLVE_S2(false, 1); }
+    else if (layout == ORYON_LAYOUT_NHWC) RESOLVE_S(true); else RESOLVE_S(false);
 #undef RESOLVE_S
+#undef RESOLVE_S2
     ORYON_CHECK_LAUNCH();
     if (n_undecided) {       // anchors the int8 stage could not fully decide: the fp16-stage anchors of eager pairs + the ambiguous anchors of lazy pairs
         hipLaunchKernelGGL(match_sum_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, w.n_amb, lw.n_amb_total, n_undecided);

@@ -68,7 +68,7 @@ class NativeStep:
     }
 
     def __init__(self, solver: PointDSC, cfg: "MatchPoseConfig", key: Tuple, dev: torch.device, overlap: int, n_slots: int = 6,
-                 gather_sets: int = 3, reg_streams: int = 2, reg_lag: int = 0):
+                 gather_sets: int = 3, reg_streams: int = 2, reg_lag: int = 0, screen: int = 1):
         B, C, FH, FW, HA, WA, HQ, WQ, layout = key
         self.key, self.dev = key, dev
         solver._ensure_handle(dev)
@@ -77,7 +77,7 @@ class NativeStep:
                                       n_corrs=cfg.n_corrs, src_sampling=int(cfg.src_sampling or 0), seed=int(cfg.seed) & (2**64 - 1),
                                       round_f16=int(cfg.half_descriptors), n_slots=n_slots, overlap=overlap,
                                       gather_sets=min(gather_sets, n_slots), reg_streams=reg_streams,
-                                      reg_lag=reg_lag if overlap else 0)
+                                      reg_lag=reg_lag if overlap else 0, screen=screen)
         self.cfg_sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap)
         need = lib().oryon_engine_arena_bytes(ctypes.byref(self.ecfg), solver._handle)
         if need == 0:
@@ -178,7 +178,7 @@ class MatchPoseEngine:
         self.result_views = result_views
         self._native: Optional[NativeStep] = None
         self._inflight: Dict[int, Dict[str, Tensor]] = {}       # slot -> result dict of the native step that last used it
-        self.native_geometry = dict(n_slots=6, gather_sets=3, reg_streams=2, reg_lag=0)      # NativeStep's pipeline depth (see oryon_engine_config_t)
+        self.native_geometry = dict(n_slots=6, gather_sets=3, reg_streams=2, reg_lag=0, screen=1)      # NativeStep's pipeline depth (see oryon_engine_config_t)
         self.native_timing = False          # bracket the sections of every native step with HIP events (NativeStep.timing)
         self._reg_stream = None
         self.reg_streams = 2

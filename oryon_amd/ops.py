@@ -322,6 +322,52 @@ def gather_q8(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_c
     return out8, scale, eps, norm, out32
 
 
+@_on_tensor_device
+def gather_mx6(feat: torch.Tensor, roi: torch.Tensor, count: torch.Tensor, rows_cap: int, c_pad: int, want_f32: bool = False,
+               round_f16: bool = False):
+    """K0 with MX-fp6 screening operands (oryon_gather_mx6): -> (rows uint8 [n,rows_cap,c_pad] of 32-byte slots, err_max [n] fp32,
+    row_norm [n,rows_cap], rows fp32 k-permuted | None)."""
+    dev = _lib.require_gpu(feat.device)
+    assert feat.dtype == torch.float32 and feat.dim() == 4
+    feat, layout = map_layout(feat)
+    n_maps, C, H, W = feat.shape
+    assert c_pad in (256, 512) and C <= c_pad and rows_cap % ROW_PAD == 0
+    out6 = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.uint8, device=dev)
+    err = torch.empty((n_maps,), dtype=torch.float32, device=dev)
+    norm = torch.empty((n_maps, rows_cap), dtype=torch.float32, device=dev)
+    out32 = torch.empty((n_maps, rows_cap, c_pad), dtype=torch.float32, device=dev) if want_f32 else None
+    check(lib().oryon_gather_mx6(feat.data_ptr(), n_maps, C, H * W, layout, ptr(roi), roi.shape[1], ptr(count), rows_cap, c_pad, ptr(out6),
+                                 ptr(err), ptr(norm), ptr(out32), int(bool(round_f16)), stream_ptr(dev)), "oryon_gather_mx6")
+    return out6, err, norm, out32
+
+
+@_on_tensor_device
+def match_corrs_mx6(a_hat, a6, a_err, feat_q, roi_a, roi_q, q_norm, q6, q_err, n_a, n_q, threshold: float, W: int, max_corrs: int,
+                    seed: int, pair_key=None, corr_rows: Optional[int] = None, n_undecided=None, round_f16: bool = False):
+    """oryon_match_corrs_mx6: the lazy matcher + sampler on MX-fp6 operands; same outputs as match_corrs_i8."""
+    dev = _lib.require_gpu(a_hat.device)
+    feat_q, layout = map_layout(feat_q)
+    B, cap_a, Cp = a_hat.shape
+    cap_q = q6.shape[1]
+    C_true, HW = feat_q.shape[1], feat_q.shape[2] * feat_q.shape[3]
+    corr_rows = int(corr_rows or max_corrs)
+    min_dist = torch.empty((B, cap_a), dtype=torch.float32, device=dev)
+    argmin = torch.empty((B, cap_a), dtype=torch.int32, device=dev)
+    valid = torch.empty((B, cap_a), dtype=torch.uint8, device=dev)
+    corrs = torch.zeros((B, corr_rows, 4), dtype=torch.int32, device=dev)
+    n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
+    n_sel = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    wsb = lib().oryon_match_corrs_i8_workspace_bytes(B, Cp, cap_a, cap_q, corr_rows)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+    check(lib().oryon_match_corrs_mx6(ptr(a_hat), ptr(a6), ptr(a_err), feat_q.data_ptr(), C_true, HW, layout, ptr(roi_a), roi_a.shape[1],
+                                      ptr(roi_q), roi_q.shape[1], ptr(q_norm), ptr(q6), ptr(q_err), B, Cp, cap_a, cap_q, ptr(n_a), ptr(n_q),
+                                      float(threshold), int(W), int(max_corrs), corr_rows, int(seed) & (2**64 - 1), ptr(pair_key),
+                                      ptr(min_dist), ptr(argmin), ptr(valid), ptr(corrs), ptr(n_valid), ptr(n_sel), ptr(status),
+                                      ptr(n_undecided), int(bool(round_f16)), ptr(ws), ws.numel(), stream_ptr(dev)), "oryon_match_corrs_mx6")
+    return corrs, n_valid, n_sel, status, min_dist, argmin, valid
+
+
 import threading
 
 _raw_ws = {}                      # (device, stream) -> cached matcher workspace (holds room for the rarely used fp32 fall-back rows)

@@ -514,9 +514,17 @@ def _lazy_vs_eager(fa, fq, ma, mq, C_pad, thr, max_corrs=500, subsample=None, ch
                               corr_rows=ops.round_up(max_corrs, 128), n_undecided=und)
     eager = ops.match_corrs_i8(a_hat, a8, a_sc, fq, roi_a, roi_q, q_norm, q8, q_sc, q_eps, na, nq, thr, W, max_corrs, 1, key,
                                corr_rows=ops.round_up(max_corrs, 128), force_eager=True)
+    # the MX-fp6 screen (round 3) in front of the same lazy tail: different operands, different bound, identical results
+    a6, a_err, _, a_hat6 = ops.gather_mx6(fa, roi_a, na, cap_a, C_pad, want_f32=True)
+    q6, q_err, q_norm6, _ = ops.gather_mx6(fq, roi_q, nq, cap_q, C_pad)
+    for b in range(B):                                    # same canonical fp32 rows / norms as K0v3 (rows beyond the counts are not written)
+        assert torch.equal(a_hat6[b, : int(na[b])], a_hat[b, : int(na[b])]) and torch.equal(q_norm6[b, : int(nq[b])], q_norm[b, : int(nq[b])])
+    und6 = torch.zeros((B,), dtype=torch.int32, device=fa.device)
+    mx6 = ops.match_corrs_mx6(a_hat, a6, a_err, fq, roi_a, roi_q, q_norm, q6, q_err, na, nq, thr, W, max_corrs, 1, key,
+                              corr_rows=ops.round_up(max_corrs, 128), n_undecided=und6)
     md0, am0, va0 = ops.match(a_hat, q_hat, na, nq, thr)
     c_ref, nv_ref, ns_ref, st_ref = ops.select_corrs(roi_a, roi_q, na, nq, am0, va0, W, max_corrs, 1, key, corr_rows=ops.round_up(max_corrs, 128))
-    for name, out in (("lazy", lazy), ("eager", eager)):
+    for name, out in (("lazy", lazy), ("eager", eager), ("mx6", mx6)):
         corrs, n_valid, n_sel, status, md, am, va = out
         assert torch.equal(status, st_ref) and torch.equal(n_valid, nv_ref) and torch.equal(n_sel, ns_ref), name
         for b in range(B):
@@ -599,3 +607,63 @@ def test_lazy_corrs_exact_ties_and_single_candidates():
     mq = torch.ones((4, H, H), dtype=torch.int32, device=dev)
     (corrs, n_valid, n_sel, status, md, am, va), und, va0, na = _lazy_vs_eager(fa, fq, ma, mq, 256, 0.25)
     assert status.tolist() == [0, 0, 0, 0] and min(n_valid.tolist()) > 1500
+
+
+def _decode_mx6(rows: torch.Tensor) -> torch.Tensor:
+    """uint8 mx6 rows [..., C_pad] (32-byte slots: 24 B of fp6 e2m3 codes, exponent byte, padding) -> float64 values [..., C_pad]."""
+    r = rows.cpu().numpy().astype(np.uint64)
+    lead, cp = r.shape[:-1], r.shape[-1]
+    slots = r.reshape(*lead, cp // 32, 32)
+    bits = np.zeros(slots.shape[:-1], dtype=object)
+    out = np.zeros((*lead, cp // 32, 32), dtype=np.float64)
+    code_bytes = slots[..., :24]
+    for t in range(32):
+        bit = 6 * t
+        b0, sh = bit // 8, bit % 8
+        word = code_bytes[..., b0] | (code_bytes[..., min(b0 + 1, 23)] << np.uint64(8))
+        c = (word >> np.uint64(sh)) & np.uint64(63)
+        sgn = np.where((c >> np.uint64(5)) & np.uint64(1), -1.0, 1.0)
+        e = ((c >> np.uint64(3)) & np.uint64(3)).astype(np.int64)
+        m = (c & np.uint64(7)).astype(np.float64)
+        val = np.where(e == 0, m / 8.0, (1.0 + m / 8.0) * np.power(2.0, np.maximum(e - 1, 0)))
+        out[..., t] = sgn * val
+    scale = np.power(2.0, slots[..., 24].astype(np.int64) - 127)
+    assert (slots[..., 25:] == 0).all()
+    return torch.from_numpy((out * scale[..., None]).reshape(*lead, cp))
+
+
+@pytest.mark.parametrize("C,C_pad,channels_last", [(256, 256, False), (200, 256, True), (400, 512, False)])
+def test_k0_mx6_rows_decode_to_the_unit_rows_within_the_measured_error(C, C_pad, channels_last):
+    """oryon_gather_mx6: every live row's slots decode (element t at bits [6t, 6t+6) of a slot, times 2^(byte 24 - 127)) to the canonical
+    unit row within fp6's resolution; the reported err_max is an upper bound of every row's |x^ - dequant|_2 and tight (largest row);
+    block maxima sit in (3.75, 7.5] code units; dead rows of the last 256-row group are zero rows; fp32 rows / norms equal K0v3's."""
+    from oryon_amd import ops
+    dev = "cuda"
+    H = 24
+    g = torch.Generator(device=dev).manual_seed(5)
+    feat = torch.randn(2, C, H, H, generator=g, device=dev) * torch.rand(2, C, 1, 1, generator=g, device=dev) * 3.0
+    feat[1, :, 3, 4] = 0.0                                              # a zero descriptor (eps path of the norm)
+    feat[0, 5:40, 7, 7] *= 1e-4                                         # a block of tiny values next to large ones
+    if channels_last:
+        feat = feat.contiguous(memory_format=torch.channels_last)
+    mask = torch.ones((2, H, H), dtype=torch.int32, device=dev)
+    mask[1, :, ::3] = 0
+    roi, n = ops.roi_compact(mask)
+    cap = ops.round_up(H * H, 256)
+    r6, err, norm, hat = ops.gather_mx6(feat, roi, n, cap, C_pad, want_f32=True)
+    r8, _, _, norm8, hat8 = ops.gather_q8(feat, roi, n, cap, C_pad, want_f32=True)
+    assert torch.equal(norm[0, : int(n[0])], norm8[0, : int(n[0])]) and torch.equal(hat[1, : int(n[1])], hat8[1, : int(n[1])])
+    unit = ops.unpermute_k(hat).double().cpu()
+    for m_ in range(2):
+        k = int(n[m_])
+        dec = torch.zeros((2, cap, C_pad), dtype=torch.float64)
+        dec[m_, : (k + 255) // 256 * 256] = _decode_mx6(r6[m_, : (k + 255) // 256 * 256])      # rows beyond are not written
+        e = (dec[m_, :k] - unit[m_, :k]).norm(dim=1)
+        assert float(e.max()) <= float(err[m_]) * (1 + 1e-6) + 1e-7 and float(e.max()) >= 0.98 * float(err[m_]), (float(e.max()), float(err[m_]))
+        assert float(err[m_]) < 0.05                                     # e2m3 with per-block exponents: ~2-3 % of a unit row
+        kf = (k + 255) // 256 * 256
+        assert (r6[m_, k:kf].cpu()[..., :24] == 0).all() and (dec[m_, k:kf] == 0).all()
+        blocks = (dec[m_, :k].reshape(k, C_pad // 32, 32).abs().amax(dim=2)
+                  / torch.pow(2.0, r6[m_, :k].cpu().reshape(k, C_pad // 32, 32)[..., 24].double() - 127))
+        live = dec[m_, :k].reshape(k, C_pad // 32, 32).abs().amax(dim=2) > 0
+        assert float(blocks[live].min()) > 3.7 and float(blocks[live].max()) <= 7.5

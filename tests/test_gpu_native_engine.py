@@ -132,7 +132,7 @@ def test_native_result_views_and_timing():
     n, tot, last = nat.host_stats()
     assert n == 8 and 0 < last < 50 and tot >= last
     from oryon_amd._lib import lib
-    assert lib().oryon_dominant_kernel().decode().startswith("match_i8_screen")
+    assert lib().oryon_dominant_kernel().decode().startswith("match_mx6_screen")
 
 
 def test_engine_c_abi_argument_checks():
@@ -142,7 +142,7 @@ def test_engine_c_abi_argument_checks():
     solver = _solver()
     solver._ensure_handle(torch.device("cuda", 0))
     cfg = _lib.EngineConfig(B=2, C=32, FH=16, FW=16, HA=16, WA=16, HQ=16, WQ=16, layout=0, dist_th=0.25, n_corrs=500, src_sampling=5000,
-                            seed=1, round_f16=0, n_slots=2, overlap=2, gather_sets=2, reg_streams=2, reg_lag=0)
+                            seed=1, round_f16=0, n_slots=2, overlap=2, gather_sets=2, reg_streams=2, reg_lag=0, screen=0)
     assert lib().oryon_engine_arena_bytes(ctypes.byref(cfg), solver._handle) == 0          # C <= 128 is not the int8 route
     cfg.C = 256
     need = lib().oryon_engine_arena_bytes(ctypes.byref(cfg), solver._handle)
