@@ -1,4 +1,5 @@
-"""Extended randomised sweep of the screened matchers (K1s8 -> K1s -> exact re-scoring) against the exact fp32 scan (K1).
+"""Extended randomised sweep of the screened matchers (K1s8 -> K1s -> exact re-scoring; the lazy int8 and MX-fp6 routes with the sampler)
+against the exact fp32 scan (K1).
 Same generator families as tests/test_gpu_matcher.py::test_screened_paths_randomised_stress plus adversarial ones: anchors placed
 at the threshold, near-duplicate query rows at graded distances (around the fp16 / int8 decision margins), tiny and huge norms.
 usage (GPU box): python tools/stress_matcher.py [n_cases] [seed]"""
@@ -11,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from test_gpu_matcher import _screen_vs_exact  # noqa: E402
+from test_gpu_matcher import _lazy_vs_eager, _screen_vs_exact  # noqa: E402
 
 dev = "cuda"
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -74,6 +75,9 @@ for case in range(n_cases):
     c_pad = 256 if C <= 256 else 512
     try:
         va, na = _screen_vs_exact(fa.contiguous(), fq.contiguous(), ma, mq, c_pad, thr=thr)
+        # the lazy routes (int8 screen, MX-fp6 screen) + sampler against select_corrs on the exact scan: same valid set, same counts,
+        # same sampled correspondences
+        _lazy_vs_eager(fa.contiguous(), fq.contiguous(), ma, mq, c_pad, thr, max_corrs=int(rng.choice([16, 100, 500])))
         for b in range(B):
             stats[kind][0] += int(va[b, : int(na[b])].sum())
             stats[kind][1] += int(na[b])
