@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
     const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride,
     const int32_t *__restrict__ count, const int32_t *__restrict__ map_enable, int rows_cap, int n_maps, int chunk_tiles,
     int chunks_per_map, int8_t *__restrict__ out8, float *__restrict__ scale, unsigned *__restrict__ eps_max,
-    float *__restrict__ norm, float *__restrict__ out32, int round_f16)
+    float *__restrict__ norm, float *__restrict__ out32, int round_f16, void *__restrict__ aux)
 {
     constexpr int ROWS = 64 / LPR;             // ROI rows per wave
     constexpr int KPL = CP / LPR;              // channels per lane
@@ -240,6 +240,41 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
     }
     if (seg == 0 && norm) norm[(size_t)m * rows_cap + my_row] = d;
 
+    if constexpr (FMT == 2) {
+        // error-compensated fp16 operands of the canonical unit row u = RN(x / d): hi = half(u), lo = half(u - hi) (22 significant
+        // bits together), natural k order, as two row arrays [n_maps, rows_cap, CP] of halves (out8 = hi rows, aux = lo rows): the
+        // operands of match_x3_scan_kernel.
+        static_assert(LPR == 1 || FMT != 2, "FMT = 2 is instantiated for one lane per row");
+        constexpr int HB = CP * 2;                              // bytes per half row
+#pragma unroll
+        for (int part = 0; part < KPL / 64; ++part) {           // 64 channels per staging pass: slots 0-7 = hi halves, 8-15 = lo halves
+            const int c0 = part * 64;
+            WAVE_LDS_ORDER();
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                unsigned wh[4], wl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float u0 = __fdiv_rn(VG(c0 + 8 * s + 2 * j), d), u1 = __fdiv_rn(VG(c0 + 8 * s + 2 * j + 1), d);
+                    const __half h0 = __float2half_rn(u0), h1 = __float2half_rn(u1);
+                    const __half l0 = __float2half_rn(u0 - __half2float(h0)), l1 = __float2half_rn(u1 - __half2float(h1));
+                    wh[j] = (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16);
+                    wl[j] = (unsigned)__half_as_ushort(l0) | ((unsigned)__half_as_ushort(l1) << 16);
+                }
+                *reinterpret_cast<uint4 *>(stage + stage_addr(lane, s, 256)) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+                *reinterpret_cast<uint4 *>(stage + stage_addr(lane, s + 8, 256)) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+            }
+            WAVE_LDS_ORDER();
+            char *oh = reinterpret_cast<char *>(out8) + ((size_t)m * rows_cap + row0) * HB + c0 * 2;
+            char *ol = reinterpret_cast<char *>(aux) + ((size_t)m * rows_cap + row0) * HB + c0 * 2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int f = j * 64 + lane, t = f / 16, s = f % 16;
+                const uint4 q = *reinterpret_cast<const uint4 *>(stage + stage_addr(t, s, 256));
+                *reinterpret_cast<uint4 *>((s < 8 ? oh : ol) + (size_t)t * HB + (s & 7) * 16) = q;
+            }
+        }
+    }
     if constexpr (FMT == 0) {
     // int8 rows: magic-number rounding (RN-even, like rintf) - the low byte of (x*rs + 1.5*2^23) is the two's complement of the integer
         constexpr int RB8 = KPL;                              // bytes per tile-lane row
@@ -360,7 +395,8 @@ using namespace oryon;
 namespace {
 template <int CP, int LPR, bool NHWC, int FMT = 0>
 void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, const int32_t *roi, int roi_stride, const int32_t *count,
-               const int32_t *map_enable, int rows_cap, int8_t *out8, float *scale, float *eps, float *norm, float *out32, int round_f16)
+               const int32_t *map_enable, int rows_cap, int8_t *out8, float *scale, float *eps, float *norm, float *out32, int round_f16,
+               void *aux = nullptr)
 {
     constexpr int WG_ROWS = 4 * (64 / LPR);
     const int T = (rows_cap + WG_ROWS - 1) / WG_ROWS;                 // workgroup tiles per map
@@ -371,7 +407,7 @@ void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, con
     auto kern = gather_q8_v3_kernel<CP, LPR, NHWC, FMT>;
     allow_dynamic_lds(reinterpret_cast<const void *>(kern), 4 * G8_STAGE_BYTES);
     hipLaunchKernelGGL(kern, dim3(groups), dim3(256), 4 * G8_STAGE_BYTES, st, feat, C, HW, roi, roi_stride, count, map_enable, rows_cap,
-                       n_maps, chunk_tiles, chunks_per_map, out8, scale, reinterpret_cast<unsigned *>(eps), norm, out32, round_f16);
+                       n_maps, chunk_tiles, chunks_per_map, out8, scale, reinterpret_cast<unsigned *>(eps), norm, out32, round_f16, aux);
 }
 }  // namespace
 
@@ -380,7 +416,7 @@ namespace oryon {
 // the call must not touch eps_max (fall-back pass)
 int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
                      const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
-                     float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt)
+                     float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt, void *aux)
 {
     const int lpr = C_pad == 512 ? 2 : (lanes_per_row == 2 ? 2 : 1);
 #define G8(CPV, LPRV, FMTV)                                                                                                    \
@@ -388,8 +424,14 @@ int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, c
         if (layout == ORYON_LAYOUT_NHWC) launch_g8<CPV, LPRV, true, FMTV>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
         else launch_g8<CPV, LPRV, false, FMTV>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
     } while (0)
-    if (fmt == 1) {
+    if (fmt == 2) {
+        // hi / lo half rows for the fp16x3 scan (C_pad 256 only): out8 = hi rows, aux = lo rows
+        if (C_pad != 256 || !aux) return ORYON_ERR_INVALID_ARG;
+        if (layout == ORYON_LAYOUT_NHWC) launch_g8<256, 1, true, 2>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16, aux);
+        else launch_g8<256, 1, false, 2>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16, aux);
+    } else if (fmt == 1) {
         if (C_pad == 512) G8(512, 2, 1);
+        else if (lpr == 2) G8(256, 2, 1);
         else G8(256, 1, 1);
     } else if (C_pad == 512) G8(512, 2, 0);
     else if (lpr == 2) G8(256, 2, 0);
@@ -412,7 +454,7 @@ extern "C" int oryon_gather_q8(const float *feat, int n_maps, int C, int HW, int
     ORYON_CHECK_HIP(hipMemsetAsync(eps_max, 0, (size_t)n_maps * sizeof(float), st));
     static const int lpr_env = getenv("ORYON_GATHER8_LPR") ? atoi(getenv("ORYON_GATHER8_LPR")) : 1;
     const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad, out_i8, slice_scale,
-                                    eps_max, row_norm, out_f32, lpr_env, round_f16, st, 0);
+                                    eps_max, row_norm, out_f32, lpr_env, round_f16, st, 0, nullptr);
     if (rc) { set_error("oryon_gather_q8: launch failed"); return rc; }
     return ORYON_OK;
 }
@@ -428,8 +470,9 @@ extern "C" int oryon_gather_mx6(const float *feat, int n_maps, int C, int HW, in
     if (n_maps == 0) return ORYON_OK;
     hipStream_t st = as_stream(stream);
     ORYON_CHECK_HIP(hipMemsetAsync(err_max, 0, (size_t)n_maps * sizeof(float), st));
+    static const int lpr_env = getenv("ORYON_GATHER8_LPR") ? atoi(getenv("ORYON_GATHER8_LPR")) : 1;
     const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad,
-                                    reinterpret_cast<int8_t *>(out_mx6), nullptr, err_max, row_norm, out_f32, 1, round_f16, st, 1);
+                                    reinterpret_cast<int8_t *>(out_mx6), nullptr, err_max, row_norm, out_f32, lpr_env, round_f16, st, 1, nullptr);
     if (rc) { set_error("oryon_gather_mx6: launch failed"); return rc; }
     return ORYON_OK;
 }

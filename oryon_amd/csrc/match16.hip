@@ -1501,7 +1501,7 @@ extern "C" int oryon_match_screened8(const float *a_hat, const float *q_hat, con
 namespace oryon {
 int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
                      const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
-                     float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt = 0);
+                     float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt = 0, void *aux = nullptr);
 }
 
 namespace {
@@ -1636,7 +1636,7 @@ constexpr uint8_t LZ_INVALID = 0, LZ_VALID = 1, LZ_UNCERTAIN = 2, LZ_AMB_VALID =
 __global__ __launch_bounds__(256) void match_decide_lite_kernel(
     int cap_a, const int32_t *__restrict__ n_a, int S, const float *__restrict__ ws_m1, const int32_t *__restrict__ ws_i1,
     const float *__restrict__ ws_m2, const float *__restrict__ a_scale8, const float *__restrict__ eps_q8, float cut0, float sqrt_c,
-    float c_true, int force_eager, int fmt, float *__restrict__ m_final, int32_t *__restrict__ sid_final, float *__restrict__ margin_out,
+    float c_true, int force_eager, int fmt, int x3, float *__restrict__ m_final, int32_t *__restrict__ sid_final, float *__restrict__ margin_out,
     uint8_t *__restrict__ state, uint8_t *__restrict__ valid, float *__restrict__ min_dist, int32_t *__restrict__ argmin,
     int32_t *__restrict__ pair_eager, int32_t *__restrict__ n_unc, int32_t *__restrict__ unc_idx, int32_t *__restrict__ n_ambu,
     int32_t *__restrict__ ambu_idx, int32_t *__restrict__ need_f32_lazy, int32_t *__restrict__ n_amb_total)
@@ -1685,7 +1685,9 @@ __global__ __launch_bounds__(256) void match_decide_lite_kernel(
     if (st == LZ_UNCERTAIN) unc_idx[(size_t)p * cap_a + atomicAdd(&n_unc[p], 1)] = a;
     if (st == LZ_AMB_UNCERTAIN) ambu_idx[(size_t)p * cap_a + atomicAdd(&n_ambu[p], 1)] = a;
     if (st == LZ_AMB_VALID || st == LZ_AMB_UNCERTAIN) {
-        need_f32_lazy[p] = 1;                                  // this pair's fp32 query rows get materialised (device-gated launch)
+        // this pair's fp32 query rows get materialised (device-gated launch) - with the fp16x3 second level (x3) only when an
+        // ambiguous anchor's VALIDITY is open too: the sampled valid ones are then resolved from hi / lo half rows made later
+        if (st == LZ_AMB_UNCERTAIN || !x3) need_f32_lazy[p] = 1;
         atomicAdd(&n_amb_total[p], 1);
     }
 }
@@ -1961,6 +1963,12 @@ struct LazyWs {
     int32_t *n_ambu, *ambu_idx, *n_ambv, *ambv_idx, *need_f32_lazy, *n_amb_total, *mark;
     void *exact_ws;
     size_t exact_ws_bytes;
+    // K1x3 (C_pad 256): hi / lo anchor rows, the overflow fall-back's compact rows and outputs, candidate lists
+    __half *x3_ah, *x3_al;
+    float *x3_a_ovf, *x3_md_o;
+    int32_t *x3_am_o;
+    uint8_t *x3_va_o;
+    void *x3_scratch;
     uint8_t *state;
     size_t bytes, zero_off, zero_bytes;
 };
@@ -1987,6 +1995,13 @@ LazyWs carve_lazy(void *base, int B, int C, int cap_a, int cap_q, int S, int cor
     const size_t e1 = oryon_match_workspace_bytes(B, cap_a), e2 = oryon_match_workspace_bytes(B, cap_s);
     w.exact_ws_bytes = e1 > e2 ? e1 : e2;                                  // split-merge scratch of the exact scan (either list capacity)
     const size_t o_ew = take(w.exact_ws_bytes > 16 ? w.exact_ws_bytes : 16);
+    const size_t o_xah = take((size_t)B * cap_s * C * sizeof(__half));
+    const size_t o_xal = take((size_t)B * cap_s * C * sizeof(__half));
+    const size_t o_xao = take((size_t)B * cap_s * C * sizeof(float));
+    const size_t o_xmd = take((size_t)B * cap_s * sizeof(float));
+    const size_t o_xam = take((size_t)B * cap_s * sizeof(int32_t));
+    const size_t o_xva = take((size_t)B * cap_s);
+    const size_t o_xsc = take(match_x3_scratch_bytes(B, cap_s, 8));
     w.zero_off = off;
     const size_t o_pe = take((size_t)B * sizeof(int32_t));
     const size_t o_nu = take((size_t)B * sizeof(int32_t));
@@ -2011,6 +2026,13 @@ LazyWs carve_lazy(void *base, int B, int C, int cap_a, int cap_q, int S, int cor
     w.ambu_idx = reinterpret_cast<int32_t *>(at(o_au));
     w.ambv_idx = reinterpret_cast<int32_t *>(at(o_av));
     w.exact_ws = at(o_ew);
+    w.x3_ah = reinterpret_cast<__half *>(at(o_xah));
+    w.x3_al = reinterpret_cast<__half *>(at(o_xal));
+    w.x3_a_ovf = reinterpret_cast<float *>(at(o_xao));
+    w.x3_md_o = reinterpret_cast<float *>(at(o_xmd));
+    w.x3_am_o = reinterpret_cast<int32_t *>(at(o_xam));
+    w.x3_va_o = reinterpret_cast<uint8_t *>(at(o_xva));
+    w.x3_scratch = at(o_xsc);
     w.n_ambu = reinterpret_cast<int32_t *>(at(o_nau));
     w.n_ambv = reinterpret_cast<int32_t *>(at(o_nav));
     w.need_f32_lazy = reinterpret_cast<int32_t *>(at(o_nfl));
@@ -2096,6 +2118,11 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     const float cut0 = 1.0f - 2.0f * threshold;
     const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
     const int groups = ((B * S + 7) / 8) * 8 * T;
+    // second level for the sampled anchors no screen can separate: fp16x3 scan (K1x3, C_pad 256) instead of the exact fp32 scan.  OFF unless
+    // ORYON_AMB_X3=1: exact (tests run both settings) but, as measured in round 3, slower than the exact scan on smooth fields - the one-pass
+    // running-maximum lists overflow there and the overflow falls back to the exact scan anyway ("K1x3")
+    static const bool x3_env = getenv("ORYON_AMB_X3") && atoi(getenv("ORYON_AMB_X3")) != 0;
+    const int use_x3 = (x3_env && C == 256 && !force_eager) ? 1 : 0;
     if (fmt == 1) {
         const uint8_t *a6 = reinterpret_cast<const uint8_t *>(a_i8), *q6 = reinterpret_cast<const uint8_t *>(q_i8);
         profile_begin(st, C == 256 ? "match_mx6_screen_kernel<256, 8>" : "match_mx6_screen_kernel<512, 4>");
@@ -2111,7 +2138,7 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     ORYON_CHECK_LAUNCH();
     const float sqrt_c = sqrtf((float)C_true);
     hipLaunchKernelGGL(match_decide_lite_kernel, dim3(cap_a / 256, B), dim3(256), 0, st, cap_a, n_a, S, w.ws_max, w.ws_i1, w.ws_m2, a_scale,
-                       q_eps_max, cut0, sqrt_c, (float)C_true, force_eager, fmt, w.m_final, lw.sid_final, lw.margin, lw.state, valid, min_dist,
+                       q_eps_max, cut0, sqrt_c, (float)C_true, force_eager, fmt, use_x3, w.m_final, lw.sid_final, lw.margin, lw.state, valid, min_dist,
                        argmin, lw.pair_eager, lw.n_unc, lw.unc_idx, lw.n_ambu, lw.ambu_idx, lw.need_f32_lazy, lw.n_amb_total);
     hipLaunchKernelGGL(match_mask_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_a, lw.pair_eager, lw.n_a_eager, lw.n_a_lazy);
     ORYON_CHECK_LAUNCH();
@@ -2189,9 +2216,31 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     hipLaunchKernelGGL(match_compact_f32_kernel, dim3((cap_s + 63) / 64, B), dim3(256), 0, st, a_hat, C, cap_a, cap_s, lw.n_ambv, lw.ambv_idx,
                        corr_rows, w8.a_hat_c);
     ORYON_CHECK_LAUNCH();
+    if (use_x3) {
+        // K1x3: hi / lo half query rows into the (now free) fp32-row area, fp16x3 scan with candidate lists, exact chain on the few
+        // candidates; anchors whose lists overflowed (duplicate crowds) fall back to the exact scan on fp32 rows materialised for their pair
+        __half *qh = reinterpret_cast<__half *>(wr.q_hat), *ql = qh + (size_t)B * cap_q * C;
+        int32_t *n_ovf = nullptr, *ovf_idx = nullptr;
+        rc = match_x3_resolve(w8.a_hat_c, lw.n_ambv, cap_s, feat_q, C_true, HW, layout, roi_q, roi_stride_q, q_norm, n_q, B, cap_q, threshold,
+                              round_f16, qh, ql, lw.x3_ah, lw.x3_al, lw.x3_scratch, w8.md_c, w8.am_c, w8.va_c, &n_ovf, &ovf_idx, st);
+        if (rc) { set_error("oryon_match_corrs: fp16x3 second-level launch failed"); return rc; }
+        ORYON_CHECK_HIP(hipMemsetAsync(wr.need_f32, 0, (size_t)B * sizeof(int32_t), st));
+        hipLaunchKernelGGL(match_need_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_ovf, wr.need_f32);
+        rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, wr.need_f32, cap_q, C, wr.q8_scratch, wr.scale_scratch,
+                              wr.eps_scratch, nullptr, wr.q_hat, 1, round_f16, st);
+        if (rc) { set_error("oryon_match_corrs: overflow fp32 gather launch failed"); return rc; }
+        hipLaunchKernelGGL(match_compact_f32_kernel, dim3((cap_s + 63) / 64, B), dim3(256), 0, st, w8.a_hat_c, C, cap_s, cap_s, n_ovf, ovf_idx,
+                           cap_s, lw.x3_a_ovf);
+        ORYON_CHECK_LAUNCH();
+        rc = oryon_match_f32(lw.x3_a_ovf, wr.q_hat, B, C, cap_s, cap_q, n_ovf, n_q, threshold, lw.x3_md_o, lw.x3_am_o, lw.x3_va_o, lw.exact_ws,
+                             lw.exact_ws_bytes, stream);
+        if (rc) return rc;
+        match_x3_scatter_ovf(B, cap_s, n_ovf, ovf_idx, lw.x3_md_o, lw.x3_am_o, lw.x3_va_o, w8.md_c, w8.am_c, w8.va_c, st);
+    } else {
     rc = oryon_match_f32(w8.a_hat_c, wr.q_hat, B, C, cap_s, cap_q, lw.n_ambv, n_q, threshold, w8.md_c, w8.am_c, w8.va_c, lw.exact_ws,
                          lw.exact_ws_bytes, stream);
     if (rc) return rc;
+    }
     hipLaunchKernelGGL(match_scatter_exact_kernel, dim3((cap_s + 255) / 256, B), dim3(256), 0, st, cap_a, cap_s, lw.n_ambv, lw.ambv_idx, corr_rows,
                        w8.md_c, w8.am_c, w8.va_c, min_dist, argmin, valid, lw.state);
     ORYON_CHECK_LAUNCH();

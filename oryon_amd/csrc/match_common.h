@@ -1,5 +1,6 @@
 // Shared bits of the matcher translation units (match.hip, match16.hip).
 #pragma once
+#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace oryon {
@@ -19,5 +20,14 @@ __device__ __forceinline__ void lex_min(float &d, int &i, float od, int oi)
 int match_f32_flagged(const float *a_hat, const float *q_hat, int B, int C, int cap_a, int cap_q, const int32_t *n_a,
                       const int32_t *n_q, float threshold, float *min_dist, int32_t *argmin, uint8_t *valid,
                       const int32_t *panel_flag, const uint8_t *row_flag, void *stream);
+
+// K1x3 (match_x3.hip): fp32-grade scan of a compacted anchor list on the fp16 matrix pipe; see the file's header
+size_t match_x3_scratch_bytes(int B, int cap_s, int S);
+int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const float *feat_q, int C_true, int HW, int layout,
+                     const int32_t *roi_q, int roi_stride_q, const float *q_norm, const int32_t *n_q, int B, int cap_q, float threshold,
+                     int round_f16, __half *qh, __half *ql, __half *ah, __half *al, void *scratch, float *md_c, int32_t *am_c, uint8_t *va_c,
+                     int32_t **n_ovf_out, int32_t **ovf_idx_out, hipStream_t st);
+void match_x3_scatter_ovf(int B, int cap_s, const int32_t *n_ovf, const int32_t *ovf_idx, const float *md_o, const int32_t *am_o,
+                          const uint8_t *va_o, float *md_c, int32_t *am_c, uint8_t *va_c, hipStream_t st);
 
 }  // namespace oryon

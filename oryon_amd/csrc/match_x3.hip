@@ -1,0 +1,364 @@
+// K1x3: fp32-GRADE scan of a few anchors per pair on the fp16 matrix pipe (round 3) - the second level behind the low-precision screens.
+//
+// Replaces, for the sampled anchors whose best and second-best match no 6- / 8-bit screen can separate (smooth descriptor fields: cosine gaps
+// of 1e-4), the exact fp32-MFMA scan of utils/pcd.py:202-204's argmin (match_f32_regb_kernel on a compacted list: 5.9 ms per cfg2 step of
+// such inputs, 157 TFLOP/s pipe) by an error-compensated fp16 contraction: every unit value u is split hi = half(u), lo = half(u - hi) (22
+// significant bits; K0 FMT = 2 writes the query rows that way, match_x3_split_anchors_kernel the anchors) and
+//     s3 = sum_k  al.qh + ah.ql + ah.qh      (three v_mfma_f32_32x32x16_f16 per 16 channels, fp32 accumulate)
+// approximates the canonical dot product within DELTA3 = 6.5e-5 (C <= 256: split error <= 1.4e-6, dropped lo.lo term <= 2.4e-7, fp32
+// accumulation of 768 terms here <= 4.6e-5 and of 256 terms in the canonical chain <= 1.5e-5, all worst case).  ONE pass: a lane keeps the
+// running maximum of its anchor column and appends (index, score) to the anchor's candidate list whenever a score reaches the running maximum
+// minus MARGIN3 = 2 DELTA3 + slack - the final maximum is at least every running one, so every row within MARGIN3 of the final maximum,
+// i.e. every exact minimiser, is in the list (plus a handful of stale entries: O(log n) new maxima per column).  match_x3_rescore_kernel then
+// drops the stale ones and runs the canonical fp32 chain on x_k / d from the raw map for the rest (typically 1-5 rows): distance, first index
+// of the minimum, validity - bit for bit what the exact scan returns.  A list that overflows (crowds of exact duplicates) sends its anchor to
+// the exact scan (device-side list; the caller materialises fp32 rows for such pairs only).
+//
+// STATE (round 3): exact and tested, NOT the default (ORYON_AMB_X3=1 enables it).  Each (pair, query split, anchor, lane half) list has one
+// writer, so the scan needs no atomics (2.6 ms per cfg2 step of smooth inputs: 760 TFLOP/s on the fp16 pipe; the first version's returning
+// atomicAdd per entry cost 9 ms).  On the smooth fields it was built for the premise "a handful of stale entries" fails: scanning towards
+// a smooth peak EVERY row is a new running maximum, 64-entry lists overflow for most anchors and the exact fall-back runs anyway (hard
+// step 14.0 ms against 10.9 ms without K1x3).  What would fix it is written up in DESIGN.md: a first hi-only sweep for a per-anchor lower
+// bound of the maximum (1/3 of the MFMAs), then this sweep with a FIXED threshold.
+#include <hip/hip_fp16.h>
+#include "common.h"
+#include "match_common.h"
+
+namespace oryon {
+
+typedef _Float16 half8x __attribute__((ext_vector_type(8)));
+
+constexpr int X3_CAPH = 64;                // candidate slots per (pair, query split, anchor, lane half): each list has ONE writer, no atomics
+constexpr float X3_MARGIN = 1.32e-4f;      // 2 * DELTA3 (6.5e-5) + 2e-6
+
+// fp32 anchor rows (k-permuted inside groups of 8: position 8g + 4h + j holds k = 8g + 2j + h) -> hi / lo half rows in natural k order
+__global__ __launch_bounds__(256) void match_x3_split_anchors_kernel(const float *__restrict__ a_c, int Cp, int cap_s,
+                                                                      const int32_t *__restrict__ n_c, __half *__restrict__ ah,
+                                                                      __half *__restrict__ al)
+{
+    const int p = blockIdx.y;
+    const int n = n_c[p] < cap_s ? n_c[p] : cap_s;
+    const int n_fill = (n + 255) / 256 * 256 < cap_s ? (n + 255) / 256 * 256 : cap_s;      // the scan reads whole 256-anchor panels: zero-fill
+    const int groups = n_fill * (Cp / 8);
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < groups; g += gridDim.x * 256) {
+        const int row = g / (Cp / 8), gi = g % (Cp / 8);
+        union { __half h[8]; uint4 u; } hi, lo;
+        if (row < n) {
+            const float4 *src = reinterpret_cast<const float4 *>(a_c + ((size_t)p * cap_s + row) * Cp) + 2 * gi;
+            const float4 x = src[0], y = src[1];                // x = k 8g+{0,2,4,6}, y = k 8g+{1,3,5,7}
+            const float v[8] = {x.x, y.x, x.y, y.y, x.z, y.z, x.w, y.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                hi.h[i] = __float2half_rn(v[i]);
+                lo.h[i] = __float2half_rn(v[i] - __half2float(hi.h[i]));
+            }
+        } else {
+            hi.u = make_uint4(0, 0, 0, 0);
+            lo.u = make_uint4(0, 0, 0, 0);
+        }
+        reinterpret_cast<uint4 *>(ah + ((size_t)p * cap_s + row) * Cp)[gi] = hi.u;
+        reinterpret_cast<uint4 *>(al + ((size_t)p * cap_s + row) * Cp)[gi] = lo.u;
+    }
+}
+
+// grid: units (pair, query split) dealt to the 8 XCDs, T = cap_s / 256 anchor panels per unit; 4 waves x 64 anchors (two B-operand sets of hi +
+// lo rows = 256 registers: one workgroup per CU with the 512-register budget - with 32 anchors per wave every pair of ds_read_b128 fed only
+// 3 MFMAs and the LDS, not the matrix pipe, set the pace: 5.1 ms); tiles of 32 query rows (hi part 16 KB + lo part 16 KB, double-buffered)
+template <int CP>
+__global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
+                                                               const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
+                                                               int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
+                                                               int S, int32_t *__restrict__ cnt, uint2 *__restrict__ cand)
+{
+    constexpr int RB = CP * 2;                 // bytes per half row
+    constexpr int ROWS = 32;
+    constexpr int PART = ROWS * RB;            // 16 KB at CP = 256
+    constexpr int STAGE = 2 * PART;
+    constexpr int NKS = CP / 16;
+    constexpr int NI = PART / 4096;            // 1 KB DMA instructions per wave, part and tile
+    constexpr int LPR = RB / 256;
+    __shared__ __attribute__((aligned(256))) char smem[2 * STAGE];
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = (slot / T) * 8 + xcd;
+    if (unit >= B * S) return;
+    const int panel = slot % T;
+    const int p = unit / S, split = unit % S;
+    const int nc = n_c[p] < cap_s ? n_c[p] : cap_s, nq = n_q[p];
+    constexpr int NAB = 2;
+    const int a0 = panel * 256;
+    if (a0 >= nc) return;
+    const int nqt = (nq + ROWS - 1) / ROWS;
+    const int qt_per = (nqt + S - 1) / S;
+    const int qt_begin = split * qt_per;
+    const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    half8x bh[NAB][NKS], bl[NAB][NKS];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const int ar = a0 + wave * 64 + ab * 32 + l31;
+        const int arc = ar < cap_s ? ar : cap_s - 1;
+        const __half *rh = ah + ((size_t)p * cap_s + arc) * CP + 8 * hi, *rl = al + ((size_t)p * cap_s + arc) * CP + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            bh[ab][s] = *reinterpret_cast<const half8x *>(rh + 16 * s);
+            bl[ab][s] = *reinterpret_cast<const half8x *>(rl + 16 * s);
+        }
+    }
+    unsigned dma_off[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        const int row = line / LPR;
+        const int cc = sl ^ (row & 15);
+        dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char *qhp = reinterpret_cast<const char *>(qh + (size_t)p * cap_q * CP), *qlp = reinterpret_cast<const char *>(ql + (size_t)p * cap_q * CP);
+    auto issue = [&](int qt, int buf) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const char *qb = (part ? qlp : qhp) + (size_t)qt * PART;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                char *dst = smem + buf * STAGE + part * PART + (wave_u * NI + j) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            }
+        }
+    };
+    unsigned koff[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) koff[c] = (unsigned)(l31 * RB) + ((((unsigned)(hi ^ (l31 & 15))) ^ (2u * c)) << 4);
+    auto rd = [&](int part, int s, unsigned tile) -> half8x {
+        return *reinterpret_cast<const half8x *>(smem + koff[s & 7] + tile + (unsigned)(part * PART + (s >> 3) * 256));
+    };
+
+    float runmax[NAB];
+    int nlist[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; nlist[ab] = 0; }
+    if (qt_end > qt_begin) issue(qt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        if (qt + 1 < qt_end) issue(qt + 1, buf ^ 1);
+        const unsigned tile = buf * STAGE;
+        f32x16 acc[NAB];
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ab][r] = 0.0f;
+        half8x xh = rd(0, 0, tile), xl = rd(1, 0, tile);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            half8x nh = xh, nl = xl;
+            if (s + 1 < NKS) { nh = rd(0, s + 1, tile); nl = rd(1, s + 1, tile); }
+            // small terms first (as the PointDSC fp16x3 kernels do): lo.hi, hi.lo, hi.hi; the two anchor blocks alternate
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, bh[ab][s], acc[ab], 0, 0, 0);
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bl[ab][s], acc[ab], 0, 0, 0);
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[ab][s], acc[ab], 0, 0, 0);
+            xh = nh;
+            xl = nl;
+        }
+        // epilogue: the lane's 16 query rows of this tile against its two anchor columns
+        const int q0 = qt * ROWS + 4 * hi;
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab) {
+            const int a = a0 + wave * 64 + ab * 32 + l31;
+            float x = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
+            runmax[ab] = fmaxf(runmax[ab], x);
+            // the running maximum is shared by the two lanes (hi = 0 / 1) of the column, so that either drops what the other already beat
+            runmax[ab] = fmaxf(runmax[ab], __shfl_xor(runmax[ab], 32));
+            const float lim = runmax[ab] - X3_MARGIN;
+            if (a < nc && x >= lim) {
+                uint2 *list = cand + ((((size_t)p * S + split) * cap_s + a) * 2 + hi) * X3_CAPH;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (acc[ab][r] >= lim && q0 + (r & 3) + 8 * (r >> 2) < nq) {          // zero-padded rows of the last tile are not candidates
+                        if (nlist[ab] < X3_CAPH) list[nlist[ab]] = make_uint2((unsigned)(q0 + (r & 3) + 8 * (r >> 2)), __float_as_uint(acc[ab][r]));
+                        ++nlist[ab];
+                    }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const int a = a0 + wave * 64 + ab * 32 + l31;
+        if (a < nc) cnt[(((size_t)p * S + split) * cap_s + a) * 2 + hi] = nlist[ab];
+    }
+}
+
+// one wave per compacted anchor: final maximum over the lists of all query splits, stale entries dropped, canonical fp32 chain on the raw
+// map for the rest (as resolve_anchor in match16.hip), result -> md_c / am_c / va_c; overflowed lists -> the pair's overflow list
+template <bool NHWC>
+__global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__restrict__ a_c, int Cp, int cap_s, const int32_t *__restrict__ n_c,
+                                                                const float *__restrict__ feat_q, int C_true, int HW,
+                                                                const int32_t *__restrict__ roi_q, int roi_stride, const float *__restrict__ norm_q,
+                                                                int cap_q, const int32_t *__restrict__ n_q, int S, float thr,
+                                                                const int32_t *__restrict__ cnt, const uint2 *__restrict__ cand,
+                                                                int round_f16, float *__restrict__ md_c,
+                                                                int32_t *__restrict__ am_c, uint8_t *__restrict__ va_c,
+                                                                int32_t *__restrict__ n_ovf, int32_t *__restrict__ ovf_idx)
+{
+    extern __shared__ float lds_x3[];
+    const int p = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    const int nc = n_c[p] < cap_s ? n_c[p] : cap_s;
+    if (row >= nc) return;
+    const int nq = n_q[p];
+    float *A = lds_x3 + wave * 2 * Cp, *Q = A + Cp;
+    // candidates: lane e handles entries e, e + 64, ... of the concatenated lists
+    bool overflow = false;
+    float m1 = -INFINITY;
+    for (int s = 0; s < 2 * S; ++s) {                      // 2 S lists: (query split, lane half)
+        const size_t o = (((size_t)p * S + (s >> 1)) * cap_s + row) * 2 + (s & 1);
+        const int c = cnt[o];
+        overflow |= c > X3_CAPH;
+        if (lane < c && lane < X3_CAPH) m1 = fmaxf(m1, __uint_as_float(cand[o * X3_CAPH + lane].y));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, off));
+    const size_t crow = (size_t)p * cap_s + row;
+    if (overflow) {                                        // wave-uniform: every lane read the same counts
+        if (lane == 0) ovf_idx[(size_t)p * cap_s + atomicAdd(&n_ovf[p], 1)] = row;
+        return;
+    }
+    for (int pos = lane; pos < Cp; pos += 64) {            // anchor row -> natural k order
+        const int g = pos >> 3, hh = (pos >> 2) & 1, jj = pos & 3;
+        A[8 * g + 2 * jj + hh] = a_c[crow * Cp + pos];
+    }
+    float d = INFINITY;
+    int j = 0x7fffffff;
+    const float *fq = feat_q + (size_t)p * C_true * HW;
+    for (int s = 0; s < 2 * S; ++s) {
+        const size_t o = (((size_t)p * S + (s >> 1)) * cap_s + row) * 2 + (s & 1);
+        const int n = cnt[o];
+        const uint2 ent = lane < n ? cand[o * X3_CAPH + lane] : make_uint2(0u, 0u);
+        const int qi = (int)ent.x;
+        const bool hit = lane < n && qi < nq && __uint_as_float(ent.y) >= m1 - X3_MARGIN;
+        unsigned long long hits = __ballot(hit);
+        while (hits) {
+            const int src = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const int jj = __shfl(qi, src);
+            const int pix = roi_q[(size_t)p * roi_stride + jj];
+            const float dq = norm_q[(size_t)p * cap_q + jj];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < Cp; k += 64) {
+                float x = 0.0f;
+                if (k < C_true) x = NHWC ? fq[(size_t)pix * C_true + k] : fq[(size_t)k * HW + pix];
+                if (round_f16) x = __half2float(__float2half_rn(x));
+                Q[k] = __fdiv_rn(x, dq);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float dot = 0.0f;                               // every lane runs the same canonical chain on broadcast LDS reads
+            for (int k = 0; k < C_true; k += 8) {
+                float av[8], qv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { av[e] = A[k + e]; qv[e] = Q[k + e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k + e < C_true) dot = __fmaf_rn(av[e], qv[e], dot);
+            }
+            lex_min(d, j, __fmaf_rn(-0.5f, dot, 0.5f), jj);
+        }
+    }
+    if (lane == 0) {
+        md_c[crow] = d;
+        am_c[crow] = j == 0x7fffffff ? 0 : j;
+        va_c[crow] = (d < thr) ? 1 : 0;
+    }
+}
+
+__global__ void match_x3_enable_kernel(int B, const int32_t *__restrict__ n_c, int32_t *__restrict__ enable)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < B) enable[p] = n_c[p] > 0 ? 1 : 0;
+}
+
+// results of the exact fall-back for overflowed anchors -> their compact rows
+__global__ __launch_bounds__(256) void match_x3_scatter_ovf_kernel(int cap_s, const int32_t *__restrict__ n_ovf, const int32_t *__restrict__ ovf_idx,
+                                                                    const float *__restrict__ md_o, const int32_t *__restrict__ am_o,
+                                                                    const uint8_t *__restrict__ va_o, float *__restrict__ md_c,
+                                                                    int32_t *__restrict__ am_c, uint8_t *__restrict__ va_c)
+{
+    const int p = blockIdx.y, sl = blockIdx.x * 256 + threadIdx.x;
+    if (sl >= n_ovf[p] || sl >= cap_s) return;
+    const size_t src = (size_t)p * cap_s + sl, dst = (size_t)p * cap_s + ovf_idx[(size_t)p * cap_s + sl];
+    md_c[dst] = md_o[src];
+    am_c[dst] = am_o[src];
+    va_c[dst] = va_o[src];
+}
+
+int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
+                     const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
+                     float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt, void *aux);
+
+size_t match_x3_scratch_bytes(int B, int cap_s, int S)
+{
+    return (size_t)B * S * cap_s * 2 * (sizeof(int32_t) + X3_CAPH * sizeof(uint2)) + (size_t)B * (cap_s + 2) * sizeof(int32_t) + 4096;
+}
+
+// a_c [B, cap_s, 256] fp32 compact anchor rows (k-permuted), n_c [B] -> md_c / am_c / va_c [B, cap_s]; n_ovf / ovf_idx: anchors whose
+// lists overflowed (to be redone by the exact scan).  qh / ql: room for [B, cap_q, 256] halves each; ah / al: [B, cap_s, 256] halves;
+// scratch: match_x3_scratch_bytes.  Every launch is gated on the device by n_c.
+int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const float *feat_q, int C_true, int HW, int layout,
+                     const int32_t *roi_q, int roi_stride_q, const float *q_norm, const int32_t *n_q, int B, int cap_q, float threshold,
+                     int round_f16, __half *qh, __half *ql, __half *ah, __half *al, void *scratch, float *md_c, int32_t *am_c, uint8_t *va_c,
+                     int32_t **n_ovf_out, int32_t **ovf_idx_out, hipStream_t st)
+{
+    constexpr int CP = 256;
+    const int T = (cap_s + 255) / 256;
+    const int S = 8;
+    char *sp = static_cast<char *>(scratch);
+    int32_t *cnt = reinterpret_cast<int32_t *>(sp);
+    size_t off = ((size_t)B * S * cap_s * 2 * sizeof(int32_t) + 255) / 256 * 256;
+    uint2 *cand = reinterpret_cast<uint2 *>(sp + off);
+    off += ((size_t)B * S * cap_s * 2 * X3_CAPH * sizeof(uint2) + 255) / 256 * 256;
+    int32_t *enable = reinterpret_cast<int32_t *>(sp + off);
+    off += ((size_t)B * sizeof(int32_t) + 255) / 256 * 256;
+    int32_t *n_ovf = reinterpret_cast<int32_t *>(sp + off);
+    off += ((size_t)B * sizeof(int32_t) + 255) / 256 * 256;
+    int32_t *ovf_idx = reinterpret_cast<int32_t *>(sp + off);
+    *n_ovf_out = n_ovf;
+    *ovf_idx_out = ovf_idx;
+    if (hipMemsetAsync(n_ovf, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess) return ORYON_ERR_HIP;
+    hipLaunchKernelGGL(match_x3_enable_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_c, enable);
+    // query rows as hi / lo halves, only for pairs that have listed anchors
+    int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, enable, cap_q, CP, reinterpret_cast<int8_t *>(qh), nullptr,
+                              nullptr, nullptr, nullptr, 1, round_f16, st, 2, ql);
+    if (rc) return rc;
+    hipLaunchKernelGGL(match_x3_split_anchors_kernel, dim3(64, B), dim3(256), 0, st, a_c, CP, cap_s, n_c, ah, al);
+    const int groups = ((B * S + 7) / 8) * 8 * T;
+    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), 0, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, cnt, cand);
+    const size_t lds = (size_t)4 * 2 * CP * sizeof(float);
+    if (layout == ORYON_LAYOUT_NHWC)
+        hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
+                           roi_stride_q, q_norm, cap_q, n_q, S, threshold, cnt, cand, round_f16, md_c, am_c, va_c, n_ovf, ovf_idx);
+    else
+        hipLaunchKernelGGL((match_x3_rescore_kernel<false>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
+                           roi_stride_q, q_norm, cap_q, n_q, S, threshold, cnt, cand, round_f16, md_c, am_c, va_c, n_ovf, ovf_idx);
+    return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+}
+
+void match_x3_scatter_ovf(int B, int cap_s, const int32_t *n_ovf, const int32_t *ovf_idx, const float *md_o, const int32_t *am_o,
+                          const uint8_t *va_o, float *md_c, int32_t *am_c, uint8_t *va_c, hipStream_t st)
+{
+    hipLaunchKernelGGL(match_x3_scatter_ovf_kernel, dim3((cap_s + 255) / 256, B), dim3(256), 0, st, cap_s, n_ovf, ovf_idx, md_o, am_o, va_o, md_c,
+                       am_c, va_c);
+}
+
+}  // namespace oryon

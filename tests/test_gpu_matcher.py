@@ -609,6 +609,19 @@ def test_lazy_corrs_exact_ties_and_single_candidates():
     assert status.tolist() == [0, 0, 0, 0] and min(n_valid.tolist()) > 1500
 
 
+def test_lazy_corrs_with_the_fp16x3_second_level():
+    """K1x3 (match_x3.hip) is off by default and switched by ORYON_AMB_X3, which the library reads once: the three lazy == eager == exact
+    tests above, again, in a child interpreter with the switch on (smooth pair -> candidate lists, overflow -> exact fall-back)."""
+    import os, subprocess, sys
+    if os.environ.get("ORYON_AMB_X3") == "1":
+        pytest.skip("already the child run")
+    env = dict(os.environ, ORYON_AMB_X3="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k", "test_lazy_corrs and not second_level"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def _decode_mx6(rows: torch.Tensor) -> torch.Tensor:
     """uint8 mx6 rows [..., C_pad] (32-byte slots: 24 B of fp6 e2m3 codes, exponent byte, padding) -> float64 values [..., C_pad]."""
     r = rows.cpu().numpy().astype(np.uint64)
