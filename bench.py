@@ -554,12 +554,12 @@ def main():
             import hashlib
             with open(tpath) as fh:
                 tj = json.load(fh)
-            with open(os.path.join(ROOT, "oryon_amd", "csrc", "match16.hip"), "rb") as fh:
+            with open(os.path.join(ROOT, "oryon_amd", "csrc", "screen_mx6.hip" if a.screen == "mx6" else "match16.hip"), "rb") as fh:
                 sha = hashlib.sha256(fh.read()).hexdigest()
             if tj.get("kernel_source_sha256") == sha:
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source", "profiles/r03_pmc_counters.md")
             else:
-                traffic_src = "profiles/r03_traffic.json is stale (match16.hip changed since the PMC passes): not reported"
+                traffic_src = "profiles/r03_traffic.json is stale (the screen kernel source changed since the PMC passes): not reported"
         rec = {
             "metric": METRIC, "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -22,6 +22,7 @@
 // error <= 2^-25 each: <= 2 * 2^-25 * sqrt(C) ~= 1.3e-6 in the dot product, inside the slack of SCREEN_DELTA.
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "match_common.h"
 
@@ -941,185 +942,7 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_i8_screen
 }
 
 
-// ------------------------------------------------------------------------------------------------ K1s6: MX-fp6 screen (round 3)
-// The same single-pass (m1, slice, m2) screening on v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 (e2m3) operands: 64 channels per
-// instruction at the int8 instruction's issue rate, i.e. twice the multiply-accumulates per matrix-pipe cycle (guide: 8.9 PFLOP/s
-// measured for MX-fp6 32x32x64 against 4.4 POP/s for i8 32x32x32).  Operands are K0's mx6 rows (gather8.hip, FMT = 1): per row and
-// 32-channel block one 32-byte slot = 24 bytes of codes + the block's E8M0 exponent - the share of one lane (row l & 31, block
-// 2 S + (l >> 5) of k-step S), so a lane's A operand is two ds_read_b128 and the hardware applies both exponents: accumulators are
-// the dequantised dot products themselves (no per-slice integer scale).  Row bytes, tile geometry, LDS image, DMA, swizzle, block
-// map, outputs and the meaning of a slice are those of match_i8_screen_v2_kernel.
-//
-// Bound.  With e = x^ - dequant(x^) the MEASURED quantisation error of a row (K0 accumulates |e|_2 per row and keeps the largest per
-// map), s6_ij - a^_i.q^_j = a^_i.eq_j + ea_i.q^_j + ea_i.eq_j, hence by Cauchy-Schwarz on unit rows
-//     |s6_ij - a^_i.q^_j| <= |eq| + |ea| + |ea||eq| (+ 1.2e-4: fp32 accumulation of 256-512 exact products here and in the canonical chain)
-// - a 2-norm bound on errors that really occur (~0.02 per row for e2m3 with a per-block exponent) instead of a worst-case 1-norm one.
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16s __attribute__((ext_vector_type(16)));
-
-template <int CP, int WAVES = 8>
-__global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_screen_kernel(
-    const uint8_t *__restrict__ a6, const uint8_t *__restrict__ q6, int B, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
-    const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
-{
-    constexpr int RB = CP;
-    constexpr int TILE_BYTES = screen8_tile_bytes(CP);
-    constexpr int ROWS = 128, NQB = 4, NAB = 2;
-    constexpr int NKS = CP / 64;                          // k-steps of 64 channels (two 32-channel blocks, one per lane half)
-    constexpr int NI = TILE_BYTES / (1024 * WAVES);
-    constexpr int LPR = RB / 256;
-    char *smem;
-    if constexpr (2 * TILE_BYTES > 65536) {
-        extern __shared__ __attribute__((aligned(256))) char smem_dyn6[];
-        smem = smem_dyn6;
-    } else {
-        __shared__ __attribute__((aligned(256))) char smem_st6[2 * TILE_BYTES];
-        smem = smem_st6;
-    }
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int unit = (slot / T) * 8 + xcd;
-    if (unit >= B * S) return;
-    const int panel = slot % T;
-    const int p = unit / S, split = unit % S;
-    const int na = n_a[p], nq = n_q[p];
-    const int a0 = panel * (64 * WAVES);
-    if (a0 >= na) return;
-    const int nqt = (nq + ROWS - 1) / ROWS;
-    const int qt_per = (nqt + S - 1) / S;
-    const int qt_begin = split * qt_per;
-    const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
-    const char *qp = reinterpret_cast<const char *>(q6) + (size_t)p * cap_q * RB;
-
-    // stationary B operand: this wave's 64 anchors, slot (2 S + hi) of every k-step (dwords 0-5 codes, dword 6 = exponent byte)
-    i32x8 breg[NAB][NKS];
-#pragma unroll
-    for (int ab = 0; ab < NAB; ++ab) {
-        const int arow_i = a0 + wave * 64 + ab * 32 + l31;
-        const char *arow = reinterpret_cast<const char *>(a6) + ((size_t)p * cap_a + (arow_i < cap_a ? arow_i : cap_a - 1)) * RB + 32 * hi;
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const i32x4 lo = *reinterpret_cast<const i32x4 *>(arow + 64 * s), up = *reinterpret_cast<const i32x4 *>(arow + 64 * s + 16);
-            breg[ab][s] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], 0};
-        }
-    }
-    unsigned dma_off[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
-        const int row = line / LPR;
-        const int cc = sl ^ (row & 15);
-        dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
-    }
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto issue_one = [&](int qt, int buf, int j) {
-        const char *qb = qp + (size_t)qt * TILE_BYTES;
-        char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
-                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    };
-    // LDS offsets of the two 16-byte chunks of slot (2 (S & 3) + hi) in the lane's row: chunk index XOR (row & 15) inside a 256-byte line
-    unsigned koff[4][2];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) koff[c][e] = (unsigned)(l31 * RB) + ((((unsigned)(4 * c + 2 * hi + e)) ^ (unsigned)(l31 & 15)) << 4);
-    auto rd = [&](int s, int qb, unsigned tile) -> i32x8 {
-        const unsigned base = tile + (unsigned)(qb * 32 * RB + (s >> 2) * 256);
-        const i32x4 lo = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][0] + base);
-        const i32x4 up = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][1] + base);
-        return i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], 0};
-    };
-
-    float runmax[NAB], run2[NAB];
-    int runidx[NAB];
-#pragma unroll
-    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; run2[ab] = -INFINITY; runidx[ab] = 0; }
-    auto reduce_block = [&](const f32x16s &c, int sid, int ab) {
-        const float m0 = fmaxf(fmaxf(c[0], c[1]), c[2]), m1 = fmaxf(fmaxf(c[3], c[4]), c[5]), m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
-        const float m3 = fmaxf(fmaxf(c[9], c[10]), c[11]), m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
-        const float x = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
-        const bool improved = x > runmax[ab];
-        run2[ab] = fmaxf(fminf(runmax[ab], x), run2[ab]);
-        runmax[ab] = fmaxf(runmax[ab], x);
-        runidx[ab] = improved ? sid : runidx[ab];
-    };
-    const f32x16s zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-    if (qt_end > qt_begin) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) issue_one(qt_begin, 0, j);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    i32x8 areg[NKS];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, 0u);
-    f32x16s prev[NAB];
-#pragma unroll
-    for (int ab = 0; ab < NAB; ++ab)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) prev[ab][r] = -3.0e38f;          // the dummy "previous block" before the first one never wins
-    int prev_sid = 0;
-    int buf = 0;
-    for (int qt = qt_begin; qt < qt_end; ++qt) {
-        const unsigned tile = buf * TILE_BYTES;
-        const int qt_next = qt + 1 < qt_end ? qt + 1 : qt;
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) {
-            f32x16s acc[NAB];
-            if (qb == 0) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) issue_one(qt_next, buf ^ 1, j);
-            }
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-#pragma unroll
-                for (int ab = 0; ab < NAB; ++ab)
-                    acc[ab] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(areg[s], breg[ab][s], s == 0 ? zero16 : acc[ab], 2, 2, 0,
-                                                                               areg[s][6], 0, breg[ab][s][6]);
-                if (qb + 1 < NQB) areg[s] = rd(s, qb + 1, tile);
-            }
-#pragma unroll
-            for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sid, ab);
-            // pin the interleave: the previous block's epilogue (~24 VALU) and the next A operand's reads under this block's 2 NKS MFMAs
-#pragma unroll
-            for (int i = 0; i < NKS; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 24 / (2 * NKS), 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 24 / (2 * NKS), 0);
-                if (qb + 1 < NQB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-#pragma unroll
-            for (int ab = 0; ab < NAB; ++ab) prev[ab] = acc[ab];
-            prev_sid = (qt * NQB + qb) * 2 + hi;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        buf ^= 1;
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
-    }
-#pragma unroll
-    for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sid, ab);
-#pragma unroll
-    for (int ab = 0; ab < NAB; ++ab) {
-        const float om1 = __shfl_xor(runmax[ab], 32), om2 = __shfl_xor(run2[ab], 32);
-        const int oi1 = __shfl_xor(runidx[ab], 32);
-        const float m1 = fmaxf(runmax[ab], om1);
-        const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
-        const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
-        const int a = a0 + wave * 64 + ab * 32 + l31;
-        if (hi == 0 && a < cap_a) {
-            const size_t o = ((size_t)p * S + split) * cap_a + a;
-            ws_max[o] = m1;
-            ws_i1[o] = i1;
-            ws_m2[o] = m2;
-        }
-    }
-}
+// K1s6, the MX-fp6 screen (round 3), lives in screen_mx6.hip (own translation unit: compiled with -fno-honor-nans)
 
 // fp32 rows (k permuted inside groups of 8: position 8g+4h+j holds k = 8g+2j+h) -> fp16 rows in natural k order, the values K0's
 // fp16 output would hold.  One lane per group of 8.
@@ -1421,21 +1244,6 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
 }
 }  // namespace
 
-namespace {
-template <int CP>
-void launch_screen_mx6(int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q, const int32_t *n_a,
-                       const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
-{
-    // C_pad 256: 512-anchor panels (8 waves; `groups` was sized for 256-anchor panels, T of them per unit).  C_pad 512: the stationary
-    // operand is 128 registers, so 4 waves per workgroup and one workgroup per CU (512 registers per wave), as the int8 kernel
-    constexpr size_t dyn = 2 * screen8_tile_bytes(CP) > 65536 ? 2 * screen8_tile_bytes(CP) : 0;
-    constexpr int W_ = CP == 512 ? 4 : 8;
-    const int Tw = (cap_a + 64 * W_ - 1) / (64 * W_);
-    if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_mx6_screen_kernel<CP, W_>), (int)dyn);
-    hipLaunchKernelGGL((match_mx6_screen_kernel<CP, W_>), dim3(groups / T * Tw), dim3(64 * W_), dyn, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw, S,
-                       ws_max, ws_i1, ws_m2);
-}
-}  // namespace
 
 extern "C" size_t oryon_match_screened8_workspace_bytes(int B, int C, int cap_a, int cap_q)
 {
@@ -2125,9 +1933,8 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     const int use_x3 = (x3_env && C == 256 && !force_eager) ? 1 : 0;
     if (fmt == 1) {
         const uint8_t *a6 = reinterpret_cast<const uint8_t *>(a_i8), *q6 = reinterpret_cast<const uint8_t *>(q_i8);
-        profile_begin(st, C == 256 ? "match_mx6_screen_kernel<256, 8>" : "match_mx6_screen_kernel<512, 4>");
-        if (C == 256) launch_screen_mx6<256>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2);
-        else launch_screen_mx6<512>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2);
+        profile_begin(st, screen_mx6_name(C));
+        launch_screen_mx6(C, groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2);
         profile_end(st);
     } else {
     profile_begin(st, C == 256 ? screen8_name<256>() : screen8_name<512>());

@@ -30,4 +30,9 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
 void match_x3_scatter_ovf(int B, int cap_s, const int32_t *n_ovf, const int32_t *ovf_idx, const float *md_o, const int32_t *am_o,
                           const uint8_t *va_o, float *md_c, int32_t *am_c, uint8_t *va_c, hipStream_t st);
 
+const char *screen_mx6_name(int C);
+// screen_mx6.hip: K1s6 launch (C = 256 / 512); groups / T as sized for 256-anchor panels by the caller
+void launch_screen_mx6(int C, int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q,
+                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2);
+
 }  // namespace oryon

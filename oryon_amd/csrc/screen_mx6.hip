@@ -1,0 +1,456 @@
+// K1s6: the MX-fp6 screen of the lazy matcher (round 3) - the dominant kernel of the cfg2 step, in its own translation unit.
+// (Measured and not kept: compiling this file with -fno-honor-nans removes the operand quieting - v_max_f32 x, x, x - in front of the
+// fmaxf chains, 12 % of the loop's VALU instructions; same kernel time on the same box, 1.47 ms, so the default semantics stay.)
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "match_common.h"
+
+namespace oryon {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int screen8_tile_bytes(int CP) { return CP * 128; }     // 128 query rows per tile (as the int8 screen, match16.hip)
+
+// ------------------------------------------------------------------------------------------------ K1s6: MX-fp6 screen (round 3)
+// The same single-pass (m1, slice, m2) screening on v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 (e2m3) operands: 64 channels per
+// instruction at the int8 instruction's issue rate, i.e. twice the multiply-accumulates per matrix-pipe cycle (guide: 8.9 PFLOP/s
+// measured for MX-fp6 32x32x64 against 4.4 POP/s for i8 32x32x32).  Operands are K0's mx6 rows (gather8.hip, FMT = 1): per row and
+// 32-channel block one 32-byte slot = 24 bytes of codes + the block's E8M0 exponent - the share of one lane (row l & 31, block
+// 2 S + (l >> 5) of k-step S), so a lane's A operand is two ds_read_b128 and the hardware applies both exponents: accumulators are
+// the dequantised dot products themselves (no per-slice integer scale).  Row bytes, tile geometry, LDS image, DMA, swizzle, block
+// map, outputs and the meaning of a slice are those of match_i8_screen_v2_kernel.
+//
+// Bound.  With e = x^ - dequant(x^) the MEASURED quantisation error of a row (K0 accumulates |e|_2 per row and keeps the largest per
+// map), s6_ij - a^_i.q^_j = a^_i.eq_j + ea_i.q^_j + ea_i.eq_j, hence by Cauchy-Schwarz on unit rows
+//     |s6_ij - a^_i.q^_j| <= |eq| + |ea| + |ea||eq| (+ 1.2e-4: fp32 accumulation of 256-512 exact products here and in the canonical chain)
+// - a 2-norm bound on errors that really occur (~0.02 per row for e2m3 with a per-block exponent) instead of a worst-case 1-norm one.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+// VAR: 0 = the product kernel; 1 = DIAGNOSTIC (epilogue reduced to one max per block: wrong results, prices the VALU share)
+template <int CP, int WAVES = 8, int VAR = 0>
+__global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_screen_kernel(
+    const uint8_t *__restrict__ a6, const uint8_t *__restrict__ q6, int B, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
+    const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
+{
+    constexpr int RB = CP;
+    constexpr int TILE_BYTES = screen8_tile_bytes(CP);
+    constexpr int ROWS = 128, NQB = 4, NAB = 2;
+    constexpr int NKS = CP / 64;                          // k-steps of 64 channels (two 32-channel blocks, one per lane half)
+    constexpr int NI = TILE_BYTES / (1024 * WAVES);
+    constexpr int LPR = RB / 256;
+    char *smem;
+    if constexpr (2 * TILE_BYTES > 65536) {
+        extern __shared__ __attribute__((aligned(256))) char smem_dyn6[];
+        smem = smem_dyn6;
+    } else {
+        __shared__ __attribute__((aligned(256))) char smem_st6[2 * TILE_BYTES];
+        smem = smem_st6;
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = (slot / T) * 8 + xcd;
+    if (unit >= B * S) return;
+    const int panel = slot % T;
+    const int p = unit / S, split = unit % S;
+    const int na = n_a[p], nq = n_q[p];
+    const int a0 = panel * (64 * WAVES);
+    if (a0 >= na) return;
+    const int nqt = (nq + ROWS - 1) / ROWS;
+    const int qt_per = (nqt + S - 1) / S;
+    const int qt_begin = split * qt_per;
+    const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const char *qp = reinterpret_cast<const char *>(q6) + (size_t)p * cap_q * RB;
+
+    // stationary B operand: this wave's 64 anchors, slot (2 S + hi) of every k-step (dwords 0-5 codes, dword 6 = exponent byte)
+    i32x8 breg[NAB][NKS];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const int arow_i = a0 + wave * 64 + ab * 32 + l31;
+        const char *arow = reinterpret_cast<const char *>(a6) + ((size_t)p * cap_a + (arow_i < cap_a ? arow_i : cap_a - 1)) * RB + 32 * hi;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const i32x4 lo = *reinterpret_cast<const i32x4 *>(arow + 64 * s), up = *reinterpret_cast<const i32x4 *>(arow + 64 * s + 16);
+            breg[ab][s] = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);      // dword 7 (padding) is not read by the fp6 format
+        }
+    }
+    unsigned dma_off[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        const int row = line / LPR;
+        const int cc = sl ^ (row & 15);
+        dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_one = [&](int qt, int buf, int j) {
+        const char *qb = qp + (size_t)qt * TILE_BYTES;
+        char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    // LDS offsets of the two 16-byte chunks of slot (2 (S & 3) + hi) in the lane's row: chunk index XOR (row & 15) inside a 256-byte line
+    unsigned koff[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) koff[c][e] = (unsigned)(l31 * RB) + ((((unsigned)(4 * c + 2 * hi + e)) ^ (unsigned)(l31 & 15)) << 4);
+    // the constant part of an address (tile buffer, 32-row block, 256-byte line) goes into the instruction's 16-bit offset field where it fits
+    auto rd = [&](int s, int qb, unsigned tile) -> i32x8 {
+        const unsigned base = tile + (unsigned)(qb * 32 * RB + (s >> 2) * 256);
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][0] + base);
+        const i32x4 up = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][1] + base);
+        return __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    float runmax[NAB], run2[NAB];
+    int runidx[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; run2[ab] = -INFINITY; runidx[ab] = 0; }
+    auto reduce_block = [&](const f32x16s &c, int sid, int ab) {
+        if constexpr (VAR == 1) { runmax[ab] = fmaxf(runmax[ab], c[0] + c[15]); runidx[ab] = sid; return; }
+        const float m0 = fmaxf(fmaxf(c[0], c[1]), c[2]), m1 = fmaxf(fmaxf(c[3], c[4]), c[5]), m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
+        const float m3 = fmaxf(fmaxf(c[9], c[10]), c[11]), m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+        const float x = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
+        const bool improved = x > runmax[ab];
+        run2[ab] = __builtin_amdgcn_fmed3f(runmax[ab], run2[ab], x);              // run2 <= runmax: the median is the second largest
+        runmax[ab] = fmaxf(runmax[ab], x);
+        runidx[ab] = improved ? sid : runidx[ab];
+    };
+    const f32x16s zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    if (qt_end > qt_begin) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) issue_one(qt_begin, 0, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    i32x8 areg[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, 0u);
+    f32x16s prev[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[ab][r] = -3.0e38f;          // the dummy "previous block" before the first one never wins
+    int prev_sid = 0;
+    // one 128-row tile out of buffer BUF (a compile-time constant: the loop below alternates the two instances)
+    auto do_tile = [&](int qt, auto BUFC) {
+        constexpr int BUF = decltype(BUFC)::value;
+        constexpr unsigned tile = BUF * TILE_BYTES;
+        const int qt_next = qt + 1 < qt_end ? qt + 1 : qt;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            f32x16s acc[NAB];
+            if (qb == 0) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) issue_one(qt_next, BUF ^ 1, j);
+            }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab)
+                    acc[ab] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(areg[s], breg[ab][s], s == 0 ? zero16 : acc[ab], 2, 2, 0,
+                                                                               areg[s][6], 0, breg[ab][s][6]);
+                if (qb + 1 < NQB) areg[s] = rd(s, qb + 1, tile);
+            }
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sid, ab);
+            // pin the interleave: the previous block's epilogue (~22 VALU) and the next A operand's reads under this block's 2 NKS MFMAs
+#pragma unroll
+            for (int i = 0; i < NKS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 24 / (2 * NKS), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 24 / (2 * NKS), 0);
+                if (qb + 1 < NQB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) prev[ab] = acc[ab];
+            prev_sid = (qt * NQB + qb) * 2 + hi;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, (BUF ^ 1) * TILE_BYTES);
+    };
+    for (int qt = qt_begin; qt < qt_end; qt += 2) {
+        do_tile(qt, std::integral_constant<int, 0>{});
+        if (qt + 1 < qt_end) do_tile(qt + 1, std::integral_constant<int, 1>{});
+    }
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) reduce_block(prev[ab], prev_sid, ab);
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const float om1 = __shfl_xor(runmax[ab], 32), om2 = __shfl_xor(run2[ab], 32);
+        const int oi1 = __shfl_xor(runidx[ab], 32);
+        const float m1 = fmaxf(runmax[ab], om1);
+        const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
+        const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
+        const int a = a0 + wave * 64 + ab * 32 + l31;
+        if (hi == 0 && a < cap_a) {
+            const size_t o = ((size_t)p * S + split) * cap_a + a;
+            ws_max[o] = m1;
+            ws_i1[o] = i1;
+            ws_m2[o] = m2;
+        }
+    }
+}
+
+// K1s6 at C_pad = 256, second cut (round 3): 128 anchors per wave.  The kernel above feeds every 32x32x64 MFMA one kilobyte of LDS reads
+// (each wave reads the whole 32-row block of the query tile for its TWO anchor blocks): at four MFMAs per 32 cycles and CU that is the
+// LDS's entire 128 B/clk - an epilogue-free diagnostic build of it ran no faster than the product kernel: the LDS and the matrix pipe
+// saturate together.  Here a wave keeps FOUR anchor blocks stationary (96 code + 4 packed exponent registers; the instruction picks the
+// exponent byte by op_sel), so one A-operand read feeds four MFMAs: half the LDS bytes per MFMA.  No accumulator copies: the accumulators
+// of anchor blocks 0/1 and 2/3 alternate - while the MFMAs of one pair run, the VALU reduces the other pair's previous block.  246 VGPRs,
+// two waves per SIMD.  WAVES = 8 (default): 1024-anchor panels, ONE 64 KB workgroup per CU - half the L2 -> LDS bytes as well, and K0 /
+// the registration still find LDS beside it (1.46 ms alone against 1.58-1.61, pipelined step 3.84 against 3.87 ms on the same box).
+// WAVES = 4: 512-anchor panels, two workgroups per CU: 1.47 ms alone, but its 128 KB of LDS keep K0 off the CU (pipelined 3.94 ms).
+// Outputs and slice meaning unchanged.
+typedef int i32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+
+template <int CP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void match_mx6_screen_w4_kernel(
+    const uint8_t *__restrict__ a6, const uint8_t *__restrict__ q6, int B, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
+    const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
+{
+    static_assert(CP == 256, "four stationary anchor blocks fit the register file at C_pad = 256 only");
+    constexpr int RB = CP, NAB = 4;
+    constexpr int TILE_BYTES = screen8_tile_bytes(CP);
+    constexpr int ROWS = 128, NQB = 4;
+    constexpr int NKS = CP / 64;
+    constexpr int NI = TILE_BYTES / (1024 * WAVES);
+    constexpr int LPR = RB / 256;
+    __shared__ __attribute__((aligned(256))) char smem[2 * TILE_BYTES];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = (slot / T) * 8 + xcd;
+    if (unit >= B * S) return;
+    const int panel = slot % T;
+    const int p = unit / S, split = unit % S;
+    const int na = n_a[p], nq = n_q[p];
+    const int a0 = panel * (32 * NAB * WAVES);
+    if (a0 >= na) return;
+    const int nqt = (nq + ROWS - 1) / ROWS;
+    const int qt_per = (nqt + S - 1) / S;
+    const int qt_begin = split * qt_per;
+    const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const char *qp = reinterpret_cast<const char *>(q6) + (size_t)p * cap_q * RB;
+
+    // stationary B operands: slot (2 s + hi) of k-step s of the lane's anchor row in each of the four blocks; the four exponent bytes of a
+    // block packed into one register (the instruction picks the byte by op_sel)
+    i32x8 breg[NAB][NKS];
+    int bsc[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const int arow_i = a0 + wave * (32 * NAB) + ab * 32 + l31;
+        const char *arow = reinterpret_cast<const char *>(a6) + ((size_t)p * cap_a + (arow_i < cap_a ? arow_i : cap_a - 1)) * RB + 32 * hi;
+        unsigned sc = 0;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const i32x4 lo = *reinterpret_cast<const i32x4 *>(arow + 64 * s), up = *reinterpret_cast<const i32x4 *>(arow + 64 * s + 16);
+            breg[ab][s] = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, -1, -1);   // the fp6 format reads six dwords
+            sc |= ((unsigned)up[2] & 0xffu) << (8 * s);
+        }
+        bsc[ab] = (int)sc;
+    }
+    // DMA instruction j of a wave moves rows (wave NI + j) 4 .. + 3 of the tile; rows 16 apart share the swizzle, so instructions j and j + 4
+    // differ by 4096 bytes - in the scalar base, not in another pair of address registers
+    static_assert(LPR == 1 && (NI == 8 || NI == 4), "C_pad 256 geometry");
+    unsigned dma_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        dma_off[j] = (unsigned)(row * RB + ((sl ^ (row & 15)) << 4));
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_one = [&](int qt, int buf, int j) {
+        const char *qb = qp + (size_t)qt * TILE_BYTES + (j >> 2) * 4096;
+        char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j & 3]),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    unsigned koff[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) koff[c][e] = (unsigned)(l31 * RB) + ((((unsigned)(4 * c + 2 * hi + e)) ^ (unsigned)(l31 & 15)) << 4);
+    // A operand of one k-step: 16 + 12 bytes of the lane's slot (dword 6 = exponent byte, the scale operand)
+    auto rd = [&](int s, int qb, unsigned tile) -> i32x8 {
+        const unsigned base = tile + (unsigned)(qb * 32 * RB + (s >> 2) * 256);
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][0] + base);
+        const i32x4 up = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][1] + base);
+        return __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, -1);
+    };
+
+    float runmax[NAB], run2[NAB];
+    int runidx[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; run2[ab] = -INFINITY; runidx[ab] = 0; }
+    auto reduce_block = [&](const f32x16s &c, int sid, int ab) {
+        const float m0 = fmaxf(fmaxf(c[0], c[1]), c[2]), m1 = fmaxf(fmaxf(c[3], c[4]), c[5]), m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
+        const float m3 = fmaxf(fmaxf(c[9], c[10]), c[11]), m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+        const float x = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
+        const bool improved = x > runmax[ab];
+        run2[ab] = __builtin_amdgcn_fmed3f(runmax[ab], run2[ab], x);              // run2 <= runmax: the median is the second largest
+        runmax[ab] = __builtin_amdgcn_fmed3f(runmax[ab], x, INFINITY);           // = max (no NaNs here); as the intrinsic it needs no operand
+        runidx[ab] = improved ? sid : runidx[ab];                                // canonicalisation (v_max x, x) of the loop-carried state
+    };
+    const f32x16s zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    if (qt_end > qt_begin) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) issue_one(qt_begin, 0, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    i32x8 areg[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, 0u);
+    f32x16s acc[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ab][r] = -3.0e38f;           // "previous block" of the pairs before the first one: never wins
+    int sid01 = 0, sid23 = 0;                                         // slice ids of the blocks acc[0..1] / acc[2..3] currently hold
+
+    // one MFMA: k-step SC (a compile-time constant: it is also the op_sel byte of the packed B exponents) of anchor block ab
+    auto mfma = [&](f32x16s &d, int ab, auto SC) {
+        constexpr int s_ = decltype(SC)::value;
+        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(areg[s_], breg[ab][s_], s_ == 0 ? zero16 : d, 2, 2, 0, areg[s_][6], s_, bsc[ab]);
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    static_assert(NKS == 4, "k-steps are spelled out below");
+    int buf = 0;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        const unsigned tile = buf * TILE_BYTES;
+        const int qt_next = qt + 1 < qt_end ? qt + 1 : qt;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            const int sid = (qt * NQB + qb) * 2 + hi;
+            if (qb == 0) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) issue_one(qt_next, buf ^ 1, j);
+            }
+            // first half: the VALU reduces the previous block of anchor blocks 2 / 3, the matrix pipe starts this block for 0 / 1
+            reduce_block(acc[2], sid23, 2);
+            reduce_block(acc[3], sid23, 3);
+            // (the reductions read acc[2..3] before the second half overwrites them: program order)
+            mfma(acc[0], 0, K0{}); mfma(acc[1], 1, K0{});
+            mfma(acc[0], 0, K1{}); mfma(acc[1], 1, K1{});
+            mfma(acc[0], 0, K2{}); mfma(acc[1], 1, K2{});
+            mfma(acc[0], 0, K3{}); mfma(acc[1], 1, K3{});
+#pragma unroll
+            for (int i = 0; i < 2 * NKS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            // second half: this block for 2 / 3 while the VALU reduces what 0 / 1 just finished; next A operand behind its last use
+            mfma(acc[2], 2, K0{}); mfma(acc[3], 3, K0{});
+            if (qb + 1 < NQB) areg[0] = rd(0, qb + 1, tile);
+            mfma(acc[2], 2, K1{}); mfma(acc[3], 3, K1{});
+            if (qb + 1 < NQB) areg[1] = rd(1, qb + 1, tile);
+            mfma(acc[2], 2, K2{}); mfma(acc[3], 3, K2{});
+            if (qb + 1 < NQB) areg[2] = rd(2, qb + 1, tile);
+            mfma(acc[2], 2, K3{}); mfma(acc[3], 3, K3{});
+            if (qb + 1 < NQB) areg[3] = rd(3, qb + 1, tile);
+            reduce_block(acc[0], sid, 0);
+            reduce_block(acc[1], sid, 1);
+#pragma unroll
+            for (int i = 0; i < 2 * NKS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if (qb + 1 < NQB && (i & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            sid01 = sid;
+            sid23 = sid;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
+    }
+    (void)sid01;
+    reduce_block(acc[2], sid23, 2);
+    reduce_block(acc[3], sid23, 3);
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const float om1 = __shfl_xor(runmax[ab], 32), om2 = __shfl_xor(run2[ab], 32);
+        const int oi1 = __shfl_xor(runidx[ab], 32);
+        const float m1 = fmaxf(runmax[ab], om1);
+        const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
+        const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
+        const int a = a0 + wave * (32 * NAB) + ab * 32 + l31;
+        if (hi == 0 && a < cap_a) {
+            const size_t o = ((size_t)p * S + split) * cap_a + a;
+            ws_max[o] = m1;
+            ws_i1[o] = i1;
+            ws_m2[o] = m2;
+        }
+    }
+}
+
+static int mx6_var()
+{
+    // 0: default; 1: diagnostic build of the 8-wave loop (wrong results); 2: the first 8-wave kernel at C_pad 256; 3: 4-wave workgroups
+    static const int var = getenv("ORYON_MX6_VAR") ? atoi(getenv("ORYON_MX6_VAR")) : 0;
+    return var;
+}
+
+namespace {
+template <int CP>
+void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q, const int32_t *n_a,
+                       const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
+{
+    // C_pad 256: 512-anchor panels (8 waves; `groups` was sized for 256-anchor panels, T of them per unit).  C_pad 512: the stationary
+    // operand is 128 registers, so 4 waves per workgroup and one workgroup per CU (512 registers per wave), as the int8 kernel
+    constexpr size_t dyn = 2 * screen8_tile_bytes(CP) > 65536 ? 2 * screen8_tile_bytes(CP) : 0;
+    constexpr int W_ = CP == 512 ? 4 : 8;
+    const int Tw = (cap_a + 64 * W_ - 1) / (64 * W_);
+    const int var = mx6_var();
+    if (var == 1) {
+        if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_mx6_screen_kernel<CP, W_, 1>), (int)dyn);
+        hipLaunchKernelGGL((match_mx6_screen_kernel<CP, W_, 1>), dim3(groups / T * Tw), dim3(64 * W_), dyn, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw,
+                           S, ws_max, ws_i1, ws_m2);
+        return;
+    }
+    if constexpr (CP == 256) {
+        if (var == 0) {                                          // default: 8 waves x 128 anchors (1024-anchor panels, one workgroup per CU)
+            const int T8 = (cap_a + 1023) / 1024;
+            hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 8>), dim3(groups / T * T8), dim3(512), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, T8, S,
+                               ws_max, ws_i1, ws_m2);
+            return;
+        }
+        if (var == 3) {                                          // 4 waves x 128 anchors (512-anchor panels, two workgroups per CU)
+            hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 4>), dim3(groups / T * Tw), dim3(256), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw, S,
+                               ws_max, ws_i1, ws_m2);
+            return;
+        }
+    }
+    if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_mx6_screen_kernel<CP, W_>), (int)dyn);
+    hipLaunchKernelGGL((match_mx6_screen_kernel<CP, W_>), dim3(groups / T * Tw), dim3(64 * W_), dyn, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw, S,
+                       ws_max, ws_i1, ws_m2);
+}
+}  // namespace
+
+// the kernel launch_screen_mx6 dispatches (for oryon_dominant_kernel / profile markers)
+const char *screen_mx6_name(int C)
+{
+    if (C != 256) return "match_mx6_screen_kernel<512, 4, 0>";
+    return mx6_var() == 0 ? "match_mx6_screen_w4_kernel<256, 8>" : mx6_var() == 3 ? "match_mx6_screen_w4_kernel<256, 4>" : mx6_var() == 1 ? "match_mx6_screen_kernel<256, 8, 1>" : "match_mx6_screen_kernel<256, 8, 0>";
+}
+
+void launch_screen_mx6(int C, int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q,
+                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
+{
+    if (C == 256) launch_screen_mx6_t<256>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, ws_max, ws_i1, ws_m2);
+    else launch_screen_mx6_t<512>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, ws_max, ws_i1, ws_m2);
+}
+
+}  // namespace oryon

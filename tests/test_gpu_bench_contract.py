@@ -66,7 +66,7 @@ def test_line_carries_timing_diagnostics():
     assert t["host_submit_ms_per_step"] > 0 and t["host_submit_ms_per_step_c_abi"] > 0
     assert all(d == 0 for d in t["device_allocs_in_window"]) and max(t["torch_allocs_per_step"]) < 1.0
     assert set(t["stream_busy_ms_per_step"]) == {"gather_ms", "match_ms", "screen_kernel_ms", "registration_ms"}
-    assert rec["roofline"]["kernel"].startswith("match_mx6_screen_kernel<256, 8>") and rec["roofline"]["peak"] == 10000.0
+    assert rec["roofline"]["kernel"].startswith("match_mx6_screen_w4_kernel<256, 8>") and rec["roofline"]["peak"] == 10000.0
     assert 0 < rec["roofline"]["unshared"]["frac"] < 1
     rec8 = _run("--steps", "2", "--warmup", "1", "--batch", "8", "--reps", "1", "--no-cpu-baseline", "--no-stage-sets", "--screen", "int8")
     assert rec8["roofline"]["kernel"].startswith("match_i8_screen_v2_kernel<256, 0, 8>") and rec8["roofline"]["peak"] == 5000.0
