@@ -327,13 +327,19 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
         if (sg != sm && e->n_submit >= c.gather_sets)       // K0 overwrites the rows the matcher of step k - gather_sets read
             ORYON_CHECK_HIP(hipStreamWaitEvent(sg, e->ev_matched[(e->n_submit - c.gather_sets) % c.n_slots], 0));
     }
+    // development aid (tools/ablate_native.sh): ORYON_ENGINE_ABLATE bit 0 / 1 / 2 leaves out K0's gathers / the matcher / the registration
+    // once every buffer set has been filled by a complete step - the following steps then time the REST of the pipeline on stale buffers
+    // (identical inputs every step, as in bench.py).  Never set in production: results are those of an earlier step.
+    static const int ablate_env = getenv("ORYON_ENGINE_ABLATE") ? atoi(getenv("ORYON_ENGINE_ABLATE")) : 0;
+    const int ablate = e->n_submit >= (int64_t)(c.n_slots + c.gather_sets) ? ablate_env : 0;
     // ---- K0 on the gather stream
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[0], sg));
     if ((rc = oryon_roi_compact(mask_a, B, HW, b.roi_a, b.n_a, sg))) return rc;
     if ((rc = oryon_roi_compact(mask_q, B, HW, b.roi_q, b.n_q, sg))) return rc;
     if (c.src_sampling > 0 && (rc = oryon_roi_subsample(b.roi_a, b.n_a, B, HW, c.src_sampling, c.seed, pair_key, sg))) return rc;
     const bool mx6 = c.screen == 1 && !force_eager;           // the eager route (complete min_dist / argmin arrays) keeps the int8 operands
-    if (mx6) {
+    if (ablate & 1) {
+    } else if (mx6) {
         // the row buffers hold 32-byte mx6 slots instead of int8 rows (same size); the per-map error norms go where eps_max went
         if ((rc = oryon_gather_mx6(feat_q, B, c.C, HW, c.layout, b.roi_q, HW, b.n_q, e->L.cap_q, e->L.c_pad, reinterpret_cast<uint8_t *>(g.q8),
                                    g.q_eps, g.q_norm, nullptr, c.round_f16, sg))) return rc;
@@ -356,7 +362,8 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
         (void)oryon_profile_events(tev[4], tev[5]);
     }
     // corrs rows beyond max_corrs are never written by the sampler and K2 only reads n_sel rows: no zero-fill needed
-    if (mx6) {
+    if (ablate & 2) {
+    } else if (mx6) {
         if ((rc = oryon_match_corrs_mx6(g.a_hat, reinterpret_cast<const uint8_t *>(g.a8), g.a_eps, feat_q, c.C, HW, c.layout, b.roi_a, HW, b.roi_q,
                                         HW, g.q_norm, reinterpret_cast<const uint8_t *>(g.q8), g.q_eps, B, e->L.c_pad, e->L.cap_a, e->L.cap_q,
                                         b.n_a, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key, b.min_dist, b.argmin, b.valid,
@@ -367,8 +374,8 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
                                    B, e->L.c_pad, e->L.cap_a, e->L.cap_q, b.n_a, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key,
                                    force_eager, b.min_dist, b.argmin, b.valid, b.corrs, b.n_valid, b.n_sel, b.status, b.n_und, c.round_f16,
                                    e->L.match_ws, e->L.match_ws_bytes, sm))) return rc;
-    if ((rc = oryon_lift_pairs(b.corrs, b.n_sel, B, e->L.n_cap, c.FH, c.FW, depth_a, c.HA, c.WA, depth_q, c.HQ, c.WQ, cam_a, cam_q, b.status,
-                               b.pcd_a, b.pcd_q, b.n_lift, sm))) return rc;
+    if (!(ablate & 2) && (rc = oryon_lift_pairs(b.corrs, b.n_sel, B, e->L.n_cap, c.FH, c.FW, depth_a, c.HA, c.WA, depth_q, c.HQ, c.WQ, cam_a, cam_q,
+                                                b.status, b.pcd_a, b.pcd_q, b.n_lift, sm))) return rc;
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[3], sm));
     if (c.overlap >= 1) {
         ORYON_CHECK_HIP(hipEventRecord(e->ev_matched[slot], sm));
@@ -376,8 +383,8 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
     }
     // ---- K3-K10 on the slot's registration stream
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[6], sr));
-    if ((rc = oryon_pointdsc_register(e->solver, b.pcd_a, b.pcd_q, b.n_lift, B, e->L.n_cap, b.status, b.pdsc_ws, e->L.pdsc_ws_bytes, b.pose,
-                                      nullptr, b.status_out, sr))) return rc;
+    if (!(ablate & 4) && (rc = oryon_pointdsc_register(e->solver, b.pcd_a, b.pcd_q, b.n_lift, B, e->L.n_cap, b.status, b.pdsc_ws, e->L.pdsc_ws_bytes,
+                                                       b.pose, nullptr, b.status_out, sr))) return rc;
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[7], sr));
     if (c.overlap >= 1) ORYON_CHECK_HIP(hipEventRecord(e->ev_done[slot], sr));
     e->used[slot] = true;

@@ -10,6 +10,7 @@
 // Ordering semantics: torch.argsort / topk tie order is implementation-defined in the reference
 // (SURVEY.md §7); here every ranking is "by value, ties by ascending index" (rank counting), which is what
 // a stable sort gives.
+#include <stdlib.h>
 #include "common.h"
 #include "kabsch.h"
 #include "pdsc.h"
@@ -235,6 +236,139 @@ __global__ __launch_bounds__(256) void pdsc_knn_matrix_kernel(const float *__res
     const int n_pairs = k * (k - 1) / 2;
     for (int e = t; e < n_pairs; e += 256) {
         // e -> (a, c2), a < c2, row-major over the strict upper triangle
+        int a = (int)((2.0f * k - 1.0f - sqrt_rn((2.0f * k - 1.0f) * (2.0f * k - 1.0f) - 8.0f * (float)e)) * 0.5f);
+        while (a > 0 && a * (2 * k - a - 1) / 2 > e) --a;
+        while ((a + 1) * (2 * k - a - 2) / 2 <= e) ++a;
+        const int c2 = a + 1 + (e - a * (2 * k - a - 1) / 2);
+        float dot = 0.0f;
+        const float4 *fa = reinterpret_cast<const float4 *>(kf + a * (C + 4)), *fb = reinterpret_cast<const float4 *>(kf + c2 * (C + 4));
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const float4 x = fa[c4], y = fb[c4];
+            dot = fmaf(x.x, y.x, dot);
+            dot = fmaf(x.y, y.y, dot);
+            dot = fmaf(x.z, y.z, dot);
+            dot = fmaf(x.w, y.w, dot);
+        }
+        float fm = 1.0f - (1.0f - dot) * inv_sigma2;
+        fm = fm > 0.0f ? fm : 0.0f;
+        const float *pa = kc + a * 6, *pb = kc + c2 * 6;
+        const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+        const float ex = pa[3] - pb[3], ey = pa[4] - pb[4], ez = pa[5] - pb[5];
+        const float df = sqrt_rn(dx * dx + dy * dy + dz * dz) - sqrt_rn(ex * ex + ey * ey + ez * ez);
+        float smv = 1.0f - df * df * inv_sigma_d2;
+        smv = smv > 0.0f ? smv : 0.0f;
+        const float v = fm * smv;
+        Mo[a * k_cfg + c2] = v;
+        Mo[c2 * k_cfg + a] = v;
+    }
+}
+
+// The same kNN + compatibility matrix with ONE WAVE per (seed, pair) and no workgroup barrier (round 3; n_cap <= 64 R, distances from
+// pdsc_seed_dist_kernel): the 256-thread kernel above spends its time in the 45 barrier-separated stages of a 512-element bitonic sort of
+// which only ranks 1..k (k = 40) are used (100 us per 64 registrations, 219 us outliers).  Here a lane holds R distances as order-preserving
+// integer keys, sorts its own R (stable odd-even transposition in registers: ties keep the smaller row index first), and the wave then
+// extracts the k + 1 smallest (key, row) pairs one by one: minimum over the lanes' heads (two 6-step xor reductions: key, then the smallest
+// row among the lanes that hold it), the winning lane pops its head.  Same order as the full sort - ascending distance, ties by row index -
+// hence the same neighbours, the same matrix, bit for bit.  The neighbour rows go to LDS (22 KB per wave: 7 waves per CU) for the matrix phase.
+// MEASURED: 91.5 us against 100 us - the kernel is bound by its instruction count (3200 waves x ~7.5 k VALU instructions over 1024 SIMDs:
+// the 780 k-ordered 128-term dot products of the matrix phase and the 41 extraction rounds), not by the barriers; ORYON_PDSC_KNN_WAVE=1
+// selects it, the tests run both.
+// wave-wide minimum on the DPP data path (row shifts inside the 16-lane rows, then the two row broadcasts gfx9 has), result read from lane 63:
+// ~10 dependent VALU instructions; the same reduction written with __shfl_xor is six dependent ds_bpermute round trips (the first version of
+// this kernel, latency-bound on them, was no faster than the sort it replaces)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#define ORYON_DPP_MIN(ctrl, rmask)                                                                                              \
+    {                                                                                                                           \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false);                      \
+        v = o < v ? o : v;                                                                                                      \
+    }
+    ORYON_DPP_MIN(0x111, 0xf)      // row_shr:1
+    ORYON_DPP_MIN(0x112, 0xf)      // row_shr:2
+    ORYON_DPP_MIN(0x114, 0xf)      // row_shr:4
+    ORYON_DPP_MIN(0x118, 0xf)      // row_shr:8   -> lane 15 of every row holds the row's minimum
+    ORYON_DPP_MIN(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+    ORYON_DPP_MIN(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+#undef ORYON_DPP_MIN
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int C, int R>
+__global__ __launch_bounds__(64) void pdsc_knn_wave_kernel(const float *__restrict__ feat_n, const float *__restrict__ src,
+                                                            const float *__restrict__ tgt, const int32_t *__restrict__ n_rows, int n_cap,
+                                                            const int32_t *__restrict__ n_seeds, int S_cap, int k_cfg, float inv_sigma2,
+                                                            float inv_sigma_d2, int32_t *__restrict__ knn_out, float *__restrict__ M_out,
+                                                            const float *__restrict__ dist_pre /* [B,S_cap,n_cap] */, int n_batch)
+{
+    extern __shared__ float sm[];
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int b = (lin / 8 / (int)gridDim.x) * 8 + (lin & 7), s = (lin / 8) % (int)gridDim.x;
+    if (b >= n_batch || s >= n_seeds[b]) return;
+    const int n = n_rows[b];
+    const int k = k_cfg < n - 1 ? k_cfg : n - 1;
+    float *kf = sm;                               // [k_cfg][C + 4]
+    float *kc = kf + k_cfg * (C + 4);             // [k_cfg][6]
+    const int lane = threadIdx.x;
+    const float *F = feat_n + (size_t)b * n_cap * C;
+    const float *dp = dist_pre + ((size_t)b * S_cap + s) * n_cap;
+    // order-preserving keys (no -0.0 / NaN among 2 - 2 dot); absent rows: the largest key
+    unsigned key[R];
+    int rr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = lane + 64 * r;
+        unsigned kx = 0xffffffffu;
+        if (j < n) {
+            const unsigned bits = __float_as_uint(dp[j]);
+            kx = (bits >> 31) ? ~bits : (bits | 0x80000000u);
+        }
+        key[r] = kx;
+        rr[r] = r;
+    }
+    // the lane's own R entries, ascending, stable (strict >): equal keys keep ascending row order
+#pragma unroll
+    for (int pass = 0; pass < R; ++pass) {
+#pragma unroll
+        for (int r = pass & 1; r + 1 < R; r += 2) {
+            const bool sw = key[r] > key[r + 1];
+            const unsigned ka = key[r], kb = key[r + 1];
+            const int ra = rr[r], rb = rr[r + 1];
+            key[r] = sw ? kb : ka; key[r + 1] = sw ? ka : kb;
+            rr[r] = sw ? rb : ra;  rr[r + 1] = sw ? ra : rb;
+        }
+    }
+    int mine = 0;                                 // lane t holds neighbour t (rank t + 1 of the order)
+    for (int t = 0; t <= k; ++t) {
+        const unsigned mk = wave_min_u32(key[0]);
+        const unsigned cand = key[0] == mk ? (unsigned)(lane + 64 * rr[0]) : 0xffffffffu;
+        const unsigned mi = wave_min_u32(cand);
+        if (lane == (int)(mi & 63u)) {
+#pragma unroll
+            for (int r = 0; r + 1 < R; ++r) { key[r] = key[r + 1]; rr[r] = rr[r + 1]; }
+            key[R - 1] = 0xffffffffu;
+        }
+        if (t >= 1 && lane == t - 1) mine = (int)mi;
+    }
+    if (lane < k) knn_out[((size_t)b * S_cap + s) * k_cfg + lane] = mine;
+    // neighbour features / coordinates -> LDS
+    static_assert(C == 128, "two channels per lane");
+    for (int a = 0; a < k; ++a) {
+        const int row = __shfl(mine, a);
+        const float2 v = reinterpret_cast<const float2 *>(F + (size_t)row * C)[lane];
+        *reinterpret_cast<float2 *>(kf + a * (C + 4) + 2 * lane) = v;
+    }
+    if (lane < k) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            kc[lane * 6 + d] = src[((size_t)b * n_cap + mine) * 3 + d];
+            kc[lane * 6 + 3 + d] = tgt[((size_t)b * n_cap + mine) * 3 + d];
+        }
+    }
+    __syncthreads();
+    float *Mo = M_out + ((size_t)b * S_cap + s) * k_cfg * k_cfg;
+    for (int e = lane; e < k; e += 64) Mo[e * k_cfg + e] = 0.0f;
+    const int n_pairs = k * (k - 1) / 2;
+    for (int e = lane; e < n_pairs; e += 64) {
         int a = (int)((2.0f * k - 1.0f - sqrt_rn((2.0f * k - 1.0f) * (2.0f * k - 1.0f) - 8.0f * (float)e)) * 0.5f);
         while (a > 0 && a * (2 * k - a - 1) / 2 > e) --a;
         while ((a + 1) * (2 * k - a - 2) / 2 <= e) ++a;
@@ -513,6 +647,17 @@ int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float
                            n_cap, seeds, n_seeds, S_cap, ws.seed_dist);
         dist_pre = ws.seed_dist;
     }
+    // 1: the one-wave-per-seed kernel (same results; 91 vs 100 us per 64 registrations in the kernel trace, no difference in the step: not the default)
+    static const bool knn_wave = getenv("ORYON_PDSC_KNN_WAVE") && atoi(getenv("ORYON_PDSC_KNN_WAVE")) != 0;
+    if (knn_wave && dist_pre && n_cap <= 1024 && k <= 63) {
+        const size_t shw = ((size_t)k * (128 + 4) + (size_t)k * 6) * sizeof(float);
+        if (n_cap <= 512)
+            hipLaunchKernelGGL((pdsc_knn_wave_kernel<128, 8>), dim3(S_cap, (B + 7) / 8 * 8), dim3(64), shw, st, feat_n, src, tgt, n_rows, n_cap,
+                               n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, dist_pre, B);
+        else
+            hipLaunchKernelGGL((pdsc_knn_wave_kernel<128, 16>), dim3(S_cap, (B + 7) / 8 * 8), dim3(64), shw, st, feat_n, src, tgt, n_rows, n_cap,
+                               n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, dist_pre, B);
+    } else
     hipLaunchKernelGGL(pdsc_knn_matrix_kernel, dim3(S_cap, (B + 7) / 8 * 8), dim3(256), sh1, st, feat_n, src, tgt, n_rows, n_cap, C, seeds,
                        n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, dist_pre, B);
     if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
