@@ -1,6 +1,10 @@
-// K1s6: the MX-fp6 screen of the lazy matcher (round 3) - the dominant kernel of the cfg2 step, in its own translation unit.
-// (Measured and not kept: compiling this file with -fno-honor-nans removes the operand quieting - v_max_f32 x, x, x - in front of the
-// fmaxf chains, 12 % of the loop's VALU instructions; same kernel time on the same box, 1.47 ms, so the default semantics stay.)
+// K1s6: the MX-fp6 screen of the lazy matcher (round 3) - the dominant kernel of the cfg2 step.  Its own translation unit because it is
+// compiled with -fno-honor-nans (Makefile): the running-maximum reductions are chains of fmaxf, and with NaNs honoured the compiler
+// quiets every operand it cannot prove canonical (v_max_f32 x, x, x: three extra VALU instructions per 32x32 block) - extra live values
+// that push match_mx6_screen_w4_kernel<256, 8> from 246 VGPRs to 52 spilled registers (266 MB of scratch writes per launch in the
+// WRITE_SIZE counter, +12 % time).  No NaN can occur here: fp6 e2m3 has no NaN / Inf codes, the E8M0 exponents K0 writes are finite
+// (dead rows of a tile are zero rows with exponent byte 0), and a garbage anchor row beyond the pair's count only feeds its own,
+// ignored, output column.  match16.hip, which uses a NaN as a marker (resolve_anchor), keeps the default semantics.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <type_traits>

@@ -147,3 +147,27 @@ def test_bench_self_launches_for_gpus_2():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["global_pairs"] == 10 and rec["collated_in_order"] is True
+
+
+def test_hot_kernels_do_not_spill():
+    """The kernels of the cfg2 step keep their working set in registers (tools/check_kernel_resources.py reads the AMDGPU metadata of the
+    built objects): a compiler-flag change that silently spilled 52 registers of the MX-fp6 screen cost 12 % in round 3."""
+    import glob, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not glob.glob(os.path.join(root, "oryon_amd", "csrc", "*.o")):
+        pytest.skip("objects not built in this tree")
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_kernel_resources as ckr
+    rows = ckr.report()
+    if not rows:
+        pytest.skip("LLVM object tools not available")
+    hot = ("match_mx6_screen_w4_kernelILi256ELi8E", "match_i8_screen_v2_kernelILi256E", "gather_q8_v3_kernelILi256ELi1ELb0ELi1E",
+           "gather_q8_v3_kernelILi256ELi1ELb0ELi0E", "pdsc_attention_x3_img_kernel", "pdsc_pcn_qkv_x3_kernel", "pdsc_mlp3_x3_kernel",
+           "match_decide_lite_kernel", "match_resolve_selected_kernel")
+    seen = set()
+    for k in rows:
+        for h in hot:
+            if h in k["name"]:
+                seen.add(h)
+                assert k["scratch"] == 0, f"{k['name']}: {k['spill']} spilled registers, {k['scratch']} B of scratch per lane"
+    assert seen == set(hot), sorted(set(hot) - seen)
