@@ -4,7 +4,7 @@ sha256 of the kernel's source so that bench.py can tell when the record has gone
 import hashlib, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-KERN = sys.argv[2] if len(sys.argv) > 2 else "match_mx6_screen_w4_kernel<256"
+KERN = sys.argv[2] if len(sys.argv) > 2 else "match_mx6_screen_w4_kernel<256, 8"
 md = open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.md")).read()
 def per_dispatch(kernel, counter):
     m = re.search(r"\| `[^`]*" + re.escape(kernel) + r"[^`]*` \| " + counter + r" \| [^|]+\| (\d+) \| ([^|]+)\|", md)
