@@ -663,8 +663,9 @@ def main():
             dist.all_reduce(hel, op=dist.ReduceOp.MAX)
         if rank == 0:
             hard = {"descriptors": "smooth rank-8 fields + 1-2 % noise (anchor map = query map + noise): the int8 bound settles every anchor's VALIDITY "
-                                   "but cannot separate its near-ties, so the argmin of the <= 500 sampled anchors per pair comes from an exact fp32 scan "
-                                   "of just those rows (lazy tail) against fp32 query rows materialised for the pair",
+                                   "but cannot separate its near-ties, so the argmin of the <= 500 sampled anchors per pair comes from the second level: the "
+                                   "fp16x3 two-sweep scan of just those rows (K1x3, match_x3.hip) + the canonical fp32 chain on its few candidates "
+                                   "(ORYON_AMB_X3=0: exact fp32 scan against fp32 query rows materialised for the pair)",
                     "value": total * 5 / float(hel.item()), "unit": "pairs/s", "ms_per_step": float(hel.item()) / 5 * 1e3,
                     "int8_undecided_fraction": float(engine._i8_frac), "int8_stage_skipped": bool(engine._i8_frac > engine.i8_max_undecided),
                     "pairs_ok": int((hstatus[:total] == 0).sum())}

@@ -246,6 +246,14 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
         // operands of match_x3_scan_kernel.
         static_assert(LPR == 1 || FMT != 2, "FMT = 2 is instantiated for one lane per row");
         constexpr int HB = CP * 2;                              // bytes per half row
+        float lo2 = 0.0f;                                       // |lo|^2 of the lane's row: K1x3's first sweep multiplies hi parts only
+        // the unit values replace the raw ones in place first (computed inside the staging passes, all 256 quotients were hoisted and
+        // lived beside the 256 raw values: ~100 registers in scratch)
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            VS(i, __fdiv_rn(VG(i), d));
+            if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int part = 0; part < KPL / 64; ++part) {           // 64 channels per staging pass: slots 0-7 = hi halves, 8-15 = lo halves
             const int c0 = part * 64;
@@ -253,14 +261,19 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 unsigned wh[4], wl[4];
+                float sq[4];                                    // per-slot partial sums: ONE long fmaf chain over all 256 values made the
+                                                                // scheduler hoist every conversion in front of it (~100 registers in scratch)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float u0 = __fdiv_rn(VG(c0 + 8 * s + 2 * j), d), u1 = __fdiv_rn(VG(c0 + 8 * s + 2 * j + 1), d);
+                    const float u0 = VG(c0 + 8 * s + 2 * j), u1 = VG(c0 + 8 * s + 2 * j + 1);
                     const __half h0 = __float2half_rn(u0), h1 = __float2half_rn(u1);
-                    const __half l0 = __float2half_rn(u0 - __half2float(h0)), l1 = __float2half_rn(u1 - __half2float(h1));
+                    const float d0 = u0 - __half2float(h0), d1 = u1 - __half2float(h1);          // exact: hi is u rounded to 11 bits
+                    const __half l0 = __float2half_rn(d0), l1 = __float2half_rn(d1);
                     wh[j] = (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16);
                     wl[j] = (unsigned)__half_as_ushort(l0) | ((unsigned)__half_as_ushort(l1) << 16);
+                    sq[j] = fmaf(d0, d0, d1 * d1);                                                // |lo| <= |d| (1 + 2^-11)
                 }
+                lo2 += (sq[0] + sq[1]) + (sq[2] + sq[3]);
                 *reinterpret_cast<uint4 *>(stage + stage_addr(lane, s, 256)) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
                 *reinterpret_cast<uint4 *>(stage + stage_addr(lane, s + 8, 256)) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
             }
@@ -273,6 +286,13 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
                 const uint4 q = *reinterpret_cast<const uint4 *>(stage + stage_addr(t, s, 256));
                 *reinterpret_cast<uint4 *>((s < 8 ? oh : ol) + (size_t)t * HB + (s & 7) * 16) = q;
             }
+        }
+        if (eps_max) {                                          // largest |u - hi|_2^2 of the map's rows (|lo| <= |u - hi| (1 + 2^-11))
+            // No wave reduction here: any cross-lane operation at this point (shuffles, DPP) cost ~100 registers of scratch in this
+            // instantiation.  Every lane compares with the map's current maximum (a cached broadcast load; stale values only cost an extra
+            // atomic) and only lanes that would raise it issue the atomic: a few per map after the first waves.  Dead rows are zero rows.
+            // The SQUARE goes out (the consumer takes the root).
+            if (lo2 > 0.0f && __float_as_uint(lo2) > __atomic_load_n(&eps_max[m], __ATOMIC_RELAXED)) atomicMax(&eps_max[m], __float_as_uint(lo2));
         }
     }
     if constexpr (FMT == 0) {

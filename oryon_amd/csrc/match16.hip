@@ -1926,10 +1926,10 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     const float cut0 = 1.0f - 2.0f * threshold;
     const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    // second level for the sampled anchors no screen can separate: fp16x3 scan (K1x3, C_pad 256) instead of the exact fp32 scan.  OFF unless
-    // ORYON_AMB_X3=1: exact (tests run both settings) but, as measured in round 3, slower than the exact scan on smooth fields - the one-pass
-    // running-maximum lists overflow there and the overflow falls back to the exact scan anyway ("K1x3")
-    static const bool x3_env = getenv("ORYON_AMB_X3") && atoi(getenv("ORYON_AMB_X3")) != 0;
+    // second level for the sampled anchors no screen can separate: fp16x3 two-sweep scan (K1x3, match_x3.hip; C_pad 256) instead of the
+    // exact fp32 scan - same results, hard-descriptor step 9.8 -> 8.5 ms; ~30 us of empty launches per step when no anchor needs it.
+    // ORYON_AMB_X3=0 keeps the exact scan (the tests run both settings).
+    static const bool x3_env = !getenv("ORYON_AMB_X3") || atoi(getenv("ORYON_AMB_X3")) != 0;
     const int use_x3 = (x3_env && C == 256 && !force_eager) ? 1 : 0;
     if (fmt == 1) {
         const uint8_t *a6 = reinterpret_cast<const uint8_t *>(a_i8), *q6 = reinterpret_cast<const uint8_t *>(q_i8);

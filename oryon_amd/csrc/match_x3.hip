@@ -6,21 +6,24 @@
 // significant bits; K0 FMT = 2 writes the query rows that way, match_x3_split_anchors_kernel the anchors) and
 //     s3 = sum_k  al.qh + ah.ql + ah.qh      (three v_mfma_f32_32x32x16_f16 per 16 channels, fp32 accumulate)
 // approximates the canonical dot product within DELTA3 = 6.5e-5 (C <= 256: split error <= 1.4e-6, dropped lo.lo term <= 2.4e-7, fp32
-// accumulation of 768 terms here <= 4.6e-5 and of 256 terms in the canonical chain <= 1.5e-5, all worst case).  ONE pass: a lane keeps the
-// running maximum of its anchor column and appends (index, score) to the anchor's candidate list whenever a score reaches the running maximum
-// minus MARGIN3 = 2 DELTA3 + slack - the final maximum is at least every running one, so every row within MARGIN3 of the final maximum,
-// i.e. every exact minimiser, is in the list (plus a handful of stale entries: O(log n) new maxima per column).  match_x3_rescore_kernel then
-// drops the stale ones and runs the canonical fp32 chain on x_k / d from the raw map for the rest (typically 1-5 rows): distance, first index
-// of the minimum, validity - bit for bit what the exact scan returns.  A list that overflows (crowds of exact duplicates) sends its anchor to
-// the exact scan (device-side list; the caller materialises fp32 rows for such pairs only).
+// accumulation of 768 terms here <= 4.6e-5 and of 256 terms in the canonical chain <= 1.5e-5, all worst case).  TWO sweeps over a workgroup's
+// share of the query rows: the first multiplies the hi parts only (a third of the MFMAs) and keeps the maximum per anchor column - with
+//     |s_hi - s| <= (|al|_2 + |ql|_2)(1 + 2^-10) + |al||ql| + 3.1e-5
+// (|al| per anchor from match_x3_split_anchors_kernel, the largest |ql| of the pair from K0 FMT = 2: ~1.4e-4 each on unit rows of 256) that is a
+// lower bound of the anchor's true maximum; the second sweep computes s3 and appends (index, score) to the anchor's candidate list whenever
+// s3 >= bound - DELTA3, a FIXED limit, so every exact minimiser is listed and the lists hold what lies within ~4e-4 of the maximum (tens of
+// rows on the smoothest fields probed).  match_x3_rescore_kernel then keeps the entries within MARGIN3 = 2 DELTA3 + slack of the best listed
+// score and runs the canonical fp32 chain on x_k / d from the raw map for them (typically 1-5 rows): distance, first index of the minimum,
+// validity - bit for bit what the exact scan returns.  A list that overflows (crowds of near-duplicates) sends its anchor to the exact scan
+// (device-side list; the caller materialises fp32 rows for such pairs only).
 //
-// STATE (round 3): exact and tested, NOT the default (ORYON_AMB_X3=1 enables it).  Each (pair, query split, anchor, lane half) list has one
-// writer, so the scan needs no atomics (2.6 ms per cfg2 step of smooth inputs: 760 TFLOP/s on the fp16 pipe; the first version's returning
-// atomicAdd per entry cost 9 ms).  On the smooth fields it was built for the premise "a handful of stale entries" fails: scanning towards
-// a smooth peak EVERY row is a new running maximum, 64-entry lists overflow for most anchors and the exact fall-back runs anyway (hard
-// step 14.0 ms against 10.9 ms without K1x3).  What would fix it is written up in DESIGN.md: a first hi-only sweep for a per-anchor lower
-// bound of the maximum (1/3 of the MFMAs), then this sweep with a FIXED threshold.
+// History: the first version kept a RUNNING maximum in one sweep and listed everything within MARGIN3 of it - scanning row-major towards a
+// smooth peak nearly every row is a new running maximum, the lists overflowed and the exact fall-back ran anyway (hard step 14.0 ms against
+// 10.9 without K1x3); its first list writer used a returning atomicAdd per entry (9 ms per launch; now one writer per list, no atomics).
 #include <hip/hip_fp16.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 #include "common.h"
 #include "match_common.h"
 
@@ -28,22 +31,28 @@ namespace oryon {
 
 typedef _Float16 half8x __attribute__((ext_vector_type(8)));
 
-constexpr int X3_CAPH = 64;                // candidate slots per (pair, query split, anchor, lane half): each list has ONE writer, no atomics
+constexpr int X3_CAPH = 128;               // candidate slots per (pair, query split, anchor, lane half): each list has ONE writer, no atomics
 constexpr float X3_MARGIN = 1.32e-4f;      // 2 * DELTA3 (6.5e-5) + 2e-6
 
 // fp32 anchor rows (k-permuted inside groups of 8: position 8g + 4h + j holds k = 8g + 2j + h) -> hi / lo half rows in natural k order
+// + al_norm [B, cap_s]: an upper bound of |lo|_2 of every row (Cp = 256: the 32 groups of a row are 32 consecutive lanes)
 __global__ __launch_bounds__(256) void match_x3_split_anchors_kernel(const float *__restrict__ a_c, int Cp, int cap_s,
                                                                       const int32_t *__restrict__ n_c, __half *__restrict__ ah,
-                                                                      __half *__restrict__ al)
+                                                                      __half *__restrict__ al, float *__restrict__ al_norm)
 {
     const int p = blockIdx.y;
     const int n = n_c[p] < cap_s ? n_c[p] : cap_s;
     const int n_fill = (n + 255) / 256 * 256 < cap_s ? (n + 255) / 256 * 256 : cap_s;      // the scan reads whole 256-anchor panels: zero-fill
     const int groups = n_fill * (Cp / 8);
-    for (int g = blockIdx.x * 256 + threadIdx.x; g < groups; g += gridDim.x * 256) {
+    const int groups_up = (groups + 255) / 256 * 256;          // whole workgroups stay in the loop: the row reduction below uses shuffles
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < groups_up; g += gridDim.x * 256) {
         const int row = g / (Cp / 8), gi = g % (Cp / 8);
         union { __half h[8]; uint4 u; } hi, lo;
-        if (row < n) {
+        float l2 = 0.0f;
+        if (g >= groups) {
+            hi.u = make_uint4(0, 0, 0, 0);
+            lo.u = make_uint4(0, 0, 0, 0);
+        } else if (row < n) {
             const float4 *src = reinterpret_cast<const float4 *>(a_c + ((size_t)p * cap_s + row) * Cp) + 2 * gi;
             const float4 x = src[0], y = src[1];                // x = k 8g+{0,2,4,6}, y = k 8g+{1,3,5,7}
             const float v[8] = {x.x, y.x, x.y, y.y, x.z, y.z, x.w, y.w};
@@ -51,13 +60,19 @@ __global__ __launch_bounds__(256) void match_x3_split_anchors_kernel(const float
             for (int i = 0; i < 8; ++i) {
                 hi.h[i] = __float2half_rn(v[i]);
                 lo.h[i] = __float2half_rn(v[i] - __half2float(hi.h[i]));
+                l2 = fmaf(__half2float(lo.h[i]), __half2float(lo.h[i]), l2);
             }
         } else {
             hi.u = make_uint4(0, 0, 0, 0);
             lo.u = make_uint4(0, 0, 0, 0);
         }
-        reinterpret_cast<uint4 *>(ah + ((size_t)p * cap_s + row) * Cp)[gi] = hi.u;
-        reinterpret_cast<uint4 *>(al + ((size_t)p * cap_s + row) * Cp)[gi] = lo.u;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) l2 += __shfl_xor(l2, off);          // Cp / 8 = 32 lanes per row
+        if (g < groups) {
+            reinterpret_cast<uint4 *>(ah + ((size_t)p * cap_s + row) * Cp)[gi] = hi.u;
+            reinterpret_cast<uint4 *>(al + ((size_t)p * cap_s + row) * Cp)[gi] = lo.u;
+            if (gi == 0) al_norm[(size_t)p * cap_s + row] = sqrtf(l2) * 1.0001f + 1e-12f;
+        }
     }
 }
 
@@ -68,7 +83,8 @@ template <int CP>
 __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
                                                                const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
                                                                int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
-                                                               int S, int32_t *__restrict__ cnt, uint2 *__restrict__ cand)
+                                                               int S, const float *__restrict__ al_norm, const float *__restrict__ ql_max,
+                                                               int32_t *__restrict__ cnt, uint2 *__restrict__ cand)
 {
     constexpr int RB = CP * 2;                 // bytes per half row
     constexpr int ROWS = 32;
@@ -134,6 +150,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
         return *reinterpret_cast<const half8x *>(smem + koff[s & 7] + tile + (unsigned)(part * PART + (s >> 3) * 256));
     };
 
+    // ---- sweep 1: hi.hi only (a third of the MFMAs) -> a lower bound of every anchor's maximum over this split's rows
     float runmax[NAB];
     int nlist[NAB];
 #pragma unroll
@@ -142,6 +159,52 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        // the last iteration already requests the first tile of sweep 2
+        issue(qt + 1 < qt_end ? qt + 1 : qt_begin, buf ^ 1);
+        const unsigned tile = buf * STAGE;
+        f32x16 acc[NAB];
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ab][r] = 0.0f;
+        half8x xh = rd(0, 0, tile);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            half8x nh = xh;
+            if (s + 1 < NKS) nh = rd(0, s + 1, tile);
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[ab][s], acc[ab], 0, 0, 0);
+            xh = nh;
+        }
+        const int q0 = qt * ROWS + 4 * hi;
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab) {
+            float x = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
+            runmax[ab] = fmaxf(runmax[ab], x);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+    // |s_hi - s| <= (|al| + |ql|)(1 + 2^-10) + |al||ql| + 3.1e-5 (fp32 accumulation of 256 products here and in the canonical chain),
+    // so max_j s_j >= runmax - e_hi, and every exact maximiser has s3 >= max_j s_j - DELTA3: a FIXED emission limit per anchor column
+    float lim[NAB];
+    const float qlm = sqrtf(ql_max[p]) * 1.002f;            // K0 FMT = 2 hands over the largest |u - hi|^2 of the pair's query rows
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const int a = a0 + wave * 64 + ab * 32 + l31;
+        const float aln = al_norm[(size_t)p * cap_s + (a < cap_s ? a : cap_s - 1)];
+        runmax[ab] = fmaxf(runmax[ab], __shfl_xor(runmax[ab], 32));
+        const float e_hi = (aln + qlm) * 1.001f + aln * qlm + 3.1e-5f;
+        lim[ab] = runmax[ab] - e_hi - 0.5f * X3_MARGIN;
+    }
+    float run3[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) run3[ab] = -INFINITY;
+    // ---- sweep 2: hi / lo compensated products, candidates against the fixed limit (the first tile is already in `buf`)
     for (int qt = qt_begin; qt < qt_end; ++qt) {
         if (qt + 1 < qt_end) issue(qt + 1, buf ^ 1);
         const unsigned tile = buf * STAGE;
@@ -165,7 +228,6 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
             xh = nh;
             xl = nl;
         }
-        // epilogue: the lane's 16 query rows of this tile against its two anchor columns
         const int q0 = qt * ROWS + 4 * hi;
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab) {
@@ -173,15 +235,15 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
             float x = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
-            runmax[ab] = fmaxf(runmax[ab], x);
-            // the running maximum is shared by the two lanes (hi = 0 / 1) of the column, so that either drops what the other already beat
-            runmax[ab] = fmaxf(runmax[ab], __shfl_xor(runmax[ab], 32));
-            const float lim = runmax[ab] - X3_MARGIN;
-            if (a < nc && x >= lim) {
+            // the s3 scores themselves tighten the limit as they come in (the maximum is at least every s3 - DELTA3): rows behind the peak
+            // that the fixed limit alone would still list are dropped
+            run3[ab] = fmaxf(run3[ab], fmaxf(x, __shfl_xor(x, 32)));
+            lim[ab] = fmaxf(lim[ab], run3[ab] - X3_MARGIN);
+            if (a < nc && x >= lim[ab]) {
                 uint2 *list = cand + ((((size_t)p * S + split) * cap_s + a) * 2 + hi) * X3_CAPH;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (acc[ab][r] >= lim && q0 + (r & 3) + 8 * (r >> 2) < nq) {          // zero-padded rows of the last tile are not candidates
+                    if (acc[ab][r] >= lim[ab] && q0 + (r & 3) + 8 * (r >> 2) < nq) {      // zero-padded rows of the last tile are not candidates
                         if (nlist[ab] < X3_CAPH) list[nlist[ab]] = make_uint2((unsigned)(q0 + (r & 3) + 8 * (r >> 2)), __float_as_uint(acc[ab][r]));
                         ++nlist[ab];
                     }
@@ -224,7 +286,7 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
         const size_t o = (((size_t)p * S + (s >> 1)) * cap_s + row) * 2 + (s & 1);
         const int c = cnt[o];
         overflow |= c > X3_CAPH;
-        if (lane < c && lane < X3_CAPH) m1 = fmaxf(m1, __uint_as_float(cand[o * X3_CAPH + lane].y));
+        for (int e = lane; e < c && e < X3_CAPH; e += 64) m1 = fmaxf(m1, __uint_as_float(cand[o * X3_CAPH + e].y));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, off));
@@ -243,9 +305,11 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
     for (int s = 0; s < 2 * S; ++s) {
         const size_t o = (((size_t)p * S + (s >> 1)) * cap_s + row) * 2 + (s & 1);
         const int n = cnt[o];
-        const uint2 ent = lane < n ? cand[o * X3_CAPH + lane] : make_uint2(0u, 0u);
+        for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e_ = e0 + lane;
+        const uint2 ent = e_ < n ? cand[o * X3_CAPH + e_] : make_uint2(0u, 0u);
         const int qi = (int)ent.x;
-        const bool hit = lane < n && qi < nq && __uint_as_float(ent.y) >= m1 - X3_MARGIN;
+        const bool hit = e_ < n && qi < nq && __uint_as_float(ent.y) >= m1 - X3_MARGIN;
         unsigned long long hits = __ballot(hit);
         while (hits) {
             const int src = __ffsll((long long)hits) - 1;
@@ -274,6 +338,7 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
                     if (k + e < C_true) dot = __fmaf_rn(av[e], qv[e], dot);
             }
             lex_min(d, j, __fmaf_rn(-0.5f, dot, 0.5f), jj);
+        }
         }
     }
     if (lane == 0) {
@@ -309,7 +374,7 @@ int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, c
 
 size_t match_x3_scratch_bytes(int B, int cap_s, int S)
 {
-    return (size_t)B * S * cap_s * 2 * (sizeof(int32_t) + X3_CAPH * sizeof(uint2)) + (size_t)B * (cap_s + 2) * sizeof(int32_t) + 4096;
+    return (size_t)B * S * cap_s * 2 * (sizeof(int32_t) + X3_CAPH * sizeof(uint2)) + (size_t)B * (2 * cap_s + 3) * sizeof(int32_t) + 8192;
 }
 
 // a_c [B, cap_s, 256] fp32 compact anchor rows (k-permuted), n_c [B] -> md_c / am_c / va_c [B, cap_s]; n_ovf / ovf_idx: anchors whose
@@ -333,17 +398,22 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     int32_t *n_ovf = reinterpret_cast<int32_t *>(sp + off);
     off += ((size_t)B * sizeof(int32_t) + 255) / 256 * 256;
     int32_t *ovf_idx = reinterpret_cast<int32_t *>(sp + off);
+    off += ((size_t)B * cap_s * sizeof(int32_t) + 255) / 256 * 256;
+    float *ql_max = reinterpret_cast<float *>(sp + off);
+    off += ((size_t)B * sizeof(float) + 255) / 256 * 256;
+    float *al_norm = reinterpret_cast<float *>(sp + off);
     *n_ovf_out = n_ovf;
     *ovf_idx_out = ovf_idx;
     if (hipMemsetAsync(n_ovf, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess) return ORYON_ERR_HIP;
+    if (hipMemsetAsync(ql_max, 0, (size_t)B * sizeof(float), st) != hipSuccess) return ORYON_ERR_HIP;
     hipLaunchKernelGGL(match_x3_enable_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_c, enable);
     // query rows as hi / lo halves, only for pairs that have listed anchors
     int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, enable, cap_q, CP, reinterpret_cast<int8_t *>(qh), nullptr,
-                              nullptr, nullptr, nullptr, 1, round_f16, st, 2, ql);
+                              ql_max, nullptr, nullptr, 1, round_f16, st, 2, ql);
     if (rc) return rc;
-    hipLaunchKernelGGL(match_x3_split_anchors_kernel, dim3(64, B), dim3(256), 0, st, a_c, CP, cap_s, n_c, ah, al);
+    hipLaunchKernelGGL(match_x3_split_anchors_kernel, dim3(64, B), dim3(256), 0, st, a_c, CP, cap_s, n_c, ah, al, al_norm);
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), 0, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, cnt, cand);
+    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), 0, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, cnt, cand);
     const size_t lds = (size_t)4 * 2 * CP * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
@@ -351,6 +421,34 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     else
         hipLaunchKernelGGL((match_x3_rescore_kernel<false>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
                            roi_stride_q, q_norm, cap_q, n_q, S, threshold, cnt, cand, round_f16, md_c, am_c, va_c, n_ovf, ovf_idx);
+    static const bool dbg = getenv("ORYON_X3_DEBUG") != nullptr;          // development aid: list statistics of this call on stderr
+    if (dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<int32_t> hc((size_t)B * S * cap_s * 2), hn(B), hov(B);
+        std::vector<float> hq(B), ha((size_t)B * cap_s);
+        (void)hipMemcpy(hc.data(), cnt, hc.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hn.data(), n_c, (size_t)B * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hov.data(), n_ovf, (size_t)B * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hq.data(), ql_max, (size_t)B * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ha.data(), al_norm, ha.size() * 4, hipMemcpyDeviceToHost);
+        long tot = 0, nl = 0, over = 0, mx = 0, anchors = 0, novf = 0;
+        double amax = 0, qmax = 0;
+        for (int p = 0; p < B; ++p) {
+            const int n = hn[p] < cap_s ? hn[p] : cap_s;
+            anchors += n; novf += hov[p];
+            qmax = sqrtf(hq[p]) > qmax ? sqrtf(hq[p]) : qmax;
+            for (int a = 0; a < n; ++a) {
+                amax = ha[(size_t)p * cap_s + a] > amax ? ha[(size_t)p * cap_s + a] : amax;
+                for (int sp = 0; sp < S; ++sp)
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = hc[((((size_t)p * S + sp) * cap_s + a) * 2) + h];
+                        tot += c; nl += 1; over += c > X3_CAPH; mx = c > mx ? c : mx;
+                    }
+            }
+        }
+        fprintf(stderr, "[x3] anchors %ld, lists %ld, entries %ld (%.1f per anchor), longest %ld, overflowed lists %ld, overflowed anchors %ld, max|al| %.3g, max|ql| %.3g\n",
+                anchors, nl, tot, anchors ? (double)tot / anchors : 0.0, mx, over, novf, amax, qmax);
+    }
     return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
 }
 

@@ -609,13 +609,45 @@ def test_lazy_corrs_exact_ties_and_single_candidates():
     assert status.tolist() == [0, 0, 0, 0] and min(n_valid.tolist()) > 1500
 
 
-def test_lazy_corrs_with_the_fp16x3_second_level():
-    """K1x3 (match_x3.hip) is off by default and switched by ORYON_AMB_X3, which the library reads once: the three lazy == eager == exact
-    tests above, again, in a child interpreter with the switch on (smooth pair -> candidate lists, overflow -> exact fall-back)."""
+def test_lazy_corrs_smooth_fields_and_duplicate_crowds():
+    """The second level behind the screens (K1x3, the fp16x3 two-sweep scan; the exact fp32 scan with ORYON_AMB_X3=0) on what it exists for:
+    smooth rank-8 descriptor fields (best and second-best match ~1e-4 apart: every sampled anchor is ambiguous for the 6- / 8-bit screens)
+    with noise levels from 0 to 2 %, and query maps in which 400 pixels are exact copies / 1e-5-perturbed copies of one descriptor - more
+    candidates than a list holds, so the anchors that match the crowd take the overflow route (exact scan of just those anchors).
+    Lazy == eager == exact scan, bit for bit."""
+    dev = "cuda"
+    C, H = 256, 56
+    g = torch.Generator(device=dev).manual_seed(57)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, H, device=dev), indexing="ij")
+    coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy), torch.sin(7 * yy), torch.cos(5 * xx)])
+    fqs, fas = [], []
+    for noise_q, noise_a in ((0.02, 0.01), (0.0, 0.0), (0.001, 0.0005), (0.02, 0.01), (0.02, 0.01)):
+        fq = torch.einsum("ck,khw->chw", rn(C, 8), coef) + noise_q * rn(C, H, H)
+        fqs.append(fq)
+        fas.append(fq + noise_a * rn(C, H, H))
+    # crowds: 400 query pixels copy pixel 0 exactly (pair 3) / up to 1e-5 relative noise (pair 4)
+    for b, eps in ((3, 0.0), (4, 1e-5)):
+        flat = fqs[b].view(C, -1)
+        # pair 3: a CONTIGUOUS run (one query split holds them all: > 128 entries per list -> overflow route); pair 4: scattered
+        dst = torch.arange(1, 401, device=dev) if b == 3 else torch.randperm(H * H, generator=g, device=dev)[:400]
+        flat[:, dst] = flat[:, :1] * (1.0 + eps * rn(C, 400))
+        fas[b] = fqs[b] + 0.001 * rn(C, H, H)
+    fa, fq = torch.stack(fas), torch.stack(fqs)
+    ma = torch.ones((5, H, H), dtype=torch.int32, device=dev)
+    mq = torch.ones((5, H, H), dtype=torch.int32, device=dev)
+    (corrs, n_valid, n_sel, status, md, am, va), und, va0, na = _lazy_vs_eager(fa, fq, ma, mq, 256, 0.25)
+    assert status.tolist() == [0] * 5 and min(n_valid.tolist()) > 2000
+    assert int(und[0]) > 1000                                                      # the screens leave (nearly) every anchor of the smooth pairs ambiguous
+
+
+def test_lazy_corrs_with_the_exact_second_level():
+    """ORYON_AMB_X3 is read once by the library: the lazy == eager == exact tests above again in a child interpreter with K1x3 OFF
+    (the exact fp32 scan of the sampled ambiguous anchors, round 2's second level)."""
     import os, subprocess, sys
-    if os.environ.get("ORYON_AMB_X3") == "1":
+    if os.environ.get("ORYON_AMB_X3") == "0":
         pytest.skip("already the child run")
-    env = dict(os.environ, ORYON_AMB_X3="1")
+    env = dict(os.environ, ORYON_AMB_X3="0")
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k", "test_lazy_corrs and not second_level"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
