@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <type_traits>
 #include "common.h"
 #include "match_common.h"
 
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
     constexpr int NKS = CP / 16;
     constexpr int NI = PART / 4096;            // 1 KB DMA instructions per wave, part and tile
     constexpr int LPR = RB / 256;
-    __shared__ __attribute__((aligned(256))) char smem[2 * STAGE];
+    constexpr int NST = 4;                     // stages of the tile ring: 128 KB of dynamic LDS, one workgroup per CU
+    extern __shared__ __attribute__((aligned(256))) char smem[];
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int unit = (slot / T) * 8 + xcd;
@@ -131,9 +133,10 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char *qhp = reinterpret_cast<const char *>(qh + (size_t)p * cap_q * CP), *qlp = reinterpret_cast<const char *>(ql + (size_t)p * cap_q * CP);
-    auto issue = [&](int qt, int buf) {
+    auto issue = [&](int qt, int buf, int parts) {
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
+            if (part >= parts) break;
             const char *qb = (part ? qlp : qhp) + (size_t)qt * PART;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
@@ -150,19 +153,34 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
         return *reinterpret_cast<const half8x *>(smem + koff[s & 7] + tile + (unsigned)(part * PART + (s >> 3) * 256));
     };
 
-    // ---- sweep 1: hi.hi only (a third of the MFMAs) -> a lower bound of every anchor's maximum over this split's rows
+    // Tile ring.  With one wave per SIMD nothing hides a DMA's latency (1-2 us, longer than a tile's MFMAs: 0.5 us in sweep 1, 1.5 us in
+    // sweep 2 - the double-buffered first version spent more time waiting than multiplying), so tiles are requested NST - 1 = 3 ahead.
+    // Iteration qt: wait until tile qt has landed (at most min(2, tiles left) later tiles may still be in flight - loads return in order,
+    // the candidate stores of sweep 2 only make the count conservative), barrier (everyone's share of tile qt is visible AND everyone is
+    // done with tile qt - 1), request tile qt + 3 into the buffer tile qt - 1 just left, multiply tile qt.
+#define X3_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    auto sweep = [&](auto PARTS_C, auto &&body) {
+        constexpr int PARTS = decltype(PARTS_C)::value;
+        constexpr int PER = NI * PARTS;                       // DMA instructions per wave and tile
+        __syncthreads();                                       // the previous sweep's last tile is still being read by slower waves
+#pragma unroll
+        for (int d = 0; d < NST - 1; ++d)
+            if (qt_begin + d < qt_end) issue(qt_begin + d, d, PARTS);
+        for (int qt = qt_begin; qt < qt_end; ++qt) {
+            const int rem = qt_end - 1 - qt;
+            if (rem >= 2) X3_WAIT(2 * PER); else if (rem == 1) X3_WAIT(PER); else X3_WAIT(0);
+            __syncthreads();
+            const int ahead = qt + NST - 1;
+            if (ahead < qt_end) issue(ahead, (ahead - qt_begin) % NST, PARTS);
+            body(qt, (unsigned)(((qt - qt_begin) % NST) * STAGE));
+        }
+    };
+    // ---- sweep 1: hi.hi only (a third of the MFMAs, half of the tile bytes) -> a lower bound of every anchor's maximum over this split's rows
     float runmax[NAB];
     int nlist[NAB];
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; nlist[ab] = 0; }
-    if (qt_end > qt_begin) issue(qt_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int buf = 0;
-    for (int qt = qt_begin; qt < qt_end; ++qt) {
-        // the last iteration already requests the first tile of sweep 2
-        issue(qt + 1 < qt_end ? qt + 1 : qt_begin, buf ^ 1);
-        const unsigned tile = buf * STAGE;
+    sweep(std::integral_constant<int, 1>{}, [&](int qt, unsigned tile) {
         f32x16 acc[NAB];
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab)
@@ -185,13 +203,10 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
             for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
             runmax[ab] = fmaxf(runmax[ab], x);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        buf ^= 1;
-    }
+    });
     // |s_hi - s| <= (|al| + |ql|)(1 + 2^-10) + |al||ql| + 3.1e-5 (fp32 accumulation of 256 products here and in the canonical chain),
     // so max_j s_j >= runmax - e_hi, and every exact maximiser has s3 >= max_j s_j - DELTA3: a FIXED emission limit per anchor column
-    float lim[NAB];
+    float lim[NAB], run3[NAB];
     const float qlm = sqrtf(ql_max[p]) * 1.002f;            // K0 FMT = 2 hands over the largest |u - hi|^2 of the pair's query rows
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
@@ -200,14 +215,10 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
         runmax[ab] = fmaxf(runmax[ab], __shfl_xor(runmax[ab], 32));
         const float e_hi = (aln + qlm) * 1.001f + aln * qlm + 3.1e-5f;
         lim[ab] = runmax[ab] - e_hi - 0.5f * X3_MARGIN;
+        run3[ab] = -INFINITY;
     }
-    float run3[NAB];
-#pragma unroll
-    for (int ab = 0; ab < NAB; ++ab) run3[ab] = -INFINITY;
-    // ---- sweep 2: hi / lo compensated products, candidates against the fixed limit (the first tile is already in `buf`)
-    for (int qt = qt_begin; qt < qt_end; ++qt) {
-        if (qt + 1 < qt_end) issue(qt + 1, buf ^ 1);
-        const unsigned tile = buf * STAGE;
+    // ---- sweep 2: hi / lo compensated products, candidates against the limit
+    sweep(std::integral_constant<int, 2>{}, [&](int qt, unsigned tile) {
         f32x16 acc[NAB];
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab)
@@ -249,10 +260,8 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
                     }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        buf ^= 1;
-    }
+    });
+#undef X3_WAIT
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
         const int a = a0 + wave * 64 + ab * 32 + l31;
@@ -279,13 +288,18 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
     if (row >= nc) return;
     const int nq = n_q[p];
     float *A = lds_x3 + wave * 2 * Cp, *Q = A + Cp;
-    // candidates: lane e handles entries e, e + 64, ... of the concatenated lists
-    bool overflow = false;
+    // the 2 S list lengths at once (lane l < 2 S: list (query split l >> 1, lane half l & 1)); most lists are empty - a workgroup of the scan
+    // only lists what comes within ~4e-4 of ITS split's maximum - so the loops below visit the non-empty ones only (walking all 16 lists with a
+    // dependent load each cost 0.9 ms per cfg2 step of smooth inputs)
+    int my_cnt = 0;
+    if (lane < 2 * S) my_cnt = cnt[(((size_t)p * S + (lane >> 1)) * cap_s + row) * 2 + (lane & 1)];
+    const bool overflow = __ballot(my_cnt > X3_CAPH) != 0ull;
+    const unsigned long long nonempty = __ballot(my_cnt > 0);
     float m1 = -INFINITY;
-    for (int s = 0; s < 2 * S; ++s) {                      // 2 S lists: (query split, lane half)
-        const size_t o = (((size_t)p * S + (s >> 1)) * cap_s + row) * 2 + (s & 1);
-        const int c = cnt[o];
-        overflow |= c > X3_CAPH;
+    for (unsigned long long m = nonempty; m; m &= m - 1) {
+        const int l = __ffsll((long long)m) - 1;
+        const int c = __shfl(my_cnt, l);
+        const size_t o = (((size_t)p * S + (l >> 1)) * cap_s + row) * 2 + (l & 1);
         for (int e = lane; e < c && e < X3_CAPH; e += 64) m1 = fmaxf(m1, __uint_as_float(cand[o * X3_CAPH + e].y));
     }
 #pragma unroll
@@ -302,9 +316,10 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
     float d = INFINITY;
     int j = 0x7fffffff;
     const float *fq = feat_q + (size_t)p * C_true * HW;
-    for (int s = 0; s < 2 * S; ++s) {
-        const size_t o = (((size_t)p * S + (s >> 1)) * cap_s + row) * 2 + (s & 1);
-        const int n = cnt[o];
+    for (unsigned long long m = nonempty; m; m &= m - 1) {
+        const int l = __ffsll((long long)m) - 1;
+        const int n = __shfl(my_cnt, l);
+        const size_t o = (((size_t)p * S + (l >> 1)) * cap_s + row) * 2 + (l & 1);
         for (int e0 = 0; e0 < n; e0 += 64) {
         const int e_ = e0 + lane;
         const uint2 ent = e_ < n ? cand[o * X3_CAPH + e_] : make_uint2(0u, 0u);
@@ -413,7 +428,9 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     if (rc) return rc;
     hipLaunchKernelGGL(match_x3_split_anchors_kernel, dim3(64, B), dim3(256), 0, st, a_c, CP, cap_s, n_c, ah, al, al_norm);
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), 0, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, cnt, cand);
+    constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2;       // NST stages x (hi + lo) x 32 rows x CP halves
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP>), X3_SCAN_LDS);
+    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, cnt, cand);
     const size_t lds = (size_t)4 * 2 * CP * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
