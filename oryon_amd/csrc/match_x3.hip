@@ -34,6 +34,8 @@ typedef _Float16 half8x __attribute__((ext_vector_type(8)));
 
 constexpr int X3_CAPH = 128;               // candidate slots per (pair, query split, anchor, lane half): each list has ONE writer, no atomics
 constexpr float X3_MARGIN = 1.32e-4f;      // 2 * DELTA3 (6.5e-5) + 2e-6
+constexpr float X3_MARGIN_R = 3.4e-5f;     // 2 * DELTA_R (1.63e-5: refined fp64 score against the canonical fp32 chain) + slack
+constexpr int X3_SURV = 256;               // survivors of the first filter kept per anchor (more: exact-scan route)
 
 // fp32 anchor rows (k-permuted inside groups of 8: position 8g + 4h + j holds k = 8g + 2j + h) -> hi / lo half rows in natural k order
 // + al_norm [B, cap_s]: an upper bound of |lo|_2 of every row (Cp = 256: the 32 groups of a row are 32 consecutive lanes)
@@ -277,6 +279,8 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
                                                                 const int32_t *__restrict__ roi_q, int roi_stride, const float *__restrict__ norm_q,
                                                                 int cap_q, const int32_t *__restrict__ n_q, int S, float thr,
                                                                 const int32_t *__restrict__ cnt, const uint2 *__restrict__ cand,
+                                                                const __half *__restrict__ ah, const __half *__restrict__ al,
+                                                                const __half *__restrict__ qh, const __half *__restrict__ ql,
                                                                 int round_f16, float *__restrict__ md_c,
                                                                 int32_t *__restrict__ am_c, uint8_t *__restrict__ va_c,
                                                                 int32_t *__restrict__ n_ovf, int32_t *__restrict__ ovf_idx)
@@ -287,7 +291,9 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
     const int nc = n_c[p] < cap_s ? n_c[p] : cap_s;
     if (row >= nc) return;
     const int nq = n_q[p];
-    float *A = lds_x3 + wave * 2 * Cp, *Q = A + Cp;
+    float *A = lds_x3 + wave * (2 * Cp + 2 * X3_SURV), *Q = A + Cp;
+    int *sj = reinterpret_cast<int *>(Q + Cp);              // survivors of the first filter: row index, refined score
+    float *sref = reinterpret_cast<float *>(sj + X3_SURV);
     // the 2 S list lengths at once (lane l < 2 S: list (query split l >> 1, lane half l & 1)); most lists are empty - a workgroup of the scan
     // only lists what comes within ~4e-4 of ITS split's maximum - so the loops below visit the non-empty ones only (walking all 16 lists with a
     // dependent load each cost 0.9 ms per cfg2 step of smooth inputs)
@@ -313,23 +319,69 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
         const int g = pos >> 3, hh = (pos >> 2) & 1, jj = pos & 3;
         A[8 * g + 2 * jj + hh] = a_c[crow * Cp + pos];
     }
-    float d = INFINITY;
-    int j = 0x7fffffff;
-    const float *fq = feat_q + (size_t)p * C_true * HW;
+    // second filter: entries within MARGIN3 of the best listed s3 get a REFINED score from the hi / lo rows - the exact products
+    // (ah + al)(qh + ql) summed in fp64 - which is within DELTA_R = 1.63e-5 of the canonical fp32 chain (256 roundings of the chain:
+    // 1.53e-5; split residuals, lo parts being subnormal halves: 9.6e-7; the score's own rounding to float), a quarter of the s3 bound
+    // (whose two 256- / 768-term fp32 accumulations cost it 6e-5).  Rows are read as two coalesced
+    // 512-byte loads per candidate; only entries within 2 DELTA_R of the best refined score go on to the canonical chain, whose raw-map
+    // gather (one 64-byte sector per channel in NCHW: 16 KB per candidate) is what this kernel's time goes into.
+    double a4[4];
+    {
+        const uint2 h = reinterpret_cast<const uint2 *>(ah + crow * Cp)[lane], l = reinterpret_cast<const uint2 *>(al + crow * Cp)[lane];
+        const __half2 h0 = *reinterpret_cast<const __half2 *>(&h.x), h1 = *reinterpret_cast<const __half2 *>(&h.y);
+        const __half2 l0 = *reinterpret_cast<const __half2 *>(&l.x), l1 = *reinterpret_cast<const __half2 *>(&l.y);
+        a4[0] = (double)__low2float(h0) + (double)__low2float(l0);
+        a4[1] = (double)__high2float(h0) + (double)__high2float(l0);
+        a4[2] = (double)__low2float(h1) + (double)__low2float(l1);
+        a4[3] = (double)__high2float(h1) + (double)__high2float(l1);
+    }
+    int ns = 0;
+    float ref_max = -INFINITY;
     for (unsigned long long m = nonempty; m; m &= m - 1) {
         const int l = __ffsll((long long)m) - 1;
         const int n = __shfl(my_cnt, l);
         const size_t o = (((size_t)p * S + (l >> 1)) * cap_s + row) * 2 + (l & 1);
         for (int e0 = 0; e0 < n; e0 += 64) {
-        const int e_ = e0 + lane;
-        const uint2 ent = e_ < n ? cand[o * X3_CAPH + e_] : make_uint2(0u, 0u);
-        const int qi = (int)ent.x;
-        const bool hit = e_ < n && qi < nq && __uint_as_float(ent.y) >= m1 - X3_MARGIN;
-        unsigned long long hits = __ballot(hit);
-        while (hits) {
-            const int src = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            const int jj = __shfl(qi, src);
+            const int e_ = e0 + lane;
+            const uint2 ent = e_ < n ? cand[o * X3_CAPH + e_] : make_uint2(0u, 0u);
+            const int qi = (int)ent.x;
+            const bool hit = e_ < n && qi < nq && __uint_as_float(ent.y) >= m1 - X3_MARGIN;
+            unsigned long long hits = __ballot(hit);
+            while (hits) {
+                const int src = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                const int jj = __shfl(qi, src);
+                const size_t qrow = ((size_t)p * cap_q + jj) * Cp;
+                const uint2 h = reinterpret_cast<const uint2 *>(qh + qrow)[lane], lo_ = reinterpret_cast<const uint2 *>(ql + qrow)[lane];
+                const __half2 h0 = *reinterpret_cast<const __half2 *>(&h.x), h1 = *reinterpret_cast<const __half2 *>(&h.y);
+                const __half2 l0 = *reinterpret_cast<const __half2 *>(&lo_.x), l1 = *reinterpret_cast<const __half2 *>(&lo_.y);
+                double v = a4[0] * ((double)__low2float(h0) + (double)__low2float(l0));
+                v = fma(a4[1], (double)__high2float(h0) + (double)__high2float(l0), v);
+                v = fma(a4[2], (double)__low2float(h1) + (double)__low2float(l1), v);
+                v = fma(a4[3], (double)__high2float(h1) + (double)__high2float(l1), v);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                const float r = (float)v;
+                ref_max = fmaxf(ref_max, r);
+                if (ns < X3_SURV && lane == 0) { sj[ns] = jj; sref[ns] = r; }
+                ++ns;
+            }
+        }
+    }
+    if (ns > X3_SURV) {                                     // a crowd of near-duplicates: the exact scan takes this anchor (wave-uniform)
+        if (lane == 0) ovf_idx[(size_t)p * cap_s + atomicAdd(&n_ovf[p], 1)] = row;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float d = INFINITY;
+    int j = 0x7fffffff;
+    const float *fq = feat_q + (size_t)p * C_true * HW;
+    for (int i = 0; i < ns; ++i) {
+        if (!(sref[i] >= ref_max - X3_MARGIN_R)) continue;  // wave-uniform (LDS broadcast)
+        const int jj = sj[i];
+        {
             const int pix = roi_q[(size_t)p * roi_stride + jj];
             const float dq = norm_q[(size_t)p * cap_q + jj];
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -353,7 +405,6 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
                     if (k + e < C_true) dot = __fmaf_rn(av[e], qv[e], dot);
             }
             lex_min(d, j, __fmaf_rn(-0.5f, dot, 0.5f), jj);
-        }
         }
     }
     if (lane == 0) {
@@ -431,13 +482,13 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2;       // NST stages x (hi + lo) x 32 rows x CP halves
     allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP>), X3_SCAN_LDS);
     hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, cnt, cand);
-    const size_t lds = (size_t)4 * 2 * CP * sizeof(float);
+    const size_t lds = (size_t)4 * (2 * CP + 2 * X3_SURV) * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
-                           roi_stride_q, q_norm, cap_q, n_q, S, threshold, cnt, cand, round_f16, md_c, am_c, va_c, n_ovf, ovf_idx);
+                           roi_stride_q, q_norm, cap_q, n_q, S, threshold, cnt, cand, ah, al, qh, ql, round_f16, md_c, am_c, va_c, n_ovf, ovf_idx);
     else
         hipLaunchKernelGGL((match_x3_rescore_kernel<false>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
-                           roi_stride_q, q_norm, cap_q, n_q, S, threshold, cnt, cand, round_f16, md_c, am_c, va_c, n_ovf, ovf_idx);
+                           roi_stride_q, q_norm, cap_q, n_q, S, threshold, cnt, cand, ah, al, qh, ql, round_f16, md_c, am_c, va_c, n_ovf, ovf_idx);
     static const bool dbg = getenv("ORYON_X3_DEBUG") != nullptr;          // development aid: list statistics of this call on stderr
     if (dbg) {
         (void)hipStreamSynchronize(st);
