@@ -1554,23 +1554,43 @@ __global__ __launch_bounds__(256) void match_scatter_exact_kernel(int cap_a, int
     state[dst] = LZ_RESOLVED;
 }
 
-// the sampled slots whose anchor row is AMB_VALID (argmin still unknown) -> work list for the post-sampling exact scan.  One
-// workgroup per pair.
+// the sampled slots whose anchor row is AMB_VALID (argmin still unknown) -> work list for the second level (K1x3 / exact scan).  One
+// workgroup per pair.  The list comes out in ASCENDING anchor-row order, i.e. in image order: neighbouring anchors share a wave of
+// match_x3_scan_kernel, their matches are neighbours in the query map, and the scan can skip the query tiles none of a wave's anchors
+// can match (it is also deterministic; the first version appended in atomic order).
 __global__ __launch_bounds__(256) void match_list_sampled_amb_kernel(int cap_a, const uint8_t *__restrict__ state,
                                                                       const int32_t *__restrict__ pair_eager, const int32_t *__restrict__ n_sel,
                                                                       const int32_t *__restrict__ sel_rows, int corr_rows,
                                                                       int32_t *__restrict__ mark, int32_t *__restrict__ n_list,
                                                                       int32_t *__restrict__ list)
 {
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
     const int p = blockIdx.x;
     if (pair_eager[p]) return;
-    const int n = n_sel[p];
-    for (int s = threadIdx.x; s < n; s += 256) {
+    const int n = n_sel[p], t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // a row drawn several times (sampling with replacement) is marked once
+    for (int s = t; s < n; s += 256) {
         const int a = sel_rows[(size_t)p * corr_rows + s];
-        // a row drawn several times (sampling with replacement) is listed once
-        if (state[(size_t)p * cap_a + a] == LZ_AMB_VALID && atomicExch(&mark[(size_t)p * cap_a + a], 1) == 0)
-            list[(size_t)p * corr_rows + atomicAdd(&n_list[p], 1)] = a;
+        if (state[(size_t)p * cap_a + a] == LZ_AMB_VALID) mark[(size_t)p * cap_a + a] = 1;
     }
+    if (t == 0) base = 0;
+    __threadfence_block();
+    __syncthreads();
+    for (int a0 = 0; a0 < cap_a; a0 += 256) {
+        const int a = a0 + t;
+        const bool m = a < cap_a && mark[(size_t)p * cap_a + a] != 0;
+        const unsigned long long b = __ballot(m);
+        if (lane == 0) wave_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (m) list[(size_t)p * corr_rows + off + __popcll(b & ((1ull << lane) - 1ull))] = a;
+        __syncthreads();
+        if (t == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (t == 0) n_list[p] = base;
 }
 
 // Exact resolution of ONE unambiguous anchor by one wave: candidates = rows of the winning 16-row slice within the int8 margin of its

@@ -35,6 +35,7 @@ typedef _Float16 half8x __attribute__((ext_vector_type(8)));
 constexpr int X3_CAPH = 128;               // candidate slots per (pair, query split, anchor, lane half): each list has ONE writer, no atomics
 constexpr float X3_MARGIN = 1.32e-4f;      // 2 * DELTA3 (6.5e-5) + 2e-6
 constexpr float X3_MARGIN_R = 3.4e-5f;     // 2 * DELTA_R (1.63e-5: refined fp64 score against the canonical fp32 chain) + slack
+constexpr int X3_MAX_TILES = 256;          // tile flags per wave of the scan (a workgroup's share of the query rows: cap_q / 32 / S tiles)
 constexpr int X3_SURV = 256;               // survivors of the first filter kept per anchor (more: exact-scan route)
 
 // fp32 anchor rows (k-permuted inside groups of 8: position 8g + 4h + j holds k = 8g + 2j + h) -> hi / lo half rows in natural k order
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
                                                                const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
                                                                int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
                                                                int S, const float *__restrict__ al_norm, const float *__restrict__ ql_max,
-                                                               int32_t *__restrict__ cnt, uint2 *__restrict__ cand)
+                                                               int32_t *__restrict__ cnt, uint2 *__restrict__ cand, int32_t *__restrict__ dbg)
 {
     constexpr int RB = CP * 2;                 // bytes per half row
     constexpr int ROWS = 32;
@@ -177,6 +178,26 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
             body(qt, (unsigned)(((qt - qt_begin) % NST) * STAGE));
         }
     };
+    // |s_hi - s| <= e_hi = (|al| + |ql|)(1 + 2^-10) + |al||ql| + 3.1e-5 (Cauchy-Schwarz on the measured norms; fp32 accumulation of 256
+    // products here and in the canonical chain)
+    float e_hi[NAB];
+    const float qlm = sqrtf(ql_max[p]) * 1.002f;            // K0 FMT = 2 hands over the largest |u - hi|^2 of the pair's query rows
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const int a = a0 + wave * 64 + ab * 32 + l31;
+        const float aln = al_norm[(size_t)p * cap_s + (a < cap_s ? a : cap_s - 1)];
+        e_hi[ab] = (aln + qlm) * 1.001f + aln * qlm + 3.1e-5f;
+    }
+    // Tile flags: sweep 2 lists a row only if s3 >= max - e_hi - DELTA3, and s3 <= s_hi + e_hi + DELTA3, so a tile none of whose rows
+    // has s_hi >= max_hi - 2 e_hi - 2 DELTA3 for any of the wave's anchors holds no candidate for this wave.  Sweep 1 flags the tiles that
+    // pass against the RUNNING maximum (a superset of those that pass against the final one); sweep 2 multiplies only flagged tiles.
+    // The anchors arrive in image order (match_list_sampled_amb_kernel), so a wave's 64 anchors - and their matches - cover a band of the
+    // image: on coherent scenes many (wave, tile) pairs are skipped (hard cfg2 step: 46 % flagged), on scrambled ones nothing is lost but the
+    // flag test.  Measured: 2.64 -> 2.46 ms only - a workgroup's four waves share every tile's barrier, so a tile costs what its slowest
+    // wave costs; skipping pays in energy more than in time.
+    unsigned char *tile_flag = reinterpret_cast<unsigned char *>(smem + NST * STAGE) + wave * X3_MAX_TILES;
+    for (int i = t; i < 4 * X3_MAX_TILES; i += 256) reinterpret_cast<unsigned char *>(smem + NST * STAGE)[i] = 0;
+    const bool flags_ok = qt_end - qt_begin <= X3_MAX_TILES;
     // ---- sweep 1: hi.hi only (a third of the MFMAs, half of the tile bytes) -> a lower bound of every anchor's maximum over this split's rows
     float runmax[NAB];
     int nlist[NAB];
@@ -198,29 +219,34 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
             xh = nh;
         }
         const int q0 = qt * ROWS + 4 * hi;
+        bool hit = false;
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab) {
             float x = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
             runmax[ab] = fmaxf(runmax[ab], x);
+            hit |= x >= runmax[ab] - 2.0f * e_hi[ab] - X3_MARGIN;
         }
+        if (__ballot(hit) != 0ull && flags_ok && lane == 0) tile_flag[qt - qt_begin] = 1;
     });
-    // |s_hi - s| <= (|al| + |ql|)(1 + 2^-10) + |al||ql| + 3.1e-5 (fp32 accumulation of 256 products here and in the canonical chain),
-    // so max_j s_j >= runmax - e_hi, and every exact maximiser has s3 >= max_j s_j - DELTA3: a FIXED emission limit per anchor column
+    if (dbg && lane == 0) {                                  // ORYON_X3_DEBUG: flagged / all (wave, tile) pairs
+        int f = 0;
+        for (int i = 0; i < qt_end - qt_begin && i < X3_MAX_TILES; ++i) f += tile_flag[i];
+        atomicAdd(&dbg[0], f);
+        atomicAdd(&dbg[1], qt_end - qt_begin);
+    }
+    // max_j s_j >= runmax - e_hi, and every exact maximiser has s3 >= max_j s_j - DELTA3: a FIXED emission limit per anchor column
     float lim[NAB], run3[NAB];
-    const float qlm = sqrtf(ql_max[p]) * 1.002f;            // K0 FMT = 2 hands over the largest |u - hi|^2 of the pair's query rows
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
-        const int a = a0 + wave * 64 + ab * 32 + l31;
-        const float aln = al_norm[(size_t)p * cap_s + (a < cap_s ? a : cap_s - 1)];
         runmax[ab] = fmaxf(runmax[ab], __shfl_xor(runmax[ab], 32));
-        const float e_hi = (aln + qlm) * 1.001f + aln * qlm + 3.1e-5f;
-        lim[ab] = runmax[ab] - e_hi - 0.5f * X3_MARGIN;
+        lim[ab] = runmax[ab] - e_hi[ab] - 0.5f * X3_MARGIN;
         run3[ab] = -INFINITY;
     }
     // ---- sweep 2: hi / lo compensated products, candidates against the limit
     sweep(std::integral_constant<int, 2>{}, [&](int qt, unsigned tile) {
+        if (flags_ok && !tile_flag[qt - qt_begin]) return;   // wave-uniform: no row of this tile can be a candidate of this wave's anchors
         f32x16 acc[NAB];
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab)
@@ -479,9 +505,15 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     if (rc) return rc;
     hipLaunchKernelGGL(match_x3_split_anchors_kernel, dim3(64, B), dim3(256), 0, st, a_c, CP, cap_s, n_c, ah, al, al_norm);
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2;       // NST stages x (hi + lo) x 32 rows x CP halves
+    static const bool dbg = getenv("ORYON_X3_DEBUG") != nullptr;          // development aid: list statistics of this call on stderr
+    int32_t *dbg_dev = nullptr;
+    if (dbg) {
+        dbg_dev = reinterpret_cast<int32_t *>(al_norm + (size_t)B * cap_s + 64);      // in the scratch's 8 KB of slack
+        (void)hipMemsetAsync(dbg_dev, 0, 8, st);
+    }
+    constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2 + 4 * X3_MAX_TILES;      // NST stages x (hi + lo) x 32 rows x CP halves + the tile flags
     allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP>), X3_SCAN_LDS);
-    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, cnt, cand);
+    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, cnt, cand, dbg_dev);
     const size_t lds = (size_t)4 * (2 * CP + 2 * X3_SURV) * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
@@ -489,7 +521,6 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     else
         hipLaunchKernelGGL((match_x3_rescore_kernel<false>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
                            roi_stride_q, q_norm, cap_q, n_q, S, threshold, cnt, cand, ah, al, qh, ql, round_f16, md_c, am_c, va_c, n_ovf, ovf_idx);
-    static const bool dbg = getenv("ORYON_X3_DEBUG") != nullptr;          // development aid: list statistics of this call on stderr
     if (dbg) {
         (void)hipStreamSynchronize(st);
         std::vector<int32_t> hc((size_t)B * S * cap_s * 2), hn(B), hov(B);
@@ -514,6 +545,9 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
                     }
             }
         }
+        int32_t hd[2] = {0, 0};
+        (void)hipMemcpy(hd, dbg_dev, 8, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[x3] sweep-2 (wave, tile) pairs flagged: %d of %d\n", hd[0], hd[1]);
         fprintf(stderr, "[x3] anchors %ld, lists %ld, entries %ld (%.1f per anchor), longest %ld, overflowed lists %ld, overflowed anchors %ld, max|al| %.3g, max|ql| %.3g\n",
                 anchors, nl, tot, anchors ? (double)tot / anchors : 0.0, mx, over, novf, amax, qmax);
     }
