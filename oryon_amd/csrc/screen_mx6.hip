@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
 // two waves per SIMD.  WAVES = 8 (default): 1024-anchor panels, ONE 64 KB workgroup per CU - half the L2 -> LDS bytes as well, and K0 /
 // the registration still find LDS beside it (1.46 ms alone against 1.58-1.61, pipelined step 3.84 against 3.87 ms on the same box).
 // WAVES = 4: 512-anchor panels, two workgroups per CU: 1.47 ms alone, but its 128 KB of LDS keep K0 off the CU (pipelined 3.94 ms).
+// 256-row tiles (half the barriers, 128 KB of LDS): the eight unrolled 32-row blocks spill 22 registers - 1.58 ms alone, step 4.07 ms: not kept.
 // Outputs and slice meaning unchanged.
 typedef int i32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
