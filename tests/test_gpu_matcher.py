@@ -641,6 +641,43 @@ def test_lazy_corrs_smooth_fields_and_duplicate_crowds():
     assert int(und[0]) > 1000                                                      # the screens leave (nearly) every anchor of the smooth pairs ambiguous
 
 
+def test_lazy_corrs_half_descriptor_branch_on_smooth_fields():
+    """round_f16 (the reference's feats.half() branch, utils/pcd.py:195-197) through the second level: K0's hi / lo rows, the refined
+    rescoring and the canonical chain all start from the float16-rounded raw values - so the call with round_f16 on the fp32 maps must
+    return what the plain call returns on maps rounded beforehand, bit for bit (smooth rank-8 fields: every sampled anchor takes K1x3)."""
+    from oryon_amd import ops
+    dev = "cuda"
+    C, H, B = 256, 48, 2
+    g = torch.Generator(device=dev).manual_seed(91)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, H, device=dev), indexing="ij")
+    coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy), torch.sin(7 * yy), torch.cos(5 * xx)])
+    fq = torch.einsum("bck,khw->bchw", rn(B, C, 8), coef) + 0.02 * rn(B, C, H, H)
+    fa = fq + 0.01 * rn(B, C, H, H)
+    ma = torch.ones((B, H, H), dtype=torch.int32, device=dev)
+    mq = torch.ones((B, H, H), dtype=torch.int32, device=dev)
+    roi_a, na = ops.roi_compact(ma)
+    roi_q, nq = ops.roi_compact(mq)
+    cap = ops.round_up(H * H, 256)
+    key = torch.arange(3, 3 + B, dtype=torch.int64, device=dev)
+
+    def run(fa_, fq_, rf):
+        a6, a_err, _, a_hat = ops.gather_mx6(fa_, roi_a, na, cap, 256, want_f32=True, round_f16=rf)
+        q6, q_err, q_norm, _ = ops.gather_mx6(fq_, roi_q, nq, cap, 256, round_f16=rf)
+        und = torch.zeros((B,), dtype=torch.int32, device=dev)
+        out = ops.match_corrs_mx6(a_hat, a6, a_err, fq_, roi_a, roi_q, q_norm, q6, q_err, na, nq, 0.25, H, 500, 1, key, corr_rows=512,
+                                  n_undecided=und, round_f16=rf)
+        torch.cuda.synchronize()
+        return out, und
+
+    (c1, nv1, ns1, st1, *_), und1 = run(fa, fq, True)
+    (c0, nv0, ns0, st0, *_), und0 = run(ops.round_to_f16(fa), ops.round_to_f16(fq), False)
+    assert st1.tolist() == [0, 0] and torch.equal(st1, st0) and torch.equal(nv1, nv0) and torch.equal(ns1, ns0)
+    assert int(und1.min()) > 1000 and torch.equal(und1, und0)
+    for b in range(B):
+        assert torch.equal(c1[b, : int(ns1[b])], c0[b, : int(ns0[b])])
+
+
 def test_lazy_corrs_with_the_exact_second_level():
     """ORYON_AMB_X3 is read once by the library: the lazy == eager == exact tests above again in a child interpreter with K1x3 OFF
     (the exact fp32 scan of the sampled ambiguous anchors, round 2's second level)."""
