@@ -8,6 +8,17 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dev = torch.device("cuda", 0)
 B, H, C = 64, 224, 256
 sets = [make_inputs(B, H, C, first=100 * i, dev=dev) for i in range(3)]
+if os.environ.get("SOAK_HARD"):
+    # set 1 becomes bench.py's hard descriptors (smooth rank-8 fields: every sampled anchor goes through K1x3), sets 0 and 2 stay easy:
+    # the second level then runs on every third step, beside the K0 / registration of ordinary steps
+    gen = torch.Generator(device=dev).manual_seed(77)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, H, device=dev), indexing="ij")
+    coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy), torch.sin(7 * yy), torch.cos(5 * xx)])
+    basis = torch.randn((B, C, coef.shape[0]), generator=gen, device=dev)
+    sets[1]["feat_q"].copy_(torch.einsum("bck,khw->bchw", basis, coef))
+    sets[1]["feat_q"].add_(0.02 * torch.randn(sets[1]["feat_q"].shape, generator=gen, device=dev))
+    sets[1]["feat_a"].copy_(sets[1]["feat_q"]).add_(0.01 * torch.randn(sets[1]["feat_a"].shape, generator=gen, device=dev))
+    torch.cuda.synchronize()
 keys = [torch.arange(100 * i, 100 * i + B, dtype=torch.int64, device=dev) for i in range(3)]
 for sf in (0, 1024):
     cfg = MatchPoseConfig(dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1, match_mode="screened", sample_first=sf)
