@@ -919,21 +919,23 @@ __global__ __launch_bounds__(256) void pdsc_linear_x3_kernel(const float *__rest
 // order.  oryon_pointdsc_finalize stores the three matrices that way (pre-split into fp16 hi / lo, rows swizzled: PDSC_MLP_* image), so the
 // intermediate activations never leave the registers: bias + ReLU + split, next MFMA.  A wave owns 32 points and all channels; a workgroup
 // (4 waves, 128 points) copies the 80 KB weight image into LDS once (LDS-DMA) while its waves fetch and split their input rows.
-__global__ __launch_bounds__(256) void pdsc_mlp3_x3_kernel(const float *__restrict__ msg, const float *__restrict__ resid,
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pdsc_mlp3_x3_kernel(const float *__restrict__ msg, const float *__restrict__ resid,
                                                             const char *__restrict__ img, const float *__restrict__ b1,
                                                             const float *__restrict__ b2, const float *__restrict__ b3,
                                                             const int32_t *__restrict__ n_rows, int n_cap, float *__restrict__ out)
 {
     constexpr int C = 128;
     extern __shared__ __attribute__((aligned(1024))) char mlp_lds[];
-    const int b = blockIdx.y, q0 = blockIdx.x * 128;
+    const int b = blockIdx.y, q0 = blockIdx.x * (32 * WAVES);
     if (q0 >= n_rows[b]) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // weight image -> LDS: 80 pieces of 1 KB, 20 per wave, lane-linear
+    // weight image -> LDS: 80 pieces of 1 KB, 80 / WAVES per wave, lane-linear
+    static_assert((PDSC_MLP_IMG_BYTES / 1024) % WAVES == 0, "pieces per wave");
 #pragma unroll
-    for (int j = 0; j < PDSC_MLP_IMG_BYTES / 4096; ++j) {
-        const int piece = wave_u * (PDSC_MLP_IMG_BYTES / 4096) + j;
+    for (int j = 0; j < PDSC_MLP_IMG_BYTES / 1024 / WAVES; ++j) {
+        const int piece = wave_u * (PDSC_MLP_IMG_BYTES / 1024 / WAVES) + j;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + piece * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void *)(mlp_lds + piece * 1024), 16, 0, 0);
     }
@@ -1059,21 +1061,22 @@ __global__ __launch_bounds__(256) void pdsc_mlp3_x3_kernel(const float *__restri
 //   feat1 = relu(Wp feat + bp)  (stored: it is the residual of the layer's fc_message)      qkv = Wq feat1 + bq
 // The weights do not fit LDS together (4 x 64 KB: PointCN, q, k, v - hi and lo halves of a 128 x 128 matrix each), so they stream through
 // two 64 KB areas: PointCN | q are requested up front, k replaces PointCN once every wave has finished layer 1, v replaces q.
-__global__ __launch_bounds__(256) void pdsc_pcn_qkv_x3_kernel(const float *__restrict__ feat, const char *__restrict__ img,
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float *__restrict__ feat, const char *__restrict__ img,
                                                                const float *__restrict__ bp, const float *__restrict__ bq,
                                                                const int32_t *__restrict__ n_rows, int n_cap, float *__restrict__ feat1,
                                                                float *__restrict__ qkv, char *__restrict__ kv_img)
 {
     constexpr int C = 128, HALF = PDSC_PQ_CHUNK_BYTES / 2;
     extern __shared__ __attribute__((aligned(1024))) char pq_lds[];
-    const int b = blockIdx.y, q0 = blockIdx.x * 128;
+    const int b = blockIdx.y, q0 = blockIdx.x * (32 * WAVES);
     if (q0 >= n_rows[b]) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto dma_chunk = [&](int chunk, int area) {                       // 64 pieces of 1 KB, 16 per wave
+    auto dma_chunk = [&](int chunk, int area) {                       // 64 pieces of 1 KB, 64 / WAVES per wave
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int piece = wave_u * 16 + j;
+        for (int j = 0; j < 64 / WAVES; ++j) {
+            const int piece = wave_u * (64 / WAVES) + j;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img + (size_t)chunk * PDSC_PQ_CHUNK_BYTES + piece * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void *)(pq_lds + area * PDSC_PQ_CHUNK_BYTES + piece * 1024), 16, 0, 0);
         }
@@ -1338,10 +1341,19 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         bool use_img = false;
         if (C == 128 && x3 && fused_pq && L.pq_img) {
             // PointCN (conv + BN + ReLU, BN folded) and the q | k | v projections in one launch
-            allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_pcn_qkv_x3_kernel), 2 * PDSC_PQ_CHUNK_BYTES);
+            // 8-wave workgroups (256 points): the same 128 KB of weights feed twice the points and the launch occupies half the CUs with
+            // two waves per SIMD - latency-bound kernels lose nothing, and K0 / the other registration stream find free CUs beside them
+            static const int pw = getenv("ORYON_PDSC_WAVES") ? atoi(getenv("ORYON_PDSC_WAVES")) : 8;
+            const bool w8 = pw == 8 && n_cap % 256 == 0;
+            if (w8) allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_pcn_qkv_x3_kernel<8>), 2 * PDSC_PQ_CHUNK_BYTES);
+            else allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_pcn_qkv_x3_kernel<4>), 2 * PDSC_PQ_CHUNK_BYTES);
             use_img = ws.att_splits == 1 && ws.kv_img != nullptr && att_img;
-            hipLaunchKernelGGL(pdsc_pcn_qkv_x3_kernel, dim3(n_cap / 128, B), dim3(256), 2 * PDSC_PQ_CHUNK_BYTES, st, ws.feat, L.pq_img, L.b_pcn,
-                               L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, use_img ? ws.kv_img : nullptr);
+            if (w8)
+                hipLaunchKernelGGL(pdsc_pcn_qkv_x3_kernel<8>, dim3(n_cap / 256, B), dim3(512), 2 * PDSC_PQ_CHUNK_BYTES, st, ws.feat, L.pq_img, L.b_pcn,
+                                   L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, use_img ? ws.kv_img : nullptr);
+            else
+                hipLaunchKernelGGL(pdsc_pcn_qkv_x3_kernel<4>, dim3(n_cap / 128, B), dim3(256), 2 * PDSC_PQ_CHUNK_BYTES, st, ws.feat, L.pq_img, L.b_pcn,
+                                   L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, use_img ? ws.kv_img : nullptr);
             if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
         } else {
             // PointCN: conv + BN + ReLU (BN folded)
@@ -1372,9 +1384,16 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         // fc_message: C -> C/2 -> C/2 -> C, residual onto the PointCN output
         static const bool fused_mlp = !getenv("ORYON_PDSC_FUSED_MLP") || atoi(getenv("ORYON_PDSC_FUSED_MLP")) != 0;   // dev: 0 = three launches
         if (C == 128 && x3 && fused_mlp && L.mlp_img) {
-            allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_mlp3_x3_kernel), PDSC_MLP_IMG_BYTES);
-            hipLaunchKernelGGL(pdsc_mlp3_x3_kernel, dim3(n_cap / 128, B), dim3(256), PDSC_MLP_IMG_BYTES, st, ws.msg, ws.feat1, L.mlp_img, L.b_m1,
-                               L.b_m2, L.b_m3, n_rows, n_cap, ws.feat);
+            static const int mw = getenv("ORYON_PDSC_WAVES") ? atoi(getenv("ORYON_PDSC_WAVES")) : 8;
+            if (mw == 8 && n_cap % 256 == 0) {
+                allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_mlp3_x3_kernel<8>), PDSC_MLP_IMG_BYTES);
+                hipLaunchKernelGGL(pdsc_mlp3_x3_kernel<8>, dim3(n_cap / 256, B), dim3(512), PDSC_MLP_IMG_BYTES, st, ws.msg, ws.feat1, L.mlp_img, L.b_m1,
+                                   L.b_m2, L.b_m3, n_rows, n_cap, ws.feat);
+            } else {
+                allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_mlp3_x3_kernel<4>), PDSC_MLP_IMG_BYTES);
+                hipLaunchKernelGGL(pdsc_mlp3_x3_kernel<4>, dim3(n_cap / 128, B), dim3(256), PDSC_MLP_IMG_BYTES, st, ws.msg, ws.feat1, L.mlp_img, L.b_m1,
+                                   L.b_m2, L.b_m3, n_rows, n_cap, ws.feat);
+            }
             if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
             continue;
         }
