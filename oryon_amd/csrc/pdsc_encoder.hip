@@ -822,6 +822,189 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_img_kernel(const float 
         }
 }
 
+// The same attention with EIGHT waves per workgroup (round 3): the two 32-key blocks of every 64-key tile go to two different waves of a
+// query block (wave = query block w | key half kh), each with its own online softmax over its keys; the two partial results (O, m, l) of
+// a query block are merged once at the end through LDS - the exact softmax algebra of pdsc_attention_merge_kernel.  A wave then holds ONE
+// score block, half of the P / K / V fragments and SC values: 248 registers instead of 312 + AGPR parking, so two waves share a SIMD and
+// one's softmax VALU runs under the other's MFMAs (the 4-wave kernel is a strict sequence of phases with one wave per SIMD: MFMA 43 %,
+// softmax VALU 25 %, nothing overlapping).  Same K / V tile images, same DMA, one barrier per tile.
+template <int C>
+__global__ __launch_bounds__(512) void pdsc_attention_x3_img8_kernel(const float *__restrict__ QKV, const char *__restrict__ kv_img,
+                                                                      const float *__restrict__ sc, const int32_t *__restrict__ n_rows,
+                                                                      int n_cap, float inv_sqrt_c, float *__restrict__ msg, int n_pairs)
+{
+    static_assert(C == 128, "tile image geometry");
+    constexpr int CB = C / 32;
+    constexpr int NS = C / 16;
+    constexpr int KLD = C + 8;
+    extern __shared__ __attribute__((aligned(1024))) char att_lds[];
+    const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int b = (lin / 8 / (int)gridDim.x) * 8 + (lin & 7);
+    const int qblk = (lin / 8) % (int)gridDim.x;
+    if (b >= n_pairs) return;
+    const int n = n_rows[b];
+    const int q0 = qblk * ATT_Q;
+    if (q0 >= n) return;
+    const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave8);
+    const int wave = wave8 & 3, kb = wave8 >> 2;          // query block of the workgroup, key half of every tile
+    const int qrow = q0 + wave * 32 + l31;
+    const float *base = QKV + (size_t)b * n_cap * 3 * C;
+    const char *img = kv_img + (size_t)b * (n_cap / ATT_KT) * PDSC_KV_TILE_BYTES;
+    const float4 *sc_q = reinterpret_cast<const float4 *>(sc) + (((size_t)b * (n_cap / 32) + (q0 / 32 + wave)) * (n_cap / ATT_KT)) * 8 * 64 + lane;
+    const bool q_live = q0 + wave * 32 < n;
+    float4 scv[4];
+    auto dma_tile = [&](int j0, int buf) {
+        const char *src = img + (size_t)(j0 / ATT_KT) * PDSC_KV_TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int piece = wave_u * 9 + j;
+            if (piece < PDSC_KV_TILE_BYTES / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(att_lds + buf * PDSC_KV_TILE_BYTES + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto fetch_sc = [&](int j0) {
+        const float4 *sp = sc_q + (size_t)(j0 / ATT_KT) * 8 * 64 + (size_t)kb * 4 * 64;
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) scv[v4] = q_live ? sp[(size_t)v4 * 64] : make_float4(-1.f, -1.f, -1.f, -1.f);
+    };
+    xhalf8 qh[NS], ql[NS];
+    {
+        const float4 *qv = reinterpret_cast<const float4 *>(base + (size_t)qrow * 3 * C);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const float4 a = qv[4 * s_ + 2 * hi], c = qv[4 * s_ + 2 * hi + 1];
+            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h_, l_;
+                split_half(x[e], h_, l_);
+                qh[s_][e] = h_;
+                ql[s_][e] = l_;
+            }
+        }
+    }
+    f32x16 acc_o[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    dma_tile(0, 0);
+    fetch_sc(0);
+    int buf = 0;
+    for (int j0 = 0; j0 < n; j0 += ATT_KT, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (j0 + ATT_KT < n) dma_tile(j0 + ATT_KT, buf ^ 1);
+        const _Float16 *Kh = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES);
+        const _Float16 *Kl = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_KL);
+        const _Float16 *Vh = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_VH);
+        const _Float16 *Vl = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_VL);
+        // S^T (this wave's 32 keys x 32 queries)
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+        xhalf8 kf[2][2];                              // [buffer][hi | lo]
+        auto read_k = [&](int s_, int bf) {
+            kf[bf][0] = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+            kf[bf][1] = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+        };
+        read_k(0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int bf = s_ & 1;
+            if (s_ + 1 < NS) read_k(s_ + 1, bf ^ 1);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[bf][0], qh[s_], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[bf][0], ql[s_], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[bf][1], qh[s_], s, 0, 0, 0);
+        }
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float4 q4 = scv[r >> 2];
+            const float scq = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+            float v = scq * (s[r] * inv_sqrt_c);
+            v = (scq >= 0.0f) ? v : -INFINITY;
+            s[r] = v;
+            m_tile = fmaxf(m_tile, v);
+        }
+        if (j0 + ATT_KT < n) fetch_sc(j0 + ATT_KT);
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);
+        // a block whose keys are all masked so far keeps m = -inf: exp(-inf - (-inf)) must not produce NaN
+        const float alpha = m_new == -INFINITY ? 1.0f : __expf(m_run - m_new);
+        float l_tile = 0.0f;
+        xhalf8 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float p0 = m_new == -INFINITY ? 0.0f : __expf(s[r] - m_new);
+            const float p1 = m_new == -INFINITY ? 0.0f : __expf(s[r + 1] - m_new);
+            l_tile += p0;
+            l_tile += p1;
+            unsigned uh, ul;
+            split_pair(p0, p1, uh, ul);
+            const xf16x2 h2 = __builtin_bit_cast(xf16x2, uh), l2 = __builtin_bit_cast(xf16x2, ul);
+            ph[r >> 3][r & 7] = h2[0]; ph[r >> 3][(r & 7) + 1] = h2[1];
+            pl[r >> 3][r & 7] = l2[0]; pl[r >> 3][(r & 7) + 1] = l2[1];
+        }
+        l_run = l_run * alpha + l_tile;
+        m_run = m_new;
+        if (__ballot(alpha != 1.0f) != 0ull) {               // the running maximum moved for some query of the wave
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
+        }
+        // O^T += V^T P^T over this wave's two key octet pairs
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int oct = (kb * 2 + t2) * 2 + hi;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const xhalf8 vh = *reinterpret_cast<const xhalf8 *>(Vh + ((size_t)oct * C + cb * 32 + l31) * 8);
+                const xhalf8 vl = *reinterpret_cast<const xhalf8 *>(Vl + ((size_t)oct * C + cb * 32 + l31) * 8);
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[t2], acc_o[cb], 0, 0, 0);
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[t2], acc_o[cb], 0, 0, 0);
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[t2], acc_o[cb], 0, 0, 0);
+            }
+        }
+    }
+    // merge the two key halves of every query block: the kb = 1 waves hand (O, m, l) over through LDS (the tile buffers are free now)
+    float l_all = l_run + __shfl_xor(l_run, 32);
+    __syncthreads();
+    float *xo = reinterpret_cast<float *>(att_lds) + (size_t)wave * (64 * (CB * 16 + 2));
+    if (kb == 1) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xo[(cb * 16 + r) * 64 + lane] = acc_o[cb][r];
+        xo[(CB * 16) * 64 + lane] = m_run;
+        xo[(CB * 16 + 1) * 64 + lane] = l_all;
+    }
+    __syncthreads();
+    if (kb == 1) return;
+    const float m_b = xo[(CB * 16) * 64 + lane], l_b = xo[(CB * 16 + 1) * 64 + lane];
+    const float m = fmaxf(m_run, m_b);
+    const float wa = m_run == -INFINITY ? 0.0f : __expf(m_run - m), wb = m_b == -INFINITY ? 0.0f : __expf(m_b - m);
+    const float den = wa * l_all + wb * l_b;
+    const float inv_l = den > 0.0f ? 1.0f / den : 0.0f;      // query rows of a dead 32-row block (every key masked): zeros
+    float *mo = msg + ((size_t)b * n_cap + qrow) * C;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v;
+            v.x = (wa * acc_o[cb][4 * g + 0] + wb * xo[(cb * 16 + 4 * g + 0) * 64 + lane]) * inv_l;
+            v.y = (wa * acc_o[cb][4 * g + 1] + wb * xo[(cb * 16 + 4 * g + 1) * 64 + lane]) * inv_l;
+            v.z = (wa * acc_o[cb][4 * g + 2] + wb * xo[(cb * 16 + 4 * g + 2) * 64 + lane]) * inv_l;
+            v.w = (wa * acc_o[cb][4 * g + 3] + wb * xo[(cb * 16 + 4 * g + 3) * 64 + lane]) * inv_l;
+            *reinterpret_cast<float4 *>(mo + cb * 32 + 8 * g + 4 * hi) = v;
+        }
+}
+
 // fp16x3 version of pdsc_linear_kernel (same tile, same epilogue) for K % 32 == 0: X and W tiles are split into hi/lo halves
 // while they are staged (8-byte loads, 4-byte LDS stores; rows 80 bytes apart: the ds_read_b128 of a 16-lane group is
 // conflict-free), 12 fp16 MFMAs per k-tile and wave instead of 32 fp32 ones.
@@ -1365,7 +1548,12 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         }
         const int KS = ws.att_splits;
         dim3 ag(n_cap / ATT_Q, KS, B);
-        if (C == 128 && x3 && use_img) {
+        static const bool att8 = !getenv("ORYON_PDSC_ATT8") || atoi(getenv("ORYON_PDSC_ATT8")) != 0;       // 0: the 4-wave attention kernel
+        if (C == 128 && x3 && use_img && att8) {
+            allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_attention_x3_img8_kernel<128>), 2 * PDSC_KV_TILE_BYTES);
+            hipLaunchKernelGGL((pdsc_attention_x3_img8_kernel<128>), dim3(n_cap / ATT_Q, 1, (B + 7) / 8 * 8), dim3(512), 2 * PDSC_KV_TILE_BYTES, st,
+                               ws.qkv, ws.kv_img, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, B);
+        } else if (C == 128 && x3 && use_img) {
             allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_attention_x3_img_kernel<128>), 2 * PDSC_KV_TILE_BYTES);
             hipLaunchKernelGGL((pdsc_attention_x3_img_kernel<128>), dim3(n_cap / ATT_Q, 1, (B + 7) / 8 * 8), dim3(256), 2 * PDSC_KV_TILE_BYTES, st,
                                ws.qkv, ws.kv_img, ws.sc, n_rows, n_cap, inv_sqrt_c, ws.msg, B);
