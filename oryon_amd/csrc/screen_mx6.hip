@@ -213,23 +213,43 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
 // the registration still find LDS beside it (1.46 ms alone against 1.58-1.61, pipelined step 3.84 against 3.87 ms on the same box).
 // WAVES = 4: 512-anchor panels, two workgroups per CU: 1.47 ms alone, but its 128 KB of LDS keep K0 off the CU (pipelined 3.94 ms).
 // 256-row tiles (half the barriers, 128 KB of LDS): the eight unrolled 32-row blocks spill 22 registers - 1.58 ms alone, step 4.07 ms: not kept.
+// C_pad = 512 (cfg4): the same loop with 8 k-steps, 4 waves and one wave per SIMD (192 code + 8 exponent registers stationary, 482 VGPRs incl. AGPRs,
+// 2 x 64 KB of LDS): 19.7 ms per cfg4 launch against 21.7 ms for the two-block kernel, cfg4 shard 3.57 k -> 3.84 k pairs/s.
 // Outputs and slice meaning unchanged.
 typedef int i32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
+// compile-time loop over the k-steps (the step index is an instruction operand: the op_sel byte of the packed exponents)
+template <int S0, int N, class F>
+__device__ __forceinline__ void mx6_static_for(F &&f)
+{
+    if constexpr (S0 < N) {
+        f(std::integral_constant<int, S0>{});
+        mx6_static_for<S0 + 1, N>(f);
+    }
+}
+
+// C_pad = 512: WAVES = 4, one wave per SIMD (192 code + 8 exponent registers of stationary operands), 2 x 64 KB of dynamic LDS
 template <int CP, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void match_mx6_screen_w4_kernel(
+__global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_screen_w4_kernel(
     const uint8_t *__restrict__ a6, const uint8_t *__restrict__ q6, int B, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
     const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
 {
-    static_assert(CP == 256, "four stationary anchor blocks fit the register file at C_pad = 256 only");
+    static_assert(CP == 256 || (CP == 512 && WAVES == 4), "geometries: C_pad 256 with 4 / 8 waves, C_pad 512 with 4 waves");
     constexpr int RB = CP, NAB = 4;
     constexpr int TILE_BYTES = screen8_tile_bytes(CP);
     constexpr int ROWS = 128, NQB = 4;
     constexpr int NKS = CP / 64;
     constexpr int NI = TILE_BYTES / (1024 * WAVES);
     constexpr int LPR = RB / 256;
-    __shared__ __attribute__((aligned(256))) char smem[2 * TILE_BYTES];
+    char *smem;
+    if constexpr (2 * TILE_BYTES > 65536) {
+        extern __shared__ __attribute__((aligned(256))) char smem_dyn_w4[];
+        smem = smem_dyn_w4;
+    } else {
+        __shared__ __attribute__((aligned(256))) char smem_st_w4[2 * TILE_BYTES];
+        smem = smem_st_w4;
+    }
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int unit = (slot / T) * 8 + xcd;
     if (unit >= B * S) return;
@@ -248,34 +268,39 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match_mx6_screen_w4_kernel(
     // stationary B operands: slot (2 s + hi) of k-step s of the lane's anchor row in each of the four blocks; the four exponent bytes of a
     // block packed into one register (the instruction picks the byte by op_sel)
     i32x8 breg[NAB][NKS];
-    int bsc[NAB];
+    int bsc[NAB][NKS / 4];
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
         const int arow_i = a0 + wave * (32 * NAB) + ab * 32 + l31;
         const char *arow = reinterpret_cast<const char *>(a6) + ((size_t)p * cap_a + (arow_i < cap_a ? arow_i : cap_a - 1)) * RB + 32 * hi;
-        unsigned sc = 0;
+        unsigned sc[NKS / 4];
+#pragma unroll
+        for (int w = 0; w < NKS / 4; ++w) sc[w] = 0;
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
             const i32x4 lo = *reinterpret_cast<const i32x4 *>(arow + 64 * s), up = *reinterpret_cast<const i32x4 *>(arow + 64 * s + 16);
             breg[ab][s] = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, -1, -1);   // the fp6 format reads six dwords
-            sc |= ((unsigned)up[2] & 0xffu) << (8 * s);
+            sc[s >> 2] |= ((unsigned)up[2] & 0xffu) << (8 * (s & 3));
         }
-        bsc[ab] = (int)sc;
-    }
-    // DMA instruction j of a wave moves rows (wave NI + j) 4 .. + 3 of the tile; rows 16 apart share the swizzle, so instructions j and j + 4
-    // differ by 4096 bytes - in the scalar base, not in another pair of address registers
-    static_assert(LPR == 1 && (NI == 8 || NI == 4), "C_pad 256 geometry");
-    unsigned dma_off[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
-        dma_off[j] = (unsigned)(row * RB + ((sl ^ (row & 15)) << 4));
+        for (int w = 0; w < NKS / 4; ++w) bsc[ab][w] = (int)sc[w];
+    }
+    // DMA instruction j of a wave moves the four 256-byte lines (wave NI + j) 4 .. + 3 of the tile (4 / LPR rows); rows 16 apart share the
+    // swizzle, so instructions j and j + DJ (DJ = 4 LPR) differ by 16 rows - in the scalar base, not in another pair of address registers
+    constexpr int DJ = 4 * LPR;
+    static_assert(NI % DJ == 0 || NI == DJ, "DMA instructions per wave and tile");
+    unsigned dma_off[DJ];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        const int row = line / LPR;
+        dma_off[j] = (unsigned)(row * RB + (((line % LPR) * 16 + (sl ^ (row & 15))) << 4));
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto issue_one = [&](int qt, int buf, int j) {
-        const char *qb = qp + (size_t)qt * TILE_BYTES + (j >> 2) * 4096;
+        const char *qb = qp + (size_t)qt * TILE_BYTES + (j / DJ) * (16 * RB);
         char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j & 3]),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j % DJ]),
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
     unsigned koff[4][2];
@@ -326,11 +351,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match_mx6_screen_w4_kernel(
     // one MFMA: k-step SC (a compile-time constant: it is also the op_sel byte of the packed B exponents) of anchor block ab
     auto mfma = [&](f32x16s &d, int ab, auto SC) {
         constexpr int s_ = decltype(SC)::value;
-        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(areg[s_], breg[ab][s_], s_ == 0 ? zero16 : d, 2, 2, 0, areg[s_][6], s_, bsc[ab]);
+        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(areg[s_], breg[ab][s_], s_ == 0 ? zero16 : d, 2, 2, 0, areg[s_][6], s_ & 3,
+                                                            bsc[ab][s_ >> 2]);
     };
-    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
-    static_assert(NKS == 4, "k-steps are spelled out below");
     int buf = 0;
     for (int qt = qt_begin; qt < qt_end; ++qt) {
         const unsigned tile = buf * TILE_BYTES;
@@ -346,30 +369,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void match_mx6_screen_w4_kernel(
             reduce_block(acc[2], sid23, 2);
             reduce_block(acc[3], sid23, 3);
             // (the reductions read acc[2..3] before the second half overwrites them: program order)
-            mfma(acc[0], 0, K0{}); mfma(acc[1], 1, K0{});
-            mfma(acc[0], 0, K1{}); mfma(acc[1], 1, K1{});
-            mfma(acc[0], 0, K2{}); mfma(acc[1], 1, K2{});
-            mfma(acc[0], 0, K3{}); mfma(acc[1], 1, K3{});
+            mx6_static_for<0, NKS>([&](auto SC) { mfma(acc[0], 0, SC); mfma(acc[1], 1, SC); });
 #pragma unroll
             for (int i = 0; i < 2 * NKS; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16 / NKS, 0);
             }
             // second half: this block for 2 / 3 while the VALU reduces what 0 / 1 just finished; next A operand behind its last use
-            mfma(acc[2], 2, K0{}); mfma(acc[3], 3, K0{});
-            if (qb + 1 < NQB) areg[0] = rd(0, qb + 1, tile);
-            mfma(acc[2], 2, K1{}); mfma(acc[3], 3, K1{});
-            if (qb + 1 < NQB) areg[1] = rd(1, qb + 1, tile);
-            mfma(acc[2], 2, K2{}); mfma(acc[3], 3, K2{});
-            if (qb + 1 < NQB) areg[2] = rd(2, qb + 1, tile);
-            mfma(acc[2], 2, K3{}); mfma(acc[3], 3, K3{});
-            if (qb + 1 < NQB) areg[3] = rd(3, qb + 1, tile);
+            mx6_static_for<0, NKS>([&](auto SC) {
+                constexpr int s_ = decltype(SC)::value;
+                mfma(acc[2], 2, SC); mfma(acc[3], 3, SC);
+                if (qb + 1 < NQB) areg[s_] = rd(s_, qb + 1, tile);
+            });
             reduce_block(acc[0], sid, 0);
             reduce_block(acc[1], sid, 1);
 #pragma unroll
             for (int i = 0; i < 2 * NKS; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16 / NKS, 0);
                 if (qb + 1 < NQB && (i & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
             sid01 = sid;
@@ -438,6 +455,14 @@ void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, c
             return;
         }
     }
+    if constexpr (CP == 512) {
+        if (var == 0) {                                          // default at C_pad 512: 4 waves x 128 anchors, one wave per SIMD
+            allow_dynamic_lds(reinterpret_cast<const void *>(&match_mx6_screen_w4_kernel<CP, 4>), (int)dyn);
+            hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 4>), dim3(groups / T * Tw), dim3(256), dyn, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw,
+                               S, ws_max, ws_i1, ws_m2);
+            return;
+        }
+    }
     if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_mx6_screen_kernel<CP, W_>), (int)dyn);
     hipLaunchKernelGGL((match_mx6_screen_kernel<CP, W_>), dim3(groups / T * Tw), dim3(64 * W_), dyn, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw, S,
                        ws_max, ws_i1, ws_m2);
@@ -447,7 +472,7 @@ void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, c
 // the kernel launch_screen_mx6 dispatches (for oryon_dominant_kernel / profile markers)
 const char *screen_mx6_name(int C)
 {
-    if (C != 256) return "match_mx6_screen_kernel<512, 4, 0>";
+    if (C != 256) return mx6_var() == 0 ? "match_mx6_screen_w4_kernel<512, 4>" : "match_mx6_screen_kernel<512, 4, 0>";
     return mx6_var() == 0 ? "match_mx6_screen_w4_kernel<256, 8>" : mx6_var() == 3 ? "match_mx6_screen_w4_kernel<256, 4>" : mx6_var() == 1 ? "match_mx6_screen_kernel<256, 8, 1>" : "match_mx6_screen_kernel<256, 8, 0>";
 }
 
