@@ -57,6 +57,9 @@ def run(n):
     eng.finish(prev)
 
 
+if os.environ.get("ENG_SIDE_STREAM"):
+    _side = torch.cuda.Stream()
+    torch.cuda.set_stream(_side)          # the caller's stream is not the legacy default stream: blocking streams do not synchronise with it
 run(5)
 torch.cuda.synchronize()
 import time
