@@ -2051,9 +2051,8 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
         rc = match_x3_resolve(w8.a_hat_c, lw.n_ambv, cap_s, feat_q, C_true, HW, layout, roi_q, roi_stride_q, q_norm, n_q, B, cap_q, threshold,
                               round_f16, qh, ql, lw.x3_ah, lw.x3_al, lw.x3_scratch, w8.md_c, w8.am_c, w8.va_c, &n_ovf, &ovf_idx, st);
         if (rc) { set_error("oryon_match_corrs: fp16x3 second-level launch failed"); return rc; }
-        ORYON_CHECK_HIP(hipMemsetAsync(wr.need_f32, 0, (size_t)B * sizeof(int32_t), st));
-        hipLaunchKernelGGL(match_need_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_ovf, wr.need_f32);
-        rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, wr.need_f32, cap_q, C, wr.q8_scratch, wr.scale_scratch,
+        // fp32 query rows for the pairs with overflowed anchors only: the gather's per-map gate reads n_ovf itself
+        rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, n_ovf, cap_q, C, wr.q8_scratch, wr.scale_scratch,
                               wr.eps_scratch, nullptr, wr.q_hat, 1, round_f16, st);
         if (rc) { set_error("oryon_match_corrs: overflow fp32 gather launch failed"); return rc; }
         hipLaunchKernelGGL(match_compact_f32_kernel, dim3((cap_s + 63) / 64, B), dim3(256), 0, st, w8.a_hat_c, C, cap_s, cap_s, n_ovf, ovf_idx,

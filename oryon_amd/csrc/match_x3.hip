@@ -440,12 +440,6 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
     }
 }
 
-__global__ void match_x3_enable_kernel(int B, const int32_t *__restrict__ n_c, int32_t *__restrict__ enable)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < B) enable[p] = n_c[p] > 0 ? 1 : 0;
-}
-
 // results of the exact fall-back for overflowed anchors -> their compact rows
 __global__ __launch_bounds__(256) void match_x3_scatter_ovf_kernel(int cap_s, const int32_t *__restrict__ n_ovf, const int32_t *__restrict__ ovf_idx,
                                                                     const float *__restrict__ md_o, const int32_t *__restrict__ am_o,
@@ -485,22 +479,19 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     size_t off = ((size_t)B * S * cap_s * 2 * sizeof(int32_t) + 255) / 256 * 256;
     uint2 *cand = reinterpret_cast<uint2 *>(sp + off);
     off += ((size_t)B * S * cap_s * 2 * X3_CAPH * sizeof(uint2) + 255) / 256 * 256;
-    int32_t *enable = reinterpret_cast<int32_t *>(sp + off);
-    off += ((size_t)B * sizeof(int32_t) + 255) / 256 * 256;
-    int32_t *n_ovf = reinterpret_cast<int32_t *>(sp + off);
-    off += ((size_t)B * sizeof(int32_t) + 255) / 256 * 256;
+    int32_t *n_ovf = reinterpret_cast<int32_t *>(sp + off);             // n_ovf | ql_max: adjacent, zeroed by ONE memset
+    const size_t cnt_block = ((size_t)B * sizeof(int32_t) + 255) / 256 * 256;
+    off += cnt_block;
+    float *ql_max = reinterpret_cast<float *>(sp + off);
+    off += cnt_block;
     int32_t *ovf_idx = reinterpret_cast<int32_t *>(sp + off);
     off += ((size_t)B * cap_s * sizeof(int32_t) + 255) / 256 * 256;
-    float *ql_max = reinterpret_cast<float *>(sp + off);
-    off += ((size_t)B * sizeof(float) + 255) / 256 * 256;
     float *al_norm = reinterpret_cast<float *>(sp + off);
     *n_ovf_out = n_ovf;
     *ovf_idx_out = ovf_idx;
-    if (hipMemsetAsync(n_ovf, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess) return ORYON_ERR_HIP;
-    if (hipMemsetAsync(ql_max, 0, (size_t)B * sizeof(float), st) != hipSuccess) return ORYON_ERR_HIP;
-    hipLaunchKernelGGL(match_x3_enable_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, n_c, enable);
-    // query rows as hi / lo halves, only for pairs that have listed anchors
-    int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, enable, cap_q, CP, reinterpret_cast<int8_t *>(qh), nullptr,
+    if (hipMemsetAsync(n_ovf, 0, 2 * cnt_block, st) != hipSuccess) return ORYON_ERR_HIP;
+    // query rows as hi / lo halves, only for pairs that have listed anchors (the gather's per-map gate reads the counts themselves)
+    int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, n_c, cap_q, CP, reinterpret_cast<int8_t *>(qh), nullptr,
                               ql_max, nullptr, nullptr, 1, round_f16, st, 2, ql);
     if (rc) return rc;
     hipLaunchKernelGGL(match_x3_split_anchors_kernel, dim3(64, B), dim3(256), 0, st, a_c, CP, cap_s, n_c, ah, al, al_norm);
