@@ -81,9 +81,9 @@ __device__ __forceinline__ unsigned stage_addr(int t, int s, int RB)
 // v_cvt_scalef32_pk32_f32_fp6, so the row's quantisation error e = x^ - dequant is MEASURED: eps_max[m] receives the largest
 // |e|_2 over the map's live rows (float bits, atomic max) - the bound of the mx6 screen is |s6 - a^.q^| <= |ea| + |eq| + |ea||eq|.
 // `scale` is not written in this mode.
-template <int CP, int LPR, bool NHWC, int FMT = 0>
-__global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_kernel(
-    const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride,
+template <int CP, int LPR, bool NHWC, int FMT>
+__device__ __forceinline__ void gather_q8_v3_tile(
+    const int bid, char *__restrict__ stage_all, const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride,
     const int32_t *__restrict__ count, const int32_t *__restrict__ map_enable, int rows_cap, int n_maps, int chunk_tiles,
     int chunks_per_map, int8_t *__restrict__ out8, float *__restrict__ scale, unsigned *__restrict__ eps_max,
     float *__restrict__ norm, float *__restrict__ out32, int round_f16, void *__restrict__ aux)
@@ -92,11 +92,9 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
     constexpr int KPL = CP / LPR;              // channels per lane
     constexpr int WG_ROWS = 4 * ROWS;
     static_assert(KPL % 64 == 0 && (LPR == 1 || LPR == 2), "geometry");
-    extern __shared__ __attribute__((aligned(256))) char stage_all[];
-
     // XCD-aware unit map: a unit is a contiguous chunk of a map's tiles and lives on ONE XCD (block b runs on XCD b % 8), so tiles that
     // share a 128-byte line at their common border share it through that XCD's L2 and a map's channel planes are walked in order
-    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int xcd = bid & 7, pos = bid >> 3;
     const int unit = (pos / chunk_tiles) * 8 + xcd;
     if (unit >= n_maps * chunks_per_map) return;
     const int m = unit / chunks_per_map;
@@ -408,6 +406,43 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ke
 #undef VS
 }
 
+// one workgroup tile per block (the K0 passes proper)
+template <int CP, int LPR, bool NHWC, int FMT = 0>
+__global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_kernel(
+    const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride,
+    const int32_t *__restrict__ count, const int32_t *__restrict__ map_enable, int rows_cap, int n_maps, int chunk_tiles,
+    int chunks_per_map, int8_t *__restrict__ out8, float *__restrict__ scale, unsigned *__restrict__ eps_max,
+    float *__restrict__ norm, float *__restrict__ out32, int round_f16, void *__restrict__ aux)
+{
+    extern __shared__ __attribute__((aligned(256))) char stage_all[];
+    gather_q8_v3_tile<CP, LPR, NHWC, FMT>((int)blockIdx.x, stage_all, feat, C, HW, roi, roi_stride, count, map_enable, rows_cap, n_maps, chunk_tiles,
+                                           chunks_per_map, out8, scale, eps_max, norm, out32, round_f16, aux);
+}
+
+// The matcher's device-gated passes (fp32 query rows for pairs with ambiguous anchors, hi / lo rows for K1x3, overflow rows): on most steps
+// no map is enabled, and a grid of one block per tile then dispatches ~40 k workgroups only to let them exit (15-35 us per launch on the
+// matcher's stream, three launches per step).  Here a fixed grid walks the tiles (stride = grid size, a multiple of 8: a block keeps its XCD).
+template <int CP, int LPR, bool NHWC, int FMT>
+__global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_gated_kernel(
+    int total_blocks, const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride,
+    const int32_t *__restrict__ count, const int32_t *__restrict__ map_enable, int rows_cap, int n_maps, int chunk_tiles,
+    int chunks_per_map, int8_t *__restrict__ out8, float *__restrict__ scale, unsigned *__restrict__ eps_max,
+    float *__restrict__ norm, float *__restrict__ out32, int round_f16, void *__restrict__ aux)
+{
+    extern __shared__ __attribute__((aligned(256))) char stage_all[];
+    // nothing enabled (the usual case): one parallel look at the gates instead of a dependent load per tile
+    {
+        bool any = false;
+        for (int m = threadIdx.x & 63; m < n_maps; m += 64) any |= map_enable[m] != 0;
+        if (__ballot(any) == 0ull) return;
+    }
+    for (int bid = (int)blockIdx.x; bid < total_blocks; bid += (int)gridDim.x) {
+        WAVE_LDS_ORDER();                                         // the previous tile's staging reads precede this tile's writes
+        gather_q8_v3_tile<CP, LPR, NHWC, FMT>(bid, stage_all, feat, C, HW, roi, roi_stride, count, map_enable, rows_cap, n_maps, chunk_tiles,
+                                               chunks_per_map, out8, scale, eps_max, norm, out32, round_f16, aux);
+    }
+}
+
 }  // namespace oryon
 
 using namespace oryon;
@@ -424,6 +459,14 @@ void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, con
     const int chunk_tiles = (T + chunks_per_map - 1) / chunks_per_map;
     const int units = n_maps * chunks_per_map;
     const int groups = ((units + 7) / 8) * 8 * chunk_tiles;
+    if (map_enable) {
+        auto gk = gather_q8_v3_gated_kernel<CP, LPR, NHWC, FMT>;
+        allow_dynamic_lds(reinterpret_cast<const void *>(gk), 4 * G8_STAGE_BYTES);
+        const int grid = groups < 2048 ? groups : 2048;
+        hipLaunchKernelGGL(gk, dim3(grid), dim3(256), 4 * G8_STAGE_BYTES, st, groups, feat, C, HW, roi, roi_stride, count, map_enable, rows_cap,
+                           n_maps, chunk_tiles, chunks_per_map, out8, scale, reinterpret_cast<unsigned *>(eps), norm, out32, round_f16, aux);
+        return;
+    }
     auto kern = gather_q8_v3_kernel<CP, LPR, NHWC, FMT>;
     allow_dynamic_lds(reinterpret_cast<const void *>(kern), 4 * G8_STAGE_BYTES);
     hipLaunchKernelGGL(kern, dim3(groups), dim3(256), 4 * G8_STAGE_BYTES, st, feat, C, HW, roi, roi_stride, count, map_enable, rows_cap,
