@@ -14,7 +14,7 @@ from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda", 0)
-B, H, C = 64, 224, 256
+B, H, C = int(os.environ.get("ENG_B", 64)), int(os.environ.get("ENG_H", 224)), int(os.environ.get("ENG_C", 256))
 inp = bench.make_inputs(B, H, C, 0, dev)
 inp["cam"] = inp["cam"].reshape(B, 9).float().contiguous()
 ser = bool(os.environ.get("ENG_SERIAL"))
