@@ -1565,7 +1565,6 @@ __global__ __launch_bounds__(256) void match_list_sampled_amb_kernel(int cap_a, 
                                                                       int32_t *__restrict__ list)
 {
     __shared__ int wave_cnt[4];
-    __shared__ int base;
     const int p = blockIdx.x;
     if (pair_eager[p]) return;
     const int n = n_sel[p], t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1574,23 +1573,31 @@ __global__ __launch_bounds__(256) void match_list_sampled_amb_kernel(int cap_a, 
         const int a = sel_rows[(size_t)p * corr_rows + s];
         if (state[(size_t)p * cap_a + a] == LZ_AMB_VALID) mark[(size_t)p * cap_a + a] = 1;
     }
-    if (t == 0) base = 0;
     __threadfence_block();
     __syncthreads();
-    for (int a0 = 0; a0 < cap_a; a0 += 256) {
-        const int a = a0 + t;
-        const bool m = a < cap_a && mark[(size_t)p * cap_a + a] != 0;
-        const unsigned long long b = __ballot(m);
-        if (lane == 0) wave_cnt[wave] = __popcll(b);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (m) list[(size_t)p * corr_rows + off + __popcll(b & ((1ull << lane) - 1ull))] = a;
-        __syncthreads();
-        if (t == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+    // ordered compaction in ONE scan: thread t owns the consecutive rows [t R, (t + 1) R), counts its marks, the block scans the 256 counts
+    const int R = (cap_a + 255) / 256;
+    const int32_t *mk = mark + (size_t)p * cap_a;
+    int mine = 0;
+    for (int i = 0; i < R; ++i) {
+        const int a = t * R + i;
+        mine += (a < cap_a && mk[a] != 0) ? 1 : 0;
     }
-    if (t == 0) n_list[p] = base;
+    int incl = mine;                                            // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
+    int off0 = incl - mine;
+    for (int w = 0; w < wave; ++w) off0 += wave_cnt[w];
+    for (int i = 0; i < R; ++i) {
+        const int a = t * R + i;
+        if (a < cap_a && mk[a] != 0) list[(size_t)p * corr_rows + off0++] = a;
+    }
+    if (t == 255) n_list[p] = off0;
 }
 
 // Exact resolution of ONE unambiguous anchor by one wave: candidates = rows of the winning 16-row slice within the int8 margin of its
