@@ -1948,7 +1948,7 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     ScreenWs &w = w8.top;
     hipStream_t st = as_stream(stream);
     ORYON_CHECK_HIP(hipMemsetAsync(static_cast<char *>(workspace) + w.zero_off, 0, w.zero_bytes, st));
-    ORYON_CHECK_HIP(hipMemsetAsync(wr.need_f32, 0, (size_t)B * sizeof(int32_t), st));
+    if (force_eager) ORYON_CHECK_HIP(hipMemsetAsync(wr.need_f32, 0, (size_t)B * sizeof(int32_t), st));      // only the eager route reads it
     ORYON_CHECK_HIP(hipMemsetAsync(static_cast<char *>(workspace) + lw.zero_off, 0, lw.zero_bytes, st));
     const float cut0 = 1.0f - 2.0f * threshold;
     const float valid_cut16 = cut0 - SCREEN_DELTA - 1e-6f;
