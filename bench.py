@@ -656,7 +656,7 @@ def main():
         run_steps(3)                                  # lets the asynchronous statistics arrive
         barrier()
         t0 = time.perf_counter()
-        HARD_STEPS = 15                               # enough steps for the pipeline's fill and drain not to dominate the figure
+        HARD_STEPS = 40                               # enough steps for the pipeline's fill and drain not to dominate the figure
         hout, _, hstatus = run_steps(HARD_STEPS)
         barrier()
         hel = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
