@@ -383,6 +383,10 @@ typedef struct {
     int reg_lag;             /* > 0: the matcher of step k waits for the registration of step k - reg_lag (< n_slots); 0 = never (default) */
     int screen;              /* 0 = int8 screen (oryon_gather_q8 + oryon_match_corrs_i8), 1 = MX-fp6 screen (oryon_gather_mx6 +
                                 oryon_match_corrs_mx6; steps submitted with force_eager take the int8 route) */
+    int sample_first;        /* 0 = off (default).  N > 0: the "sample first" schedule (see oryon_sample_first_gate): the matcher first
+                                sees a uniformly random N-anchor subset per pair; pairs whose subset holds fewer than n_corrs valid rows are
+                                redone on all anchors, gated on the device.  Same distribution of the sampled correspondences, not the same
+                                sample as the default schedule; steps submitted with force_eager ignore it */
 } oryon_engine_config_t;
 size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver);
 int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,

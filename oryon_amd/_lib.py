@@ -22,7 +22,7 @@ class OryonError(RuntimeError):
 class EngineConfig(ctypes.Structure):
     _fields_ = [("B", c_int), ("C", c_int), ("FH", c_int), ("FW", c_int), ("HA", c_int), ("WA", c_int), ("HQ", c_int), ("WQ", c_int),
                 ("layout", c_int), ("dist_th", c_float), ("n_corrs", c_int), ("src_sampling", c_int), ("seed", c_uint64),
-                ("round_f16", c_int), ("n_slots", c_int), ("overlap", c_int), ("gather_sets", c_int), ("reg_streams", c_int), ("reg_lag", c_int), ("screen", c_int)]
+                ("round_f16", c_int), ("n_slots", c_int), ("overlap", c_int), ("gather_sets", c_int), ("reg_streams", c_int), ("reg_lag", c_int), ("screen", c_int), ("sample_first", c_int)]
 
 
 class PointDSCConfig(ctypes.Structure):

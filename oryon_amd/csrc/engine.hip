@@ -34,6 +34,9 @@ inline size_t up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct GatherBuf {
     int8_t *a8, *q8;
     float *a_sc, *q_sc, *a_eps, *q_eps, *a_norm, *q_norm, *a_hat;
+    // cfg.sample_first: the first-stage anchor subset's operands (cap_a1 rows); a8 / a_hat then serve the gated second stage
+    int8_t *a8_1;
+    float *a_sc_1, *a_eps_1, *a_norm_1, *a_hat_1;
 };
 
 struct SlotBuf {
@@ -42,6 +45,7 @@ struct SlotBuf {
     int32_t *argmin;
     uint8_t *valid;
     int32_t *corrs, *n_valid, *n_sel, *status, *n_und;
+    int32_t *roi_a1, *n_a1, *n_a2, *corrs2, *n_valid2, *n_sel2, *status2;      // cfg.sample_first only
     float *pcd_a, *pcd_q;
     int32_t *n_lift;
     float *pose;
@@ -61,7 +65,7 @@ struct Layout {
     std::vector<Named> names[MAX_SLOTS];
     void *match_ws;
     size_t match_ws_bytes, pdsc_ws_bytes, bytes;
-    int cap_a, cap_q, c_pad, n_cap;
+    int cap_a, cap_q, c_pad, n_cap, cap_a1;
 };
 }  // namespace
 
@@ -94,6 +98,7 @@ int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver,
     L.cap_a = (int)up((size_t)keep, ROW_PAD);
     L.cap_q = (int)up((size_t)HW, ROW_PAD);
     L.n_cap = (int)up((size_t)c.n_corrs, 128);
+    L.cap_a1 = c.sample_first > 0 ? (int)up((size_t)(c.sample_first < HW ? c.sample_first : HW), ROW_PAD) : 0;
     const size_t B = (size_t)c.B;
     L.match_ws_bytes = oryon_match_corrs_i8_workspace_bytes(c.B, L.c_pad, L.cap_a, L.cap_q, L.n_cap);
     L.pdsc_ws_bytes = oryon_pointdsc_workspace_bytes(solver, c.B, L.n_cap);
@@ -116,6 +121,15 @@ int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver,
         TAKE(a_norm, float, B * L.cap_a);
         TAKE(q_norm, float, B * L.cap_q);
         TAKE(a_hat, float, B * L.cap_a * L.c_pad);
+        b.a8_1 = nullptr;
+        b.a_sc_1 = b.a_eps_1 = b.a_norm_1 = b.a_hat_1 = nullptr;
+        if (L.cap_a1) {
+            TAKE(a8_1, int8_t, B * L.cap_a1 * L.c_pad);
+            TAKE(a_sc_1, float, B * (L.cap_a1 / 16));
+            TAKE(a_eps_1, float, B);
+            TAKE(a_norm_1, float, B * L.cap_a1);
+            TAKE(a_hat_1, float, B * L.cap_a1 * L.c_pad);
+        }
 #undef TAKE
     }
     for (int s = 0; s < c.n_slots; ++s) {
@@ -141,6 +155,16 @@ int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver,
         TAKE(n_sel, int32_t, B);
         TAKE(status, int32_t, B);
         TAKE(n_und, int32_t, B);
+        b.roi_a1 = b.n_a1 = b.n_a2 = b.corrs2 = b.n_valid2 = b.n_sel2 = b.status2 = nullptr;
+        if (L.cap_a1) {
+            TAKE(roi_a1, int32_t, B * HW);
+            TAKE(n_a1, int32_t, B);
+            TAKE(n_a2, int32_t, B);
+            TAKE(corrs2, int32_t, B * L.n_cap * 4);
+            TAKE(n_valid2, int32_t, B);
+            TAKE(n_sel2, int32_t, B);
+            TAKE(status2, int32_t, B);
+        }
         TAKE(pcd_a, float, B * L.n_cap * 3);
         TAKE(pcd_q, float, B * L.n_cap * 3);
         TAKE(n_lift, int32_t, B);
@@ -166,6 +190,7 @@ int check_cfg(const oryon_engine_config_t *c)
     ORYON_CHECK_ARG((c->layout == ORYON_LAYOUT_NCHW || c->layout == ORYON_LAYOUT_NHWC) && (c->screen == 0 || c->screen == 1));
     ORYON_CHECK_ARG(c->overlap >= 0 && c->overlap <= 2 && (c->overlap == 0 || c->n_slots >= 2));      // results of step k live until submit k + n_slots
     ORYON_CHECK_ARG((size_t)c->C * (size_t)c->FH * (size_t)c->FW * 4u < (1ull << 32));
+    ORYON_CHECK_ARG(c->sample_first >= 0);
     return ORYON_OK;
 }
 }  // namespace
@@ -338,18 +363,33 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
     if ((rc = oryon_roi_compact(mask_q, B, HW, b.roi_q, b.n_q, sg))) return rc;
     if (c.src_sampling > 0 && (rc = oryon_roi_subsample(b.roi_a, b.n_a, B, HW, c.src_sampling, c.seed, pair_key, sg))) return rc;
     const bool mx6 = c.screen == 1 && !force_eager;           // the eager route (complete min_dist / argmin arrays) keeps the int8 operands
+    // "sample first" (cfg.sample_first = N, oryon_sample_first_gate): the matcher first sees a uniformly random N-anchor subset of every pair
+    // (second-level device-RNG subsample, row order kept); only pairs whose subset holds fewer than n_corrs valid rows are redone on all
+    // anchors - gated on the device, so the second K0 pass and the second matcher call see zero anchors for every other pair
+    const bool sf = e->L.cap_a1 > 0 && !force_eager;
+    const int32_t *roi_a_k0 = b.roi_a, *n_a_k0 = b.n_a;
+    int cap_a_k0 = e->L.cap_a;
+    int8_t *a8_k0 = g.a8;
+    float *a_sc_k0 = g.a_sc, *a_eps_k0 = g.a_eps, *a_norm_k0 = g.a_norm, *a_hat_k0 = g.a_hat;
+    if (sf) {
+        ORYON_CHECK_HIP(hipMemcpyAsync(b.roi_a1, b.roi_a, (size_t)B * HW * sizeof(int32_t), hipMemcpyDeviceToDevice, sg));
+        ORYON_CHECK_HIP(hipMemcpyAsync(b.n_a1, b.n_a, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, sg));
+        if ((rc = oryon_roi_subsample(b.roi_a1, b.n_a1, B, HW, c.sample_first, c.seed ^ 0x5A17F125ull, pair_key, sg))) return rc;
+        roi_a_k0 = b.roi_a1; n_a_k0 = b.n_a1; cap_a_k0 = e->L.cap_a1;
+        a8_k0 = g.a8_1; a_sc_k0 = g.a_sc_1; a_eps_k0 = g.a_eps_1; a_norm_k0 = g.a_norm_1; a_hat_k0 = g.a_hat_1;
+    }
     if (ablate & 1) {
     } else if (mx6) {
         // the row buffers hold 32-byte mx6 slots instead of int8 rows (same size); the per-map error norms go where eps_max went
         if ((rc = oryon_gather_mx6(feat_q, B, c.C, HW, c.layout, b.roi_q, HW, b.n_q, e->L.cap_q, e->L.c_pad, reinterpret_cast<uint8_t *>(g.q8),
                                    g.q_eps, g.q_norm, nullptr, c.round_f16, sg))) return rc;
-        if ((rc = oryon_gather_mx6(feat_a, B, c.C, HW, c.layout, b.roi_a, HW, b.n_a, e->L.cap_a, e->L.c_pad, reinterpret_cast<uint8_t *>(g.a8),
-                                   g.a_eps, g.a_norm, g.a_hat, c.round_f16, sg))) return rc;
+        if ((rc = oryon_gather_mx6(feat_a, B, c.C, HW, c.layout, roi_a_k0, HW, n_a_k0, cap_a_k0, e->L.c_pad, reinterpret_cast<uint8_t *>(a8_k0),
+                                   a_eps_k0, a_norm_k0, a_hat_k0, c.round_f16, sg))) return rc;
     } else {
     if ((rc = oryon_gather_q8(feat_q, B, c.C, HW, c.layout, b.roi_q, HW, b.n_q, e->L.cap_q, e->L.c_pad, g.q8, g.q_sc, g.q_eps, g.q_norm,
                               nullptr, c.round_f16, sg))) return rc;
-    if ((rc = oryon_gather_q8(feat_a, B, c.C, HW, c.layout, b.roi_a, HW, b.n_a, e->L.cap_a, e->L.c_pad, g.a8, g.a_sc, g.a_eps, g.a_norm,
-                              g.a_hat, c.round_f16, sg))) return rc;
+    if ((rc = oryon_gather_q8(feat_a, B, c.C, HW, c.layout, roi_a_k0, HW, n_a_k0, cap_a_k0, e->L.c_pad, a8_k0, a_sc_k0, a_eps_k0, a_norm_k0,
+                              a_hat_k0, c.round_f16, sg))) return rc;
     }
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[1], sg));
     if (sg != sm) {
@@ -362,18 +402,37 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
         (void)oryon_profile_events(tev[4], tev[5]);
     }
     // corrs rows beyond max_corrs are never written by the sampler and K2 only reads n_sel rows: no zero-fill needed
+    // one matcher call (the engine's screen setting) on the given anchor operands
+    auto match_call = [&](const float *a_hat_, const int8_t *a8_, const float *a_sc_, const float *a_eps_, const int32_t *roi_a_, int cap_a_,
+                          const int32_t *n_a_, int32_t *corrs_, int32_t *n_valid_, int32_t *n_sel_, int32_t *status_, int32_t *n_und_) -> int {
+        if (mx6)
+            return oryon_match_corrs_mx6(a_hat_, reinterpret_cast<const uint8_t *>(a8_), a_eps_, feat_q, c.C, HW, c.layout, roi_a_, HW, b.roi_q, HW,
+                                         g.q_norm, reinterpret_cast<const uint8_t *>(g.q8), g.q_eps, B, e->L.c_pad, cap_a_, e->L.cap_q, n_a_, b.n_q,
+                                         c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key, b.min_dist, b.argmin, b.valid, corrs_, n_valid_,
+                                         n_sel_, status_, n_und_, c.round_f16, e->L.match_ws, e->L.match_ws_bytes, sm);
+        return oryon_match_corrs_i8(a_hat_, a8_, a_sc_, feat_q, c.C, HW, c.layout, roi_a_, HW, b.roi_q, HW, g.q_norm, g.q8, g.q_sc, g.q_eps, B,
+                                    e->L.c_pad, cap_a_, e->L.cap_q, n_a_, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key, force_eager,
+                                    b.min_dist, b.argmin, b.valid, corrs_, n_valid_, n_sel_, status_, n_und_, c.round_f16, e->L.match_ws,
+                                    e->L.match_ws_bytes, sm);
+    };
     if (ablate & 2) {
-    } else if (mx6) {
-        if ((rc = oryon_match_corrs_mx6(g.a_hat, reinterpret_cast<const uint8_t *>(g.a8), g.a_eps, feat_q, c.C, HW, c.layout, b.roi_a, HW, b.roi_q,
-                                        HW, g.q_norm, reinterpret_cast<const uint8_t *>(g.q8), g.q_eps, B, e->L.c_pad, e->L.cap_a, e->L.cap_q,
-                                        b.n_a, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key, b.min_dist, b.argmin, b.valid,
-                                        b.corrs, b.n_valid, b.n_sel, b.status, b.n_und, c.round_f16, e->L.match_ws, e->L.match_ws_bytes, sm)))
+    } else if (sf) {
+        if ((rc = match_call(g.a_hat_1, g.a8_1, g.a_sc_1, g.a_eps_1, b.roi_a1, e->L.cap_a1, b.n_a1, b.corrs, b.n_valid, b.n_sel, b.status, b.n_und)))
             return rc;
-    } else
-    if ((rc = oryon_match_corrs_i8(g.a_hat, g.a8, g.a_sc, feat_q, c.C, HW, c.layout, b.roi_a, HW, b.roi_q, HW, g.q_norm, g.q8, g.q_sc, g.q_eps,
-                                   B, e->L.c_pad, e->L.cap_a, e->L.cap_q, b.n_a, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key,
-                                   force_eager, b.min_dist, b.argmin, b.valid, b.corrs, b.n_valid, b.n_sel, b.status, b.n_und, c.round_f16,
-                                   e->L.match_ws, e->L.match_ws_bytes, sm))) return rc;
+        if ((rc = oryon_sample_first_gate(b.n_valid, b.n_a1, b.n_a, B, c.n_corrs, b.n_a2, sm))) return rc;
+        // second stage for the pairs that came up short: their anchors' operands (every other pair has a zero count: nothing is gathered or
+        // matched for it), the matcher on all anchors, rows / counts / status of those pairs copied over the first stage's
+        if (mx6) {
+            if ((rc = oryon_gather_mx6(feat_a, B, c.C, HW, c.layout, b.roi_a, HW, b.n_a2, e->L.cap_a, e->L.c_pad, reinterpret_cast<uint8_t *>(g.a8),
+                                       g.a_eps, g.a_norm, g.a_hat, c.round_f16, sm))) return rc;
+        } else if ((rc = oryon_gather_q8(feat_a, B, c.C, HW, c.layout, b.roi_a, HW, b.n_a2, e->L.cap_a, e->L.c_pad, g.a8, g.a_sc, g.a_eps, g.a_norm,
+                                         g.a_hat, c.round_f16, sm))) return rc;
+        if ((rc = match_call(g.a_hat, g.a8, g.a_sc, g.a_eps, b.roi_a, e->L.cap_a, b.n_a2, b.corrs2, b.n_valid2, b.n_sel2, b.status2, nullptr)))
+            return rc;
+        if ((rc = oryon_sample_first_merge(b.n_a2, b.corrs2, b.n_valid2, b.n_sel2, b.status2, B, e->L.n_cap, b.corrs, b.n_valid, b.n_sel, b.status,
+                                           sm))) return rc;
+    } else if ((rc = match_call(g.a_hat, g.a8, g.a_sc, g.a_eps, b.roi_a, e->L.cap_a, b.n_a, b.corrs, b.n_valid, b.n_sel, b.status, b.n_und)))
+        return rc;
     if (!(ablate & 2) && (rc = oryon_lift_pairs(b.corrs, b.n_sel, B, e->L.n_cap, c.FH, c.FW, depth_a, c.HA, c.WA, depth_q, c.HQ, c.WQ, cam_a, cam_q,
                                                 b.status, b.pcd_a, b.pcd_q, b.n_lift, sm))) return rc;
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[3], sm));

@@ -77,8 +77,9 @@ class NativeStep:
                                       n_corrs=cfg.n_corrs, src_sampling=int(cfg.src_sampling or 0), seed=int(cfg.seed) & (2**64 - 1),
                                       round_f16=int(cfg.half_descriptors), n_slots=n_slots, overlap=overlap,
                                       gather_sets=min(gather_sets, n_slots), reg_streams=reg_streams,
-                                      reg_lag=reg_lag if overlap else 0, screen=screen)
-        self.cfg_sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap)
+                                      reg_lag=reg_lag if overlap else 0, screen=screen,
+                                      sample_first=int(cfg.sample_first) if cfg.sample_first and cfg.sample_first > 0 else 0)
+        self.cfg_sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap, int(cfg.sample_first))
         need = lib().oryon_engine_arena_bytes(ctypes.byref(self.ecfg), solver._handle)
         if need == 0:
             raise _lib.OryonError(f"oryon_engine_arena_bytes: {lib().oryon_last_error().decode()}")
@@ -286,7 +287,7 @@ class MatchPoseEngine:
         cam_a, cam_q = as_type(cam_a, torch.float32, (B, 9)), as_type(cam_q, torch.float32, (B, 9))
         key = (B, C, FH, FW, depth_a.shape[1], depth_a.shape[2], depth_q.shape[1], depth_q.shape[2], lay_a)
         overlap = 2 if (self.overlap and self.overlap_gather) else (1 if self.overlap else 0)
-        sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap)
+        sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap, int(cfg.sample_first))
         nat = self._native
         if nat is None or nat.key != key or nat.cfg_sig != sig or nat.dev != dev:
             self._collect_inflight()                  # results still living in the old arena
@@ -341,7 +342,7 @@ class MatchPoseEngine:
                     use_i8 = False
                 else:
                     self._i8_skipped, self._i8_frac = 0, 0.0
-        if use_i8 and self.native and cfg.sample_first <= 0:
+        if use_i8 and self.native:
             return self._run_native(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, keep, inputs_event,
                                     inputs_resident, dev)
         if pair_key is None:

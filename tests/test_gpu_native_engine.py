@@ -160,3 +160,32 @@ def test_engine_c_abi_argument_checks():
     assert lib().oryon_engine_buffer(h, 0, b"nope", ctypes.byref(off), ctypes.byref(nb)) == -1
     assert lib().oryon_engine_wait(h, 0, None) == -1                                          # nothing submitted to that slot yet
     lib().oryon_engine_destroy(h)
+
+
+def test_native_sample_first_schedule_equals_python_schedule():
+    """oryon_engine_config_t.sample_first: the same two-stage schedule as the Python engine's (random N-anchor subset first, pairs that come
+    up short redone on all anchors - one pair here has a mask that is too thin for the subset), same RNG keys: identical poses, statuses
+    and correspondences; `keep` steps (complete matcher outputs wanted) ignore it in both."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    solver = _solver()
+    ins = list(_inputs(400, 4, 128, 256))
+    ins[2] = ins[2].clone()
+    live = ins[2][3].view(-1).nonzero().flatten()
+    ins[2][3].view(-1)[live[1400:]] = 0               # pair 3: 1400 anchors, of which a 1024-subset holds < 500 valid rows at times -> second stage
+    key = torch.arange(40, 44, device="cuda")
+    cfg = MatchPoseConfig(sample_first=1024)
+    a = MatchPoseEngine(solver, cfg, native=False).run(*ins, key)
+    b = MatchPoseEngine(solver, cfg, native=True).run(*ins, key)
+    torch.cuda.synchronize()
+    for k in ("pose", "status", "n_valid", "n_lifted"):
+        assert torch.equal(a[k], b[k]), k
+    plain = MatchPoseEngine(solver, MatchPoseConfig(), native=True).run(*ins, key)
+    torch.cuda.synchronize()
+    assert b["status"].tolist() == [0, 0, 0, 0] and torch.equal(plain["status"], b["status"])
+    assert int(b["n_a"].min()) > 1024 if "n_a" in b else True
+    assert not torch.equal(plain["pose"], b["pose"])                           # another (equally valid) sample
+    assert float((plain["pose"] - b["pose"]).abs().max()) < 5e-2
+    ak = MatchPoseEngine(solver, cfg, native=False).run(*ins, key, keep=True)
+    bk = MatchPoseEngine(solver, cfg, native=True).run(*ins, key, keep=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ak["pose"], bk["pose"]) and torch.equal(bk["pose"], plain["pose"])
