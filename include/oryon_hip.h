@@ -388,6 +388,7 @@ typedef struct {
                                 redone on all anchors, gated on the device.  Same distribution of the sampled correspondences, not the same
                                 sample as the default schedule; steps submitted with force_eager ignore it */
 } oryon_engine_config_t;
+size_t oryon_engine_config_bytes(void);      /* sizeof(oryon_engine_config_t) in the built library: a binding's mirror of the struct must match */
 size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver);
 int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,
                         size_t arena_bytes);

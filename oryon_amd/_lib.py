@@ -95,6 +95,7 @@ _PROTOS = {
     "oryon_engine_set_timing": (c_int, [c_void_p, c_int]),
     "oryon_engine_timing": (c_int, [c_void_p, c_int64, POINTER(c_float)]),
     "oryon_engine_elapsed": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, POINTER(c_float)]),
+    "oryon_engine_config_bytes": (c_size_t, []),
     "oryon_engine_host_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "oryon_pointdsc_create": (c_int, [POINTER(c_void_p), POINTER(PointDSCConfig)]),
     "oryon_pointdsc_destroy": (None, [c_void_p]),
@@ -127,6 +128,9 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.oryon_engine_config_bytes() != ctypes.sizeof(EngineConfig):
+            raise OryonError(f"{LIB_PATH}: oryon_engine_config_t is {L.oryon_engine_config_bytes()} bytes in the library, "
+                             f"{ctypes.sizeof(EngineConfig)} in oryon_amd/_lib.py (stale build?)")
         _lib = L
     return _lib
 

@@ -195,6 +195,9 @@ int check_cfg(const oryon_engine_config_t *c)
 }
 }  // namespace
 
+// sizeof(oryon_engine_config_t) as this library was built: bindings in other languages check their mirror of the struct against it
+extern "C" size_t oryon_engine_config_bytes(void) { return sizeof(oryon_engine_config_t); }
+
 extern "C" size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver)
 {
     if (check_cfg(cfg) || !solver) return 0;

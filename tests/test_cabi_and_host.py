@@ -171,3 +171,22 @@ def test_hot_kernels_do_not_spill():
                 seen.add(h)
                 assert k["scratch"] == 0, f"{k['name']}: {k['spill']} spilled registers, {k['scratch']} B of scratch per lane"
     assert seen == set(hot), sorted(set(hot) - seen)
+
+
+def test_engine_config_struct_matches_the_library():
+    """The ctypes mirror of oryon_engine_config_t has the size the library was built with (a field added on one side only would shift
+    every later field silently)."""
+    import ctypes
+    from oryon_amd import _lib
+    assert _lib.lib().oryon_engine_config_bytes() == ctypes.sizeof(_lib.EngineConfig)
+    names = [f[0] for f in _lib.EngineConfig._fields_]
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "oryon_hip.h")).read()
+    body = header[header.index("typedef struct {", header.index("typedef struct oryon_engine oryon_engine_t;")):header.index("} oryon_engine_config_t;")]
+    import re
+    decl = []
+    for line in body.splitlines()[1:]:
+        code = line.split("/*")[0]
+        m = re.match(r"\s*(?:int|float|uint64_t)\s+([^;]+);", code)
+        if m:
+            decl += [x.strip() for x in m.group(1).split(",")]
+    assert decl == names, (decl, names)
