@@ -17,14 +17,17 @@ import os
 import sys
 import time
 
-# five HIP streams (the caller's + the engine's four) need more than the runtime's default of four hardware queues - see oryon_amd/__init__.py
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import oryon_amd  # noqa: E402
+
+# five HIP streams (the caller's + the engine's four) need more than the runtime's default of four hardware queues: an explicit
+# process-level setting, made before anything initialises HIP (oryon_amd.configure; importing the package changes nothing)
+oryon_amd.configure()
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
 
 from oryon_amd import ops  # noqa: E402
 from oryon_amd.dist import gather_poses, init_from_env  # noqa: E402
@@ -559,7 +562,10 @@ def main():
             if tj.get("kernel_source_sha256") == sha:
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source", "profiles/r03_pmc_counters.md")
             else:
-                traffic_src = "profiles/r03_traffic.json is stale (the screen kernel source changed since the PMC passes): not reported"
+                # loud, not silent: a reader (and tests/test_gpu_bench_contract.py) sees that the committed counters describe an older kernel
+                traffic = "stale"
+                traffic_src = ("profiles/r03_traffic.json is STALE: the screen kernel source changed since the PMC passes were collected "
+                               "(sha256 mismatch) - re-run tools/make_traffic_json.py on fresh rocprofv3 --pmc passes")
         rec = {
             "metric": METRIC, "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -347,7 +347,9 @@ int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const floa
  * with exactly the arguments oryon_amd/engine.py passes to those entry points, so results are identical bit for bit.  The K0
  * outputs alternate between two buffer sets, everything else a step produces between n_slots result slots, registrations between
  * two streams: K0 of step k+1 and the registrations of steps k-1, k-2 overlap the matching of step k.
- * Route: the int8-screened matcher (128 < C <= 512, 0 < dist_th <= 0.5); other routes stay with the per-call entry points.
+ * Route: the screened lazy matcher (C <= 512, 0 < dist_th <= 0.5; descriptors narrower than 256 channels - the reference's own
+ *          C = 32 @ 192^2, configs/config.yaml:34-35 - are zero-padded to the 256-channel operand rows by K0, which changes no result);
+ *          wider descriptors / other thresholds stay with the per-call entry points.
  *
  * overlap: 0 = everything on the caller's stream (no engine streams), 1 = match on an engine stream, registration on one stream
  *          per slot, 2 = additionally K0 on its own stream (n_slots >= 2 for overlap >= 1).
@@ -355,6 +357,11 @@ int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const floa
  *          "status_out" [B] i32, "n_valid", "n_lift", "n_a", "n_q", "n_und" [B] i32, "corrs" [B,n_cap,4] i32, "pcd_a", "pcd_q"
  *          [B,n_cap,3] fp32, "roi_a", "roi_q" [B,FH*FW] i32, "min_dist", "argmin", "valid" [B,cap_a], ...); a slot's buffers are valid
  *          from oryon_engine_wait(slot) until the n_slots-th next submit.
+ *          Slot lifetime, precisely: that submit orders the overwrite of "pose" / "status_out" after everything queued on
+ *          caller_stream before it, whatever inputs_resident says.  K0 and the matcher overwrite the slot's OTHER buffers (ROI lists,
+ *          counts, matcher outputs, correspondences, lifted points) without waiting for caller_stream when inputs_resident != 0: a
+ *          caller that may still have reads of those queued when the slot comes round again passes inputs_resident = 0 for that submit.
+ *          "corrs" rows >= the pair's n_sel are undefined (a re-used slot keeps an earlier step's rows there; K2 reads n_sel rows).
  * oryon_engine_submit returns the slot index (>= 0) or a negative error.  inputs_resident != 0: the inputs were complete before
  *          the call (nothing pending on caller_stream produces them), so K0 need not wait for the caller's stream.  The caller
  *          must not overwrite the inputs before oryon_engine_wait(slot, stream) has been passed on the stream that overwrites them.

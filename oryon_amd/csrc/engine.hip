@@ -93,6 +93,10 @@ namespace {
 int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver, char *base, Layout &L)
 {
     const int HW = c.FH * c.FW;
+    // narrow descriptors (the reference's own C = 32 @ 192^2, configs/config.yaml:34-35) run the same screened route zero-padded to the
+    // 256-channel operand rows: zero columns change neither the canonical fmaf chain nor any bound, K0v3 reads C planes and writes
+    // 256-byte rows, and 8x padding on the MX-fp6 pipe (64 channels per MFMA) is still several times faster than the exact fp32-MFMA
+    // scan the per-call schedule runs at these widths
     L.c_pad = c.C <= 256 ? 256 : 512;
     const int keep = c.src_sampling > 0 ? (c.src_sampling < HW ? c.src_sampling : HW) : HW;
     L.cap_a = (int)up((size_t)keep, ROW_PAD);
@@ -101,6 +105,13 @@ int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver,
     L.cap_a1 = c.sample_first > 0 ? (int)up((size_t)(c.sample_first < HW ? c.sample_first : HW), ROW_PAD) : 0;
     const size_t B = (size_t)c.B;
     L.match_ws_bytes = oryon_match_corrs_i8_workspace_bytes(c.B, L.c_pad, L.cap_a, L.cap_q, L.n_cap);
+    if (L.cap_a1) {
+        // the first stage of the sample-first schedule calls the matcher with cap_a1 anchors: fewer rows, but its query split (and with it
+        // the per-split partial arrays) can be LARGER than the full call's - the one workspace serves both calls
+        const size_t w1 = oryon_match_corrs_i8_workspace_bytes(c.B, L.c_pad, L.cap_a1, L.cap_q, L.n_cap);
+        if (!w1) return ORYON_ERR_INVALID_ARG;
+        if (w1 > L.match_ws_bytes) L.match_ws_bytes = w1;
+    }
     L.pdsc_ws_bytes = oryon_pointdsc_workspace_bytes(solver, c.B, L.n_cap);
     if (!L.match_ws_bytes || !L.pdsc_ws_bytes) return ORYON_ERR_INVALID_ARG;
     size_t off = 0;
@@ -182,7 +193,7 @@ int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver,
 
 int check_cfg(const oryon_engine_config_t *c)
 {
-    ORYON_CHECK_ARG(c && c->B > 0 && c->C > 128 && c->C <= 512 && c->FH > 0 && c->FW > 0);
+    ORYON_CHECK_ARG(c && c->B > 0 && c->C > 0 && c->C <= 512 && c->FH > 0 && c->FW > 0);
     ORYON_CHECK_ARG(c->HA > 0 && c->WA > 0 && c->HQ > 0 && c->WQ > 0 && c->n_corrs > 0 && c->src_sampling >= 0);
     ORYON_CHECK_ARG(c->dist_th > 0.0f && c->dist_th <= 0.5f && c->n_slots >= 1 && c->n_slots <= MAX_SLOTS);
     ORYON_CHECK_ARG(c->gather_sets >= 1 && c->gather_sets <= MAX_G_SLOTS && c->gather_sets <= c->n_slots);
@@ -250,10 +261,13 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     }
     for (int r = 0; r < TIMING_RING; ++r)
         for (int i = 0; i < 8; ++i) ok(hipEventCreate(&e->tev[r][i]));
-    // rows of `corrs` beyond n_corrs are never written by the sampler: zero them once, so that the slot reads like the freshly zeroed
-    // tensor the per-call schedule hands out
+    // rows of `corrs` beyond n_corrs are never written by the sampler: zero them once, so that a slot's first use reads like the freshly
+    // zeroed tensor the per-call schedule hands out.  (When a slot is re-used, the rows of a pair that selects nothing - n_sel == 0 - keep
+    // what the slot's previous step left there: rows >= n_sel are undefined, K2 reads n_sel rows only; the header says so.)
+    // The engine's streams are non-blocking (not ordered against the null stream these memsets run on): wait for them here, once.
     for (int s = 0; s < cfg->n_slots; ++s)
         ok(hipMemset(e->L.slot[s].corrs, 0, (size_t)cfg->B * e->L.n_cap * 4 * sizeof(int32_t)));
+    ok(hipDeviceSynchronize());
     if (err != hipSuccess) {
         set_error("oryon_engine_create: stream / event creation failed: %s", hipGetErrorString(err));
         oryon_engine_destroy(e);
@@ -337,9 +351,13 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
         // before this call (its reads of the slot's previous results).  The gather / match streams wait for the caller's stream only
         // when the inputs are not known to be complete already (inputs_resident): that wait is what keeps K0 of step k+1 from running
         // under the matching of step k when the caller's stream is itself waiting for step k-1.
+        // The first n_slots submits always wait: the arena itself was handed over on the caller's stream (an allocator may have given
+        // it memory whose previous owner still has work queued there), and the engine's streams are not otherwise ordered after it.
+        // A caller that still has reads of the slot's OTHER buffers (everything but pose / status_out) queued on its stream when the
+        // slot comes round again must pass inputs_resident = 0 for that submit (header: "slot lifetime"); oryon_amd/engine.py does.
         ORYON_CHECK_HIP(hipEventRecord(e->ev_inputs[slot], caller));
         ORYON_CHECK_HIP(hipStreamWaitEvent(sr, e->ev_inputs[slot], 0));
-        if (!inputs_resident) {
+        if (!inputs_resident || e->n_submit < c.n_slots) {
             ORYON_CHECK_HIP(hipStreamWaitEvent(sg, e->ev_inputs[slot], 0));
             if (sm != sg) ORYON_CHECK_HIP(hipStreamWaitEvent(sm, e->ev_inputs[slot], 0));
         }
@@ -400,9 +418,16 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
         ORYON_CHECK_HIP(hipStreamWaitEvent(sm, e->ev_gathered[slot], 0));
     }
     // ---- K1s8 + K1b + K2 on the match stream (one shared workspace: matcher calls are serial on this stream)
+    // the profile events are armed for the screening launch of THIS call only: whatever path leaves the function disarms them, so a
+    // failed sub-call (or an ablated matcher) cannot leave them to be recorded by an unrelated matcher call of this thread later
+    struct Disarm {
+        bool armed = false;
+        ~Disarm() { if (armed) (void)oryon_profile_events(nullptr, nullptr); }
+    } disarm;
     if (timing) {
         ORYON_CHECK_HIP(hipEventRecord(tev[2], sm));
         (void)oryon_profile_events(tev[4], tev[5]);
+        disarm.armed = true;
     }
     // corrs rows beyond max_corrs are never written by the sampler and K2 only reads n_sel rows: no zero-fill needed
     // one matcher call (the engine's screen setting) on the given anchor operands

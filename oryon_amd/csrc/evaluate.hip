@@ -158,6 +158,10 @@ __device__ __forceinline__ void apply34(const Pose34 &T, double x, double y, dou
 }
 
 // grid (symmetry index, pair); workspace [B, max_syms, 2] = per symmetry (max 3-D distance, max projected distance)
+// max that PROPAGATES NaN like numpy's max (the reference's my_mssd / my_mspd, bop_toolkit_lib/pose_error.py:339-427, take `.max()` of the
+// per-point errors: a degenerate projection - w = 0 - makes the whole error NaN there); fmax alone would drop it
+__device__ __forceinline__ double nmax(double a, double b) { return (a != a) ? a : (b != b) ? b : fmax(a, b); }
+
 __global__ __launch_bounds__(256) void pose_bop_kernel(const double *__restrict__ pred, const double *__restrict__ gt, const double *__restrict__ Kc,
                                                        const double *__restrict__ pts, const int32_t *__restrict__ pts_offset,
                                                        const double *__restrict__ syms, const int32_t *__restrict__ sym_offset,
@@ -187,22 +191,22 @@ __global__ __launch_bounds__(256) void pose_bop_kernel(const double *__restrict_
         apply34(E, x[0], x[1], x[2], ax, ay, az);
         apply34(GS, x[0], x[1], x[2], bx, by, bz);
         const double ex = ax - bx, ey = ay - by, ez = az - bz;
-        d3 = fmax(d3, sqrt(ex * ex + ey * ey + ez * ez));
+        d3 = nmax(d3, sqrt(ex * ex + ey * ey + ez * ez));
         // my_project_pts: (R x + t) K^T, divided by its third component
         const double aw = ax * K[6] + ay * K[7] + az * K[8], bw = bx * K[6] + by * K[7] + bz * K[8];
         const double au = (ax * K[0] + ay * K[1] + az * K[2]) / aw, av = (ax * K[3] + ay * K[4] + az * K[5]) / aw;
         const double bu = (bx * K[0] + by * K[1] + bz * K[2]) / bw, bv = (bx * K[3] + by * K[4] + bz * K[5]) / bw;
         const double du = au - bu, dv = av - bv;
-        d2 = fmax(d2, sqrt(du * du + dv * dv));
+        d2 = nmax(d2, sqrt(du * du + dv * dv));
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { d3 = fmax(d3, __shfl_xor(d3, off)); d2 = fmax(d2, __shfl_xor(d2, off)); }
+    for (int off = 32; off > 0; off >>= 1) { d3 = nmax(d3, __shfl_xor(d3, off)); d2 = nmax(d2, __shfl_xor(d2, off)); }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[0][wave] = d3; red[1][wave] = d2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        ws[((size_t)p * max_syms + si) * 2 + 0] = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
-        ws[((size_t)p * max_syms + si) * 2 + 1] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+        ws[((size_t)p * max_syms + si) * 2 + 0] = nmax(nmax(red[0][0], red[0][1]), nmax(red[0][2], red[0][3]));
+        ws[((size_t)p * max_syms + si) * 2 + 1] = nmax(nmax(red[1][0], red[1][1]), nmax(red[1][2], red[1][3]));
     }
 }
 
@@ -214,7 +218,9 @@ __global__ void pose_bop_finish_kernel(int B, const int32_t *__restrict__ sym_of
     const int model = model_of_pair ? model_of_pair[p] : 0;
     const int S = sym_offset[model + 1] - sym_offset[model];
     double a = INFINITY, b = INFINITY;
-    for (int s = 0; s < S; ++s) { a = fmin(a, ws[((size_t)p * max_syms + s) * 2]); b = fmin(b, ws[((size_t)p * max_syms + s) * 2 + 1]); }
+    // numpy's .min() over the symmetries propagates NaN as well (dist.min(), pose_error.py:398,427)
+    auto nmin = [](double x, double y) { return (x != x) ? x : (y != y) ? y : fmin(x, y); };
+    for (int s = 0; s < S; ++s) { a = nmin(a, ws[((size_t)p * max_syms + s) * 2]); b = nmin(b, ws[((size_t)p * max_syms + s) * 2 + 1]); }
     out[2 * p] = a;
     out[2 * p + 1] = b;
 }

@@ -15,7 +15,7 @@ void set_error(const char *fmt, ...)
 
 namespace oryon {
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-static const char *g_dominant = "";
+static thread_local const char *g_dominant = "";       // per host thread, like the events it describes
 void profile_begin(hipStream_t st, const char *kernel_name)
 {
     if (!g_ev_start) return;

@@ -71,6 +71,9 @@ class NativeStep:
                  gather_sets: int = 3, reg_streams: int = 2, reg_lag: int = 0, screen: int = 1):
         B, C, FH, FW, HA, WA, HQ, WQ, layout = key
         self.key, self.dev = key, dev
+        if overlap >= 2:
+            from . import configure
+            configure()                 # no-op when the host program configured the process; warns when HIP started with too few queues
         solver._ensure_handle(dev)
         self._solver = solver                                   # keeps the C handle alive
         self.ecfg = _lib.EngineConfig(B=B, C=C, FH=FH, FW=FW, HA=HA, WA=WA, HQ=HQ, WQ=WQ, layout=layout, dist_th=cfg.dist_th,
@@ -94,6 +97,10 @@ class NativeStep:
         self.n_slots = n_slots
         self.steps = 0                                          # submits so far; step k used slot k % n_slots
         self._views = [dict() for _ in range(n_slots)]
+        # slots whose buffers OTHER than pose / status_out the caller may still read asynchronously (views handed out by a `keep` step,
+        # copies / statistics queued on the caller's stream): their next submit must order K0 / the matcher after the caller's
+        # stream (include/oryon_hip.h, "slot lifetime") - i.e. it cannot claim inputs_resident
+        self.reads_pending = [None] * n_slots          # None | True | torch.cuda.Event
 
     def __del__(self):
         try:
@@ -161,7 +168,7 @@ class MatchPoseEngine:
         """result_views: `finish` leaves the native step's results as views of its slot buffers
         instead of copying pose / status / counts (four tiny tensors) out of the arena: the allocation-free mode of bench.py
         (valid until the sixth-next `run`).
-        native: on the int8-screened route (the default for 128 < C <= 512) the whole step is enqueued by ONE call of the C ABI's
+        native: on the screened route (match_mode "screened", C <= 512) the whole step is enqueued by ONE call of the C ABI's
         step engine (`oryon_engine_submit`, csrc/engine.hip) over a persistent arena - no torch allocation, stream or event per step;
         the returned tensors are views of the slot buffers and stay valid until the sixth-next `run`.  False keeps the per-call
         schedule below (same entry points, same results bit for bit); other routes always take it.
@@ -203,12 +210,24 @@ class MatchPoseEngine:
         if slot is not None:
             self._native.wait(slot)
             out.pop("_inputs", None)
+            queued = False
             if (self.collect_i8_stats or self.i8_max_undecided < 1.0) and self._i8_pending is None:
                 self._queue_i8_stats(self._native.view(slot, "n_und"), self._native.view(slot, "n_a"))
+                queued = True
             if not self.result_views:
                 for k, v in list(out.items()):           # the slot buffers are re-used n_slots steps later: hand out copies
                     if isinstance(v, Tensor):
                         out[k] = v.clone()
+                queued = True
+            elif len(out) > 4:
+                # views of a `keep` step (more than pose / status / n_valid / n_lifted): the caller may read them whenever it likes
+                self._native.reads_pending[slot] = True
+            if queued and self._native.reads_pending[slot] is not True:
+                # reads of the slot's unprotected buffers now sit on the caller's stream: remember where they end.  If they have
+                # completed by the time the slot comes round again (the usual case, n_slots steps later) nothing needs ordering
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self._native.dev))
+                self._native.reads_pending[slot] = ev
             if self._inflight.get(slot) is out:
                 del self._inflight[slot]
             return out
@@ -300,8 +319,13 @@ class MatchPoseEngine:
             inputs_resident = False
         # the slot this step takes still holds the results of a step the caller has not collected: collect them now (copies)
         self._collect_inflight(nat.next_slot())
-        slot = nat.submit(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, keep,
-                          inputs_resident and not converted)
+        nslot = nat.next_slot()
+        pend = nat.reads_pending[nslot]
+        if pend is not None and pend is not True and pend.query():
+            pend = None                               # the reads queued at `finish` have completed
+        resident = inputs_resident and not converted and pend is None
+        nat.reads_pending[nslot] = None
+        slot = nat.submit(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, keep, resident)
         # the engine's streams read the inputs asynchronously: the result dict keeps them alive until `finish` has ordered the caller's
         # stream after the step (an input freed earlier could be handed to a new tensor and overwritten while the step still reads it)
         out = dict(pose=nat.view(slot, "pose"), status=nat.view(slot, "status_out"), n_valid=nat.view(slot, "n_valid"),
@@ -342,7 +366,10 @@ class MatchPoseEngine:
                     use_i8 = False
                 else:
                     self._i8_skipped, self._i8_frac = 0, 0.0
-        if use_i8 and self.native:
+        # the native step engine serves every width up to 512 on the screened route (narrow maps zero-padded to 256 channels by K0);
+        # the per-call schedule below keeps its own choice per width (exact scan for C <= 64, fp16 screen for C <= 128)
+        native_ok = cfg.match_mode == "screened" and C <= 512 and 0.0 < cfg.dist_th <= 0.5 and (use_i8 or C <= 128)
+        if native_ok and self.native:
             return self._run_native(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, keep, inputs_event,
                                     inputs_resident, dev)
         if pair_key is None:

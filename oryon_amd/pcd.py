@@ -37,8 +37,12 @@ def match_presample(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor
     mode: "exact" = full fp32-MFMA scan (K1); "screened16" = fp16-MFMA screening + exact fp32 re-scoring (K1s);
     "screened8" = int8-MFMA pre-screen in front of K1s (K1s8, the batched engine's default).  The screened modes return the same
     `valid` set and, on valid rows, the same argmin / min_dist bits; rows that provably cannot reach the threshold report
-    valid = 0, argmin = 0 and the screening estimate of the distance.  Channels are zero-padded to the kernels' widths."""
-    if mode not in ("exact", "screened16", "screened8"):
+    valid = 0, argmin = 0 and the screening estimate of the distance.  Channels are zero-padded to the kernels' widths.
+    "screened6" = the step engine's default route (K0 oryon_gather_mx6 -> oryon_match_corrs_mx6: MX-fp6 screen, lazy tail, K1x3 second
+    level, device-RNG sampler): `valid` is exact on every row; `argmin` is exact on the SAMPLED rows only and `min_dist` only where the
+    route needed the fp32 comparison (include/oryon_hip.h) - the dict additionally carries `corrs` [n_sel,4] i64 (y1,x1,y2,x2), the
+    sampled correspondences (seed 1, max_corrs 500), and `status`."""
+    if mode not in ("exact", "screened16", "screened8", "screened6"):
         raise ValueError(f"match_presample: unknown mode {mode!r}")
     if mode != "exact" and not (0.0 < threshold <= 0.5):
         mode = "exact"                       # the screens' validity cut needs 1 - 2*threshold >= 0
@@ -68,12 +72,21 @@ def match_presample(feats1: Tensor, feats2: Tensor, mask1: Tensor, mask2: Tensor
     if n1 == 0 or n2 == 0:
         out.update(min_dist=torch.zeros(n1, device=dev), argmin=torch.zeros(n1, dtype=torch.int64, device=dev),
                    valid=torch.zeros(n1, dtype=torch.bool, device=dev))
+        if mode == "screened6":
+            out.update(corrs=torch.zeros((0, 4), dtype=torch.int64, device=dev), status=torch.tensor(1, device=dev))
         return out
     C = f1.shape[1]
     cap1, cap2 = ops.round_up(n1, ops.ROW_PAD), ops.round_up(n2, ops.ROW_PAD)
     if mode != "exact" and C > 512:
         mode = "exact"                       # the screening kernels are built for C_pad 128 / 256 / 512
-    if mode == "screened8":
+    if mode == "screened6":
+        c_pad = 256 if C <= 256 else 512
+        a6, a_err, _, a_hat = ops.gather_mx6(f1, roi1_lin, c1, cap1, c_pad, want_f32=True)
+        q6, q_err, q_norm, _ = ops.gather_mx6(f2, roi2_lin, c2, cap2, c_pad)
+        corrs, n_valid, n_sel, status, min_dist, argmin, valid = ops.match_corrs_mx6(
+            a_hat, a6, a_err, f2, roi1_lin, roi2_lin, q_norm, q6, q_err, c1, c2, threshold, W2, 500, 1, corr_rows=512)
+        out.update(corrs=corrs[0, : int(n_sel.item())].to(torch.int64), status=status[0])
+    elif mode == "screened8":
         c_pad = 256 if C <= 256 else 512
         a_hat, _, a8, a_sc, _ = ops.gather_normalise_q8(f1, roi1_lin, c1, cap1, c_pad)
         q_hat, _, q8, q_sc, q_eps = ops.gather_normalise_q8(f2, roi2_lin, c2, cap2, c_pad)

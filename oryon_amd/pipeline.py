@@ -34,6 +34,7 @@ def default_args(**overrides) -> SimpleNamespace:
         model=SimpleNamespace(image_encoder=SimpleNamespace(img_size=[192, 192], out_channels=32)),
         test=SimpleNamespace(mask="predicted", src_sampling=5000, solver="pointdsc", n_corrs=500, dist_th=0.25,
                              mask_threshold=0.5),
+        loss=SimpleNamespace(hard_negatives=True),
     )
     for k, v in overrides.items():
         node = args
@@ -147,10 +148,42 @@ class Pipeline:
         self.pred_lines.append(line)
         return line
 
+    # ------------------------------------------------------------------ pipeline.py:311 -> losses.py:64-88,196-199,250
+    def feature_loss_rng_draws(self, batch: Dict, outputs: Dict) -> int:
+        """The reference's test_step calls `self.feature_loss.forward(batch, outputs)` before the per-sample loop (pipeline.py:311) - for
+        its mask post-processing, but the call also samples contrastive negatives and thereby CONSUMES random numbers ahead of the
+        matcher's two draws.  The loss values are not part of the path; the generator state is: with `seed: 1` the matcher's samples
+        depend on it.  This replays exactly those draws (same generator, same order, same arguments) and returns how many were made:
+          loss.hard_negatives (config.yaml:43, default True): per side (anchor, then query) and per pair with batch['valid'] == 1,
+              `torch_sample_select(featmap_i, 2000)` when FH*FW > 2000 (losses.py:196-199) = multinomial(ones(HW, float64), 2000, False)
+              on the FEATURE MAP's device - the CUDA generator in a GPU run, i.e. it only interacts with the matcher's draws
+              (CPU generator, `corrs_device: cpu`) when everything runs on one device;
+          otherwise `torch.randint(0, HW, (n_gt_corrs,))` on the CPU generator (losses.py:250).
+        Batches without the loader's 'valid' / 'corrs' entries (synthetic drivers) draw nothing."""
+        if "valid" not in batch or "corrs" not in batch:
+            return 0
+        fm = outputs["featmap_a"]
+        HW = fm.shape[2] * fm.shape[3]
+        hard = bool(getattr(getattr(self.args, "loss", None), "hard_negatives", True))
+        valid = batch["valid"]
+        n = 0
+        for _side in ("a", "q"):
+            for i_b in range(fm.shape[0]):
+                if valid[i_b] == 1:
+                    if hard:
+                        if HW > 2000:
+                            torch.multinomial(torch.ones(HW, dtype=float).to(fm.device), 2000, replacement=False)
+                            n += 1
+                    else:
+                        torch.randint(0, HW, (batch["corrs"].shape[1],))
+                        n += 1
+        return n
+
     # ------------------------------------------------------------------ pipeline.py:306-355
     def test_step(self, batch: Dict, batch_idx: int = 0) -> List[Dict]:
         outputs = self.model.forward(batch)
         BS = outputs["featmap_a"].shape[0]
+        self.feature_loss_rng_draws(batch, outputs)          # generator state as after pipeline.py:311
         # the reference evaluates the predicted masks (and logs their IoU) whatever test.mask says (pipeline.py:311,352-354);
         # only the masks fed to the matcher switch to the external ones
         if "mask_a" in outputs and "mask_q" in outputs:

@@ -37,11 +37,26 @@ def _rotation(axis: torch.Tensor, angle: float) -> torch.Tensor:
     return torch.eye(3, dtype=torch.float64) + math.sin(angle) * Kx + (1 - math.cos(angle)) * (Kx @ Kx)
 
 
+def smooth_field(index: int, H: int, W: int, C: int, dev: torch.device, salt: int = 0) -> torch.Tensor:
+    """[C, H*W] rank-8 descriptor field (constant, x, y, xy and four slow sinusoids with random per-channel coefficients): neighbouring
+    pixels are nearly parallel, so every pixel has many near-ties in cosine - what a decoder's smooth output looks like and what no
+    6- or 8-bit screen can separate (the `hard_descriptors` workload of bench.py uses the same basis)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(9000 + 2 * index + salt)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, W, device=dev), indexing="ij")
+    coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy), torch.sin(7 * yy), torch.cos(5 * xx)])
+    basis = torch.randn((C, coef.shape[0]), generator=g, device=dev)
+    return (basis @ coef.reshape(coef.shape[0], H * W)).contiguous()
+
+
 def make_pair(index: int, H: int, W: int, C: int, device: str = "cpu", noise: float = 0.05,
-              feat_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
+              feat_dtype: torch.dtype = torch.float32, smooth: float = 0.0) -> Dict[str, torch.Tensor]:
     """One synthetic pair.  Returns feat_a/feat_q [C,H,W], mask_a/mask_q [H,W] int32,
     depth_a/depth_q [H,W] fp32 (mm), camera [3,3] fp64, sizes (H,W), pose [4,4] fp64 (metres,
-    maps anchor-camera points to query-camera points)."""
+    maps anchor-camera points to query-camera points).
+    smooth > 0: the Gaussian descriptors become `smooth` x N(0,1) noise on top of rank-8 smooth fields (one for the anchor map, another
+    for the query background); the re-projected query pixels still carry their anchor pixel's descriptor + `noise` x N(0,1), so the
+    geometry (and the ground-truth pose) is unchanged while every anchor now has a crowd of near-ties around its true match."""
     dev = torch.device(device)
     g = torch.Generator(device="cpu")
     g.manual_seed(1000 + index)
@@ -77,6 +92,9 @@ def make_pair(index: int, H: int, W: int, C: int, device: str = "cpu", noise: fl
     feat_a = torch.randn(C, H * W, generator=gd, device=dev, dtype=torch.float32)
     feat_q = torch.randn(C, H * W, generator=gd, device=dev, dtype=torch.float32)
     pert = torch.randn(C, int(hit.sum()), generator=gd, device=dev, dtype=torch.float32) * noise
+    if smooth > 0.0:
+        feat_a = smooth_field(index, H, W, C, dev, 0) + smooth * feat_a
+        feat_q = smooth_field(index, H, W, C, dev, 1) + smooth * feat_q
     hit_d = hit.to(dev)
     win_d = winner[hit].to(dev)
     feat_q[:, hit_d] = feat_a[:, win_d] + pert

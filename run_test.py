@@ -19,8 +19,8 @@ Real assets (BASELINE.json configs[2] / configs[4]; the reference's `python run_
 reads the fixed split through oryon_amd.datasets.FixedSplit (PNG decode on the host, resize / collate on the device), loads the
 Lightning checkpoint's `model.*` weights into Oryon (after the CATSeg remap, net.py:102-134) and the released PointDSC weights,
 runs the batched pipeline and reports ADD(S)-0.1d, rotation / translation errors and mask IoU per the reference's evaluator
-(utils/evaluator.py:206-256); the prediction CSV has the reference's format.  VSD / MSSD / MSPD need the BOP toolkit and an OpenGL
-renderer (out of scope).
+(utils/evaluator.py:206-256) plus MSSD / MSPD on float16-rounded poses (oryon_pose_bop_errors, pinned to the reference's my_mssd / my_mspd by
+golden G9); the prediction CSV has the reference's format.  VSD / AR need the BOP toolkit's OpenGL renderer (out of scope).
 
 Needs an MI355X (the match / lift / registration path has no CPU fallback by design).
 """
@@ -36,6 +36,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+import oryon_amd  # noqa: E402
+
+oryon_amd.configure()        # hardware queues for the step engine's streams (before the first HIP call)
 
 from oryon_amd import evaluation as ev  # noqa: E402
 from oryon_amd import ops  # noqa: E402
@@ -119,7 +123,10 @@ def run_real(a) -> dict:
     collate = DeviceCollate(args.dataset.max_corrs, args.dataset.img_size, dev)
     n = len(split) if a.pairs <= 0 else min(a.pairs, len(split))
     from oryon_amd.evaluation import Evaluator, evaluate_batch
-    evaluator = None
+    # mask IoUs exist on the batched path when the model's predicted masks are evaluated (test_step_batched: 'iou_a' in out): decided here,
+    # once, from the run's mode - not from whatever the first batch happened to return (and an empty split still gets its summary)
+    compute_iou = not a.per_sample
+    evaluator = Evaluator(exp_tag=f"{a.dataset}_{a.split}_{a.mask}", compute_iou=compute_iou)
     n_rows, t0 = 0, time.perf_counter()
     for first in range(0, n, a.batch):
         idx = list(range(first, min(first + a.batch, n)))
@@ -144,12 +151,12 @@ def run_real(a) -> dict:
         # pred_q = pose_rel @ anchor.pose with the errors computed on the device (ADD / ADD-S with the float16 model transform,
         # rotation / translation errors, MSSD / MSPD on float16-rounded poses)
         objects = {k: split.object_info(k) for k in dict.fromkeys(batch["cls_id"])}
-        if evaluator is None:                 # mask IoUs exist on the batched path with predicted masks only
-            evaluator = Evaluator(exp_tag=f"{a.dataset}_{a.split}_{a.mask}", compute_iou=iou is not None)
+        if compute_iou and iou is None:       # a model without mask logits on the batched path: the reference logs IoU 1 for external masks
+            iou = (torch.ones(len(idx)), torch.ones(len(idx)))
         evaluate_batch(evaluator, pred_pose_rel=pose_rel.numpy(), anchor_pose=batch["anchor"]["pose"].cpu().numpy(),
                        gt_pose=batch["query"]["pose"].cpu().numpy(), K=batch["query"]["camera"].cpu().numpy().reshape(-1, 3, 3),
                        status=[int(s_) for s_ in status], cls_ids=list(batch["cls_id"]), instance_ids=list(batch["instance_id"]),
-                       objects=objects, iou_a=None if iou is None else iou[0].numpy(), iou_q=None if iou is None else iou[1].numpy(),
+                       objects=objects, iou_a=iou[0].numpy() if compute_iou else None, iou_q=iou[1].numpy() if compute_iou else None,
                        device=dev)
         n_rows += len(idx)
     torch.cuda.synchronize()
@@ -157,6 +164,10 @@ def run_real(a) -> dict:
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "w") as f:
         f.writelines(pipe.pred_lines)
+    if n_rows == 0:
+        print(json.dumps({"dataset": a.dataset, "split": a.split, "obj": a.obj, "mask": a.mask, "pairs": 0, "csv": a.out,
+                          "note": "the split / filter selected no pair: nothing to evaluate"}))
+        return {"pairs": 0}
     means = evaluator.get_means()
     metric_file = os.path.splitext(a.out)[0] + ".json"           # what scripts/evaluation/compute_metrics.py:52,116-118 writes next to the CSV
     with open(metric_file, "w") as f:

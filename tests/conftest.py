@@ -7,5 +7,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+import oryon_amd  # noqa: E402
+
+oryon_amd.configure()        # hardware queues for the step engine's streams, before any test initialises HIP
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")

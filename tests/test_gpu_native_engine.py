@@ -31,7 +31,8 @@ def _inputs(first, n, H, C, dev="cuda", nhwc=False):
 KEEP_KEYS = ("pose", "status", "n_valid", "n_lifted", "n_a", "n_q", "roi_a", "roi_q", "corrs", "pcd_a", "pcd_q", "valid")
 
 
-@pytest.mark.parametrize("H,C,nhwc", [(56, 256, False), (48, 160, False), (40, 512, False), (56, 256, True)])
+@pytest.mark.parametrize("H,C,nhwc", [(56, 256, False), (48, 160, False), (40, 512, False), (56, 256, True),
+                                      (192, 32, False), (96, 64, False), (64, 128, False), (64, 32, True)])
 def test_native_step_equals_python_schedule(H, C, nhwc):
     from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
     solver = _solver()
@@ -143,7 +144,9 @@ def test_engine_c_abi_argument_checks():
     solver._ensure_handle(torch.device("cuda", 0))
     cfg = _lib.EngineConfig(B=2, C=32, FH=16, FW=16, HA=16, WA=16, HQ=16, WQ=16, layout=0, dist_th=0.25, n_corrs=500, src_sampling=5000,
                             seed=1, round_f16=0, n_slots=2, overlap=2, gather_sets=2, reg_streams=2, reg_lag=0, screen=0)
-    assert lib().oryon_engine_arena_bytes(ctypes.byref(cfg), solver._handle) == 0          # C <= 128 is not the int8 route
+    assert lib().oryon_engine_arena_bytes(ctypes.byref(cfg), solver._handle) > 0           # the reference's own width: zero-padded rows
+    cfg.C = 513
+    assert lib().oryon_engine_arena_bytes(ctypes.byref(cfg), solver._handle) == 0          # wider than the screening kernels
     cfg.C = 256
     need = lib().oryon_engine_arena_bytes(ctypes.byref(cfg), solver._handle)
     assert need > 0

@@ -10,6 +10,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+import oryon_amd
+oryon_amd.configure()
 from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20

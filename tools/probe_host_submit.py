@@ -2,6 +2,8 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_inputs, build_solver
+import oryon_amd
+oryon_amd.configure()
 from oryon_amd.engine import MatchPoseEngine, MatchPoseConfig
 dev = torch.device("cuda", 0)
 B, H, C = 64, 224, 256

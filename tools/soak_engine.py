@@ -3,6 +3,8 @@ N steps, every result compared bit for bit with the serial engine's for that inp
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_inputs, build_solver
+import oryon_amd
+oryon_amd.configure()
 from oryon_amd.engine import MatchPoseEngine, MatchPoseConfig
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dev = torch.device("cuda", 0)
