@@ -134,11 +134,30 @@ __device__ __forceinline__ void gather_q8_v3_tile(
             // with the fast path nor keeps 256 predicate masks alive across the loads (it spilled 434 SGPRs doing that).
             int hw_b = HW, c_b = C;
             asm volatile("" : "+s"(hw_b), "+s"(c_b));
+            if constexpr (LPR == 1 && FMT != 2) {        // (the hi / lo instantiation keeps the plain loop: one more branch costs it a spill)
+                // narrow maps (the reference's own C = 32 zero-padded to the 256-channel rows): 32-channel blocks beyond C are not loaded
+                // at all - a wave-uniform scalar branch per block, no per-lane predicate - instead of 224 clamped re-reads of plane C - 1
+#pragma unroll
+                for (int b = 0; b < KPL / 32; ++b) {
+                    if (32 * b < c_b) {
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                            int k = 32 * b + i;
+                            k = k < c_b ? k : c_b - 1;
+                            VS(32 * b + i, *reinterpret_cast<const float *>(fb + (size_t)k * hw_b * 4 + (unsigned)pix * 4u));
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) VS(32 * b + i, 0.0f);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < KPL; ++i) {
                 int k = seg * KPL + i;
                 k = k < c_b ? k : c_b - 1;
                 VS(i, *reinterpret_cast<const float *>(fb + (size_t)k * hw_b * 4 + (unsigned)pix * 4u));
+            }
             }
             int c_c = C;
             asm volatile("" : "+s"(c_c));

@@ -2056,7 +2056,8 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
         __half *qh = reinterpret_cast<__half *>(wr.q_hat), *ql = qh + (size_t)B * cap_q * C;
         int32_t *n_ovf = nullptr, *ovf_idx = nullptr;
         rc = match_x3_resolve(w8.a_hat_c, lw.n_ambv, cap_s, feat_q, C_true, HW, layout, roi_q, roi_stride_q, q_norm, n_q, B, cap_q, threshold,
-                              round_f16, qh, ql, lw.x3_ah, lw.x3_al, lw.x3_scratch, w8.md_c, w8.am_c, w8.va_c, &n_ovf, &ovf_idx, st);
+                              round_f16, qh, ql, lw.x3_ah, lw.x3_al, lw.x3_scratch, w8.md_c, w8.am_c, w8.va_c, &n_ovf, &ovf_idx, lw.ambv_idx, corr_rows,
+                              lw.sid_final, cap_a, st);
         if (rc) { set_error("oryon_match_corrs: fp16x3 second-level launch failed"); return rc; }
         // fp32 query rows for the pairs with overflowed anchors only: the gather's per-map gate reads n_ovf itself
         rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, n_ovf, cap_q, C, wr.q8_scratch, wr.scale_scratch,

@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 #include <type_traits>
 #include "common.h"
 #include "match_common.h"
@@ -80,15 +81,59 @@ __global__ __launch_bounds__(256) void match_x3_split_anchors_kernel(const float
     }
 }
 
+// Seed of the scan's running maxima (round 4): s_hi of the 16 query rows of the anchor's WINNING SLICE of the low-precision screen
+// (sid_final: slice (blk, half) = rows blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, r = 0..15).  On smooth fields the screen cannot tell
+// which row of the neighbourhood wins, but its winning slice sits at the peak: the best hi.hi score there is within ~1e-3 of the anchor's
+// true maximum.  It is the score of a real row, so it is a valid start for the running maximum of EVERY query split of the anchor:
+// sweep 1's tile flags (tested against the running maximum) then single out the few tiles around the peak from the first tile on instead
+// of flagging every tile on the way up to it (hard cfg2 step: 46 % of the (wave, tile) pairs flagged without the seed), and the splits
+// that do not hold the peak list almost nothing.  One wave per compacted anchor; 16 lanes x 4 segments of 64 channels.
+__global__ __launch_bounds__(256) void match_x3_seed_kernel(const __half *__restrict__ ah, const __half *__restrict__ qh, int Cp, int cap_s,
+                                                             int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q,
+                                                             const int32_t *__restrict__ orig_idx, int orig_stride,
+                                                             const int32_t *__restrict__ sid_final, int cap_a, float *__restrict__ seed)
+{
+    const int p = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    const int nc = n_c[p] < cap_s ? n_c[p] : cap_s;
+    if (row >= nc) return;
+    const int nq = n_q[p];
+    const int sid = sid_final[(size_t)p * cap_a + orig_idx[(size_t)p * orig_stride + row]];
+    const int half = sid & 1, blk = sid >> 1;
+    const int r = lane >> 2, seg = lane & 3;
+    const int q = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    float s = 0.0f;
+    if (q < nq) {
+        const uint4 *ar = reinterpret_cast<const uint4 *>(ah + ((size_t)p * cap_s + row) * Cp) + seg * (Cp / 32);
+        const uint4 *qr = reinterpret_cast<const uint4 *>(qh + ((size_t)p * cap_q + q) * Cp) + seg * (Cp / 32);
+        for (int i = 0; i < Cp / 32; ++i) {
+            const uint4 av = ar[i], qv = qr[i];
+            const __half2 *a2 = reinterpret_cast<const __half2 *>(&av), *q2 = reinterpret_cast<const __half2 *>(&qv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s = fmaf(__low2float(a2[e]), __low2float(q2[e]), s);
+                s = fmaf(__high2float(a2[e]), __high2float(q2[e]), s);
+            }
+        }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    float mx = (q < nq) ? s : -INFINITY;
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) seed[(size_t)p * cap_s + row] = mx;
+}
+
 // grid: units (pair, query split) dealt to the 8 XCDs, T = cap_s / 256 anchor panels per unit; 4 waves x 64 anchors (two B-operand sets of hi +
 // lo rows = 256 registers: one workgroup per CU with the 512-register budget - with 32 anchors per wave every pair of ds_read_b128 fed only
 // 3 MFMAs and the LDS, not the matrix pipe, set the pace: 5.1 ms); tiles of 32 query rows (hi part 16 KB + lo part 16 KB, double-buffered)
 template <int CP>
-__global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
-                                                               const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
-                                                               int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
-                                                               int S, const float *__restrict__ al_norm, const float *__restrict__ ql_max,
-                                                               int32_t *__restrict__ cnt, uint2 *__restrict__ cand, int32_t *__restrict__ dbg)
+__device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot, char *__restrict__ smem, const __half *__restrict__ ah,
+                                                   const __half *__restrict__ al, const __half *__restrict__ qh, const __half *__restrict__ ql, int B,
+                                                   int cap_s, int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T, int S,
+                                                   const float *__restrict__ al_norm, const float *__restrict__ ql_max,
+                                                   const float *__restrict__ seed, int32_t *__restrict__ cnt, uint2 *__restrict__ cand,
+                                                   int32_t *__restrict__ dbg, long long *__restrict__ dbg_wg)
 {
     constexpr int RB = CP * 2;                 // bytes per half row
     constexpr int ROWS = 32;
@@ -97,27 +142,28 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
     constexpr int NKS = CP / 16;
     constexpr int NI = PART / 4096;            // 1 KB DMA instructions per wave, part and tile
     constexpr int LPR = RB / 256;
-    constexpr int NST = 4;                     // stages of the tile ring: 128 KB of dynamic LDS, one workgroup per CU
-    extern __shared__ __attribute__((aligned(256))) char smem[];
 
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int unit = (slot / T) * 8 + xcd;
     if (unit >= B * S) return;
     const int panel = slot % T;
     const int p = unit / S, split = unit % S;
     const int nc = n_c[p] < cap_s ? n_c[p] : cap_s, nq = n_q[p];
     constexpr int NAB = 2;
+    // (measured, not kept: dealing the 32-anchor blocks round-robin over panels / waves so that the few blocks whose matches lie in this
+    // split's band do not share a wave - each wave then covers two bands and flags 40 % more tiles: scan 1.69 instead of 1.60 ms)
     const int a0 = panel * 256;
     if (a0 >= nc) return;
+#define X3_ANCHOR(ab_) (a0 + wave * 64 + (ab_) * 32 + l31)
     const int nqt = (nq + ROWS - 1) / ROWS;
     const int qt_per = (nqt + S - 1) / S;
     const int qt_begin = split * qt_per;
     const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    long long tk0 = dbg ? wall_clock64() : 0;
     half8x bh[NAB][NKS], bl[NAB][NKS];
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
-        const int ar = a0 + wave * 64 + ab * 32 + l31;
+        const int ar = X3_ANCHOR(ab);
         const int arc = ar < cap_s ? ar : cap_s - 1;
         const __half *rh = ah + ((size_t)p * cap_s + arc) * CP + 8 * hi, *rl = al + ((size_t)p * cap_s + arc) * CP + 8 * hi;
 #pragma unroll
@@ -136,19 +182,6 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char *qhp = reinterpret_cast<const char *>(qh + (size_t)p * cap_q * CP), *qlp = reinterpret_cast<const char *>(ql + (size_t)p * cap_q * CP);
-    auto issue = [&](int qt, int buf, int parts) {
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            if (part >= parts) break;
-            const char *qb = (part ? qlp : qhp) + (size_t)qt * PART;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                char *dst = smem + buf * STAGE + part * PART + (wave_u * NI + j) * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
-                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-            }
-        }
-    };
     unsigned koff[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) koff[c] = (unsigned)(l31 * RB) + ((((unsigned)(hi ^ (l31 & 15))) ^ (2u * c)) << 4);
@@ -156,26 +189,22 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
         return *reinterpret_cast<const half8x *>(smem + koff[s & 7] + tile + (unsigned)(part * PART + (s >> 3) * 256));
     };
 
-    // Tile ring.  With one wave per SIMD nothing hides a DMA's latency (1-2 us, longer than a tile's MFMAs: 0.5 us in sweep 1, 1.5 us in
-    // sweep 2 - the double-buffered first version spent more time waiting than multiplying), so tiles are requested NST - 1 = 3 ahead.
-    // Iteration qt: wait until tile qt has landed (at most min(2, tiles left) later tiles may still be in flight - loads return in order,
-    // the candidate stores of sweep 2 only make the count conservative), barrier (everyone's share of tile qt is visible AND everyone is
-    // done with tile qt - 1), request tile qt + 3 into the buffer tile qt - 1 just left, multiply tile qt.
+    // Round 4 (measured with ORYON_X3_DEBUG's phase clocks: sweep 1 took 1.0 us per tile against 0.5 us of MFMAs, sweep 2 2.3 us per visited
+    // tile with 1.2 of the 4 waves multiplying on average - both were waiting, not computing):
+    //  * sweep 1 moves hi parts only, so the 128 KB ring holds EIGHT 16 KB tiles: requests run 7 tiles ahead instead of 3;
+    //  * sweep 2 is wave-private.  A wave's anchors cover a band of the image, so the tiles that can hold its candidates are mostly not
+    //    the ones its neighbours need: with workgroup-wide tiles and a barrier per tile every wave waited for whichever wave had work.
+    //    Now each wave walks ITS OWN flagged tiles through ITS OWN quarter of the LDS (32 KB = four 8 KB chunks of 64 channels, hi + lo
+    //    parts of the 32 rows; chunk c of every tile lives in slot c, requested three chunks ahead), with no barrier at all.
 #define X3_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-    auto sweep = [&](auto PARTS_C, auto &&body) {
-        constexpr int PARTS = decltype(PARTS_C)::value;
-        constexpr int PER = NI * PARTS;                       // DMA instructions per wave and tile
-        __syncthreads();                                       // the previous sweep's last tile is still being read by slower waves
+    constexpr int NS1 = 8;                                       // sweep 1: ring slots of PART bytes
+    auto issue1 = [&](int qt, int slot1) {
+        const char *qb = qhp + (size_t)qt * PART;
 #pragma unroll
-        for (int d = 0; d < NST - 1; ++d)
-            if (qt_begin + d < qt_end) issue(qt_begin + d, d, PARTS);
-        for (int qt = qt_begin; qt < qt_end; ++qt) {
-            const int rem = qt_end - 1 - qt;
-            if (rem >= 2) X3_WAIT(2 * PER); else if (rem == 1) X3_WAIT(PER); else X3_WAIT(0);
-            __syncthreads();
-            const int ahead = qt + NST - 1;
-            if (ahead < qt_end) issue(ahead, (ahead - qt_begin) % NST, PARTS);
-            body(qt, (unsigned)(((qt - qt_begin) % NST) * STAGE));
+        for (int j = 0; j < NI; ++j) {
+            char *dst = smem + slot1 * PART + (wave_u * NI + j) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j]),
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
     };
     // |s_hi - s| <= e_hi = (|al| + |ql|)(1 + 2^-10) + |al||ql| + 3.1e-5 (Cauchy-Schwarz on the measured norms; fp32 accumulation of 256
@@ -184,57 +213,127 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
     const float qlm = sqrtf(ql_max[p]) * 1.002f;            // K0 FMT = 2 hands over the largest |u - hi|^2 of the pair's query rows
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
-        const int a = a0 + wave * 64 + ab * 32 + l31;
+        const int a = X3_ANCHOR(ab);
         const float aln = al_norm[(size_t)p * cap_s + (a < cap_s ? a : cap_s - 1)];
         e_hi[ab] = (aln + qlm) * 1.001f + aln * qlm + 3.1e-5f;
     }
     // Tile flags: sweep 2 lists a row only if s3 >= max - e_hi - DELTA3, and s3 <= s_hi + e_hi + DELTA3, so a tile none of whose rows
     // has s_hi >= max_hi - 2 e_hi - 2 DELTA3 for any of the wave's anchors holds no candidate for this wave.  Sweep 1 flags the tiles that
-    // pass against the RUNNING maximum (a superset of those that pass against the final one); sweep 2 multiplies only flagged tiles.
-    // The anchors arrive in image order (match_list_sampled_amb_kernel), so a wave's 64 anchors - and their matches - cover a band of the
-    // image: on coherent scenes many (wave, tile) pairs are skipped (hard cfg2 step: 46 % flagged), on scrambled ones nothing is lost but the
-    // flag test.  Measured: 2.64 -> 2.46 ms only - a workgroup's four waves share every tile's barrier, so a tile costs what its slowest
-    // wave costs; skipping pays in energy more than in time.
-    unsigned char *tile_flag = reinterpret_cast<unsigned char *>(smem + NST * STAGE) + wave * X3_MAX_TILES;
-    for (int i = t; i < 4 * X3_MAX_TILES; i += 256) reinterpret_cast<unsigned char *>(smem + NST * STAGE)[i] = 0;
-    const bool flags_ok = qt_end - qt_begin <= X3_MAX_TILES;
+    // pass against the RUNNING maximum (a superset of those that pass against the final one) - started from the seed, i.e. close to the
+    // final maximum from the first tile on; sweep 2 multiplies only flagged tiles.  The anchors arrive in image order
+    // (match_list_sampled_amb_kernel), so a wave's 64 anchors - and their matches - cover a band of the image (hard cfg2 step: 19 % of
+    // the (wave, tile) pairs flagged with the seed, 46 % without).
+    constexpr int FLAG_BASE = NS1 * PART;                       // behind the ring: 4 x X3_MAX_TILES flag bytes, 4 x X3_MAX_TILES list entries
+    unsigned char *tile_flag = reinterpret_cast<unsigned char *>(smem + FLAG_BASE) + wave * X3_MAX_TILES;
+    unsigned short *my_list = reinterpret_cast<unsigned short *>(smem + FLAG_BASE + 4 * X3_MAX_TILES) + wave * X3_MAX_TILES;
+    for (int i = t; i < 4 * X3_MAX_TILES; i += 256) reinterpret_cast<unsigned char *>(smem + FLAG_BASE)[i] = 0;
+    const int ntl = qt_end - qt_begin;
+    const bool flags_ok = ntl <= X3_MAX_TILES;
+    long long tk1 = dbg ? wall_clock64() : 0;
     // ---- sweep 1: hi.hi only (a third of the MFMAs, half of the tile bytes) -> a lower bound of every anchor's maximum over this split's rows
     float runmax[NAB];
     int nlist[NAB];
 #pragma unroll
-    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; nlist[ab] = 0; }
-    sweep(std::integral_constant<int, 1>{}, [&](int qt, unsigned tile) {
+    for (int ab = 0; ab < NAB; ++ab) {
+        // start from the seed (match_x3_seed_kernel: the hi.hi score of a real row of this anchor - whichever split holds it)
+        const int a = X3_ANCHOR(ab);
+        runmax[ab] = (seed && a < nc) ? seed[(size_t)p * cap_s + a] : -INFINITY;
+        nlist[ab] = 0;
+    }
+    // The A fragments of a tile are read into registers one tile AHEAD (two sets of NKS fragments): as first written, every k-step was a
+    // ds_read followed at once by the two MFMAs that need it - with one wave per SIMD the ~140-cycle LDS latency of each of the 16 reads
+    // lay bare between 64-cycle MFMA pairs (measured 1.1 us per tile against 0.5 us of MFMAs).  Now tile it + 1's sixteen reads are issued
+    // as a block and return under tile it's 32 MFMAs.
+    auto wait_tiles = [&](int n) {           // at most n tiles of this wave's DMA still in flight
+        switch (n) {
+            case 0: X3_WAIT(0); break;
+            case 1: X3_WAIT(NI); break;
+            case 2: X3_WAIT(2 * NI); break;
+            case 3: X3_WAIT(3 * NI); break;
+            case 4: X3_WAIT(4 * NI); break;
+            case 5: X3_WAIT(5 * NI); break;
+            default: X3_WAIT(6 * NI); break;
+        }
+    };
+    auto load_frag = [&](half8x (&f)[NKS], int it) {
+        const unsigned tile = (unsigned)((it % NS1) * PART);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) f[s] = rd(0, s, tile);
+    };
+    auto step1 = [&](const half8x (&cur)[NKS], half8x (&nxt)[NKS], int it) {
+        if (it + 1 < ntl) {
+            const int later = ntl - 2 - it;                  // tiles behind tile it + 1
+            wait_tiles(later < NS1 - 3 ? later : NS1 - 3);   // tile it + 1 (this wave's share) has landed
+        }
+        __syncthreads();                     // every wave's share of tile it + 1 is visible; every wave has consumed tile it - 1
+        const int ahead = it + NS1 - 1;
+        if (ahead < ntl) issue1(qt_begin + ahead, ahead % NS1);          // into the slot tile it - 1 has left
+        if (it + 1 < ntl) load_frag(nxt, it + 1);
+        __builtin_amdgcn_sched_barrier(0);   // the reads above are ISSUED before the MFMAs below (the compiler would sink them to their first use)
+        const int qt = qt_begin + it;
         f32x16 acc[NAB];
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ab][r] = 0.0f;
-        half8x xh = rd(0, 0, tile);
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            half8x nh = xh;
-            if (s + 1 < NKS) nh = rd(0, s + 1, tile);
+        for (int s = 0; s < NKS; ++s)
 #pragma unroll
-            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[ab][s], acc[ab], 0, 0, 0);
-            xh = nh;
-        }
+            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], bh[ab][s], acc[ab], 0, 0, 0);
         const int q0 = qt * ROWS + 4 * hi;
-        bool hit = false;
+        int fl = 0;
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab) {
             float x = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
             runmax[ab] = fmaxf(runmax[ab], x);
-            hit |= x >= runmax[ab] - 2.0f * e_hi[ab] - X3_MARGIN;
+            // dead anchor columns (beyond the pair's count: zero rows, every score 0 = their own running maximum) must not flag anything -
+            // until round 4 the wave that holds the list's tail (500 sampled anchors in 512 slots) flagged every tile through them
+            const bool h = (X3_ANCHOR(ab) < nc) && x >= runmax[ab] - 2.0f * e_hi[ab] - X3_MARGIN;
+            fl |= (__ballot(h) != 0ull) ? (1 << ab) : 0;
         }
-        if (__ballot(hit) != 0ull && flags_ok && lane == 0) tile_flag[qt - qt_begin] = 1;
-    });
+        if (fl && flags_ok && lane == 0) tile_flag[it] = (unsigned char)fl;          // bit ab: anchor block ab of this wave needs the tile
+    };
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < NS1 - 1; ++d)
+        if (d < ntl) issue1(qt_begin + d, d);
+    {
+        half8x fa[NKS], fb[NKS];
+        if (ntl > 0) {
+            wait_tiles(ntl - 1 < NS1 - 2 ? ntl - 1 : NS1 - 2);
+            __syncthreads();
+            load_frag(fa, 0);
+        }
+        for (int it = 0; it < ntl; it += 2) {
+            step1(fa, fb, it);
+            if (it + 1 < ntl) step1(fb, fa, it + 1);
+        }
+    }
+    __syncthreads();                         // the ring is free: sweep 2's private regions overlay it
+    long long tk2 = dbg ? wall_clock64() : 0;
     if (dbg && lane == 0) {                                  // ORYON_X3_DEBUG: flagged / all (wave, tile) pairs
         int f = 0;
-        for (int i = 0; i < qt_end - qt_begin && i < X3_MAX_TILES; ++i) f += tile_flag[i];
+        for (int i = 0; i < ntl && i < X3_MAX_TILES; ++i) f += tile_flag[i] != 0;
         atomicAdd(&dbg[0], f);
-        atomicAdd(&dbg[1], qt_end - qt_begin);
+        atomicAdd(&dbg[1], ntl);
+    }
+    // this wave's flagged tiles, in order (every tile when the split is too long for the flag array)
+    int n_t2 = 0;
+    if (flags_ok) {
+        for (int b0 = 0; b0 < ntl; b0 += 64) {
+            const int i = b0 + lane;
+            const bool f = i < ntl && tile_flag[i];
+            const unsigned long long m = __ballot(f);
+            if (f) my_list[n_t2 + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            n_t2 += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        n_t2 = ntl;
     }
     // max_j s_j >= runmax - e_hi, and every exact maximiser has s3 >= max_j s_j - DELTA3: a FIXED emission limit per anchor column
     float lim[NAB], run3[NAB];
@@ -244,56 +343,176 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
         lim[ab] = runmax[ab] - e_hi[ab] - 0.5f * X3_MARGIN;
         run3[ab] = -INFINITY;
     }
-    // ---- sweep 2: hi / lo compensated products, candidates against the limit
-    sweep(std::integral_constant<int, 2>{}, [&](int qt, unsigned tile) {
-        if (flags_ok && !tile_flag[qt - qt_begin]) return;   // wave-uniform: no row of this tile can be a candidate of this wave's anchors
-        f32x16 acc[NAB];
+    // ---- sweep 2 (wave-private): hi / lo compensated products on the wave's flagged tiles, candidates against the limit
+    {
+        constexpr int CH = 64;                                  // channels per chunk
+        constexpr int NCH = CP / CH;                            // 4 chunks per tile = the 4 slots of the wave's region
+        constexpr int CHB = 2 * ROWS * CH * 2;                  // 8 KB: [part][row][128 B]
+        constexpr int NJ = ROWS * CH * 2 / 1024;                // 4 DMA instructions per part and chunk (8 rows x 128 B each)
+        static_assert(NCH * CHB == STAGE && CH * 2 == 128, "a wave's region is one stage of the old ring");
+        char *reg = smem + wave_u * STAGE;
+        // DMA source: lane L of instruction j lands at LDS (row j*8 + L/8, 16-byte slot L%8); slots are XOR-swizzled with (row >> 1) & 7 so
+        // that the 16 lanes of a ds_read_b128 phase (rows r .. r+15 at one logical slot) cover all 64 banks
+        unsigned src2[NJ];
 #pragma unroll
-        for (int ab = 0; ab < NAB; ++ab)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ab][r] = 0.0f;
-        half8x xh = rd(0, 0, tile), xl = rd(1, 0, tile);
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            half8x nh = xh, nl = xl;
-            if (s + 1 < NKS) { nh = rd(0, s + 1, tile); nl = rd(1, s + 1, tile); }
-            // small terms first (as the PointDSC fp16x3 kernels do): lo.hi, hi.lo, hi.hi; the two anchor blocks alternate
-#pragma unroll
-            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, bh[ab][s], acc[ab], 0, 0, 0);
-#pragma unroll
-            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bl[ab][s], acc[ab], 0, 0, 0);
-#pragma unroll
-            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[ab][s], acc[ab], 0, 0, 0);
-            xh = nh;
-            xl = nl;
+        for (int j = 0; j < NJ; ++j) {
+            const int row = j * 8 + (lane >> 3), sl = lane & 7;
+            src2[j] = (unsigned)(row * RB + ((sl ^ ((row >> 1) & 7)) << 4));
         }
-        const int q0 = qt * ROWS + 4 * hi;
+        unsigned ko2[CH / 16];
 #pragma unroll
-        for (int ab = 0; ab < NAB; ++ab) {
-            const int a = a0 + wave * 64 + ab * 32 + l31;
-            float x = -INFINITY;
+        for (int s4 = 0; s4 < CH / 16; ++s4) ko2[s4] = (unsigned)(l31 * 128 + (((2 * s4 + hi) ^ ((l31 >> 1) & 7)) << 4));
+        auto tile_at = [&](int i) { return qt_begin + (flags_ok ? (int)my_list[i] : i); };
+        auto issue2 = [&](int g) {                               // chunk g = (tile index g / NCH of the wave's list, k-chunk g % NCH)
+            const int qt = tile_at(g / NCH), c = g % NCH;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
-            // the s3 scores themselves tighten the limit as they come in (the maximum is at least every s3 - DELTA3): rows behind the peak
-            // that the fixed limit alone would still list are dropped
-            run3[ab] = fmaxf(run3[ab], fmaxf(x, __shfl_xor(x, 32)));
-            lim[ab] = fmaxf(lim[ab], run3[ab] - X3_MARGIN);
-            if (a < nc && x >= lim[ab]) {
-                uint2 *list = cand + ((((size_t)p * S + split) * cap_s + a) * 2 + hi) * X3_CAPH;
+            for (int part = 0; part < 2; ++part) {
+                const char *qb = (part ? qlp : qhp) + (size_t)qt * PART + c * (CH * 2);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (acc[ab][r] >= lim[ab] && q0 + (r & 3) + 8 * (r >> 2) < nq) {      // zero-padded rows of the last tile are not candidates
-                        if (nlist[ab] < X3_CAPH) list[nlist[ab]] = make_uint2((unsigned)(q0 + (r & 3) + 8 * (r >> 2)), __float_as_uint(acc[ab][r]));
-                        ++nlist[ab];
+                for (int j = 0; j < NJ; ++j)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + src2[j]),
+                                                     (__attribute__((address_space(3))) void *)(reg + c * CHB + part * (CHB / 2) + j * 1024), 16, 0, 0);
+            }
+        };
+        const int n_g = n_t2 * NCH;
+        constexpr int PERC = 2 * NJ;                            // DMA instructions per chunk
+#pragma unroll
+        for (int d = 0; d < NCH - 1; ++d)
+            if (d < n_g) issue2(d);
+        for (int i = 0; i < n_t2; ++i) {
+            const int qt = tile_at(i);
+            const int fmask = flags_ok ? (int)tile_flag[qt - qt_begin] : 3;          // wave-uniform: which anchor blocks need this tile
+            f32x16 acc[NAB];
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ab][r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int g = i * NCH + c;
+                const int rem = n_g - 1 - g;
+                // chunk g has landed when at most min(2, chunks left) later chunks are in flight (the candidate stores of earlier tiles only
+                // make the count conservative)
+                if (rem >= 2) X3_WAIT(2 * PERC); else if (rem == 1) X3_WAIT(PERC); else X3_WAIT(0);
+                __builtin_amdgcn_wave_barrier();
+                // slot (c + 3) % 4 held chunk g - 1, whose operand reads completed before its MFMAs were issued
+                if (g + NCH - 1 < n_g) issue2(g + NCH - 1);
+                const char *cb = reg + c * CHB;
+#pragma unroll
+                for (int s4 = 0; s4 < CH / 16; ++s4) {
+                    const half8x xh = *reinterpret_cast<const half8x *>(cb + ko2[s4]);
+                    const half8x xl = *reinterpret_cast<const half8x *>(cb + CHB / 2 + ko2[s4]);
+                    const int s = c * (CH / 16) + s4;
+                    // small terms first (as the PointDSC fp16x3 kernels do): lo.hi, hi.lo, hi.hi; the two anchor blocks alternate
+                    if (fmask == 3) {
+#pragma unroll
+                        for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, bh[ab][s], acc[ab], 0, 0, 0);
+#pragma unroll
+                        for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bl[ab][s], acc[ab], 0, 0, 0);
+#pragma unroll
+                        for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[ab][s], acc[ab], 0, 0, 0);
+                    } else if (fmask == 1) {                  // one anchor block only: half the MFMAs
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, bh[0][s], acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bl[0][s], acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[0][s], acc[0], 0, 0, 0);
+                    } else {
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, bh[1][s], acc[1], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bl[1][s], acc[1], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[1][s], acc[1], 0, 0, 0);
                     }
+                }
+            }
+            const int q0 = qt * ROWS + 4 * hi;
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) {
+                if (!((fmask >> ab) & 1)) continue;           // this block's accumulators were not computed: none of its anchors can list a row here
+                const int a = X3_ANCHOR(ab);
+                float x = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
+                // the s3 scores themselves tighten the limit as they come in (the maximum is at least every s3 - DELTA3): rows behind the
+                // peak that the fixed limit alone would still list are dropped
+                run3[ab] = fmaxf(run3[ab], fmaxf(x, __shfl_xor(x, 32)));
+                lim[ab] = fmaxf(lim[ab], run3[ab] - X3_MARGIN);
+                if (a < nc && x >= lim[ab]) {
+                    uint2 *list = cand + ((((size_t)p * S + split) * cap_s + a) * 2 + hi) * X3_CAPH;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (acc[ab][r] >= lim[ab] && q0 + (r & 3) + 8 * (r >> 2) < nq) {      // zero-padded rows of the last tile are not candidates
+                            if (nlist[ab] < X3_CAPH) list[nlist[ab]] = make_uint2((unsigned)(q0 + (r & 3) + 8 * (r >> 2)), __float_as_uint(acc[ab][r]));
+                            ++nlist[ab];
+                        }
+                }
             }
         }
-    });
+    }
 #undef X3_WAIT
+    if (dbg && t == 0) {                                     // phase times (100 MHz ticks) summed over workgroups, sweep-2 tiles visited
+        const long long tk3 = wall_clock64();
+        atomicAdd(&dbg[2], (int)(tk1 - tk0));
+        atomicAdd(&dbg[3], (int)(tk2 - tk1));
+        atomicAdd(&dbg[4], (int)(tk3 - tk2));
+        atomicAdd(&dbg[5], n_t2);
+        atomicAdd(&dbg[6], 1);
+        atomicMin(reinterpret_cast<unsigned long long *>(dbg + 8), (unsigned long long)tk0);
+        atomicMax(reinterpret_cast<unsigned long long *>(dbg + 10), (unsigned long long)tk3);
+        // slowest workgroup
+        atomicMax(&dbg[7], (int)(tk3 - tk0));
+        if (dbg_wg) {
+            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 0] = tk0;
+            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 1] = tk3;
+            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+        }
+    }
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
-        const int a = a0 + wave * 64 + ab * 32 + l31;
+        const int a = X3_ANCHOR(ab);
         if (a < nc) cnt[(((size_t)p * S + split) * cap_s + a) * 2 + hi] = nlist[ab];
+    }
+}
+
+#undef X3_ANCHOR
+// Persistent launch (round 4).  Launched one block per work item (1024 blocks of ~220 us, one per CU at a time: 512 registers per lane,
+// 130 KB of LDS) the scan took 2.4 ms although its workgroups' own times summed to 0.9 ms per CU: ORYON_X3_DEBUG's per-workgroup clocks
+// showed the dispatcher leaving most CUs empty after the first round (256 running, then 30-180).  So the grid is one workgroup per CU and
+// the workgroups pull items themselves: one queue per XCD (an item's two anchor panels and its query rows stay in that XCD's L2), in the
+// order the one-block-per-item grid used; a workgroup whose XCD has run dry takes items of the others.
+template <int CP>
+__global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
+                                                               const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
+                                                               int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
+                                                               int S, const float *__restrict__ al_norm, const float *__restrict__ ql_max,
+                                                               const float *__restrict__ seed, int32_t *__restrict__ cnt,
+                                                               uint2 *__restrict__ cand, int32_t *__restrict__ queue /*[8], zeroed*/,
+                                                               int items_per_xcd, int32_t *__restrict__ dbg, long long *__restrict__ dbg_wg)
+{
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    __shared__ int item_s;
+    {
+        // nothing listed in any pair (the usual step): one parallel look at the counts instead of a walk through the queues
+        bool any = false;
+        for (int m = threadIdx.x; m < B; m += 256) any |= n_c[m] > 0;
+        if (!__syncthreads_or(any)) return;
+    }
+    const int my_xcd = blockIdx.x & 7;
+    for (;;) {
+        __syncthreads();                                  // everyone is done with the previous item (its LDS, item_s)
+        if (threadIdx.x == 0) {
+            int it = -1;
+            for (int k = 0; k < 8 && it < 0; ++k) {       // own XCD's queue first, then the others'
+                const int x = (my_xcd + k) & 7;
+                if (__atomic_load_n(&queue[x], __ATOMIC_RELAXED) < items_per_xcd) {
+                    const int got = atomicAdd(&queue[x], 1);
+                    if (got < items_per_xcd) it = got * 8 + x;
+                }
+            }
+            item_s = it;
+        }
+        __syncthreads();
+        const int it = item_s;
+        if (it < 0) return;
+        match_x3_scan_item<CP>(it & 7, it >> 3, smem, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed, cnt, cand, dbg, dbg_wg);
     }
 }
 
@@ -460,7 +679,7 @@ int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, c
 
 size_t match_x3_scratch_bytes(int B, int cap_s, int S)
 {
-    return (size_t)B * S * cap_s * 2 * (sizeof(int32_t) + X3_CAPH * sizeof(uint2)) + (size_t)B * (2 * cap_s + 3) * sizeof(int32_t) + 8192;
+    return (size_t)B * S * cap_s * 2 * (sizeof(int32_t) + X3_CAPH * sizeof(uint2)) + (size_t)B * (3 * cap_s + 3) * sizeof(int32_t) + 8192 + 2048;
 }
 
 // a_c [B, cap_s, 256] fp32 compact anchor rows (k-permuted), n_c [B] -> md_c / am_c / va_c [B, cap_s]; n_ovf / ovf_idx: anchors whose
@@ -469,7 +688,8 @@ size_t match_x3_scratch_bytes(int B, int cap_s, int S)
 int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const float *feat_q, int C_true, int HW, int layout,
                      const int32_t *roi_q, int roi_stride_q, const float *q_norm, const int32_t *n_q, int B, int cap_q, float threshold,
                      int round_f16, __half *qh, __half *ql, __half *ah, __half *al, void *scratch, float *md_c, int32_t *am_c, uint8_t *va_c,
-                     int32_t **n_ovf_out, int32_t **ovf_idx_out, hipStream_t st)
+                     int32_t **n_ovf_out, int32_t **ovf_idx_out, const int32_t *orig_idx, int orig_stride, const int32_t *sid_final, int cap_a,
+                     hipStream_t st)
 {
     constexpr int CP = 256;
     const int T = (cap_s + 255) / 256;
@@ -484,12 +704,16 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     off += cnt_block;
     float *ql_max = reinterpret_cast<float *>(sp + off);
     off += cnt_block;
+    int32_t *queue = reinterpret_cast<int32_t *>(sp + off);            // the scan's per-XCD item counters (zeroed by the same memset)
+    off += 256;
     int32_t *ovf_idx = reinterpret_cast<int32_t *>(sp + off);
     off += ((size_t)B * cap_s * sizeof(int32_t) + 255) / 256 * 256;
     float *al_norm = reinterpret_cast<float *>(sp + off);
+    off += ((size_t)B * cap_s * sizeof(float) + 255) / 256 * 256;
+    float *seed = reinterpret_cast<float *>(sp + off);
     *n_ovf_out = n_ovf;
     *ovf_idx_out = ovf_idx;
-    if (hipMemsetAsync(n_ovf, 0, 2 * cnt_block, st) != hipSuccess) return ORYON_ERR_HIP;
+    if (hipMemsetAsync(n_ovf, 0, 2 * cnt_block + 256, st) != hipSuccess) return ORYON_ERR_HIP;
     // query rows as hi / lo halves, only for pairs that have listed anchors (the gather's per-map gate reads the counts themselves)
     int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, n_c, cap_q, CP, reinterpret_cast<int8_t *>(qh), nullptr,
                               ql_max, nullptr, nullptr, 1, round_f16, st, 2, ql);
@@ -499,12 +723,32 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     static const bool dbg = getenv("ORYON_X3_DEBUG") != nullptr;          // development aid: list statistics of this call on stderr
     int32_t *dbg_dev = nullptr;
     if (dbg) {
-        dbg_dev = reinterpret_cast<int32_t *>(al_norm + (size_t)B * cap_s + 64);      // in the scratch's 8 KB of slack
-        (void)hipMemsetAsync(dbg_dev, 0, 8, st);
+        dbg_dev = reinterpret_cast<int32_t *>(seed + (size_t)B * cap_s + 64);         // in the scratch's 8 KB of slack
+        (void)hipMemsetAsync(dbg_dev, 0, 48, st);
+        (void)hipMemsetAsync(dbg_dev + 8, 0xff, 8, st);
     }
-    constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2 + 4 * X3_MAX_TILES;      // NST stages x (hi + lo) x 32 rows x CP halves + the tile flags
+    // seeds of the running maxima from the screen's winning slices (ORYON_X3_SEED=0: the round-3 scan, for A/B timing; same results)
+    static const bool use_seed = !getenv("ORYON_X3_SEED") || atoi(getenv("ORYON_X3_SEED")) != 0;
+    const float *seed_arg = nullptr;
+    if (use_seed && orig_idx && sid_final) {
+        hipLaunchKernelGGL(match_x3_seed_kernel, dim3((cap_s + 3) / 4, B), dim3(256), 0, st, ah, qh, CP, cap_s, cap_q, n_c, n_q, orig_idx, orig_stride,
+                           sid_final, cap_a, seed);
+        seed_arg = seed;
+    }
+    static long long *dbg_wg = nullptr;
+    if (dbg && !dbg_wg) (void)hipMalloc(&dbg_wg, (size_t)65536 * 4 * sizeof(long long));
+    if (dbg && dbg_wg) (void)hipMemsetAsync(dbg_wg, 0, (size_t)(groups < 65536 ? groups : 65536) * 4 * sizeof(long long), st);
+    constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2 + 4 * X3_MAX_TILES + 4 * 2 * X3_MAX_TILES + 64;   // 128 KB of tile ring / wave regions + tile flags + the waves' tile lists
     allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP>), X3_SCAN_LDS);
-    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(groups), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, cnt, cand, dbg_dev);
+    // one workgroup per CU, items pulled from per-XCD queues (see the kernel)
+    static int n_cus = 0;
+    if (!n_cus) {
+        int dev_ = 0, v = 0;
+        (void)hipGetDevice(&dev_);
+        n_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess && v > 0) ? v : 256;
+    }
+    const int grid = groups < n_cus ? groups : n_cus / 8 * 8;
+    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(grid), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, cnt, cand, queue, groups / 8, dbg_dev, dbg_wg);
     const size_t lds = (size_t)4 * (2 * CP + 2 * X3_SURV) * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
@@ -536,9 +780,44 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
                     }
             }
         }
-        int32_t hd[2] = {0, 0};
-        (void)hipMemcpy(hd, dbg_dev, 8, hipMemcpyDeviceToHost);
+        int32_t hd[12] = {0};
+        (void)hipMemcpy(hd, dbg_dev, 48, hipMemcpyDeviceToHost);
+        {
+            unsigned long long t_lo, t_hi;
+            memcpy(&t_lo, hd + 8, 8);
+            memcpy(&t_hi, hd + 10, 8);
+            fprintf(stderr, "[x3] scan span %.1f us (first start to last end), slowest workgroup %.1f us\n", (double)(t_hi - t_lo) * 0.01, hd[7] * 0.01);
+        }
         fprintf(stderr, "[x3] sweep-2 (wave, tile) pairs flagged: %d of %d\n", hd[0], hd[1]);
+        if (dbg_wg && groups <= 65536) {
+            std::vector<long long> w((size_t)groups * 4);
+            (void)hipMemcpy(w.data(), dbg_wg, w.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            long long t0 = -1;
+            for (int g = 0; g < groups; ++g) if (w[4 * g + 1] && (t0 < 0 || w[4 * g] < t0)) t0 = w[4 * g];
+            std::vector<unsigned long long> ids;
+            for (int g = 0; g < groups; ++g) if (w[4 * g + 1]) ids.push_back(((unsigned long long)(w[4 * g + 3] & 0xf) << 32) | (unsigned long long)(w[4 * g + 2] & 0xff00));
+            std::sort(ids.begin(), ids.end());
+            const size_t distinct = std::unique(ids.begin(), ids.end()) - ids.begin();
+            fprintf(stderr, "[x3] workgroups ran on %zu distinct (xcc, se, sh, cu) places\n", distinct);
+            // concurrency profile: workgroups running at 10 sample times, and the start time of every 128th workgroup in launch order
+            long long t1 = 0;
+            for (int g = 0; g < groups; ++g) if (w[4 * g + 1] > t1) t1 = w[4 * g + 1];
+            fprintf(stderr, "[x3] running at 5%%..95%% of the span:");
+            for (int k = 0; k < 10; ++k) {
+                const long long ts = t0 + (t1 - t0) * (2 * k + 1) / 20;
+                int r = 0;
+                for (int g = 0; g < groups; ++g) r += w[4 * g + 1] && w[4 * g] <= ts && ts < w[4 * g + 1];
+                fprintf(stderr, " %d", r);
+            }
+            fprintf(stderr, "\n[x3] start (us) of block 0, 128, 256, ...:");
+            for (int g = 0; g < groups; g += 128) fprintf(stderr, " %.0f", w[4 * g + 1] ? (w[4 * g] - t0) * 0.01 : -1.0);
+            fprintf(stderr, "\n[x3] raw ids of blocks 0..11 (hw_id, xcc_id):");
+            for (int g = 0; g < 12 && g < groups; ++g) fprintf(stderr, " (%llx,%llx)", (unsigned long long)w[4 * g + 2], (unsigned long long)w[4 * g + 3]);
+            fprintf(stderr, "\n");
+        }
+        if (hd[6] > 0)
+            fprintf(stderr, "[x3] per workgroup (%d ran): operand load %.1f us, sweep 1 %.1f us, list + sweep 2 %.1f us; sweep-2 tiles visited %.1f of %.1f\n", hd[6],
+                    hd[2] * 0.01 / hd[6], hd[3] * 0.01 / hd[6], hd[4] * 0.01 / hd[6], (double)hd[5] / hd[6], (double)hd[1] / (4.0 * hd[6]));
         fprintf(stderr, "[x3] anchors %ld, lists %ld, entries %ld (%.1f per anchor), longest %ld, overflowed lists %ld, overflowed anchors %ld, max|al| %.3g, max|ql| %.3g\n",
                 anchors, nl, tot, anchors ? (double)tot / anchors : 0.0, mx, over, novf, amax, qmax);
     }

@@ -6,6 +6,7 @@
 // (dead rows of a tile are zero rows with exponent byte 0), and a garbage anchor row beyond the pair's count only feeds its own,
 // ignored, output column.  match16.hip, which uses a NaN as a marker (resolve_anchor), keeps the default semantics.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -233,7 +234,8 @@ __device__ __forceinline__ void mx6_static_for(F &&f)
 template <int CP, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_screen_w4_kernel(
     const uint8_t *__restrict__ a6, const uint8_t *__restrict__ q6, int B, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
-    const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2)
+    const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2,
+    long long *__restrict__ dbg_wg /* ORYON_MX6_DEBUG: per-workgroup (start, end, hw_id, xcc_id), else NULL */)
 {
     static_assert(CP == 256 || (CP == 512 && WAVES == 4), "geometries: C_pad 256 with 4 / 8 waves, C_pad 512 with 4 waves");
     constexpr int RB = CP, NAB = 4;
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
     const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const char *qp = reinterpret_cast<const char *>(q6) + (size_t)p * cap_q * RB;
+    const long long tk0 = dbg_wg ? wall_clock64() : 0;
 
     // stationary B operands: slot (2 s + hi) of k-step s of the lane's anchor row in each of the four blocks; the four exponent bytes of a
     // block packed into one register (the instruction picks the byte by op_sel)
@@ -416,6 +419,44 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
             ws_m2[o] = m2;
         }
     }
+    if (dbg_wg && t == 0) {
+        dbg_wg[(size_t)blockIdx.x * 4 + 0] = tk0;
+        dbg_wg[(size_t)blockIdx.x * 4 + 1] = wall_clock64();
+        dbg_wg[(size_t)blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+        dbg_wg[(size_t)blockIdx.x * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+    }
+}
+
+// ORYON_MX6_DEBUG=1 (development aid; synchronises): per-workgroup wall-clock records of the screen launch -> how many workgroups were
+// resident over the launch, i.e. whether the dispatcher keeps the CUs full (the K1x3 scan's were not: match_x3.hip)
+static void mx6_debug_report(const long long *dbg_dev, int groups, hipStream_t st)
+{
+    (void)hipStreamSynchronize(st);
+    long long *w = static_cast<long long *>(malloc((size_t)groups * 4 * sizeof(long long)));
+    (void)hipMemcpy(w, dbg_dev, (size_t)groups * 4 * sizeof(long long), hipMemcpyDeviceToHost);
+    long long t0 = -1, t1 = 0;
+    double sum = 0;
+    int ran = 0;
+    long long longest = 0;
+    for (int g = 0; g < groups; ++g)
+        if (w[4 * g + 1]) {
+            if (t0 < 0 || w[4 * g] < t0) t0 = w[4 * g];
+            if (w[4 * g + 1] > t1) t1 = w[4 * g + 1];
+            sum += (double)(w[4 * g + 1] - w[4 * g]);
+            if (w[4 * g + 1] - w[4 * g] > longest) longest = w[4 * g + 1] - w[4 * g];
+            ++ran;
+        }
+    fprintf(stderr, "[mx6] %d of %d workgroups ran: span %.1f us, mean %.1f us, longest %.1f us, mean residency %.1f workgroups\n", ran, groups,
+            (t1 - t0) * 0.01, ran ? sum * 0.01 / ran : 0.0, longest * 0.01, t1 > t0 ? sum / (double)(t1 - t0) : 0.0);
+    fprintf(stderr, "[mx6] resident at 5%%..95%% of the span:");
+    for (int k = 0; k < 10; ++k) {
+        const long long ts = t0 + (t1 - t0) * (2 * k + 1) / 20;
+        int r = 0;
+        for (int g = 0; g < groups; ++g) r += w[4 * g + 1] && w[4 * g] <= ts && ts < w[4 * g + 1];
+        fprintf(stderr, " %d", r);
+    }
+    fprintf(stderr, "\n");
+    free(w);
 }
 
 static int mx6_var()
@@ -445,13 +486,19 @@ void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, c
     if constexpr (CP == 256) {
         if (var == 0) {                                          // default: 8 waves x 128 anchors (1024-anchor panels, one workgroup per CU)
             const int T8 = (cap_a + 1023) / 1024;
-            hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 8>), dim3(groups / T * T8), dim3(512), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, T8, S,
-                               ws_max, ws_i1, ws_m2);
+            static const bool dbg = getenv("ORYON_MX6_DEBUG") != nullptr;
+            static long long *dbg_wg = nullptr;
+            const int g8 = groups / T * T8;
+            if (dbg && !dbg_wg) (void)hipMalloc(&dbg_wg, (size_t)65536 * 4 * sizeof(long long));
+            if (dbg && dbg_wg && g8 <= 65536) (void)hipMemsetAsync(dbg_wg, 0, (size_t)g8 * 4 * sizeof(long long), st);
+            hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 8>), dim3(g8), dim3(512), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, T8, S,
+                               ws_max, ws_i1, ws_m2, (dbg && g8 <= 65536) ? dbg_wg : nullptr);
+            if (dbg && dbg_wg && g8 <= 65536) mx6_debug_report(dbg_wg, g8, st);
             return;
         }
         if (var == 3) {                                          // 4 waves x 128 anchors (512-anchor panels, two workgroups per CU)
             hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 4>), dim3(groups / T * Tw), dim3(256), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw, S,
-                               ws_max, ws_i1, ws_m2);
+                               ws_max, ws_i1, ws_m2, nullptr);
             return;
         }
     }
@@ -459,7 +506,7 @@ void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, c
         if (var == 0) {                                          // default at C_pad 512: 4 waves x 128 anchors, one wave per SIMD
             allow_dynamic_lds(reinterpret_cast<const void *>(&match_mx6_screen_w4_kernel<CP, 4>), (int)dyn);
             hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 4>), dim3(groups / T * Tw), dim3(256), dyn, st, a6, q6, B, cap_a, cap_q, n_a, n_q, Tw,
-                               S, ws_max, ws_i1, ws_m2);
+                               S, ws_max, ws_i1, ws_m2, nullptr);
             return;
         }
     }

@@ -47,6 +47,7 @@ def _run_default_engine(pairs, first_key):
     key = torch.arange(first_key, first_key + B, dtype=torch.int64, device="cuda")
     eng = MatchPoseEngine(solver, MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=True, result_views=True)
     assert eng.native_geometry["screen"] == 1                     # the default: MX-fp6 screen
+    eng.native_timing = True                                      # arms the profile events: the library then reports the kernel it launched
     ins = (st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"), cam, cam)
     torch.cuda.synchronize()
     out = eng.run(*ins, key, inputs_resident=True)
