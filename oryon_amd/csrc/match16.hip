@@ -1836,7 +1836,7 @@ LazyWs carve_lazy(void *base, int B, int C, int cap_a, int cap_q, int S, int cor
     const size_t o_xmd = take((size_t)B * cap_s * sizeof(float));
     const size_t o_xam = take((size_t)B * cap_s * sizeof(int32_t));
     const size_t o_xva = take((size_t)B * cap_s);
-    const size_t o_xsc = take(match_x3_scratch_bytes(B, cap_s, 8));
+    const size_t o_xsc = take(match_x3_scratch_bytes(B, cap_s, 8, cap_q));
     w.zero_off = off;
     const size_t o_pe = take((size_t)B * sizeof(int32_t));
     const size_t o_nu = take((size_t)B * sizeof(int32_t));

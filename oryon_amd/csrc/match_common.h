@@ -22,7 +22,7 @@ int match_f32_flagged(const float *a_hat, const float *q_hat, int B, int C, int 
                       const int32_t *panel_flag, const uint8_t *row_flag, void *stream);
 
 // K1x3 (match_x3.hip): fp32-grade scan of a compacted anchor list on the fp16 matrix pipe; see the file's header
-size_t match_x3_scratch_bytes(int B, int cap_s, int S);
+size_t match_x3_scratch_bytes(int B, int cap_s, int S, int cap_q);
 int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const float *feat_q, int C_true, int HW, int layout,
                      const int32_t *roi_q, int roi_stride_q, const float *q_norm, const int32_t *n_q, int B, int cap_q, float threshold,
                      int round_f16, __half *qh, __half *ql, __half *ah, __half *al, void *scratch, float *md_c, int32_t *am_c, uint8_t *va_c,

@@ -37,6 +37,7 @@ constexpr int X3_CAPH = 128;               // candidate slots per (pair, query s
 constexpr float X3_MARGIN = 1.32e-4f;      // 2 * DELTA3 (6.5e-5) + 2e-6
 constexpr float X3_MARGIN_R = 3.4e-5f;     // 2 * DELTA_R (1.63e-5: refined fp64 score against the canonical fp32 chain) + slack
 constexpr int X3_MAX_TILES = 256;          // tile flags per wave of the scan (a workgroup's share of the query rows: cap_q / 32 / S tiles)
+constexpr int X3_JOB_TILES = 16;           // tiles per sweep-2 job (one reload of the 64 anchors' operands per job: 64 KB against 512 KB of tiles)
 constexpr int X3_SURV = 256;               // survivors of the first filter kept per anchor (more: exact-scan route)
 
 // fp32 anchor rows (k-permuted inside groups of 8: position 8g + 4h + j holds k = 8g + 2j + h) -> hi / lo half rows in natural k order
@@ -132,13 +133,13 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
                                                    const __half *__restrict__ al, const __half *__restrict__ qh, const __half *__restrict__ ql, int B,
                                                    int cap_s, int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T, int S,
                                                    const float *__restrict__ al_norm, const float *__restrict__ ql_max,
-                                                   const float *__restrict__ seed, int32_t *__restrict__ cnt, uint2 *__restrict__ cand,
-                                                   int32_t *__restrict__ dbg, long long *__restrict__ dbg_wg)
+                                                   const float *__restrict__ seed, float *__restrict__ smax, unsigned short *__restrict__ tl,
+                                                   uint2 *__restrict__ jobs, int32_t *__restrict__ njobs, int32_t *__restrict__ dbg,
+                                                   long long *__restrict__ dbg_wg)
 {
     constexpr int RB = CP * 2;                 // bytes per half row
     constexpr int ROWS = 32;
     constexpr int PART = ROWS * RB;            // 16 KB at CP = 256
-    constexpr int STAGE = 2 * PART;
     constexpr int NKS = CP / 16;
     constexpr int NI = PART / 4096;            // 1 KB DMA instructions per wave, part and tile
     constexpr int LPR = RB / 256;
@@ -160,17 +161,14 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
     const int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
     long long tk0 = dbg ? wall_clock64() : 0;
-    half8x bh[NAB][NKS], bl[NAB][NKS];
+    half8x bh[NAB][NKS];                                    // sweep 1 multiplies hi parts only
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
         const int ar = X3_ANCHOR(ab);
         const int arc = ar < cap_s ? ar : cap_s - 1;
-        const __half *rh = ah + ((size_t)p * cap_s + arc) * CP + 8 * hi, *rl = al + ((size_t)p * cap_s + arc) * CP + 8 * hi;
+        const __half *rh = ah + ((size_t)p * cap_s + arc) * CP + 8 * hi;
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            bh[ab][s] = *reinterpret_cast<const half8x *>(rh + 16 * s);
-            bl[ab][s] = *reinterpret_cast<const half8x *>(rl + 16 * s);
-        }
+        for (int s = 0; s < NKS; ++s) bh[ab][s] = *reinterpret_cast<const half8x *>(rh + 16 * s);
     }
     unsigned dma_off[NI];
 #pragma unroll
@@ -181,7 +179,7 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
         dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const char *qhp = reinterpret_cast<const char *>(qh + (size_t)p * cap_q * CP), *qlp = reinterpret_cast<const char *>(ql + (size_t)p * cap_q * CP);
+    const char *qhp = reinterpret_cast<const char *>(qh + (size_t)p * cap_q * CP);
     unsigned koff[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) koff[c] = (unsigned)(l31 * RB) + ((((unsigned)(hi ^ (l31 & 15))) ^ (2u * c)) << 4);
@@ -232,13 +230,11 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
     long long tk1 = dbg ? wall_clock64() : 0;
     // ---- sweep 1: hi.hi only (a third of the MFMAs, half of the tile bytes) -> a lower bound of every anchor's maximum over this split's rows
     float runmax[NAB];
-    int nlist[NAB];
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
         // start from the seed (match_x3_seed_kernel: the hi.hi score of a real row of this anchor - whichever split holds it)
         const int a = X3_ANCHOR(ab);
         runmax[ab] = (seed && a < nc) ? seed[(size_t)p * cap_s + a] : -INFINITY;
-        nlist[ab] = 0;
     }
     // The A fragments of a tile are read into registers one tile AHEAD (two sets of NKS fragments): as first written, every k-step was a
     // ds_read followed at once by the two MFMAs that need it - with one wave per SIMD the ~140-cycle LDS latency of each of the 16 reads
@@ -335,35 +331,177 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
     } else {
         n_t2 = ntl;
     }
-    // max_j s_j >= runmax - e_hi, and every exact maximiser has s3 >= max_j s_j - DELTA3: a FIXED emission limit per anchor column
-    float lim[NAB], run3[NAB];
+    // ---- hand-over to sweep 2 (match_x3_sweep2_kernel): this split's maxima, the wave's tile list, jobs of <= X3_JOB_TILES tiles each.
+    // One wave of this kernel often has a whole band of tiles to multiply while its neighbours have none (its anchors' matches lie in this
+    // split's rows, theirs do not), and a lone wave streaming tiles is latency-bound (3.6 us per tile measured): as a sweep inside this
+    // kernel the slowest wave set the pace of its workgroup (up to 800 us against 176 us of sweep 1).  As jobs of a second kernel the same
+    // work spreads over every SIMD of the chip.
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab) {
         runmax[ab] = fmaxf(runmax[ab], __shfl_xor(runmax[ab], 32));
-        lim[ab] = runmax[ab] - e_hi[ab] - 0.5f * X3_MARGIN;
-        run3[ab] = -INFINITY;
+        const int a = X3_ANCHOR(ab);
+        if (hi == 0 && a < nc) smax[((size_t)p * S + split) * cap_s + a] = runmax[ab];
     }
-    // ---- sweep 2 (wave-private): hi / lo compensated products on the wave's flagged tiles, candidates against the limit
     {
-        constexpr int CH = 64;                                  // channels per chunk
-        constexpr int NCH = CP / CH;                            // 4 chunks per tile = the 4 slots of the wave's region
-        constexpr int CHB = 2 * ROWS * CH * 2;                  // 8 KB: [part][row][128 B]
-        constexpr int NJ = ROWS * CH * 2 / 1024;                // 4 DMA instructions per part and chunk (8 rows x 128 B each)
-        static_assert(NCH * CHB == STAGE && CH * 2 == 128, "a wave's region is one stage of the old ring");
-        char *reg = smem + wave_u * STAGE;
-        // DMA source: lane L of instruction j lands at LDS (row j*8 + L/8, 16-byte slot L%8); slots are XOR-swizzled with (row >> 1) & 7 so
-        // that the 16 lanes of a ds_read_b128 phase (rows r .. r+15 at one logical slot) cover all 64 banks
-        unsigned src2[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int row = j * 8 + (lane >> 3), sl = lane & 7;
-            src2[j] = (unsigned)(row * RB + ((sl ^ ((row >> 1) & 7)) << 4));
+        const int owner = ((p * S + split) * T + panel) * 4 + wave;
+        if (flags_ok) {
+            unsigned short *gl = tl + (size_t)owner * X3_MAX_TILES;
+            for (int i = lane; i < n_t2; i += 64) {
+                const int ti = my_list[i];
+                gl[i] = (unsigned short)(ti | ((int)tile_flag[ti] << 14));      // bits 14-15: which anchor block needs the tile
+            }
         }
-        unsigned ko2[CH / 16];
+        const int nj = (n_t2 + X3_JOB_TILES - 1) / X3_JOB_TILES;
+        if (nj > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(njobs, nj);
+            base = __shfl(base, 0);
+            for (int j = lane; j < nj; j += 64) {
+                const int first = j * X3_JOB_TILES;
+                const int c = n_t2 - first < X3_JOB_TILES ? n_t2 - first : X3_JOB_TILES;
+                jobs[base + j] = make_uint2((unsigned)owner, (flags_ok ? 0u : 0x80000000u) | ((unsigned)first << 8) | (unsigned)c);
+            }
+        }
+    }
+#undef X3_WAIT
+    if (dbg && t == 0) {                                     // phase times (100 MHz ticks) summed over workgroups, sweep-2 tiles visited
+        const long long tk3 = wall_clock64();
+        atomicAdd(&dbg[2], (int)(tk1 - tk0));
+        atomicAdd(&dbg[3], (int)(tk2 - tk1));
+        atomicAdd(&dbg[4], (int)(tk3 - tk2));
+        atomicAdd(&dbg[5], n_t2);
+        atomicAdd(&dbg[6], 1);
+        atomicMin(reinterpret_cast<unsigned long long *>(dbg + 8), (unsigned long long)tk0);
+        atomicMax(reinterpret_cast<unsigned long long *>(dbg + 10), (unsigned long long)tk3);
+        // slowest workgroup
+        atomicMax(&dbg[7], (int)(tk3 - tk0));
+        if (dbg_wg) {
+            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 0] = tk0;
+            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 1] = tk3;
+            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+        }
+    }
+}
+
+#undef X3_ANCHOR
+// Persistent launch (round 4).  Launched one block per work item (1024 blocks of ~220 us, one per CU at a time: 512 registers per lane,
+// 130 KB of LDS) the scan took 2.4 ms although its workgroups' own times summed to 0.9 ms per CU: ORYON_X3_DEBUG's per-workgroup clocks
+// showed the dispatcher leaving most CUs empty after the first round (256 running, then 30-180).  So the grid is one workgroup per CU and
+// the workgroups pull items themselves: one queue per XCD (an item's two anchor panels and its query rows stay in that XCD's L2), in the
+// order the one-block-per-item grid used; a workgroup whose XCD has run dry takes items of the others.
+template <int CP>
+__global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
+                                                               const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
+                                                               int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
+                                                               int S, const float *__restrict__ al_norm, const float *__restrict__ ql_max,
+                                                               const float *__restrict__ seed, float *__restrict__ smax,
+                                                               unsigned short *__restrict__ tl, uint2 *__restrict__ jobs,
+                                                               int32_t *__restrict__ njobs, int32_t *__restrict__ queue /*[8], zeroed*/,
+                                                               int items_per_xcd, int32_t *__restrict__ dbg, long long *__restrict__ dbg_wg)
+{
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    __shared__ int item_s;
+    {
+        // nothing listed in any pair (the usual step): one parallel look at the counts instead of a walk through the queues
+        bool any = false;
+        for (int m = threadIdx.x; m < B; m += 256) any |= n_c[m] > 0;
+        if (!__syncthreads_or(any)) return;
+    }
+    const int my_xcd = blockIdx.x & 7;
+    for (;;) {
+        __syncthreads();                                  // everyone is done with the previous item (its LDS, item_s)
+        if (threadIdx.x == 0) {
+            int it = -1;
+            for (int k = 0; k < 8 && it < 0; ++k) {       // own XCD's queue first, then the others'
+                const int x = (my_xcd + k) & 7;
+                if (__atomic_load_n(&queue[x], __ATOMIC_RELAXED) < items_per_xcd) {
+                    const int got = atomicAdd(&queue[x], 1);
+                    if (got < items_per_xcd) it = got * 8 + x;
+                }
+            }
+            item_s = it;
+        }
+        __syncthreads();
+        const int it = item_s;
+        if (it < 0) return;
+        match_x3_scan_item<CP>(it & 7, it >> 3, smem, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed, smax, tl, jobs, njobs, dbg, dbg_wg);
+    }
+}
+
+// Sweep 2 (round 4: its own kernel).  One WAVE per workgroup, four per CU (512 registers: the 64 anchors' hi + lo operands; 32 KB of LDS:
+// four 8 KB chunks of 64 channels, hi + lo parts of a tile's 32 rows, requested three chunks ahead), pulling jobs - (64-anchor group of a
+// split, <= 16 of its flagged tiles) - from the queue sweep 1 filled: hi / lo compensated products, rows scoring within the limit of the
+// anchor's maximum appended to its candidate list.  The limit comes from the maximum over ALL splits (sweep 1 has finished), so splits
+// away from the peak list nothing; several jobs can append to one list, so a lane reserves its entries with one atomic per tile.
+template <int CP>
+__global__ __launch_bounds__(64, 1) void match_x3_sweep2_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
+                                                                const __half *__restrict__ qh, const __half *__restrict__ ql, int cap_s, int cap_q,
+                                                                const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T, int S,
+                                                                const float *__restrict__ al_norm, const float *__restrict__ ql_max,
+                                                                const float *__restrict__ smax, const unsigned short *__restrict__ tl,
+                                                                const uint2 *__restrict__ jobs, const int32_t *__restrict__ njobs,
+                                                                int32_t *__restrict__ next_job, int32_t *__restrict__ cnt, uint2 *__restrict__ cand)
+{
+    constexpr int RB = CP * 2, ROWS = 32, PART = ROWS * RB, NKS = CP / 16, NAB = 2;
+    constexpr int CH = 64;                                  // channels per chunk
+    constexpr int NCH = CP / CH;                            // 4 chunks per tile = the 4 slots of the region
+    constexpr int CHB = 2 * ROWS * CH * 2;                  // 8 KB: [part][row][128 B]
+    constexpr int NJ = ROWS * CH * 2 / 1024;                // 4 DMA instructions per part and chunk (8 rows x 128 B each)
+    constexpr int PERC = 2 * NJ;                            // DMA instructions per chunk
+    __shared__ __attribute__((aligned(256))) char reg[NCH * CHB];
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int n_jobs = __atomic_load_n(njobs, __ATOMIC_RELAXED);
+    // DMA source: lane L of instruction j lands at LDS (row j*8 + L/8, 16-byte slot L%8); slots are XOR-swizzled with (row >> 1) & 7 so
+    // that the 16 lanes of a ds_read_b128 phase (rows r .. r+15 at one logical slot) cover all 64 banks
+    unsigned src2[NJ];
 #pragma unroll
-        for (int s4 = 0; s4 < CH / 16; ++s4) ko2[s4] = (unsigned)(l31 * 128 + (((2 * s4 + hi) ^ ((l31 >> 1) & 7)) << 4));
-        auto tile_at = [&](int i) { return qt_begin + (flags_ok ? (int)my_list[i] : i); };
-        auto issue2 = [&](int g) {                               // chunk g = (tile index g / NCH of the wave's list, k-chunk g % NCH)
+    for (int j = 0; j < NJ; ++j) {
+        const int row = j * 8 + (lane >> 3), sl = lane & 7;
+        src2[j] = (unsigned)(row * RB + ((sl ^ ((row >> 1) & 7)) << 4));
+    }
+    unsigned ko2[CH / 16];
+#pragma unroll
+    for (int s4 = 0; s4 < CH / 16; ++s4) ko2[s4] = (unsigned)(l31 * 128 + (((2 * s4 + hi) ^ ((l31 >> 1) & 7)) << 4));
+#define X3_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    for (;;) {
+        int jx = 0;
+        if (lane == 0) jx = atomicAdd(next_job, 1);
+        jx = __builtin_amdgcn_readfirstlane(jx);
+        if (jx >= n_jobs) return;
+        const uint2 jb = jobs[jx];
+        const int owner = (int)jb.x, first = (int)((jb.y >> 8) & 0x7fffffu), n_t = (int)(jb.y & 0xffu);
+        const bool dense = (jb.y >> 31) != 0;
+        const int wave_g = owner & 3, panel = (owner >> 2) % T, ps = owner / (4 * T), split = ps % S, p = ps / S;
+        const int nc = n_c[p] < cap_s ? n_c[p] : cap_s, nq = n_q[p];
+        const int nqt = (nq + ROWS - 1) / ROWS, qt_per = (nqt + S - 1) / S, qt_begin = split * qt_per;
+        const unsigned short *gl = tl + (size_t)owner * X3_MAX_TILES + first;
+        const char *qhp = reinterpret_cast<const char *>(qh + (size_t)p * cap_q * CP), *qlp = reinterpret_cast<const char *>(ql + (size_t)p * cap_q * CP);
+        half8x bh[NAB][NKS], bl[NAB][NKS];
+        float lim[NAB], run3[NAB];
+        const float qlm = sqrtf(ql_max[p]) * 1.002f;
+#pragma unroll
+        for (int ab = 0; ab < NAB; ++ab) {
+            const int ar = panel * 256 + wave_g * 64 + ab * 32 + l31;
+            const int arc = ar < cap_s ? ar : cap_s - 1;
+            const __half *rh = ah + ((size_t)p * cap_s + arc) * CP + 8 * hi, *rl = al + ((size_t)p * cap_s + arc) * CP + 8 * hi;
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                bh[ab][s] = *reinterpret_cast<const half8x *>(rh + 16 * s);
+                bl[ab][s] = *reinterpret_cast<const half8x *>(rl + 16 * s);
+            }
+            // max_j s_j >= (largest sweep-1 maximum of any split) - e_hi, and every exact maximiser has s3 >= max_j s_j - DELTA3: a FIXED
+            // emission limit per anchor column
+            const float aln = al_norm[(size_t)p * cap_s + arc];
+            const float e_hi = (aln + qlm) * 1.001f + aln * qlm + 3.1e-5f;
+            float gm = -INFINITY;
+            if (ar < nc)
+                for (int s2 = 0; s2 < S; ++s2) gm = fmaxf(gm, smax[((size_t)p * S + s2) * cap_s + ar]);
+            lim[ab] = gm - e_hi - 0.5f * X3_MARGIN;
+            run3[ab] = -INFINITY;
+        }
+        auto tile_at = [&](int i) { return qt_begin + (dense ? first + i : (int)(gl[i] & 0x3fffu)); };
+        auto issue2 = [&](int g) {                               // chunk g = (tile g / NCH of the job, k-chunk g % NCH)
             const int qt = tile_at(g / NCH), c = g % NCH;
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
@@ -374,14 +512,13 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
                                                      (__attribute__((address_space(3))) void *)(reg + c * CHB + part * (CHB / 2) + j * 1024), 16, 0, 0);
             }
         };
-        const int n_g = n_t2 * NCH;
-        constexpr int PERC = 2 * NJ;                            // DMA instructions per chunk
+        const int n_g = n_t * NCH;
 #pragma unroll
         for (int d = 0; d < NCH - 1; ++d)
             if (d < n_g) issue2(d);
-        for (int i = 0; i < n_t2; ++i) {
+        for (int i = 0; i < n_t; ++i) {
             const int qt = tile_at(i);
-            const int fmask = flags_ok ? (int)tile_flag[qt - qt_begin] : 3;          // wave-uniform: which anchor blocks need this tile
+            const int fmask = dense ? 3 : (int)(gl[i] >> 14);     // wave-uniform: which anchor blocks need this tile
             f32x16 acc[NAB];
 #pragma unroll
             for (int ab = 0; ab < NAB; ++ab)
@@ -391,8 +528,8 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
             for (int c = 0; c < NCH; ++c) {
                 const int g = i * NCH + c;
                 const int rem = n_g - 1 - g;
-                // chunk g has landed when at most min(2, chunks left) later chunks are in flight (the candidate stores of earlier tiles only
-                // make the count conservative)
+                // chunk g has landed when at most min(2, chunks left) later chunks are in flight (the candidate stores / atomics of earlier
+                // tiles only make the count conservative)
                 if (rem >= 2) X3_WAIT(2 * PERC); else if (rem == 1) X3_WAIT(PERC); else X3_WAIT(0);
                 __builtin_amdgcn_wave_barrier();
                 // slot (c + 3) % 4 held chunk g - 1, whose operand reads completed before its MFMAs were issued
@@ -426,7 +563,7 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
 #pragma unroll
             for (int ab = 0; ab < NAB; ++ab) {
                 if (!((fmask >> ab) & 1)) continue;           // this block's accumulators were not computed: none of its anchors can list a row here
-                const int a = X3_ANCHOR(ab);
+                const int a = panel * 256 + wave_g * 64 + ab * 32 + l31;
                 float x = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
@@ -435,85 +572,23 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
                 run3[ab] = fmaxf(run3[ab], fmaxf(x, __shfl_xor(x, 32)));
                 lim[ab] = fmaxf(lim[ab], run3[ab] - X3_MARGIN);
                 if (a < nc && x >= lim[ab]) {
-                    uint2 *list = cand + ((((size_t)p * S + split) * cap_s + a) * 2 + hi) * X3_CAPH;
+                    int n = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) n += (acc[ab][r] >= lim[ab] && q0 + (r & 3) + 8 * (r >> 2) < nq) ? 1 : 0;   // zero-padded rows of the last tile are not candidates
+                    const size_t lid = (((size_t)p * S + split) * cap_s + a) * 2 + hi;
+                    int pos = atomicAdd(&cnt[lid], n);          // other jobs of this split may hold other tiles of the same anchor
+                    uint2 *list = cand + lid * X3_CAPH;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (acc[ab][r] >= lim[ab] && q0 + (r & 3) + 8 * (r >> 2) < nq) {      // zero-padded rows of the last tile are not candidates
-                            if (nlist[ab] < X3_CAPH) list[nlist[ab]] = make_uint2((unsigned)(q0 + (r & 3) + 8 * (r >> 2)), __float_as_uint(acc[ab][r]));
-                            ++nlist[ab];
+                        if (acc[ab][r] >= lim[ab] && q0 + (r & 3) + 8 * (r >> 2) < nq) {
+                            if (pos < X3_CAPH) list[pos] = make_uint2((unsigned)(q0 + (r & 3) + 8 * (r >> 2)), __float_as_uint(acc[ab][r]));
+                            ++pos;
                         }
                 }
             }
         }
     }
 #undef X3_WAIT
-    if (dbg && t == 0) {                                     // phase times (100 MHz ticks) summed over workgroups, sweep-2 tiles visited
-        const long long tk3 = wall_clock64();
-        atomicAdd(&dbg[2], (int)(tk1 - tk0));
-        atomicAdd(&dbg[3], (int)(tk2 - tk1));
-        atomicAdd(&dbg[4], (int)(tk3 - tk2));
-        atomicAdd(&dbg[5], n_t2);
-        atomicAdd(&dbg[6], 1);
-        atomicMin(reinterpret_cast<unsigned long long *>(dbg + 8), (unsigned long long)tk0);
-        atomicMax(reinterpret_cast<unsigned long long *>(dbg + 10), (unsigned long long)tk3);
-        // slowest workgroup
-        atomicMax(&dbg[7], (int)(tk3 - tk0));
-        if (dbg_wg) {
-            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 0] = tk0;
-            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 1] = tk3;
-            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
-            dbg_wg[(size_t)(slot * 8 + xcd) * 4 + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
-        }
-    }
-#pragma unroll
-    for (int ab = 0; ab < NAB; ++ab) {
-        const int a = X3_ANCHOR(ab);
-        if (a < nc) cnt[(((size_t)p * S + split) * cap_s + a) * 2 + hi] = nlist[ab];
-    }
-}
-
-#undef X3_ANCHOR
-// Persistent launch (round 4).  Launched one block per work item (1024 blocks of ~220 us, one per CU at a time: 512 registers per lane,
-// 130 KB of LDS) the scan took 2.4 ms although its workgroups' own times summed to 0.9 ms per CU: ORYON_X3_DEBUG's per-workgroup clocks
-// showed the dispatcher leaving most CUs empty after the first round (256 running, then 30-180).  So the grid is one workgroup per CU and
-// the workgroups pull items themselves: one queue per XCD (an item's two anchor panels and its query rows stay in that XCD's L2), in the
-// order the one-block-per-item grid used; a workgroup whose XCD has run dry takes items of the others.
-template <int CP>
-__global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
-                                                               const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
-                                                               int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
-                                                               int S, const float *__restrict__ al_norm, const float *__restrict__ ql_max,
-                                                               const float *__restrict__ seed, int32_t *__restrict__ cnt,
-                                                               uint2 *__restrict__ cand, int32_t *__restrict__ queue /*[8], zeroed*/,
-                                                               int items_per_xcd, int32_t *__restrict__ dbg, long long *__restrict__ dbg_wg)
-{
-    extern __shared__ __attribute__((aligned(256))) char smem[];
-    __shared__ int item_s;
-    {
-        // nothing listed in any pair (the usual step): one parallel look at the counts instead of a walk through the queues
-        bool any = false;
-        for (int m = threadIdx.x; m < B; m += 256) any |= n_c[m] > 0;
-        if (!__syncthreads_or(any)) return;
-    }
-    const int my_xcd = blockIdx.x & 7;
-    for (;;) {
-        __syncthreads();                                  // everyone is done with the previous item (its LDS, item_s)
-        if (threadIdx.x == 0) {
-            int it = -1;
-            for (int k = 0; k < 8 && it < 0; ++k) {       // own XCD's queue first, then the others'
-                const int x = (my_xcd + k) & 7;
-                if (__atomic_load_n(&queue[x], __ATOMIC_RELAXED) < items_per_xcd) {
-                    const int got = atomicAdd(&queue[x], 1);
-                    if (got < items_per_xcd) it = got * 8 + x;
-                }
-            }
-            item_s = it;
-        }
-        __syncthreads();
-        const int it = item_s;
-        if (it < 0) return;
-        match_x3_scan_item<CP>(it & 7, it >> 3, smem, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed, cnt, cand, dbg, dbg_wg);
-    }
 }
 
 // one wave per compacted anchor: final maximum over the lists of all query splits, stale entries dropped, canonical fp32 chain on the raw
@@ -677,9 +752,19 @@ int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, c
                      const int32_t *map_enable, int rows_cap, int C_pad, int8_t *out8, float *scale, float *eps, float *norm,
                      float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt, void *aux);
 
-size_t match_x3_scratch_bytes(int B, int cap_s, int S)
+// jobs a (split, 64-anchor group) can post: its tiles in chunks of X3_JOB_TILES
+static int x3_jobs_per_owner(int cap_q, int S)
 {
-    return (size_t)B * S * cap_s * 2 * (sizeof(int32_t) + X3_CAPH * sizeof(uint2)) + (size_t)B * (3 * cap_s + 3) * sizeof(int32_t) + 8192 + 2048;
+    const int ntl_max = ((cap_q + 31) / 32 + S - 1) / S + 1;
+    return (ntl_max + X3_JOB_TILES - 1) / X3_JOB_TILES;
+}
+
+size_t match_x3_scratch_bytes(int B, int cap_s, int S, int cap_q)
+{
+    const size_t owners = (size_t)B * S * ((cap_s + 255) / 256) * 4;
+    return (size_t)B * S * cap_s * 2 * (sizeof(int32_t) + X3_CAPH * sizeof(uint2)) + (size_t)B * (3 * cap_s + 3) * sizeof(int32_t) + 8192 + 4096 +
+           (size_t)B * S * cap_s * sizeof(float) /* smax */ + owners * X3_MAX_TILES * sizeof(unsigned short) /* tile lists */ +
+           owners * x3_jobs_per_owner(cap_q, S) * sizeof(uint2) /* jobs */ + 1024;
 }
 
 // a_c [B, cap_s, 256] fp32 compact anchor rows (k-permuted), n_c [B] -> md_c / am_c / va_c [B, cap_s]; n_ovf / ovf_idx: anchors whose
@@ -704,16 +789,25 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     off += cnt_block;
     float *ql_max = reinterpret_cast<float *>(sp + off);
     off += cnt_block;
-    int32_t *queue = reinterpret_cast<int32_t *>(sp + off);            // the scan's per-XCD item counters (zeroed by the same memset)
+    int32_t *queue = reinterpret_cast<int32_t *>(sp + off);            // sweep 1's per-XCD item counters [0..7], njobs [8], next_job [9]
+    int32_t *njobs = queue + 8, *next_job = queue + 9;                  // (zeroed by the same memset)
     off += 256;
     int32_t *ovf_idx = reinterpret_cast<int32_t *>(sp + off);
     off += ((size_t)B * cap_s * sizeof(int32_t) + 255) / 256 * 256;
     float *al_norm = reinterpret_cast<float *>(sp + off);
     off += ((size_t)B * cap_s * sizeof(float) + 255) / 256 * 256;
     float *seed = reinterpret_cast<float *>(sp + off);
+    off += ((size_t)B * cap_s * sizeof(float) + 255) / 256 * 256 + 8192;                    // + the debug counters' slack
+    float *smax = reinterpret_cast<float *>(sp + off);
+    off += ((size_t)B * S * cap_s * sizeof(float) + 255) / 256 * 256;
+    const size_t owners = (size_t)B * S * T * 4;
+    unsigned short *tl = reinterpret_cast<unsigned short *>(sp + off);
+    off += (owners * X3_MAX_TILES * sizeof(unsigned short) + 255) / 256 * 256;
+    uint2 *jobs = reinterpret_cast<uint2 *>(sp + off);
     *n_ovf_out = n_ovf;
     *ovf_idx_out = ovf_idx;
     if (hipMemsetAsync(n_ovf, 0, 2 * cnt_block + 256, st) != hipSuccess) return ORYON_ERR_HIP;
+    if (hipMemsetAsync(cnt, 0, (size_t)B * S * cap_s * 2 * sizeof(int32_t), st) != hipSuccess) return ORYON_ERR_HIP;     // sweep 2 appends with atomics
     // query rows as hi / lo halves, only for pairs that have listed anchors (the gather's per-map gate reads the counts themselves)
     int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, n_c, cap_q, CP, reinterpret_cast<int8_t *>(qh), nullptr,
                               ql_max, nullptr, nullptr, 1, round_f16, st, 2, ql);
@@ -748,7 +842,9 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
         n_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess && v > 0) ? v : 256;
     }
     const int grid = groups < n_cus ? groups : n_cus / 8 * 8;
-    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(grid), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, cnt, cand, queue, groups / 8, dbg_dev, dbg_wg);
+    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(grid), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, dbg_dev, dbg_wg);
+    // sweep 2: four one-wave workgroups per CU pull the jobs sweep 1 posted (none posted: they exit at once)
+    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP>), dim3(4 * n_cus), dim3(64), 0, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, smax, tl, jobs, njobs, next_job, cnt, cand);
     const size_t lds = (size_t)4 * (2 * CP + 2 * X3_SURV) * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
