@@ -134,7 +134,7 @@ __device__ __forceinline__ void gather_q8_v3_tile(
             // with the fast path nor keeps 256 predicate masks alive across the loads (it spilled 434 SGPRs doing that).
             int hw_b = HW, c_b = C;
             asm volatile("" : "+s"(hw_b), "+s"(c_b));
-            if constexpr (LPR == 1 && FMT != 2) {        // (the hi / lo instantiation keeps the plain loop: one more branch costs it a spill)
+            if constexpr (LPR == 1) {
                 // narrow maps (the reference's own C = 32 zero-padded to the 256-channel rows): 32-channel blocks beyond C are not loaded
                 // at all - a wave-uniform scalar branch per block, no per-lane predicate - instead of 224 clamped re-reads of plane C - 1
 #pragma unroll

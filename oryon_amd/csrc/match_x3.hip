@@ -429,13 +429,13 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
     }
 }
 
-// Sweep 2 (round 4: its own kernel).  One WAVE per workgroup, four per CU (512 registers: the 64 anchors' hi + lo operands; 32 KB of LDS:
+// Sweep 2 (round 4: its own kernel).  Independent WAVES, four per CU (512 registers: the 64 anchors' hi + lo operands; 32 KB of LDS each:
 // four 8 KB chunks of 64 channels, hi + lo parts of a tile's 32 rows, requested three chunks ahead), pulling jobs - (64-anchor group of a
 // split, <= 16 of its flagged tiles) - from the queue sweep 1 filled: hi / lo compensated products, rows scoring within the limit of the
 // anchor's maximum appended to its candidate list.  The limit comes from the maximum over ALL splits (sweep 1 has finished), so splits
 // away from the peak list nothing; several jobs can append to one list, so a lane reserves its entries with one atomic per tile.
 template <int CP>
-__global__ __launch_bounds__(64, 1) void match_x3_sweep2_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
+__global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
                                                                 const __half *__restrict__ qh, const __half *__restrict__ ql, int cap_s, int cap_q,
                                                                 const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T, int S,
                                                                 const float *__restrict__ al_norm, const float *__restrict__ ql_max,
@@ -449,8 +449,11 @@ __global__ __launch_bounds__(64, 1) void match_x3_sweep2_kernel(const __half *__
     constexpr int CHB = 2 * ROWS * CH * 2;                  // 8 KB: [part][row][128 B]
     constexpr int NJ = ROWS * CH * 2 / 1024;                // 4 DMA instructions per part and chunk (8 rows x 128 B each)
     constexpr int PERC = 2 * NJ;                            // DMA instructions per chunk
-    __shared__ __attribute__((aligned(256))) char reg[NCH * CHB];
-    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    // four independent waves per workgroup, each with its own 32 KB region and its own job stream (no barrier anywhere): one workgroup per
+    // CU instead of four one-wave workgroups - a quarter of the blocks to dispatch when nothing was posted (the usual step)
+    extern __shared__ __attribute__((aligned(256))) char smem2[];
+    char *reg = smem2 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (NCH * CHB);
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int n_jobs = __atomic_load_n(njobs, __ATOMIC_RELAXED);
     // DMA source: lane L of instruction j lands at LDS (row j*8 + L/8, 16-byte slot L%8); slots are XOR-swizzled with (row >> 1) & 7 so
     // that the 16 lanes of a ds_read_b128 phase (rows r .. r+15 at one logical slot) cover all 64 banks
@@ -844,7 +847,8 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     const int grid = groups < n_cus ? groups : n_cus / 8 * 8;
     hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(grid), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, dbg_dev, dbg_wg);
     // sweep 2: four one-wave workgroups per CU pull the jobs sweep 1 posted (none posted: they exit at once)
-    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP>), dim3(4 * n_cus), dim3(64), 0, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, smax, tl, jobs, njobs, next_job, cnt, cand);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_sweep2_kernel<CP>), 4 * 32768);
+    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP>), dim3(n_cus), dim3(256), 4 * 32768, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, smax, tl, jobs, njobs, next_job, cnt, cand);
     const size_t lds = (size_t)4 * (2 * CP + 2 * X3_SURV) * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
