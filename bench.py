@@ -552,20 +552,25 @@ def main():
         # rocprofv3 --pmc passes of this exact workload AND this exact kernel source - the record carries the sha256 of the kernel's
         # source file, and a mismatch (the kernel changed since the counters were collected) reports null instead of a stale number
         traffic, traffic_src = None, "no PMC record for this workload"
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if use_i8 and (B, H, C) == (64, 224, 256) and a.layout == "nchw" and os.path.exists(tpath):
+        if use_i8 and (B, H, C) == (64, 224, 256) and a.layout == "nchw":
+            import glob
             import hashlib
-            with open(tpath) as fh:
-                tj = json.load(fh)
             with open(os.path.join(ROOT, "oryon_amd", "csrc", "screen_mx6.hip" if a.screen == "mx6" else "match16.hip"), "rb") as fh:
                 sha = hashlib.sha256(fh.read()).hexdigest()
-            if tj.get("kernel_source_sha256") == sha:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source", "profiles/r03_pmc_counters.md")
-            else:
-                # loud, not silent: a reader (and tests/test_gpu_bench_contract.py) sees that the committed counters describe an older kernel
-                traffic = "stale"
-                traffic_src = ("profiles/r03_traffic.json is STALE: the screen kernel source changed since the PMC passes were collected "
-                               "(sha256 mismatch) - re-run tools/make_traffic_json.py on fresh rocprofv3 --pmc passes")
+            want = "mx6" if a.screen == "mx6" else "i8"
+            for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):      # newest round first
+                with open(tpath) as fh:
+                    tj = json.load(fh)
+                if want not in tj.get("kernel", ""):
+                    continue
+                if tj.get("kernel_source_sha256") == sha:
+                    traffic, traffic_src = tj["traffic_bytes_per_launch"], tj.get("source", os.path.basename(tpath))
+                else:
+                    # loud, not silent: the committed counters describe an OLDER build of the kernel
+                    traffic = "stale"
+                    traffic_src = (f"profiles/{os.path.basename(tpath)} is STALE: the screen kernel source changed since the PMC passes were "
+                                   "collected (sha256 mismatch) - re-run tools/collect_profiles.sh + tools/make_traffic_json.py")
+                break
         rec = {
             "metric": METRIC, "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
