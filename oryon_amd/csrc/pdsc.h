@@ -23,7 +23,7 @@ struct PdscLayer {
 constexpr int PDSC_MLP_W1H = 0, PDSC_MLP_W1L = 16384, PDSC_MLP_W2H = 32768, PDSC_MLP_W2L = 40960, PDSC_MLP_W3H = 49152,
               PDSC_MLP_W3L = 65536, PDSC_MLP_IMG_BYTES = 81920;
 // pdsc_pcn_qkv_x3_kernel: four chunks (PointCN, q, k, v) of [hi: 128 rows x 256 B | lo: the same], slot ^ (row & 15); q|k|v K axis permuted
-constexpr int PDSC_PQ_CHUNK_BYTES = 65536, PDSC_PQ_IMG_BYTES = 4 * PDSC_PQ_CHUNK_BYTES;
+constexpr int PDSC_PQ_CHUNK_BYTES = 65536, PDSC_PQ_IMG_BYTES = 5 * PDSC_PQ_CHUNK_BYTES;   // PointCN | q | k | v | PointCN with the permuted K axis
 // K / V image of one 64-key tile (C = 128): Kh | Kl as [64 keys][136 halves] (16-byte row pad), Vh | Vl as [8 octets][128 channels][8 keys]
 constexpr int PDSC_KV_KL = 17408, PDSC_KV_VH = 34816, PDSC_KV_VL = 51200, PDSC_KV_TILE_BYTES = 67584;
 

@@ -1423,6 +1423,264 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float
     }
 }
 
+// fc_message of layer l AND PointCN + q|k|v of layer l + 1 as ONE kernel (round 4): both are per-point chains on the same transposed
+// register layout, so the layer output  feat = feat1 + W3 relu(W2 relu(W1 msg + b1) + b2) + b3  never leaves the registers - bias +
+// residual + split and it IS the B operand of the next layer's PointCN, whose weights therefore come with their K axis in
+// accumulator-register order (chunk 4 of the next layer's image; chunk 0 keeps the natural order for layer 0, whose input comes from
+// memory).  One launch, one fetch of the rows and one write of the features less per layer (11 of the encoder's 36 launches).
+// LDS: the 80 KB fc_message image at 0, PointCN' (64 KB) beside it from the start; q, k, v then stream through the two areas as in
+// pdsc_pcn_qkv_x3_kernel (area 1 = offset 0 once the fc_message image is dead, area 0 = offset 80 KB).
+// resid / feat1 may be the same buffer (a lane reads its residual row before it writes the row of the next layer): no __restrict__.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pdsc_mlp3_pcn_qkv_x3_kernel(const float *__restrict__ msg, const float *resid,
+                                                                    const char *__restrict__ mlp_img, const float *__restrict__ b1,
+                                                                    const float *__restrict__ b2, const float *__restrict__ b3,
+                                                                    const char *__restrict__ pq_img, const float *__restrict__ bp,
+                                                                    const float *__restrict__ bq, const int32_t *__restrict__ n_rows, int n_cap,
+                                                                    float *feat1, float *__restrict__ qkv, char *__restrict__ kv_img)
+{
+    constexpr int C = 128, HALF = PDSC_PQ_CHUNK_BYTES / 2;
+    constexpr int AREA0 = PDSC_MLP_IMG_BYTES, AREA1 = 0;               // byte offsets of the two 64 KB weight areas
+    extern __shared__ __attribute__((aligned(1024))) char fz_lds[];
+    const int b = blockIdx.y, q0 = blockIdx.x * (32 * WAVES);
+    if (q0 >= n_rows[b]) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    static_assert((PDSC_MLP_IMG_BYTES / 1024) % WAVES == 0, "pieces per wave");
+#pragma unroll
+    for (int j = 0; j < PDSC_MLP_IMG_BYTES / 1024 / WAVES; ++j) {
+        const int piece = wave_u * (PDSC_MLP_IMG_BYTES / 1024 / WAVES) + j;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(mlp_img + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(fz_lds + piece * 1024), 16, 0, 0);
+    }
+    auto dma_chunk = [&](int chunk, int area_off) {                   // 64 pieces of 1 KB, 64 / WAVES per wave
+#pragma unroll
+        for (int j = 0; j < 64 / WAVES; ++j) {
+            const int piece = wave_u * (64 / WAVES) + j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pq_img + (size_t)chunk * PDSC_PQ_CHUNK_BYTES + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(fz_lds + area_off + piece * 1024), 16, 0, 0);
+        }
+    };
+    dma_chunk(4, AREA0);                                               // PointCN with the permuted K axis
+    const size_t prow = (size_t)b * n_cap + q0 + wave * 32 + l31;
+    xhalf8 xh[8], xl[8];
+    {
+        const float4 *xp = reinterpret_cast<const float4 *>(msg + prow * C);
+        float4 raw[16];
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) { raw[2 * s_] = xp[4 * s_ + 2 * hi]; raw[2 * s_ + 1] = xp[4 * s_ + 2 * hi + 1]; }
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            uint4 uh, ul;
+            split_pair(raw[2 * s_].x, raw[2 * s_].y, uh.x, ul.x);
+            split_pair(raw[2 * s_].z, raw[2 * s_].w, uh.y, ul.y);
+            split_pair(raw[2 * s_ + 1].x, raw[2 * s_ + 1].y, uh.z, ul.z);
+            split_pair(raw[2 * s_ + 1].z, raw[2 * s_ + 1].w, uh.w, ul.w);
+            xh[s_] = __builtin_bit_cast(xhalf8, uh);
+            xl[s_] = __builtin_bit_cast(xhalf8, ul);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto w1_frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(fz_lds + base + o * 256 + (((2 * s_ + hi) ^ (o & 15)) << 4));
+    };
+    auto w23_frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(fz_lds + base + o * 128 + (((2 * s_ + hi) ^ ((o >> 1) & 7)) << 4));
+    };
+    auto next_operand = [&](const f32x16 (&acc)[2], const float *bias, xhalf8 (&oh)[4], xhalf8 (&ol)[4]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + rb * 32 + 8 * (2 * j + g2) + 4 * hi);
+                    const int r0 = 8 * j + 4 * g2;
+                    const float v0 = fmaxf(acc[rb][r0] + bv.x, 0.0f), v1 = fmaxf(acc[rb][r0 + 1] + bv.y, 0.0f);
+                    const float v2 = fmaxf(acc[rb][r0 + 2] + bv.z, 0.0f), v3 = fmaxf(acc[rb][r0 + 3] + bv.w, 0.0f);
+                    split_pair(v0, v1, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v2, v3, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                oh[rb * 2 + j] = __builtin_bit_cast(xhalf8, uh);
+                ol[rb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+    };
+    // two 32-row output blocks over NS k-steps (see pdsc_mlp3_x3_kernel); swap: the activations are the A operand (lane = channel)
+    auto two_blocks = [&](auto &&frag, int base_h, int base_l, int rb0, int NS, const xhalf8 *bh, const xhalf8 *bl, f32x16 (&acc)[2], bool swap) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        xhalf8 w[2][2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { w[0][i][0] = frag(base_h, rb0 + i, 0); w[0][i][1] = frag(base_l, rb0 + i, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            if (s_ < NS) {
+                const int cur = s_ & 1;
+                if (s_ + 1 < NS) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { w[cur ^ 1][i][0] = frag(base_h, rb0 + i, s_ + 1); w[cur ^ 1][i][1] = frag(base_l, rb0 + i, s_ + 1); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!swap) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bh[s_], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bh[s_], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bl[s_], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bl[s_], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][1], bh[s_], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][1], bh[s_], acc[1], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][0][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][1][0], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s_], w[cur][0][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s_], w[cur][1][0], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][0][1], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][1][1], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // ---- fc_message of layer l
+    f32x16 a1[2];
+    two_blocks(w1_frag, PDSC_MLP_W1H, PDSC_MLP_W1L, 0, 8, xh, xl, a1, false);
+    xhalf8 h1h[4], h1l[4];
+    next_operand(a1, b1, h1h, h1l);
+    f32x16 a2[2];
+    two_blocks(w23_frag, PDSC_MLP_W2H, PDSC_MLP_W2L, 0, 4, h1h, h1l, a2, false);
+    xhalf8 h2h[4], h2l[4];
+    next_operand(a2, b2, h2h, h2l);
+    // layer 3 + bias + residual = the layer's output features, kept as the 8 B fragments (permuted K order) of the next layer's PointCN
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        float4 rv[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rv[i][g] = *reinterpret_cast<const float4 *>(resid + prow * C + (2 * rp + i) * 32 + 8 * g + 4 * hi);
+        f32x16 a3[2];
+        two_blocks(w23_frag, PDSC_MLP_W3H, PDSC_MLP_W3L, 2 * rp, 4, h2h, h2l, a3, false);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rb = 2 * rp + i;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int g = 2 * j + g2;
+                    const float4 bv = *reinterpret_cast<const float4 *>(b3 + rb * 32 + 8 * g + 4 * hi);
+                    const float v0 = a3[i][4 * g + 0] + bv.x + rv[i][g].x, v1 = a3[i][4 * g + 1] + bv.y + rv[i][g].y;
+                    const float v2 = a3[i][4 * g + 2] + bv.z + rv[i][g].z, v3 = a3[i][4 * g + 3] + bv.w + rv[i][g].w;
+                    split_pair(v0, v1, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v2, v3, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                xh[rb * 2 + j] = __builtin_bit_cast(xhalf8, uh);       // (the message fragments are dead: their registers take the features)
+                xl[rb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+        }
+    }
+    // ---- PointCN + q|k|v of layer l + 1.  The fc_message image is dead once every wave is here: q lands on top of it.
+    __syncthreads();
+    dma_chunk(1, AREA1);
+    auto frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(fz_lds + base + o * 256 + (((2 * s_ + hi) ^ (o & 15)) << 4));
+    };
+    xhalf8 fh[8], fl[8];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        f32x16 acc[2];
+        two_blocks(frag, AREA0, AREA0 + HALF, 2 * rp, 8, xh, xl, acc, false);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rb = 2 * rp + i;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int c = rb * 32 + 8 * (2 * j + g2) + 4 * hi, r0 = 8 * j + 4 * g2;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bp + c);
+                    float4 v;
+                    v.x = fmaxf(acc[i][r0] + bv.x, 0.0f); v.y = fmaxf(acc[i][r0 + 1] + bv.y, 0.0f);
+                    v.z = fmaxf(acc[i][r0 + 2] + bv.z, 0.0f); v.w = fmaxf(acc[i][r0 + 3] + bv.w, 0.0f);
+                    *reinterpret_cast<float4 *>(feat1 + prow * C + c) = v;
+                    split_pair(v.x, v.y, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v.z, v.w, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                fh[rb * 2 + j] = __builtin_bit_cast(xhalf8, uh);
+                fl[rb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+        }
+    }
+    // q from area 1 while k lands in area 0, k from area 0 while v lands in area 1, v from area 1
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const int area_off = ((part + 1) & 1) ? AREA1 : AREA0, other_off = ((part + 1) & 1) ? AREA0 : AREA1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this part's chunk has landed (the feat1 stores drain with it)
+        __syncthreads();                                                // every wave is done with the other area; this part's chunk is visible
+        if (part < 2) dma_chunk(part + 2, other_off);
+        const int p_pair = q0 + wave * 32;
+        char *tile = kv_img ? kv_img + ((size_t)b * (n_cap / 64) + (p_pair >> 6)) * PDSC_KV_TILE_BYTES : nullptr;
+        const bool as_v = kv_img && part == 2;
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            f32x16 acc[2];
+            two_blocks(frag, area_off, area_off + HALF, 2 * rp, 8, fh, fl, acc, as_v);
+            if (as_v) {
+                const int kb = (p_pair >> 5) & 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ch = (2 * rp + i) * 32 + l31;
+                    const float bv = bq[2 * C + ch];
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        uint4 uh, ul;
+                        split_pair(acc[i][8 * t2 + 0] + bv, acc[i][8 * t2 + 1] + bv, uh.x, ul.x);
+                        split_pair(acc[i][8 * t2 + 2] + bv, acc[i][8 * t2 + 3] + bv, uh.y, ul.y);
+                        split_pair(acc[i][8 * t2 + 4] + bv, acc[i][8 * t2 + 5] + bv, uh.z, ul.z);
+                        split_pair(acc[i][8 * t2 + 6] + bv, acc[i][8 * t2 + 7] + bv, uh.w, ul.w);
+                        const int oct = (kb * 2 + t2) * 2 + hi;
+                        *reinterpret_cast<uint4 *>(tile + PDSC_KV_VH + ((size_t)oct * C + ch) * 16) = uh;
+                        *reinterpret_cast<uint4 *>(tile + PDSC_KV_VL + ((size_t)oct * C + ch) * 16) = ul;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cc = (2 * rp + i) * 32 + 8 * g + 4 * hi, c = part * C + cc;
+                        const float4 bv = *reinterpret_cast<const float4 *>(bq + c);
+                        float4 o;
+                        o.x = acc[i][4 * g + 0] + bv.x; o.y = acc[i][4 * g + 1] + bv.y;
+                        o.z = acc[i][4 * g + 2] + bv.z; o.w = acc[i][4 * g + 3] + bv.w;
+                        if (kv_img && part == 1) {
+                            uint2 uh, ul;
+                            split_pair(o.x, o.y, uh.x, ul.x);
+                            split_pair(o.z, o.w, uh.y, ul.y);
+                            const size_t off = (size_t)((p_pair & 63) + l31) * 272 + cc * 2;
+                            *reinterpret_cast<uint2 *>(tile + off) = uh;
+                            *reinterpret_cast<uint2 *>(tile + PDSC_KV_KL + off) = ul;
+                        } else {
+                            *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;
+                        }
+                    }
+            }
+        }
+    }
+}
+
 // Combine the key-split partials: msg = sum_s e^{m_s - m} O_s / sum_s e^{m_s - m} l_s,  m = max_s m_s.
 __global__ __launch_bounds__(256) void pdsc_attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
                                                                     const int32_t *__restrict__ n_rows, int n_cap, int C, int KS,
@@ -1522,6 +1780,14 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         static const bool fused_pq = !getenv("ORYON_PDSC_FUSED_PQ") || atoi(getenv("ORYON_PDSC_FUSED_PQ")) != 0;       // dev: 0 = two launches
         static const bool att_img = !getenv("ORYON_PDSC_ATT_IMG") || atoi(getenv("ORYON_PDSC_ATT_IMG")) != 0;           // dev: 0 = fp32 K / V
         bool use_img = false;
+        // round 4: fc_message of layer l - 1 and PointCN + q|k|v of layer l came as ONE launch at the end of the previous iteration
+        static const bool fuse_chain = !getenv("ORYON_PDSC_FUSED_CHAIN") || atoi(getenv("ORYON_PDSC_FUSED_CHAIN")) != 0;     // dev: 0 = separate launches
+        const bool chain_ok = C == 128 && x3 && fused_pq && fuse_chain && n_cap % 256 == 0 && ws.att_splits == 1 && ws.kv_img != nullptr && att_img &&
+                              (!getenv("ORYON_PDSC_FUSED_MLP") || atoi(getenv("ORYON_PDSC_FUSED_MLP")) != 0) &&
+                              (!getenv("ORYON_PDSC_WAVES") || atoi(getenv("ORYON_PDSC_WAVES")) == 8);
+        if (l > 0 && chain_ok && L.pq_img && M.layers[l - 1].mlp_img) {
+            use_img = true;                                            // (launched below, after the previous layer's attention)
+        } else
         if (C == 128 && x3 && fused_pq && L.pq_img) {
             // PointCN (conv + BN + ReLU, BN folded) and the q | k | v projections in one launch
             // 8-wave workgroups (256 points): the same 128 KB of weights feed twice the points and the launch occupies half the CUs with
@@ -1571,6 +1837,15 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
         // fc_message: C -> C/2 -> C/2 -> C, residual onto the PointCN output
         static const bool fused_mlp = !getenv("ORYON_PDSC_FUSED_MLP") || atoi(getenv("ORYON_PDSC_FUSED_MLP")) != 0;   // dev: 0 = three launches
+        if (chain_ok && L.mlp_img && l + 1 < M.cfg.num_layers && M.layers[l + 1].pq_img) {
+            const PdscLayer &N = M.layers[l + 1];
+            constexpr int FZ_LDS = PDSC_MLP_IMG_BYTES + PDSC_PQ_CHUNK_BYTES;
+            allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_mlp3_pcn_qkv_x3_kernel<8>), FZ_LDS);
+            hipLaunchKernelGGL(pdsc_mlp3_pcn_qkv_x3_kernel<8>, dim3(n_cap / 256, B), dim3(512), FZ_LDS, st, ws.msg, ws.feat1, L.mlp_img, L.b_m1, L.b_m2,
+                               L.b_m3, N.pq_img, N.b_pcn, N.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, ws.kv_img);
+            if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
+            continue;
+        }
         if (C == 128 && x3 && fused_mlp && L.mlp_img) {
             static const int mw = getenv("ORYON_PDSC_WAVES") ? atoi(getenv("ORYON_PDSC_WAVES")) : 8;
             if (mw == 8 && n_cap % 256 == 0) {

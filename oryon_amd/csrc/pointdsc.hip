@@ -289,6 +289,13 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
                             put_half(ch, ch + PDSC_PQ_CHUNK_BYTES / 2, (size_t)o * 256 + (size_t)((q ^ (o & 15)) << 4) + e * 2,
                                      wq[((size_t)part * C + o) * C + perm_src(q, e)]);
             }
+            // chunk 4: PointCN once more with K in accumulator-register order, for pdsc_mlp3_pcn_qkv_x3_kernel (its input is the previous
+            // layer's output still in registers)
+            char *c4 = im + (size_t)4 * PDSC_PQ_CHUNK_BYTES;
+            for (int o = 0; o < C; ++o)
+                for (int q = 0; q < 16; ++q)
+                    for (int e = 0; e < 8; ++e)
+                        put_half(c4, c4 + PDSC_PQ_CHUNK_BYTES / 2, (size_t)o * 256 + (size_t)((q ^ (o & 15)) << 4) + e * 2, wp[(size_t)o * C + perm_src(q, e)]);
         }
         if (h->dev_pq) { (void)hipFree(h->dev_pq); h->dev_pq = nullptr; }
         ORYON_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&h->dev_pq), pq.size()));
