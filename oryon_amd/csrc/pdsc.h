@@ -15,6 +15,7 @@ struct PdscLayer {
     const float *w_m2, *b_m2;     // [C/2,C/2] BN-folded
     const float *w_m3, *b_m3;     // [C,C/2]
     const char *mlp_img;          // fc_message weights as the LDS image of pdsc_mlp3_x3_kernel (C == 128 only, else nullptr)
+    const char *mlp_img_p;        // the same with W1's K axis in accumulator-register order (input = the attention output still in registers)
     const char *pq_img;           // PointCN + q|k|v weights as the four 64 KB LDS chunks of pdsc_pcn_qkv_x3_kernel (C == 128 only)
 };
 
@@ -43,6 +44,7 @@ struct PdscWorkspace {
     float *qkv;       // [B,n_cap,3C]
     float *msg;       // [B,n_cap,C]
     char *kv_img;     // [B,n_cap/64,PDSC_KV_TILE_BYTES] K / V of every 64-key tile as the attention kernel's LDS image (C == 128; else unused)
+    char *kv_img2;    // second image: the one-launch-per-layer kernel reads layer l's K / V while its workgroups write layer l + 1's
     float *sc;        // [B,n_cap/32,n_cap/64,8,64,4] spatial-consistency tiles in attention-register layout
     float *att_o;     // [att_splits,B,n_cap,C]   key-split attention partials (att_splits > 1 only)
     float *att_ml;    // [att_splits,B,n_cap,2]   running max, exp-sum

@@ -1681,6 +1681,442 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_mlp3_pcn_qkv_x3_kernel(const 
     }
 }
 
+// Attention + fc_message of layer l + PointCN + q|k|v of layer l + 1 as ONE kernel (round 4): the merged attention output of a query block
+// already sits in the accumulator layout the per-point chain consumes (lane = point, registers = channels), so the message never goes to
+// memory either: W1 comes with its K axis in accumulator-register order (second fc_message image).  The four key-half-0 waves run the chain
+// for the workgroup's 128 points; the other four keep moving weights (LDS-DMA) and keep the barriers.  HAS_NEXT = false (last layer): the
+// chain stops after fc_message and writes the features.  One launch per encoder layer instead of three.
+template <int C, bool HAS_NEXT>
+__global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__restrict__ QKV, const char *__restrict__ kv_img_in,
+                                                                 const float *__restrict__ sc, const int32_t *__restrict__ n_rows, int n_cap,
+                                                                 float inv_sqrt_c, int n_pairs, const float *resid, const char *__restrict__ mlp_img,
+                                                                 const float *__restrict__ b1, const float *__restrict__ b2,
+                                                                 const float *__restrict__ b3, const char *__restrict__ pq_img,
+                                                                 const float *__restrict__ bp, const float *__restrict__ bq, float *feat1,
+                                                                 float *qkv, char *kv_img, float *__restrict__ feat_out)
+{
+    constexpr int WAVES = 8, HALF = PDSC_PQ_CHUNK_BYTES / 2;
+    constexpr int AREA0 = PDSC_MLP_IMG_BYTES, AREA1 = 0;               // byte offsets of the two 64 KB weight areas (see pdsc_mlp3_pcn_qkv_x3_kernel)
+    const char *kv_img_rd = kv_img_in;
+#define kv_img kv_img_rd
+    static_assert(C == 128, "tile image geometry");
+    constexpr int CB = C / 32;
+    constexpr int NS = C / 16;
+    constexpr int KLD = C + 8;
+    extern __shared__ __attribute__((aligned(1024))) char att_lds[];
+    const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+    const int b = (lin / 8 / (int)gridDim.x) * 8 + (lin & 7);
+    const int qblk = (lin / 8) % (int)gridDim.x;
+    if (b >= n_pairs) return;
+    const int n = n_rows[b];
+    const int q0 = qblk * ATT_Q;
+    if (q0 >= n) return;
+    const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave8);
+    const int wave = wave8 & 3, kb = wave8 >> 2;          // query block of the workgroup, key half of every tile
+    const int qrow = q0 + wave * 32 + l31;
+    const float *base = QKV + (size_t)b * n_cap * 3 * C;
+    const char *img = kv_img + (size_t)b * (n_cap / ATT_KT) * PDSC_KV_TILE_BYTES;
+    const float4 *sc_q = reinterpret_cast<const float4 *>(sc) + (((size_t)b * (n_cap / 32) + (q0 / 32 + wave)) * (n_cap / ATT_KT)) * 8 * 64 + lane;
+    const bool q_live = q0 + wave * 32 < n;
+    float4 scv[4];
+    auto dma_tile = [&](int j0, int buf) {
+        const char *src = img + (size_t)(j0 / ATT_KT) * PDSC_KV_TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int piece = wave_u * 9 + j;
+            if (piece < PDSC_KV_TILE_BYTES / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(att_lds + buf * PDSC_KV_TILE_BYTES + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto fetch_sc = [&](int j0) {
+        const float4 *sp = sc_q + (size_t)(j0 / ATT_KT) * 8 * 64 + (size_t)kb * 4 * 64;
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) scv[v4] = q_live ? sp[(size_t)v4 * 64] : make_float4(-1.f, -1.f, -1.f, -1.f);
+    };
+    xhalf8 qh[NS], ql[NS];
+    {
+        const float4 *qv = reinterpret_cast<const float4 *>(base + (size_t)qrow * 3 * C);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const float4 a = qv[4 * s_ + 2 * hi], c = qv[4 * s_ + 2 * hi + 1];
+            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h_, l_;
+                split_half(x[e], h_, l_);
+                qh[s_][e] = h_;
+                ql[s_][e] = l_;
+            }
+        }
+    }
+    f32x16 acc_o[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    dma_tile(0, 0);
+    fetch_sc(0);
+    int buf = 0;
+    for (int j0 = 0; j0 < n; j0 += ATT_KT, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (j0 + ATT_KT < n) dma_tile(j0 + ATT_KT, buf ^ 1);
+        const _Float16 *Kh = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES);
+        const _Float16 *Kl = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_KL);
+        const _Float16 *Vh = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_VH);
+        const _Float16 *Vl = reinterpret_cast<const _Float16 *>(att_lds + buf * PDSC_KV_TILE_BYTES + PDSC_KV_VL);
+        // S^T (this wave's 32 keys x 32 queries)
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+        xhalf8 kf[2][2];                              // [buffer][hi | lo]
+        auto read_k = [&](int s_, int bf) {
+            kf[bf][0] = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+            kf[bf][1] = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+        };
+        read_k(0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int bf = s_ & 1;
+            if (s_ + 1 < NS) read_k(s_ + 1, bf ^ 1);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[bf][0], qh[s_], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[bf][0], ql[s_], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[bf][1], qh[s_], s, 0, 0, 0);
+        }
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float4 q4 = scv[r >> 2];
+            const float scq = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+            float v = scq * (s[r] * inv_sqrt_c);
+            v = (scq >= 0.0f) ? v : -INFINITY;
+            s[r] = v;
+            m_tile = fmaxf(m_tile, v);
+        }
+        if (j0 + ATT_KT < n) fetch_sc(j0 + ATT_KT);
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);
+        // a block whose keys are all masked so far keeps m = -inf: exp(-inf - (-inf)) must not produce NaN
+        const float alpha = m_new == -INFINITY ? 1.0f : __expf(m_run - m_new);
+        float l_tile = 0.0f;
+        xhalf8 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float p0 = m_new == -INFINITY ? 0.0f : __expf(s[r] - m_new);
+            const float p1 = m_new == -INFINITY ? 0.0f : __expf(s[r + 1] - m_new);
+            l_tile += p0;
+            l_tile += p1;
+            unsigned uh, ul;
+            split_pair(p0, p1, uh, ul);
+            const xf16x2 h2 = __builtin_bit_cast(xf16x2, uh), l2 = __builtin_bit_cast(xf16x2, ul);
+            ph[r >> 3][r & 7] = h2[0]; ph[r >> 3][(r & 7) + 1] = h2[1];
+            pl[r >> 3][r & 7] = l2[0]; pl[r >> 3][(r & 7) + 1] = l2[1];
+        }
+        l_run = l_run * alpha + l_tile;
+        m_run = m_new;
+        if (__ballot(alpha != 1.0f) != 0ull) {               // the running maximum moved for some query of the wave
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
+        }
+        // O^T += V^T P^T over this wave's two key octet pairs
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int oct = (kb * 2 + t2) * 2 + hi;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const xhalf8 vh = *reinterpret_cast<const xhalf8 *>(Vh + ((size_t)oct * C + cb * 32 + l31) * 8);
+                const xhalf8 vl = *reinterpret_cast<const xhalf8 *>(Vl + ((size_t)oct * C + cb * 32 + l31) * 8);
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[t2], acc_o[cb], 0, 0, 0);
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[t2], acc_o[cb], 0, 0, 0);
+                acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[t2], acc_o[cb], 0, 0, 0);
+            }
+        }
+    }
+#undef kv_img
+    // ---- the tiles are done: the fc_message image starts landing at [0, 80 KB) while the two key halves merge through [80 KB, 146 KB)
+    float l_all = l_run + __shfl_xor(l_run, 32);
+    __syncthreads();
+    static_assert((PDSC_MLP_IMG_BYTES / 1024) % WAVES == 0, "pieces per wave");
+#pragma unroll
+    for (int j = 0; j < PDSC_MLP_IMG_BYTES / 1024 / WAVES; ++j) {
+        const int piece = wave_u * (PDSC_MLP_IMG_BYTES / 1024 / WAVES) + j;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(mlp_img + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(att_lds + piece * 1024), 16, 0, 0);
+    }
+    float *xo = reinterpret_cast<float *>(att_lds + PDSC_MLP_IMG_BYTES) + (size_t)wave * (64 * (CB * 16 + 2));
+    if (kb == 1) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xo[(cb * 16 + r) * 64 + lane] = acc_o[cb][r];
+        xo[(CB * 16) * 64 + lane] = m_run;
+        xo[(CB * 16 + 1) * 64 + lane] = l_all;
+    }
+    __syncthreads();
+    const bool live = kb == 0;
+    const size_t prow = (size_t)b * n_cap + qrow;
+    xhalf8 xh[8], xl[8];                                              // the message as the chain's B fragments (k-step 2 cb + j: registers 8 j .. 8 j + 7 of block cb)
+    if (live) {
+        const float m_b = xo[(CB * 16) * 64 + lane], l_b = xo[(CB * 16 + 1) * 64 + lane];
+        const float m = fmaxf(m_run, m_b);
+        const float wa = m_run == -INFINITY ? 0.0f : __expf(m_run - m), wb = m_b == -INFINITY ? 0.0f : __expf(m_b - m);
+        const float den = wa * l_all + wb * l_b;
+        const float inv_l = den > 0.0f ? 1.0f / den : 0.0f;      // query rows of a dead 32-row block (every key masked): zeros
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int r0 = 8 * j + 4 * g2;
+                    const float v0 = (wa * acc_o[cb][r0 + 0] + wb * xo[(cb * 16 + r0 + 0) * 64 + lane]) * inv_l;
+                    const float v1 = (wa * acc_o[cb][r0 + 1] + wb * xo[(cb * 16 + r0 + 1) * 64 + lane]) * inv_l;
+                    const float v2 = (wa * acc_o[cb][r0 + 2] + wb * xo[(cb * 16 + r0 + 2) * 64 + lane]) * inv_l;
+                    const float v3 = (wa * acc_o[cb][r0 + 3] + wb * xo[(cb * 16 + r0 + 3) * 64 + lane]) * inv_l;
+                    split_pair(v0, v1, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v2, v3, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                xh[cb * 2 + j] = __builtin_bit_cast(xhalf8, uh);
+                xl[cb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+    }
+    __syncthreads();                                                    // the merge area is free: PointCN' lands there
+    auto dma_chunk = [&](int chunk, int area_off) {                   // 64 pieces of 1 KB, 64 / WAVES per wave
+#pragma unroll
+        for (int j = 0; j < 64 / WAVES; ++j) {
+            const int piece = wave_u * (64 / WAVES) + j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pq_img + (size_t)chunk * PDSC_PQ_CHUNK_BYTES + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(att_lds + area_off + piece * 1024), 16, 0, 0);
+        }
+    };
+    if constexpr (HAS_NEXT) dma_chunk(4, AREA0);                       // PointCN with the permuted K axis
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto w1_frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(att_lds + base + o * 256 + (((2 * s_ + hi) ^ (o & 15)) << 4));
+    };
+    auto w23_frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(att_lds + base + o * 128 + (((2 * s_ + hi) ^ ((o >> 1) & 7)) << 4));
+    };
+    auto next_operand = [&](const f32x16 (&acc)[2], const float *bias, xhalf8 (&oh)[4], xhalf8 (&ol)[4]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + rb * 32 + 8 * (2 * j + g2) + 4 * hi);
+                    const int r0 = 8 * j + 4 * g2;
+                    const float v0 = fmaxf(acc[rb][r0] + bv.x, 0.0f), v1 = fmaxf(acc[rb][r0 + 1] + bv.y, 0.0f);
+                    const float v2 = fmaxf(acc[rb][r0 + 2] + bv.z, 0.0f), v3 = fmaxf(acc[rb][r0 + 3] + bv.w, 0.0f);
+                    split_pair(v0, v1, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v2, v3, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                oh[rb * 2 + j] = __builtin_bit_cast(xhalf8, uh);
+                ol[rb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+    };
+    // two 32-row output blocks over NS k-steps (see pdsc_mlp3_x3_kernel); swap: the activations are the A operand (lane = channel)
+    auto two_blocks = [&](auto &&frag, int base_h, int base_l, int rb0, int NS, const xhalf8 *bh, const xhalf8 *bl, f32x16 (&acc)[2], bool swap) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        xhalf8 w[2][2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { w[0][i][0] = frag(base_h, rb0 + i, 0); w[0][i][1] = frag(base_l, rb0 + i, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            if (s_ < NS) {
+                const int cur = s_ & 1;
+                if (s_ + 1 < NS) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { w[cur ^ 1][i][0] = frag(base_h, rb0 + i, s_ + 1); w[cur ^ 1][i][1] = frag(base_l, rb0 + i, s_ + 1); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!swap) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bh[s_], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bh[s_], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][0], bl[s_], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][0], bl[s_], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][0][1], bh[s_], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cur][1][1], bh[s_], acc[1], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][0][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][1][0], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s_], w[cur][0][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s_], w[cur][1][0], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][0][1], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s_], w[cur][1][1], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if (live) {
+    // ---- fc_message of layer l
+    f32x16 a1[2];
+    two_blocks(w1_frag, PDSC_MLP_W1H, PDSC_MLP_W1L, 0, 8, xh, xl, a1, false);
+    xhalf8 h1h[4], h1l[4];
+    next_operand(a1, b1, h1h, h1l);
+    f32x16 a2[2];
+    two_blocks(w23_frag, PDSC_MLP_W2H, PDSC_MLP_W2L, 0, 4, h1h, h1l, a2, false);
+    xhalf8 h2h[4], h2l[4];
+    next_operand(a2, b2, h2h, h2l);
+    // layer 3 + bias + residual = the layer's output features, kept as the 8 B fragments (permuted K order) of the next layer's PointCN
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        float4 rv[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rv[i][g] = *reinterpret_cast<const float4 *>(resid + prow * C + (2 * rp + i) * 32 + 8 * g + 4 * hi);
+        f32x16 a3[2];
+        two_blocks(w23_frag, PDSC_MLP_W3H, PDSC_MLP_W3L, 2 * rp, 4, h2h, h2l, a3, false);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rb = 2 * rp + i;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int g = 2 * j + g2;
+                    const float4 bv = *reinterpret_cast<const float4 *>(b3 + rb * 32 + 8 * g + 4 * hi);
+                    const float v0 = a3[i][4 * g + 0] + bv.x + rv[i][g].x, v1 = a3[i][4 * g + 1] + bv.y + rv[i][g].y;
+                    const float v2 = a3[i][4 * g + 2] + bv.z + rv[i][g].z, v3 = a3[i][4 * g + 3] + bv.w + rv[i][g].w;
+                    split_pair(v0, v1, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v2, v3, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                xh[rb * 2 + j] = __builtin_bit_cast(xhalf8, uh);       // (the message fragments are dead: their registers take the features)
+                xl[rb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+            if constexpr (!HAS_NEXT) {                                 // last layer: the features leave as fp32 rows
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = rb * 32 + 8 * g + 4 * hi;
+                    const float4 bv = *reinterpret_cast<const float4 *>(b3 + c);
+                    float4 o;
+                    o.x = a3[i][4 * g + 0] + bv.x + rv[i][g].x; o.y = a3[i][4 * g + 1] + bv.y + rv[i][g].y;
+                    o.z = a3[i][4 * g + 2] + bv.z + rv[i][g].z; o.w = a3[i][4 * g + 3] + bv.w + rv[i][g].w;
+                    if (live) *reinterpret_cast<float4 *>(feat_out + prow * C + c) = o;
+                }
+            }
+        }
+    }
+    }
+    if constexpr (!HAS_NEXT) return;
+    // ---- PointCN + q|k|v of layer l + 1.  The fc_message image is dead once every wave is here: q lands on top of it.
+    __syncthreads();
+    dma_chunk(1, AREA1);
+    auto frag = [&](int base, int rb, int s_) {
+        const int o = rb * 32 + l31;
+        return *reinterpret_cast<const xhalf8 *>(att_lds + base + o * 256 + (((2 * s_ + hi) ^ (o & 15)) << 4));
+    };
+    xhalf8 fh[8], fl[8];
+    if (live) {
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        f32x16 acc[2];
+        two_blocks(frag, AREA0, AREA0 + HALF, 2 * rp, 8, xh, xl, acc, false);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rb = 2 * rp + i;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint4 uh, ul;
+                unsigned *ph = &uh.x, *pl = &ul.x;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int c = rb * 32 + 8 * (2 * j + g2) + 4 * hi, r0 = 8 * j + 4 * g2;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bp + c);
+                    float4 v;
+                    v.x = fmaxf(acc[i][r0] + bv.x, 0.0f); v.y = fmaxf(acc[i][r0 + 1] + bv.y, 0.0f);
+                    v.z = fmaxf(acc[i][r0 + 2] + bv.z, 0.0f); v.w = fmaxf(acc[i][r0 + 3] + bv.w, 0.0f);
+                    if (live) *reinterpret_cast<float4 *>(feat1 + prow * C + c) = v;
+                    split_pair(v.x, v.y, ph[2 * g2], pl[2 * g2]);
+                    split_pair(v.z, v.w, ph[2 * g2 + 1], pl[2 * g2 + 1]);
+                }
+                fh[rb * 2 + j] = __builtin_bit_cast(xhalf8, uh);
+                fl[rb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
+            }
+        }
+    }
+    }
+    // q from area 1 while k lands in area 0, k from area 0 while v lands in area 1, v from area 1
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const int area_off = ((part + 1) & 1) ? AREA1 : AREA0, other_off = ((part + 1) & 1) ? AREA0 : AREA1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this part's chunk has landed (the feat1 stores drain with it)
+        __syncthreads();                                                // every wave is done with the other area; this part's chunk is visible
+        if (part < 2) dma_chunk(part + 2, other_off);
+        const int p_pair = q0 + wave * 32;                           // (wave = query block 0..3 here)
+        char *tile = kv_img ? kv_img + ((size_t)b * (n_cap / 64) + (p_pair >> 6)) * PDSC_KV_TILE_BYTES : nullptr;
+        const bool as_v = kv_img && part == 2;
+        if (live) {
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            f32x16 acc[2];
+            two_blocks(frag, area_off, area_off + HALF, 2 * rp, 8, fh, fl, acc, as_v);
+            if (as_v) {
+                const int kb = (p_pair >> 5) & 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ch = (2 * rp + i) * 32 + l31;
+                    const float bv = bq[2 * C + ch];
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        uint4 uh, ul;
+                        split_pair(acc[i][8 * t2 + 0] + bv, acc[i][8 * t2 + 1] + bv, uh.x, ul.x);
+                        split_pair(acc[i][8 * t2 + 2] + bv, acc[i][8 * t2 + 3] + bv, uh.y, ul.y);
+                        split_pair(acc[i][8 * t2 + 4] + bv, acc[i][8 * t2 + 5] + bv, uh.z, ul.z);
+                        split_pair(acc[i][8 * t2 + 6] + bv, acc[i][8 * t2 + 7] + bv, uh.w, ul.w);
+                        const int oct = (kb * 2 + t2) * 2 + hi;
+                        if (live) *reinterpret_cast<uint4 *>(tile + PDSC_KV_VH + ((size_t)oct * C + ch) * 16) = uh;
+                        if (live) *reinterpret_cast<uint4 *>(tile + PDSC_KV_VL + ((size_t)oct * C + ch) * 16) = ul;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cc = (2 * rp + i) * 32 + 8 * g + 4 * hi, c = part * C + cc;
+                        const float4 bv = *reinterpret_cast<const float4 *>(bq + c);
+                        float4 o;
+                        o.x = acc[i][4 * g + 0] + bv.x; o.y = acc[i][4 * g + 1] + bv.y;
+                        o.z = acc[i][4 * g + 2] + bv.z; o.w = acc[i][4 * g + 3] + bv.w;
+                        if (kv_img && part == 1) {
+                            uint2 uh, ul;
+                            split_pair(o.x, o.y, uh.x, ul.x);
+                            split_pair(o.z, o.w, uh.y, ul.y);
+                            const size_t off = (size_t)((p_pair & 63) + l31) * 272 + cc * 2;
+                            if (live) *reinterpret_cast<uint2 *>(tile + off) = uh;
+                            if (live) *reinterpret_cast<uint2 *>(tile + PDSC_KV_KL + off) = ul;
+                        } else {
+                            if (live) *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;
+                        }
+                    }
+            }
+        }
+        }
+    }
+}
+
 // Combine the key-split partials: msg = sum_s e^{m_s - m} O_s / sum_s e^{m_s - m} l_s,  m = max_s m_s.
 __global__ __launch_bounds__(256) void pdsc_attention_merge_kernel(const float *__restrict__ part_o, const float *__restrict__ part_ml,
                                                                     const int32_t *__restrict__ n_rows, int n_cap, int C, int KS,
@@ -1782,11 +2218,17 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         bool use_img = false;
         // round 4: fc_message of layer l - 1 and PointCN + q|k|v of layer l came as ONE launch at the end of the previous iteration
         static const bool fuse_chain = !getenv("ORYON_PDSC_FUSED_CHAIN") || atoi(getenv("ORYON_PDSC_FUSED_CHAIN")) != 0;     // dev: 0 = separate launches
+        static const bool fuse_att = !getenv("ORYON_PDSC_FUSED_ATT") || atoi(getenv("ORYON_PDSC_FUSED_ATT")) != 0;           // dev: 0 = attention as its own launch
         const bool chain_ok = C == 128 && x3 && fused_pq && fuse_chain && n_cap % 256 == 0 && ws.att_splits == 1 && ws.kv_img != nullptr && att_img &&
                               (!getenv("ORYON_PDSC_FUSED_MLP") || atoi(getenv("ORYON_PDSC_FUSED_MLP")) != 0) &&
                               (!getenv("ORYON_PDSC_WAVES") || atoi(getenv("ORYON_PDSC_WAVES")) == 8);
+        // K / V images alternate between two buffers when the attention is part of the one-launch-per-layer kernel (its workgroups write
+        // layer l + 1's tiles while others still read layer l's)
+        const bool att_chain = chain_ok && fuse_att && ws.kv_img2 != nullptr && L.mlp_img_p &&
+                               (!getenv("ORYON_PDSC_ATT8") || atoi(getenv("ORYON_PDSC_ATT8")) != 0);
+        char *kv_cur = (att_chain && (l & 1)) ? ws.kv_img2 : ws.kv_img, *kv_nxt = (att_chain && !(l & 1)) ? ws.kv_img2 : ws.kv_img;
         if (l > 0 && chain_ok && L.pq_img && M.layers[l - 1].mlp_img) {
-            use_img = true;                                            // (launched below, after the previous layer's attention)
+            use_img = true;                                            // (launched at the end of the previous iteration)
         } else
         if (C == 128 && x3 && fused_pq && L.pq_img) {
             // PointCN (conv + BN + ReLU, BN folded) and the q | k | v projections in one launch
@@ -1811,6 +2253,24 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
             // q | k | v projections as one GEMM with N = 3C
             rc = launch_linear(false, false, ws.feat1, C, fb, L.w_qkv, L.b_qkv, nullptr, 0, 0, ws.qkv, 3 * C, qb, C, 3 * C, B, n_cap, n_rows, st);
             if (rc) return rc;
+        }
+        if (att_chain && use_img) {
+            // attention + fc_message (+ PointCN + q|k|v of the next layer) in one launch
+            constexpr int AC_LDS = PDSC_MLP_IMG_BYTES + 4 * 64 * (128 / 32 * 16 + 2) * 4 > 2 * PDSC_KV_TILE_BYTES
+                                       ? PDSC_MLP_IMG_BYTES + 4 * 64 * (128 / 32 * 16 + 2) * 4 : 2 * PDSC_KV_TILE_BYTES;
+            const dim3 grid(n_cap / ATT_Q, 1, (B + 7) / 8 * 8);
+            if (l + 1 < M.cfg.num_layers && M.layers[l + 1].pq_img) {
+                const PdscLayer &N = M.layers[l + 1];
+                allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_att_chain_x3_kernel<128, true>), AC_LDS);
+                hipLaunchKernelGGL((pdsc_att_chain_x3_kernel<128, true>), grid, dim3(512), AC_LDS, st, ws.qkv, kv_cur, ws.sc, n_rows, n_cap, inv_sqrt_c, B,
+                                   ws.feat1, L.mlp_img_p, L.b_m1, L.b_m2, L.b_m3, N.pq_img, N.b_pcn, N.b_qkv, ws.feat1, ws.qkv, kv_nxt, ws.feat);
+            } else {
+                allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_att_chain_x3_kernel<128, false>), AC_LDS);
+                hipLaunchKernelGGL((pdsc_att_chain_x3_kernel<128, false>), grid, dim3(512), AC_LDS, st, ws.qkv, kv_cur, ws.sc, n_rows, n_cap, inv_sqrt_c, B,
+                                   ws.feat1, L.mlp_img_p, L.b_m1, L.b_m2, L.b_m3, nullptr, nullptr, nullptr, ws.feat1, ws.qkv, kv_nxt, ws.feat);
+            }
+            if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
+            continue;
         }
         const int KS = ws.att_splits;
         dim3 ag(n_cap / ATT_Q, KS, B);

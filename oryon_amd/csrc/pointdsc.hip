@@ -50,6 +50,7 @@ size_t carve(const oryon_pointdsc_config_t &cfg, int B, int n_cap, void *ws_ptr,
     w.qkv = c.take<float>(rows * 3 * C);
     w.msg = c.take<float>(rows * C);
     w.kv_img = c.take<char>(C == 128 ? rows / 64 * PDSC_KV_TILE_BYTES : 0);
+    w.kv_img2 = c.take<char>(C == 128 ? rows / 64 * PDSC_KV_TILE_BYTES : 0);
     w.sc = c.take<float>(rows * n_cap);
     w.att_splits = pdsc_attention_splits(B, n_cap);
     w.att_o = c.take<float>(w.att_splits > 1 ? rows * C * w.att_splits : 0);
@@ -244,7 +245,7 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
     if (h->dev_mlp) { (void)hipFree(h->dev_mlp); h->dev_mlp = nullptr; }
     if (h->dev_pq) { (void)hipFree(h->dev_pq); h->dev_pq = nullptr; }
     if (C == 128) {
-        std::vector<char> img((size_t)L * PDSC_MLP_IMG_BYTES, 0);
+        std::vector<char> img((size_t)2 * L * PDSC_MLP_IMG_BYTES, 0);       // [L] natural W1 | [L] W1 with the permuted K axis
         auto put_half = [](char *dst_hi, char *dst_lo, size_t byte, float x) {
             const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
             memcpy(dst_hi + byte, &hi, 2);
@@ -268,6 +269,14 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
                 for (int q = 0; q < 8; ++q)
                     for (int e = 0; e < 8; ++e)
                         put_half(im + PDSC_MLP_W3H, im + PDSC_MLP_W3L, (size_t)o * 128 + (size_t)((q ^ ((o >> 1) & 7)) << 4) + e * 2, w3[(size_t)o * H + perm_src(q, e)]);
+            // second image: W2 / W3 as above, W1 with K in accumulator-register order (pdsc_att_chain_x3_kernel feeds it the merged
+            // attention output straight from the registers)
+            char *ip = img.data() + (size_t)(L + l) * PDSC_MLP_IMG_BYTES;
+            memcpy(ip, im, PDSC_MLP_IMG_BYTES);
+            for (int o = 0; o < H; ++o)
+                for (int q = 0; q < 16; ++q)
+                    for (int e = 0; e < 8; ++e)
+                        put_half(ip + PDSC_MLP_W1H, ip + PDSC_MLP_W1L, (size_t)o * 256 + (size_t)((q ^ (o & 15)) << 4) + e * 2, w1[(size_t)o * C + perm_src(q, e)]);
         }
         ORYON_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&h->dev_mlp), img.size()));
         ORYON_CHECK_HIP(hipMemcpyAsync(h->dev_mlp, img.data(), img.size(), hipMemcpyHostToDevice, as_stream(stream)));
@@ -316,6 +325,7 @@ extern "C" int oryon_pointdsc_finalize(oryon_pointdsc_t *h, void *stream)
         Ly.w_m2 = d + offs[i++]; Ly.b_m2 = d + offs[i++];
         Ly.w_m3 = d + offs[i++]; Ly.b_m3 = d + offs[i++];
         Ly.mlp_img = h->dev_mlp ? h->dev_mlp + (size_t)l * PDSC_MLP_IMG_BYTES : nullptr;
+        Ly.mlp_img_p = h->dev_mlp ? h->dev_mlp + (size_t)(L + l) * PDSC_MLP_IMG_BYTES : nullptr;
         Ly.pq_img = h->dev_pq ? h->dev_pq + (size_t)l * PDSC_PQ_IMG_BYTES : nullptr;
     }
     M.w_c1 = d + offs[i++]; M.b_c1 = d + offs[i++];
