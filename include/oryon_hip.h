@@ -240,6 +240,23 @@ int oryon_match_corrs_mx6(const float *a_hat, const uint8_t *a_mx6, const float 
                           float *min_dist, int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
                           int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream);
 
+/* K0 + K1x3 operands in ONE pass (round 4).  On descriptor fields where the screen cannot separate a sampled anchor's near-ties (smooth decoder
+ * outputs) the matcher needs the query rows once more as error-compensated half rows (hi = half(u), lo = half(u - hi) of the canonical unit
+ * row u) for its fp16x3 second level - a second read of the maps inside oryon_match_corrs_mx6.  oryon_gather_mx6_x3 writes them in the same
+ * pass as the mx6 slots (replaces the same reference lines as oryon_gather_mx6, utils/pcd.py:192-193, :28-29): hi_lo_f16 = [2][n_maps,
+ * rows_cap, 256] halves (all hi rows, then all lo rows), lo_sq_max [n_maps] = largest |u - hi|^2 of the map's rows.  C_pad = 256 only.
+ * oryon_match_corrs_mx6_x3 = oryon_match_corrs_mx6 that takes those rows instead of making them: same results bit for bit. */
+int oryon_gather_mx6_x3(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
+                        int rows_cap, int C_pad, uint8_t *out_mx6, float *err_max, float *row_norm, void *hi_lo_f16, float *lo_sq_max,
+                        int round_f16, void *stream);
+int oryon_match_corrs_mx6_x3(const float *a_hat, const uint8_t *a_mx6, const float *a_err_max, const float *feat_q, int C_true, int HW, int layout,
+                             const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q, const float *q_norm,
+                             const uint8_t *q_mx6, const float *q_err_max, const void *q_hi_lo_f16, const float *q_lo_sq_max, int B, int C,
+                             int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs, int corr_rows,
+                             uint64_t seed, const int64_t *pair_key, float *min_dist, int32_t *argmin, uint8_t *valid, int32_t *corrs,
+                             int32_t *n_valid, int32_t *n_sel, int32_t *status, int32_t *n_undecided, int round_f16, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 /* "Sample first" (optional engine schedule, off by default).  Only max_corrs correspondences per pair leave the matcher
  * (utils/pcd.py:205-214), drawn uniformly from the valid anchor rows - so a uniformly random first-stage subset of the anchors that
  * already holds >= max_corrs valid rows yields an identically distributed sample.  The engine runs the matcher on such a subset;
@@ -394,6 +411,10 @@ typedef struct {
                                 sees a uniformly random N-anchor subset per pair; pairs whose subset holds fewer than n_corrs valid rows are
                                 redone on all anchors, gated on the device.  Same distribution of the sampled correspondences, not the same
                                 sample as the default schedule; steps submitted with force_eager ignore it */
+    int x3_prefetch;         /* 1 (default in the Python binding): when the steps that completed most recently left more than a quarter of their
+                                anchors to the second level (n_und, read back through pinned memory without a synchronisation), K0 writes the
+                                query rows' hi / lo halves in its own pass (oryon_gather_mx6_x3) and the matcher skips its second read of the maps
+                                (oryon_match_corrs_mx6_x3).  Results are unchanged; C <= 256 and the MX-fp6 screen only.  0 = never */
 } oryon_engine_config_t;
 size_t oryon_engine_config_bytes(void);      /* sizeof(oryon_engine_config_t) in the built library: a binding's mirror of the struct must match */
 size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver);
@@ -413,6 +434,8 @@ int oryon_engine_timing(oryon_engine_t *handle, int64_t step, float *out8);
  * 2/3 match + lift begin / end, 4/5 screening kernel begin / end, 6/7 registration begin / end): timelines across steps. */
 int oryon_engine_elapsed(oryon_engine_t *handle, int64_t step_a, int event_a, int64_t step_b, int event_b, float *ms);
 int oryon_engine_host_stats(const oryon_engine_t *handle, int64_t *n_submit, double *submit_ms_total, double *submit_ms_last);
+/* number of submits so far whose K0 pass wrote the hi / lo rows (cfg.x3_prefetch) */
+int oryon_engine_x3_steps(const oryon_engine_t *handle, int64_t *n_steps);
 
 /* B4  error-compensated fp16x3 linear layer for the frozen fp32 towers (CLIP ViT-L/14@336, Swin) of Oryon.forward
  *     (net.py:142-167, models/vlm.py:43-61; the reference evaluates them with fp32 torch linears):

@@ -22,7 +22,7 @@ class OryonError(RuntimeError):
 class EngineConfig(ctypes.Structure):
     _fields_ = [("B", c_int), ("C", c_int), ("FH", c_int), ("FW", c_int), ("HA", c_int), ("WA", c_int), ("HQ", c_int), ("WQ", c_int),
                 ("layout", c_int), ("dist_th", c_float), ("n_corrs", c_int), ("src_sampling", c_int), ("seed", c_uint64),
-                ("round_f16", c_int), ("n_slots", c_int), ("overlap", c_int), ("gather_sets", c_int), ("reg_streams", c_int), ("reg_lag", c_int), ("screen", c_int), ("sample_first", c_int)]
+                ("round_f16", c_int), ("n_slots", c_int), ("overlap", c_int), ("gather_sets", c_int), ("reg_streams", c_int), ("reg_lag", c_int), ("screen", c_int), ("sample_first", c_int), ("x3_prefetch", c_int)]
 
 
 class PointDSCConfig(ctypes.Structure):
@@ -67,6 +67,10 @@ _PROTOS = {
     "oryon_match_corrs_mx6": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int,
                                       _P, _P, c_float, c_int, c_int, c_int, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P,
                                       c_size_t, _P]),
+    "oryon_gather_mx6_x3": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
+    "oryon_match_corrs_mx6_x3": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
+                                         _P, _P, c_float, c_int, c_int, c_int, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P,
+                                         c_size_t, _P]),
     "oryon_match_screened8_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oryon_match_screened8": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P,
                                       _P, _P, c_size_t, _P]),
@@ -97,6 +101,7 @@ _PROTOS = {
     "oryon_engine_elapsed": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, POINTER(c_float)]),
     "oryon_engine_config_bytes": (c_size_t, []),
     "oryon_engine_host_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+    "oryon_engine_x3_steps": (c_int, [c_void_p, POINTER(c_int64)]),
     "oryon_pointdsc_create": (c_int, [POINTER(c_void_p), POINTER(PointDSCConfig)]),
     "oryon_pointdsc_destroy": (None, [c_void_p]),
     "oryon_pointdsc_load_param": (c_int, [c_void_p, c_char_p, _P, c_int64]),

@@ -34,6 +34,8 @@ inline size_t up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct GatherBuf {
     int8_t *a8, *q8;
     float *a_sc, *q_sc, *a_eps, *q_eps, *a_norm, *q_norm, *a_hat;
+    void *q_hilo;                // cfg.x3_prefetch: [2][B, cap_q, 256] halves (hi rows | lo rows of the query rows) + q_lo_max [B]
+    float *q_lo_max;
     // cfg.sample_first: the first-stage anchor subset's operands (cap_a1 rows); a8 / a_hat then serve the gated second stage
     int8_t *a8_1;
     float *a_sc_1, *a_eps_1, *a_norm_1, *a_hat_1;
@@ -84,6 +86,13 @@ struct oryon_engine {
     bool timed[TIMING_RING];
     bool used[MAX_SLOTS];
     bool timing;
+    // feedback for cfg.x3_prefetch: per slot the step's n_und / n_a arrays in pinned host memory + an event behind the copies
+    int32_t *fb_host;                         // [MAX_SLOTS][2][B]
+    hipEvent_t ev_fb[MAX_SLOTS];
+    int64_t fb_step[MAX_SLOTS];               // submit number whose counts the slot's pinned block will hold (-1: none)
+    int64_t fb_seen;                          // newest submit whose counts have been read
+    bool hard_mode;
+    int64_t n_x3;
     int64_t n_submit;
     double host_ns_total, host_ns_last;
 };
@@ -132,6 +141,12 @@ int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver,
         TAKE(a_norm, float, B * L.cap_a);
         TAKE(q_norm, float, B * L.cap_q);
         TAKE(a_hat, float, B * L.cap_a * L.c_pad);
+        b.q_hilo = nullptr;
+        b.q_lo_max = nullptr;
+        if (c.x3_prefetch && L.c_pad == 256) {
+            b.q_hilo = take((size_t)2 * B * L.cap_q * L.c_pad * 2);
+            TAKE(q_lo_max, float, B);
+        }
         b.a8_1 = nullptr;
         b.a_sc_1 = b.a_eps_1 = b.a_norm_1 = b.a_hat_1 = nullptr;
         if (L.cap_a1) {
@@ -201,7 +216,7 @@ int check_cfg(const oryon_engine_config_t *c)
     ORYON_CHECK_ARG((c->layout == ORYON_LAYOUT_NCHW || c->layout == ORYON_LAYOUT_NHWC) && (c->screen == 0 || c->screen == 1));
     ORYON_CHECK_ARG(c->overlap >= 0 && c->overlap <= 2 && (c->overlap == 0 || c->n_slots >= 2));      // results of step k live until submit k + n_slots
     ORYON_CHECK_ARG((size_t)c->C * (size_t)c->FH * (size_t)c->FW * 4u < (1ull << 32));
-    ORYON_CHECK_ARG(c->sample_first >= 0);
+    ORYON_CHECK_ARG(c->sample_first >= 0 && (c->x3_prefetch == 0 || c->x3_prefetch == 1));
     return ORYON_OK;
 }
 }  // namespace
@@ -238,6 +253,11 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     e->sg = e->sm = nullptr;
     e->timing = false;
     e->n_submit = 0;
+    e->fb_host = nullptr;
+    e->fb_seen = -1;
+    e->hard_mode = false;
+    e->n_x3 = 0;
+    for (int s = 0; s < MAX_SLOTS; ++s) { e->ev_fb[s] = nullptr; e->fb_step[s] = -1; }
     e->host_ns_total = e->host_ns_last = 0.0;
     hipError_t err = hipSuccess;
     auto ok = [&](hipError_t x) { if (err == hipSuccess) err = x; };
@@ -261,6 +281,10 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     }
     for (int r = 0; r < TIMING_RING; ++r)
         for (int i = 0; i < 8; ++i) ok(hipEventCreate(&e->tev[r][i]));
+    if (cfg->x3_prefetch && e->L.c_pad == 256) {
+        ok(hipHostMalloc(reinterpret_cast<void **>(&e->fb_host), (size_t)MAX_SLOTS * 2 * cfg->B * sizeof(int32_t), hipHostMallocDefault));
+        for (int s = 0; s < cfg->n_slots; ++s) ok(hipEventCreateWithFlags(&e->ev_fb[s], hipEventDisableTiming));
+    }
     // rows of `corrs` beyond n_corrs are never written by the sampler: zero them once, so that a slot's first use reads like the freshly
     // zeroed tensor the per-call schedule hands out.  (When a slot is re-used, the rows of a pair that selects nothing - n_sel == 0 - keep
     // what the slot's previous step left there: rows >= n_sel are undefined, K2 reads n_sel rows only; the header says so.)
@@ -291,6 +315,9 @@ extern "C" void oryon_engine_destroy(oryon_engine_t *e)
             if (e->tev[r][i]) (void)hipEventDestroy(e->tev[r][i]);
     if (e->sm) { (void)hipStreamSynchronize(e->sm); (void)hipStreamDestroy(e->sm); }
     if (e->sg) { (void)hipStreamSynchronize(e->sg); (void)hipStreamDestroy(e->sg); }
+    for (int s = 0; s < MAX_SLOTS; ++s)
+        if (e->ev_fb[s]) (void)hipEventDestroy(e->ev_fb[s]);
+    if (e->fb_host) (void)hipHostFree(e->fb_host);
     delete e;
 }
 
@@ -399,9 +426,29 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
         roi_a_k0 = b.roi_a1; n_a_k0 = b.n_a1; cap_a_k0 = e->L.cap_a1;
         a8_k0 = g.a8_1; a_sc_k0 = g.a_sc_1; a_eps_k0 = g.a_eps_1; a_norm_k0 = g.a_norm_1; a_hat_k0 = g.a_hat_1;
     }
+    // cfg.x3_prefetch: what the most recently COMPLETED steps report (their n_und / n_a arrays in pinned memory, behind an event that is
+    // only queried, never waited for) decides whether this step's K0 pass also writes the hi / lo rows of the second level
+    bool x3_pre = false;
+    if (e->fb_host && mx6) {
+        for (int s = 0; s < c.n_slots; ++s) {
+            if (e->fb_step[s] > e->fb_seen && hipEventQuery(e->ev_fb[s]) == hipSuccess) {
+                const int32_t *h = e->fb_host + (size_t)s * 2 * B;
+                long und = 0, all = 0;
+                for (int i = 0; i < B; ++i) { und += h[i]; all += h[B + i]; }
+                e->hard_mode = all > 0 && 4 * und > all;
+                e->fb_seen = e->fb_step[s];
+            }
+        }
+        x3_pre = e->hard_mode && !sf && g.q_hilo != nullptr;
+    }
     if (ablate & 1) {
     } else if (mx6) {
         // the row buffers hold 32-byte mx6 slots instead of int8 rows (same size); the per-map error norms go where eps_max went
+        if (x3_pre) {
+            if ((rc = oryon_gather_mx6_x3(feat_q, B, c.C, HW, c.layout, b.roi_q, HW, b.n_q, e->L.cap_q, e->L.c_pad, reinterpret_cast<uint8_t *>(g.q8),
+                                          g.q_eps, g.q_norm, g.q_hilo, g.q_lo_max, c.round_f16, sg))) return rc;
+            e->n_x3 += 1;
+        } else
         if ((rc = oryon_gather_mx6(feat_q, B, c.C, HW, c.layout, b.roi_q, HW, b.n_q, e->L.cap_q, e->L.c_pad, reinterpret_cast<uint8_t *>(g.q8),
                                    g.q_eps, g.q_norm, nullptr, c.round_f16, sg))) return rc;
         if ((rc = oryon_gather_mx6(feat_a, B, c.C, HW, c.layout, roi_a_k0, HW, n_a_k0, cap_a_k0, e->L.c_pad, reinterpret_cast<uint8_t *>(a8_k0),
@@ -433,6 +480,11 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
     // one matcher call (the engine's screen setting) on the given anchor operands
     auto match_call = [&](const float *a_hat_, const int8_t *a8_, const float *a_sc_, const float *a_eps_, const int32_t *roi_a_, int cap_a_,
                           const int32_t *n_a_, int32_t *corrs_, int32_t *n_valid_, int32_t *n_sel_, int32_t *status_, int32_t *n_und_) -> int {
+        if (mx6 && x3_pre)
+            return oryon_match_corrs_mx6_x3(a_hat_, reinterpret_cast<const uint8_t *>(a8_), a_eps_, feat_q, c.C, HW, c.layout, roi_a_, HW, b.roi_q, HW,
+                                            g.q_norm, reinterpret_cast<const uint8_t *>(g.q8), g.q_eps, g.q_hilo, g.q_lo_max, B, e->L.c_pad, cap_a_,
+                                            e->L.cap_q, n_a_, b.n_q, c.dist_th, c.FW, c.n_corrs, e->L.n_cap, c.seed, pair_key, b.min_dist, b.argmin,
+                                            b.valid, corrs_, n_valid_, n_sel_, status_, n_und_, c.round_f16, e->L.match_ws, e->L.match_ws_bytes, sm);
         if (mx6)
             return oryon_match_corrs_mx6(a_hat_, reinterpret_cast<const uint8_t *>(a8_), a_eps_, feat_q, c.C, HW, c.layout, roi_a_, HW, b.roi_q, HW,
                                          g.q_norm, reinterpret_cast<const uint8_t *>(g.q8), g.q_eps, B, e->L.c_pad, cap_a_, e->L.cap_q, n_a_, b.n_q,
@@ -461,6 +513,13 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
                                            sm))) return rc;
     } else if ((rc = match_call(g.a_hat, g.a8, g.a_sc, g.a_eps, b.roi_a, e->L.cap_a, b.n_a, b.corrs, b.n_valid, b.n_sel, b.status, b.n_und)))
         return rc;
+    if (e->fb_host && mx6 && !(ablate & 2)) {
+        int32_t *h = e->fb_host + (size_t)slot * 2 * B;
+        ORYON_CHECK_HIP(hipMemcpyAsync(h, b.n_und, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+        ORYON_CHECK_HIP(hipMemcpyAsync(h + B, b.n_a, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+        ORYON_CHECK_HIP(hipEventRecord(e->ev_fb[slot], sm));
+        e->fb_step[slot] = e->n_submit;
+    }
     if (!(ablate & 2) && (rc = oryon_lift_pairs(b.corrs, b.n_sel, B, e->L.n_cap, c.FH, c.FW, depth_a, c.HA, c.WA, depth_q, c.HQ, c.WQ, cam_a, cam_q,
                                                 b.status, b.pcd_a, b.pcd_q, b.n_lift, sm))) return rc;
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[3], sm));
@@ -494,6 +553,13 @@ extern "C" int oryon_engine_host_stats(const oryon_engine_t *e, int64_t *n_submi
     if (n_submit) *n_submit = e->n_submit;
     if (submit_ms_total) *submit_ms_total = e->host_ns_total * 1e-6;
     if (submit_ms_last) *submit_ms_last = e->host_ns_last * 1e-6;
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_x3_steps(const oryon_engine_t *e, int64_t *n_steps)
+{
+    ORYON_CHECK_ARG(e && n_steps);
+    *n_steps = e->n_x3;
     return ORYON_OK;
 }
 

@@ -56,6 +56,8 @@ struct RowRegs<N, 1> {
     __device__ __forceinline__ float get(int k) const { return t[((k >> 5) << 1) | (k & 1)][(k & 31) >> 1]; }
     __device__ __forceinline__ void set(int k, float x) { t[((k >> 5) << 1) | (k & 1)][(k & 31) >> 1] = x; }
 };
+template <int N>
+struct RowRegs<N, 3> : RowRegs<N, 1> {};          // FMT = 3 (mx6 slots + hi / lo half rows in one pass) converts to fp6 as FMT = 1 does
 
 template <int N, class RR>
 __device__ __forceinline__ float chain_sq(const RR &r, float acc)
@@ -257,11 +259,14 @@ __device__ __forceinline__ void gather_q8_v3_tile(
     }
     if (seg == 0 && norm) norm[(size_t)m * rows_cap + my_row] = d;
 
-    if constexpr (FMT == 2) {
+    if constexpr (FMT == 2 || FMT == 3) {
         // error-compensated fp16 operands of the canonical unit row u = RN(x / d): hi = half(u), lo = half(u - hi) (22 significant
         // bits together), natural k order, as two row arrays [n_maps, rows_cap, CP] of halves (out8 = hi rows, aux = lo rows): the
         // operands of match_x3_scan_kernel.
-        static_assert(LPR == 1 || FMT != 2, "FMT = 2 is instantiated for one lane per row");
+        static_assert(LPR == 1, "the hi / lo rows are written with one lane per row");
+        // FMT = 2: out8 = hi rows, aux = lo rows.  FMT = 3 (round 4: the engine's K0 pass when recent steps needed the second level - one
+        // read of the maps instead of two): out8 keeps the mx6 slots, aux = hi rows followed by the lo rows ([2][n_maps, rows_cap, CP]
+        // halves), `scale` (unused by the mx6 format) receives the largest |u - hi|^2 per map, eps_max the mx6 error norm as in FMT = 1.
         constexpr int HB = CP * 2;                              // bytes per half row
         float lo2 = 0.0f;                                       // |lo|^2 of the lane's row: K1x3's first sweep multiplies hi parts only
         // the unit values replace the raw ones in place first (computed inside the staging passes, all 256 quotients were hoisted and
@@ -295,8 +300,9 @@ __device__ __forceinline__ void gather_q8_v3_tile(
                 *reinterpret_cast<uint4 *>(stage + stage_addr(lane, s + 8, 256)) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
             }
             WAVE_LDS_ORDER();
-            char *oh = reinterpret_cast<char *>(out8) + ((size_t)m * rows_cap + row0) * HB + c0 * 2;
-            char *ol = reinterpret_cast<char *>(aux) + ((size_t)m * rows_cap + row0) * HB + c0 * 2;
+            char *oh = (FMT == 3 ? reinterpret_cast<char *>(aux) : reinterpret_cast<char *>(out8)) + ((size_t)m * rows_cap + row0) * HB + c0 * 2;
+            char *ol = (FMT == 3 ? reinterpret_cast<char *>(aux) + (size_t)n_maps * rows_cap * HB : reinterpret_cast<char *>(aux)) +
+                       ((size_t)m * rows_cap + row0) * HB + c0 * 2;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int f = j * 64 + lane, t = f / 16, s = f % 16;
@@ -304,12 +310,13 @@ __device__ __forceinline__ void gather_q8_v3_tile(
                 *reinterpret_cast<uint4 *>((s < 8 ? oh : ol) + (size_t)t * HB + (s & 7) * 16) = q;
             }
         }
-        if (eps_max) {                                          // largest |u - hi|_2^2 of the map's rows (|lo| <= |u - hi| (1 + 2^-11))
+        unsigned *lo_max = FMT == 3 ? reinterpret_cast<unsigned *>(scale) : eps_max;
+        if (lo_max) {                                           // largest |u - hi|_2^2 of the map's rows (|lo| <= |u - hi| (1 + 2^-11))
             // No wave reduction here: any cross-lane operation at this point (shuffles, DPP) cost ~100 registers of scratch in this
             // instantiation.  Every lane compares with the map's current maximum (a cached broadcast load; stale values only cost an extra
             // atomic) and only lanes that would raise it issue the atomic: a few per map after the first waves.  Dead rows are zero rows.
             // The SQUARE goes out (the consumer takes the root).
-            if (lo2 > 0.0f && __float_as_uint(lo2) > __atomic_load_n(&eps_max[m], __ATOMIC_RELAXED)) atomicMax(&eps_max[m], __float_as_uint(lo2));
+            if (lo2 > 0.0f && __float_as_uint(lo2) > __atomic_load_n(&lo_max[m], __ATOMIC_RELAXED)) atomicMax(&lo_max[m], __float_as_uint(lo2));
         }
     }
     if constexpr (FMT == 0) {
@@ -366,7 +373,7 @@ __device__ __forceinline__ void gather_q8_v3_tile(
             }
         }
     }
-    if constexpr (FMT == 1) {
+    if constexpr (FMT == 1 || FMT == 3) {
         // MX-fp6 slots (see the kernel's header): one 32-channel block = staging slots 2b (code dwords 0-3) and 2b + 1 (code dwords
         // 4-5, exponent byte, zero)
         constexpr int RB8 = KPL;
@@ -377,14 +384,15 @@ __device__ __forceinline__ void gather_q8_v3_tile(
             float bm = 0.0f;
 #pragma unroll
             for (int i = 0; i < 32; ++i) bm = fmaxf(bm, fabsf(VG(32 * b + i)));
-            // block exponent e: bm / (d * 2^e) in (3.75, 7.5]; an all-zero block keeps e = -40
-            const float r = __fdiv_rn(bm, d) * (1.0f / 7.5f);
+            // block exponent e: bm / (d * 2^e) in (3.75, 7.5]; an all-zero block keeps e = -40.  (FMT = 3: the registers already hold the
+            // canonical unit values x / d - the hi / lo pass above divided in place)
+            const float r = (FMT == 3 ? bm : __fdiv_rn(bm, d)) * (1.0f / 7.5f);
             int e = r > 0.0f ? ilogbf(r) + 1 : -40;
             if (r > 0.0f && ldexpf(1.0f, e - 1) >= r) e -= 1;          // r an exact power of two: 2^(e-1) == r is enough
             e = e < -40 ? -40 : (e > 8 ? 8 : e);
             // values in code units: x / (d 2^e) (rd 2^-e is exact, a power of two times rd).  The conversions run with the constant
             // scale 1: a per-lane scale operand gave wrong codes (every row has its own exponent here)
-            const float rde = rd * ldexpf(1.0f, -e);
+            const float rde = (FMT == 3 ? 1.0f : rd) * ldexpf(1.0f, -e);
             R.t[2 * b] *= rde;                                          // in place: the raw values are not needed any more (out32 is done)
             R.t[2 * b + 1] *= rde;
             const f32x16g ev = R.t[2 * b], od = R.t[2 * b + 1];
@@ -480,7 +488,7 @@ void launch_g8(hipStream_t st, const float *feat, int n_maps, int C, int HW, con
     const int groups = ((units + 7) / 8) * 8 * chunk_tiles;
     // (the hi / lo pass of K1x3 stays one tile per block: it does real work on every step of smooth inputs and the tile loop costs it 20 %:
     // 1.53 against 1.27 ms; the fp32-row passes are rare fall-backs)
-    if (map_enable && FMT != 2) {
+    if (map_enable && FMT != 2 && FMT != 3) {
         auto gk = gather_q8_v3_gated_kernel<CP, LPR, NHWC, FMT>;
         allow_dynamic_lds(reinterpret_cast<const void *>(gk), 4 * G8_STAGE_BYTES);
         const int grid = groups < 2048 ? groups : 2048;
@@ -508,7 +516,12 @@ int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, c
         if (layout == ORYON_LAYOUT_NHWC) launch_g8<CPV, LPRV, true, FMTV>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
         else launch_g8<CPV, LPRV, false, FMTV>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
     } while (0)
-    if (fmt == 2) {
+    if (fmt == 3) {
+        // mx6 slots + hi / lo half rows in one pass (C_pad 256 only): out8 = mx6 rows, aux = hi rows | lo rows, scale = |u - hi|^2 maxima
+        if (C_pad != 256 || !aux || !scale || out32) return ORYON_ERR_INVALID_ARG;
+        if (layout == ORYON_LAYOUT_NHWC) launch_g8<256, 1, true, 3>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16, aux);
+        else launch_g8<256, 1, false, 3>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16, aux);
+    } else if (fmt == 2) {
         // hi / lo half rows for the fp16x3 scan (C_pad 256 only): out8 = hi rows, aux = lo rows
         if (C_pad != 256 || !aux) return ORYON_ERR_INVALID_ARG;
         if (layout == ORYON_LAYOUT_NHWC) launch_g8<256, 1, true, 2>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16, aux);
@@ -558,5 +571,23 @@ extern "C" int oryon_gather_mx6(const float *feat, int n_maps, int C, int HW, in
     const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad,
                                     reinterpret_cast<int8_t *>(out_mx6), nullptr, err_max, row_norm, out_f32, lpr_env, round_f16, st, 1, nullptr);
     if (rc) { set_error("oryon_gather_mx6: launch failed"); return rc; }
+    return ORYON_OK;
+}
+
+extern "C" int oryon_gather_mx6_x3(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride,
+                                   const int32_t *count, int rows_cap, int C_pad, uint8_t *out_mx6, float *err_max, float *row_norm,
+                                   void *hi_lo_f16, float *lo_sq_max, int round_f16, void *stream)
+{
+    ORYON_CHECK_ARG(feat && roi && count && out_mx6 && err_max && hi_lo_f16 && lo_sq_max);                 // row_norm may be NULL
+    ORYON_CHECK_ARG(n_maps >= 0 && C > 0 && HW > 0 && roi_stride > 0 && C_pad == 256 && C <= C_pad);
+    ORYON_CHECK_ARG(layout == ORYON_LAYOUT_NCHW || layout == ORYON_LAYOUT_NHWC);
+    ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % 256 == 0 && (size_t)C * (size_t)HW * 4u < (1ull << 32));
+    if (n_maps == 0) return ORYON_OK;
+    hipStream_t st = as_stream(stream);
+    ORYON_CHECK_HIP(hipMemsetAsync(err_max, 0, (size_t)n_maps * sizeof(float), st));
+    ORYON_CHECK_HIP(hipMemsetAsync(lo_sq_max, 0, (size_t)n_maps * sizeof(float), st));
+    const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad,
+                                    reinterpret_cast<int8_t *>(out_mx6), lo_sq_max, err_max, row_norm, nullptr, 1, round_f16, st, 3, hi_lo_f16);
+    if (rc) { set_error("oryon_gather_mx6_x3: launch failed"); return rc; }
     return ORYON_OK;
 }

@@ -1891,7 +1891,8 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
                                  int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs,
                                  int corr_rows, uint64_t seed, const int64_t *pair_key, int force_eager, float *min_dist,
                                  int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
-                                 int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream, int fmt);
+                                 int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream, int fmt,
+                                 const void *q_hi_lo = nullptr, const float *q_lo_sq_max = nullptr);
 
 extern "C" int oryon_match_corrs_i8(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW,
                                     int layout, const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q,
@@ -1922,13 +1923,30 @@ extern "C" int oryon_match_corrs_mx6(const float *a_hat, const uint8_t *a_mx6, c
                                  n_undecided, round_f16, workspace, workspace_bytes, stream, 1);
 }
 
+extern "C" int oryon_match_corrs_mx6_x3(const float *a_hat, const uint8_t *a_mx6, const float *a_err_max, const float *feat_q, int C_true, int HW,
+                                        int layout, const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q,
+                                        const float *q_norm, const uint8_t *q_mx6, const float *q_err_max, const void *q_hi_lo_f16,
+                                        const float *q_lo_sq_max, int B, int C, int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q,
+                                        float threshold, int W, int max_corrs, int corr_rows, uint64_t seed, const int64_t *pair_key,
+                                        float *min_dist, int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel,
+                                        int32_t *status, int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes,
+                                        void *stream)
+{
+    ORYON_CHECK_ARG(a_err_max && q_err_max && q_hi_lo_f16 && q_lo_sq_max && C == 256);
+    return match_corrs_lazy_impl(a_hat, reinterpret_cast<const int8_t *>(a_mx6), a_err_max, feat_q, C_true, HW, layout, roi_a, roi_stride_a, roi_q,
+                                 roi_stride_q, q_norm, reinterpret_cast<const int8_t *>(q_mx6), nullptr, q_err_max, B, C, cap_a, cap_q, n_a, n_q,
+                                 threshold, W, max_corrs, corr_rows, seed, pair_key, 0, min_dist, argmin, valid, corrs, n_valid, n_sel, status,
+                                 n_undecided, round_f16, workspace, workspace_bytes, stream, 1, q_hi_lo_f16, q_lo_sq_max);
+}
+
 static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const float *a_scale, const float *feat_q, int C_true, int HW,
                                  int layout, const int32_t *roi_a, int roi_stride_a, const int32_t *roi_q, int roi_stride_q,
                                  const float *q_norm, const int8_t *q_i8, const float *q_scale, const float *q_eps_max, int B, int C,
                                  int cap_a, int cap_q, const int32_t *n_a, const int32_t *n_q, float threshold, int W, int max_corrs,
                                  int corr_rows, uint64_t seed, const int64_t *pair_key, int force_eager, float *min_dist,
                                  int32_t *argmin, uint8_t *valid, int32_t *corrs, int32_t *n_valid, int32_t *n_sel, int32_t *status,
-                                 int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream, int fmt)
+                                 int32_t *n_undecided, int round_f16, void *workspace, size_t workspace_bytes, void *stream, int fmt,
+                                 const void *q_hi_lo, const float *q_lo_sq_max)
 {
     ORYON_CHECK_ARG(a_hat && a_i8 && a_scale && feat_q && roi_a && roi_q && q_norm && q_i8 && q_eps_max && n_a && n_q);
     ORYON_CHECK_ARG(min_dist && argmin && valid && corrs && n_valid && n_sel && status && !(fmt == 1 && force_eager));
@@ -2057,7 +2075,7 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
         int32_t *n_ovf = nullptr, *ovf_idx = nullptr;
         rc = match_x3_resolve(w8.a_hat_c, lw.n_ambv, cap_s, feat_q, C_true, HW, layout, roi_q, roi_stride_q, q_norm, n_q, B, cap_q, threshold,
                               round_f16, qh, ql, lw.x3_ah, lw.x3_al, lw.x3_scratch, w8.md_c, w8.am_c, w8.va_c, &n_ovf, &ovf_idx, lw.ambv_idx, corr_rows,
-                              lw.sid_final, cap_a, st);
+                              lw.sid_final, cap_a, static_cast<const __half *>(q_hi_lo), q_lo_sq_max, st);
         if (rc) { set_error("oryon_match_corrs: fp16x3 second-level launch failed"); return rc; }
         // fp32 query rows for the pairs with overflowed anchors only: the gather's per-map gate reads n_ovf itself
         rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, n_ovf, cap_q, C, wr.q8_scratch, wr.scale_scratch,

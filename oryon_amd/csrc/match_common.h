@@ -27,7 +27,7 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
                      const int32_t *roi_q, int roi_stride_q, const float *q_norm, const int32_t *n_q, int B, int cap_q, float threshold,
                      int round_f16, __half *qh, __half *ql, __half *ah, __half *al, void *scratch, float *md_c, int32_t *am_c, uint8_t *va_c,
                      int32_t **n_ovf_out, int32_t **ovf_idx_out, const int32_t *orig_idx, int orig_stride, const int32_t *sid_final, int cap_a,
-                     hipStream_t st);
+                     const __half *q_hi_lo_pre, const float *q_lo_sq_max_pre, hipStream_t st);
 void match_x3_scatter_ovf(int B, int cap_s, const int32_t *n_ovf, const int32_t *ovf_idx, const float *md_o, const int32_t *am_o,
                           const uint8_t *va_o, float *md_c, int32_t *am_c, uint8_t *va_c, hipStream_t st);
 

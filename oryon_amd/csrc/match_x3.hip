@@ -777,7 +777,7 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
                      const int32_t *roi_q, int roi_stride_q, const float *q_norm, const int32_t *n_q, int B, int cap_q, float threshold,
                      int round_f16, __half *qh, __half *ql, __half *ah, __half *al, void *scratch, float *md_c, int32_t *am_c, uint8_t *va_c,
                      int32_t **n_ovf_out, int32_t **ovf_idx_out, const int32_t *orig_idx, int orig_stride, const int32_t *sid_final, int cap_a,
-                     hipStream_t st)
+                     const __half *q_hi_lo_pre, const float *q_lo_sq_max_pre, hipStream_t st)
 {
     constexpr int CP = 256;
     const int T = (cap_s + 255) / 256;
@@ -811,10 +811,18 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     *ovf_idx_out = ovf_idx;
     if (hipMemsetAsync(n_ovf, 0, 2 * cnt_block + 256, st) != hipSuccess) return ORYON_ERR_HIP;
     if (hipMemsetAsync(cnt, 0, (size_t)B * S * cap_s * 2 * sizeof(int32_t), st) != hipSuccess) return ORYON_ERR_HIP;     // sweep 2 appends with atomics
-    // query rows as hi / lo halves, only for pairs that have listed anchors (the gather's per-map gate reads the counts themselves)
-    int rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, n_c, cap_q, CP, reinterpret_cast<int8_t *>(qh), nullptr,
+    // query rows as hi / lo halves, only for pairs that have listed anchors (the gather's per-map gate reads the counts themselves) -
+    // unless the caller's K0 pass already wrote them for every pair (oryon_gather_mx6_x3: the step engine does when recent steps came here)
+    int rc = ORYON_OK;
+    if (q_hi_lo_pre && q_lo_sq_max_pre) {
+        qh = const_cast<__half *>(q_hi_lo_pre);
+        ql = qh + (size_t)B * cap_q * CP;
+        ql_max = const_cast<float *>(q_lo_sq_max_pre);
+    } else {
+        rc = gather_q8_launch(feat_q, B, C_true, HW, layout, roi_q, roi_stride_q, n_q, n_c, cap_q, CP, reinterpret_cast<int8_t *>(qh), nullptr,
                               ql_max, nullptr, nullptr, 1, round_f16, st, 2, ql);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(match_x3_split_anchors_kernel, dim3(64, B), dim3(256), 0, st, a_c, CP, cap_s, n_c, ah, al, al_norm);
     const int groups = ((B * S + 7) / 8) * 8 * T;
     static const bool dbg = getenv("ORYON_X3_DEBUG") != nullptr;          // development aid: list statistics of this call on stderr

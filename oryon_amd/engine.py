@@ -68,7 +68,7 @@ class NativeStep:
     }
 
     def __init__(self, solver: PointDSC, cfg: "MatchPoseConfig", key: Tuple, dev: torch.device, overlap: int, n_slots: int = 6,
-                 gather_sets: int = 3, reg_streams: int = 2, reg_lag: int = 0, screen: int = 1):
+                 gather_sets: int = 3, reg_streams: int = 2, reg_lag: int = 0, screen: int = 1, x3_prefetch: int = 1):
         B, C, FH, FW, HA, WA, HQ, WQ, layout = key
         self.key, self.dev = key, dev
         if overlap >= 2:
@@ -81,7 +81,8 @@ class NativeStep:
                                       round_f16=int(cfg.half_descriptors), n_slots=n_slots, overlap=overlap,
                                       gather_sets=min(gather_sets, n_slots), reg_streams=reg_streams,
                                       reg_lag=reg_lag if overlap else 0, screen=screen,
-                                      sample_first=int(cfg.sample_first) if cfg.sample_first and cfg.sample_first > 0 else 0)
+                                      sample_first=int(cfg.sample_first) if cfg.sample_first and cfg.sample_first > 0 else 0,
+                                      x3_prefetch=int(bool(x3_prefetch)) if (C <= 256 and screen == 1) else 0)
         self.cfg_sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap, int(cfg.sample_first))
         need = lib().oryon_engine_arena_bytes(ctypes.byref(self.ecfg), solver._handle)
         if need == 0:
@@ -139,6 +140,12 @@ class NativeStep:
         check(lib().oryon_engine_elapsed(self._h, int(step_a), event_a, int(step_b), event_b, ctypes.byref(ms)), "oryon_engine_elapsed")
         return float(ms.value)
 
+    def x3_steps(self) -> int:
+        """Submits so far whose K0 pass also wrote the second level's hi / lo rows (oryon_engine_config_t.x3_prefetch)."""
+        n = ctypes.c_int64()
+        check(lib().oryon_engine_x3_steps(self._h, ctypes.byref(n)))
+        return n.value
+
     def host_stats(self) -> Tuple[int, float, float]:
         n, tot, last = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
         check(lib().oryon_engine_host_stats(self._h, ctypes.byref(n), ctypes.byref(tot), ctypes.byref(last)))
@@ -186,7 +193,7 @@ class MatchPoseEngine:
         self.result_views = result_views
         self._native: Optional[NativeStep] = None
         self._inflight: Dict[int, Dict[str, Tensor]] = {}       # slot -> result dict of the native step that last used it
-        self.native_geometry = dict(n_slots=6, gather_sets=3, reg_streams=2, reg_lag=0, screen=1)      # NativeStep's pipeline depth (see oryon_engine_config_t)
+        self.native_geometry = dict(n_slots=6, gather_sets=3, reg_streams=2, reg_lag=0, screen=1, x3_prefetch=1)      # NativeStep's pipeline depth (see oryon_engine_config_t)
         self.native_timing = False          # bracket the sections of every native step with HIP events (NativeStep.timing)
         self._reg_stream = None
         self.reg_streams = 2

@@ -192,3 +192,35 @@ def test_native_sample_first_schedule_equals_python_schedule():
     bk = MatchPoseEngine(solver, cfg, native=True).run(*ins, key, keep=True)
     torch.cuda.synchronize()
     assert torch.equal(ak["pose"], bk["pose"]) and torch.equal(bk["pose"], plain["pose"])
+
+
+def test_native_x3_prefetch_gives_identical_results_on_smooth_fields():
+    """oryon_engine_config_t.x3_prefetch: on smooth descriptor fields (every sampled anchor goes to the fp16x3 second level) the engine's
+    K0 pass starts writing the hi / lo rows itself once the first steps' counts have come back (oryon_gather_mx6_x3 +
+    oryon_match_corrs_mx6_x3) - poses, statuses, correspondences and lifted points must stay bit for bit those of an engine that never
+    prefetches, and of the first step (which could not have prefetched)."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    from oryon_amd.synth import make_pair
+    solver = _solver()
+    pairs = [make_pair(500 + i, 96, 96, 256, device="cuda", smooth=0.02) for i in range(3)]
+    st = lambda k: torch.stack([p[k] for p in pairs]).contiguous()
+    cam = st("camera").reshape(3, 9).float().cuda().contiguous()
+    ins = (st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"), cam, cam)
+    key = torch.arange(3, device="cuda")
+    outs = {}
+    for pre in (0, 1):
+        eng = MatchPoseEngine(solver, MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=True)
+        eng.native_geometry["x3_prefetch"] = pre
+        res = []
+        for _ in range(8):
+            o = eng.finish(eng.run(*ins, key, keep=False))
+            torch.cuda.synchronize()                      # every step's counts are back before the next submit looks at them
+            res.append({k: o[k].clone() for k in ("pose", "status", "n_valid", "n_lifted")})
+        outs[pre] = res
+        n_x3 = eng._native.x3_steps()
+        assert (n_x3 >= 6) if pre else (n_x3 == 0), n_x3
+        assert res[0]["status"].tolist() == [0, 0, 0]
+    for i in range(8):
+        for k in ("pose", "status", "n_valid", "n_lifted"):
+            assert torch.equal(outs[0][i][k], outs[1][i][k]), (i, k)
+            assert torch.equal(outs[1][i][k], outs[1][0][k]), (i, k)

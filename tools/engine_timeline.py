@@ -22,7 +22,7 @@ inp["cam"] = inp["cam"].reshape(B, 9).float().contiguous()
 ser = bool(os.environ.get("ENG_SERIAL"))
 eng = MatchPoseEngine(bench.build_solver(dev), MatchPoseConfig(), overlap_registration=not ser, overlap_gather=not ser, native=True, result_views=True)
 eng.native_timing = not os.environ.get("ENG_NO_TIMING")
-for k_ in ("n_slots", "gather_sets", "reg_streams", "reg_lag", "screen"):
+for k_ in ("n_slots", "gather_sets", "reg_streams", "reg_lag", "screen", "x3_prefetch"):
     if os.environ.get("ENG_" + k_.upper()):
         eng.native_geometry[k_] = int(os.environ["ENG_" + k_.upper()])
 if os.environ.get("ENG_PYTHON"):
