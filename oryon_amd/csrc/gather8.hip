@@ -300,14 +300,17 @@ __device__ __forceinline__ void gather_q8_v3_tile(
                 *reinterpret_cast<uint4 *>(stage + stage_addr(lane, s + 8, 256)) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
             }
             WAVE_LDS_ORDER();
-            char *oh = (FMT == 3 ? reinterpret_cast<char *>(aux) : reinterpret_cast<char *>(out8)) + ((size_t)m * rows_cap + row0) * HB + c0 * 2;
+            // Row layout of the hi / lo arrays (round 4): tiles of 32 rows, inside a tile the four 64-channel chunks one after the other -
+            // byte (row q, b) of a map at (q >> 5) * 16384 + (b >> 7) * 4096 + (q & 31) * 128 + (b & 127).  The second sweep of K1x3 streams
+            // a tile chunk by chunk: each is now one contiguous 4 KB run per part instead of 32 pieces of 128 bytes 512 bytes apart.
+            char *oh = (FMT == 3 ? reinterpret_cast<char *>(aux) : reinterpret_cast<char *>(out8)) + ((size_t)m * rows_cap + row0) * HB + part * 4096;
             char *ol = (FMT == 3 ? reinterpret_cast<char *>(aux) + (size_t)n_maps * rows_cap * HB : reinterpret_cast<char *>(aux)) +
-                       ((size_t)m * rows_cap + row0) * HB + c0 * 2;
+                       ((size_t)m * rows_cap + row0) * HB + part * 4096;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int f = j * 64 + lane, t = f / 16, s = f % 16;
                 const uint4 q = *reinterpret_cast<const uint4 *>(stage + stage_addr(t, s, 256));
-                *reinterpret_cast<uint4 *>((s < 8 ? oh : ol) + (size_t)t * HB + (s & 7) * 16) = q;
+                *reinterpret_cast<uint4 *>((s < 8 ? oh : ol) + (size_t)(t >> 5) * (32 * HB) + (t & 31) * 128 + (s & 7) * 16) = q;
             }
         }
         unsigned *lo_max = FMT == 3 ? reinterpret_cast<unsigned *>(scale) : eps_max;

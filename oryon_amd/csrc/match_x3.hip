@@ -37,6 +37,9 @@ constexpr int X3_CAPH = 128;               // candidate slots per (pair, query s
 constexpr float X3_MARGIN = 1.32e-4f;      // 2 * DELTA3 (6.5e-5) + 2e-6
 constexpr float X3_MARGIN_R = 3.4e-5f;     // 2 * DELTA_R (1.63e-5: refined fp64 score against the canonical fp32 chain) + slack
 constexpr int X3_MAX_TILES = 256;          // tile flags per wave of the scan (a workgroup's share of the query rows: cap_q / 32 / S tiles)
+// byte offset of (query row q, byte b of its 512-byte half row) inside a map's hi (or lo) array: tiles of 32 rows, chunk-major inside a tile
+// (gather8.hip, FMT = 2 / 3)
+__host__ __device__ __forceinline__ size_t x3_q_off(int q, int b) { return (size_t)(q >> 5) * 16384 + (size_t)(b >> 7) * 4096 + (size_t)(q & 31) * 128 + (size_t)(b & 127); }
 constexpr int X3_JOB_TILES = 16;           // tiles per sweep-2 job (one reload of the 64 anchors' operands per job: 64 KB against 512 KB of tiles)
 constexpr int X3_SURV = 256;               // survivors of the first filter kept per anchor (more: exact-scan route)
 
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void match_x3_seed_kernel(const __half *__rest
     float s = 0.0f;
     if (q < nq) {
         const uint4 *ar = reinterpret_cast<const uint4 *>(ah + ((size_t)p * cap_s + row) * Cp) + seg * (Cp / 32);
-        const uint4 *qr = reinterpret_cast<const uint4 *>(qh + ((size_t)p * cap_q + q) * Cp) + seg * (Cp / 32);
+        const uint4 *qr = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(qh + (size_t)p * cap_q * Cp) + x3_q_off(q, seg * 128));
         for (int i = 0; i < Cp / 32; ++i) {
             const uint4 av = ar[i], qv = qr[i];
             const __half2 *a2 = reinterpret_cast<const __half2 *>(&av), *q2 = reinterpret_cast<const __half2 *>(&qv);
@@ -176,7 +179,7 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
         const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
         const int row = line / LPR;
         const int cc = sl ^ (row & 15);
-        dma_off[j] = (unsigned)(row * RB + ((line % LPR) * 16 + cc) * 16);
+        dma_off[j] = (unsigned)x3_q_off(row, ((line % LPR) * 16 + cc) * 16);        // source of the 16 bytes that land at LDS (row, slot (line % LPR) * 16 + sl)
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char *qhp = reinterpret_cast<const char *>(qh + (size_t)p * cap_q * CP);
@@ -441,9 +444,13 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
                                                                 const float *__restrict__ al_norm, const float *__restrict__ ql_max,
                                                                 const float *__restrict__ smax, const unsigned short *__restrict__ tl,
                                                                 const uint2 *__restrict__ jobs, const int32_t *__restrict__ njobs,
-                                                                int32_t *__restrict__ next_job, int32_t *__restrict__ cnt, uint2 *__restrict__ cand)
+                                                                int32_t *__restrict__ next_job, int32_t *__restrict__ cnt, uint2 *__restrict__ cand,
+                                                                int32_t *__restrict__ dbg)
 {
     constexpr int RB = CP * 2, ROWS = 32, PART = ROWS * RB, NKS = CP / 16, NAB = 2;
+    const long long tw0 = dbg ? wall_clock64() : 0;
+    long long t_load = 0;
+    int n_tiles_done = 0, n_jobs_done = 0;
     constexpr int CH = 64;                                  // channels per chunk
     constexpr int NCH = CP / CH;                            // 4 chunks per tile = the 4 slots of the region
     constexpr int CHB = 2 * ROWS * CH * 2;                  // 8 KB: [part][row][128 B]
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int row = j * 8 + (lane >> 3), sl = lane & 7;
-        src2[j] = (unsigned)(row * RB + ((sl ^ ((row >> 1) & 7)) << 4));
+        src2[j] = (unsigned)(row * 128 + ((sl ^ ((row >> 1) & 7)) << 4));          // inside the chunk's contiguous 4 KB (32 rows x 128 bytes)
     }
     unsigned ko2[CH / 16];
 #pragma unroll
@@ -471,7 +478,19 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
         int jx = 0;
         if (lane == 0) jx = atomicAdd(next_job, 1);
         jx = __builtin_amdgcn_readfirstlane(jx);
-        if (jx >= n_jobs) return;
+        if (jx >= n_jobs) {
+            if (dbg && lane == 0) {                          // ORYON_X3_DEBUG: per-wave totals
+                const long long tw1 = wall_clock64();
+                atomicAdd(&dbg[12], (int)(tw1 - tw0));       // busy ticks of this wave (start to its last job's end)
+                atomicAdd(&dbg[13], (int)t_load);            // of which: operand loads
+                atomicAdd(&dbg[14], n_tiles_done);
+                atomicAdd(&dbg[15], n_jobs_done);
+                atomicMax(&dbg[16], (int)(tw1 - tw0));
+                atomicAdd(&dbg[17], 1);
+            }
+            return;
+        }
+        const long long tj0 = dbg ? wall_clock64() : 0;
         const uint2 jb = jobs[jx];
         const int owner = (int)jb.x, first = (int)((jb.y >> 8) & 0x7fffffu), n_t = (int)(jb.y & 0xffu);
         const bool dense = (jb.y >> 31) != 0;
@@ -503,12 +522,13 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
             lim[ab] = gm - e_hi - 0.5f * X3_MARGIN;
             run3[ab] = -INFINITY;
         }
+        if (dbg) { t_load += wall_clock64() - tj0; n_tiles_done += n_t; n_jobs_done += 1; }
         auto tile_at = [&](int i) { return qt_begin + (dense ? first + i : (int)(gl[i] & 0x3fffu)); };
         auto issue2 = [&](int g) {                               // chunk g = (tile g / NCH of the job, k-chunk g % NCH)
             const int qt = tile_at(g / NCH), c = g % NCH;
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
-                const char *qb = (part ? qlp : qhp) + (size_t)qt * PART + c * (CH * 2);
+                const char *qb = (part ? qlp : qhp) + (size_t)qt * PART + c * 4096;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + src2[j]),
@@ -674,8 +694,9 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
                 const int src = __ffsll((long long)hits) - 1;
                 hits &= hits - 1;
                 const int jj = __shfl(qi, src);
-                const size_t qrow = ((size_t)p * cap_q + jj) * Cp;
-                const uint2 h = reinterpret_cast<const uint2 *>(qh + qrow)[lane], lo_ = reinterpret_cast<const uint2 *>(ql + qrow)[lane];
+                const size_t qoff = (size_t)p * cap_q * Cp * 2 + x3_q_off(jj, lane * 8);          // bytes: lane l holds channels 4 l .. 4 l + 3
+                const uint2 h = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(qh) + qoff);
+                const uint2 lo_ = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(ql) + qoff);
                 const __half2 h0 = *reinterpret_cast<const __half2 *>(&h.x), h1 = *reinterpret_cast<const __half2 *>(&h.y);
                 const __half2 l0 = *reinterpret_cast<const __half2 *>(&lo_.x), l1 = *reinterpret_cast<const __half2 *>(&lo_.y);
                 double v = a4[0] * ((double)__low2float(h0) + (double)__low2float(l0));
@@ -829,7 +850,7 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     int32_t *dbg_dev = nullptr;
     if (dbg) {
         dbg_dev = reinterpret_cast<int32_t *>(seed + (size_t)B * cap_s + 64);         // in the scratch's 8 KB of slack
-        (void)hipMemsetAsync(dbg_dev, 0, 48, st);
+        (void)hipMemsetAsync(dbg_dev, 0, 96, st);
         (void)hipMemsetAsync(dbg_dev + 8, 0xff, 8, st);
     }
     // seeds of the running maxima from the screen's winning slices (ORYON_X3_SEED=0: the round-3 scan, for A/B timing; same results)
@@ -856,7 +877,7 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(grid), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, dbg_dev, dbg_wg);
     // sweep 2: four one-wave workgroups per CU pull the jobs sweep 1 posted (none posted: they exit at once)
     allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_sweep2_kernel<CP>), 4 * 32768);
-    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP>), dim3(n_cus), dim3(256), 4 * 32768, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, smax, tl, jobs, njobs, next_job, cnt, cand);
+    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP>), dim3(n_cus), dim3(256), 4 * 32768, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, smax, tl, jobs, njobs, next_job, cnt, cand, dbg_dev);
     const size_t lds = (size_t)4 * (2 * CP + 2 * X3_SURV) * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
@@ -888,8 +909,11 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
                     }
             }
         }
-        int32_t hd[12] = {0};
-        (void)hipMemcpy(hd, dbg_dev, 48, hipMemcpyDeviceToHost);
+        int32_t hd[24] = {0};
+        (void)hipMemcpy(hd, dbg_dev, 96, hipMemcpyDeviceToHost);
+        if (hd[17] > 0)
+            fprintf(stderr, "[x3] sweep 2: %d waves, mean alive %.1f us (longest %.1f us), operand loads %.1f us per wave, %d jobs, %d tiles (%.2f us of wave time per tile)\n",
+                    hd[17], hd[12] * 0.01 / hd[17], hd[16] * 0.01, hd[13] * 0.01 / hd[17], hd[15], hd[14], hd[14] ? (hd[12] - hd[13]) * 0.01 / hd[14] : 0.0);
         {
             unsigned long long t_lo, t_hi;
             memcpy(&t_lo, hd + 8, 8);
