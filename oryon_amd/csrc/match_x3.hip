@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void match_x3_seed_kernel(const __half *__rest
 // grid: units (pair, query split) dealt to the 8 XCDs, T = cap_s / 256 anchor panels per unit; 4 waves x 64 anchors (two B-operand sets of hi +
 // lo rows = 256 registers: one workgroup per CU with the 512-register budget - with 32 anchors per wave every pair of ds_read_b128 fed only
 // 3 MFMAs and the LDS, not the matrix pipe, set the pace: 5.1 ms); tiles of 32 query rows (hi part 16 KB + lo part 16 KB, double-buffered)
-template <int CP>
+template <int CP, int WAVES>
 __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot, char *__restrict__ smem, const __half *__restrict__ ah,
                                                    const __half *__restrict__ al, const __half *__restrict__ qh, const __half *__restrict__ ql, int B,
                                                    int cap_s, int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T, int S,
@@ -144,8 +144,9 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
     constexpr int ROWS = 32;
     constexpr int PART = ROWS * RB;            // 16 KB at CP = 256
     constexpr int NKS = CP / 16;
-    constexpr int NI = PART / 4096;            // 1 KB DMA instructions per wave, part and tile
+    constexpr int NI = PART / (1024 * WAVES);  // 1 KB DMA instructions per wave and tile
     constexpr int LPR = RB / 256;
+    constexpr int PANEL = 64 * WAVES;          // anchors of a workgroup
 
     const int unit = (slot / T) * 8 + xcd;
     if (unit >= B * S) return;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
     constexpr int NAB = 2;
     // (measured, not kept: dealing the 32-anchor blocks round-robin over panels / waves so that the few blocks whose matches lie in this
     // split's band do not share a wave - each wave then covers two bands and flags 40 % more tiles: scan 1.69 instead of 1.60 ms)
-    const int a0 = panel * 256;
+    const int a0 = panel * PANEL;
     if (a0 >= nc) return;
 #define X3_ANCHOR(ab_) (a0 + wave * 64 + (ab_) * 32 + l31)
     const int nqt = (nq + ROWS - 1) / ROWS;
@@ -226,8 +227,8 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
     // the (wave, tile) pairs flagged with the seed, 46 % without).
     constexpr int FLAG_BASE = NS1 * PART;                       // behind the ring: 4 x X3_MAX_TILES flag bytes, 4 x X3_MAX_TILES list entries
     unsigned char *tile_flag = reinterpret_cast<unsigned char *>(smem + FLAG_BASE) + wave * X3_MAX_TILES;
-    unsigned short *my_list = reinterpret_cast<unsigned short *>(smem + FLAG_BASE + 4 * X3_MAX_TILES) + wave * X3_MAX_TILES;
-    for (int i = t; i < 4 * X3_MAX_TILES; i += 256) reinterpret_cast<unsigned char *>(smem + FLAG_BASE)[i] = 0;
+    unsigned short *my_list = reinterpret_cast<unsigned short *>(smem + FLAG_BASE + WAVES * X3_MAX_TILES) + wave * X3_MAX_TILES;
+    for (int i = t; i < WAVES * X3_MAX_TILES; i += 64 * WAVES) reinterpret_cast<unsigned char *>(smem + FLAG_BASE)[i] = 0;
     const int ntl = qt_end - qt_begin;
     const bool flags_ok = ntl <= X3_MAX_TILES;
     long long tk1 = dbg ? wall_clock64() : 0;
@@ -298,7 +299,7 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
 #pragma unroll
     for (int d = 0; d < NS1 - 1; ++d)
         if (d < ntl) issue1(qt_begin + d, d);
-    {
+    if constexpr (WAVES == 4) {
         half8x fa[NKS], fb[NKS];
         if (ntl > 0) {
             wait_tiles(ntl - 1 < NS1 - 2 ? ntl - 1 : NS1 - 2);
@@ -308,6 +309,43 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
         for (int it = 0; it < ntl; it += 2) {
             step1(fa, fb, it);
             if (it + 1 < ntl) step1(fb, fa, it + 1);
+        }
+    } else {
+        // eight waves (two per SIMD, <= 256 registers each): the other wave of the SIMD covers a wave's LDS latency, so the fragments are
+        // read a k-step ahead only and a tile is consumed in the iteration it is waited for
+        for (int it = 0; it < ntl; ++it) {
+            const int rem = ntl - 1 - it;
+            wait_tiles(rem < NS1 - 2 ? rem : NS1 - 2);
+            __syncthreads();                 // every wave's share of tile `it` is visible; every wave is done with tile it - 1
+            const int ahead = it + NS1 - 1;
+            if (ahead < ntl) issue1(qt_begin + ahead, ahead % NS1);
+            const unsigned tile = (unsigned)((it % NS1) * PART);
+            f32x16 acc[NAB];
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ab][r] = 0.0f;
+            half8x xh = rd(0, 0, tile);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                half8x nh = xh;
+                if (s + 1 < NKS) nh = rd(0, s + 1, tile);
+#pragma unroll
+                for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[ab][s], acc[ab], 0, 0, 0);
+                xh = nh;
+            }
+            const int q0 = (qt_begin + it) * ROWS + 4 * hi;
+            int fl = 0;
+#pragma unroll
+            for (int ab = 0; ab < NAB; ++ab) {
+                float x = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
+                runmax[ab] = fmaxf(runmax[ab], x);
+                const bool h = (X3_ANCHOR(ab) < nc) && x >= runmax[ab] - 2.0f * e_hi[ab] - X3_MARGIN;
+                fl |= (__ballot(h) != 0ull) ? (1 << ab) : 0;
+            }
+            if (fl && flags_ok && lane == 0) tile_flag[it] = (unsigned char)fl;
         }
     }
     __syncthreads();                         // the ring is free: sweep 2's private regions overlay it
@@ -346,7 +384,7 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
         if (hi == 0 && a < nc) smax[((size_t)p * S + split) * cap_s + a] = runmax[ab];
     }
     {
-        const int owner = ((p * S + split) * T + panel) * 4 + wave;
+        const int owner = ((p * S + split) * T + panel) * WAVES + wave;      // = unit * (groups per unit) + 64-anchor group
         if (flags_ok) {
             unsigned short *gl = tl + (size_t)owner * X3_MAX_TILES;
             for (int i = lane; i < n_t2; i += 64) {
@@ -393,8 +431,8 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
 // showed the dispatcher leaving most CUs empty after the first round (256 running, then 30-180).  So the grid is one workgroup per CU and
 // the workgroups pull items themselves: one queue per XCD (an item's two anchor panels and its query rows stay in that XCD's L2), in the
 // order the one-block-per-item grid used; a workgroup whose XCD has run dry takes items of the others.
-template <int CP>
-__global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
+template <int CP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
                                                                const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
                                                                int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
                                                                int S, const float *__restrict__ al_norm, const float *__restrict__ ql_max,
@@ -408,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
     {
         // nothing listed in any pair (the usual step): one parallel look at the counts instead of a walk through the queues
         bool any = false;
-        for (int m = threadIdx.x; m < B; m += 256) any |= n_c[m] > 0;
+        for (int m = threadIdx.x; m < B; m += 64 * WAVES) any |= n_c[m] > 0;
         if (!__syncthreads_or(any)) return;
     }
     const int my_xcd = blockIdx.x & 7;
@@ -428,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
         __syncthreads();
         const int it = item_s;
         if (it < 0) return;
-        match_x3_scan_item<CP>(it & 7, it >> 3, smem, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed, smax, tl, jobs, njobs, dbg, dbg_wg);
+        match_x3_scan_item<CP, WAVES>(it & 7, it >> 3, smem, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed, smax, tl, jobs, njobs, dbg, dbg_wg);
     }
 }
 
@@ -440,7 +478,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_scan_kernel(const __half *__r
 template <int CP>
 __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
                                                                 const __half *__restrict__ qh, const __half *__restrict__ ql, int cap_s, int cap_q,
-                                                                const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T, int S,
+                                                                const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int G, int S,
                                                                 const float *__restrict__ al_norm, const float *__restrict__ ql_max,
                                                                 const float *__restrict__ smax, const unsigned short *__restrict__ tl,
                                                                 const uint2 *__restrict__ jobs, const int32_t *__restrict__ njobs,
@@ -494,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
         const uint2 jb = jobs[jx];
         const int owner = (int)jb.x, first = (int)((jb.y >> 8) & 0x7fffffu), n_t = (int)(jb.y & 0xffu);
         const bool dense = (jb.y >> 31) != 0;
-        const int wave_g = owner & 3, panel = (owner >> 2) % T, ps = owner / (4 * T), split = ps % S, p = ps / S;
+        const int a_base = (owner % G) * 64, ps = owner / G, split = ps % S, p = ps / S;      // G = 64-anchor groups per (pair, split)
         const int nc = n_c[p] < cap_s ? n_c[p] : cap_s, nq = n_q[p];
         const int nqt = (nq + ROWS - 1) / ROWS, qt_per = (nqt + S - 1) / S, qt_begin = split * qt_per;
         const unsigned short *gl = tl + (size_t)owner * X3_MAX_TILES + first;
@@ -504,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
         const float qlm = sqrtf(ql_max[p]) * 1.002f;
 #pragma unroll
         for (int ab = 0; ab < NAB; ++ab) {
-            const int ar = panel * 256 + wave_g * 64 + ab * 32 + l31;
+            const int ar = a_base + ab * 32 + l31;
             const int arc = ar < cap_s ? ar : cap_s - 1;
             const __half *rh = ah + ((size_t)p * cap_s + arc) * CP + 8 * hi, *rl = al + ((size_t)p * cap_s + arc) * CP + 8 * hi;
 #pragma unroll
@@ -586,7 +624,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
 #pragma unroll
             for (int ab = 0; ab < NAB; ++ab) {
                 if (!((fmask >> ab) & 1)) continue;           // this block's accumulators were not computed: none of its anchors can list a row here
-                const int a = panel * 256 + wave_g * 64 + ab * 32 + l31;
+                const int a = a_base + ab * 32 + l31;
                 float x = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x = fmaxf(x, (q0 + (r & 3) + 8 * (r >> 2) < nq) ? acc[ab][r] : -INFINITY);
@@ -785,7 +823,7 @@ static int x3_jobs_per_owner(int cap_q, int S)
 
 size_t match_x3_scratch_bytes(int B, int cap_s, int S, int cap_q)
 {
-    const size_t owners = (size_t)B * S * ((cap_s + 255) / 256) * 4;
+    const size_t owners = (size_t)B * S * ((cap_s + 511) / 512) * 8;
     return (size_t)B * S * cap_s * 2 * (sizeof(int32_t) + X3_CAPH * sizeof(uint2)) + (size_t)B * (3 * cap_s + 3) * sizeof(int32_t) + 8192 + 4096 +
            (size_t)B * S * cap_s * sizeof(float) /* smax */ + owners * X3_MAX_TILES * sizeof(unsigned short) /* tile lists */ +
            owners * x3_jobs_per_owner(cap_q, S) * sizeof(uint2) /* jobs */ + 1024;
@@ -801,7 +839,10 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
                      const __half *q_hi_lo_pre, const float *q_lo_sq_max_pre, hipStream_t st)
 {
     constexpr int CP = 256;
-    const int T = (cap_s + 255) / 256;
+    // sweep 1 as 8-wave workgroups (512 anchors, two waves per SIMD) unless ORYON_X3_WAVES=4 (256 anchors, one wave per SIMD)
+    static const int x3_waves = (getenv("ORYON_X3_WAVES") && atoi(getenv("ORYON_X3_WAVES")) == 4) ? 4 : 8;
+    const int T = (cap_s + 64 * x3_waves - 1) / (64 * x3_waves);
+    const int G = T * x3_waves;                                  // 64-anchor groups per (pair, split)
     const int S = 8;
     char *sp = static_cast<char *>(scratch);
     int32_t *cnt = reinterpret_cast<int32_t *>(sp);
@@ -824,7 +865,7 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     off += ((size_t)B * cap_s * sizeof(float) + 255) / 256 * 256 + 8192;                    // + the debug counters' slack
     float *smax = reinterpret_cast<float *>(sp + off);
     off += ((size_t)B * S * cap_s * sizeof(float) + 255) / 256 * 256;
-    const size_t owners = (size_t)B * S * T * 4;
+    const size_t owners = (size_t)B * S * G;
     unsigned short *tl = reinterpret_cast<unsigned short *>(sp + off);
     off += (owners * X3_MAX_TILES * sizeof(unsigned short) + 255) / 256 * 256;
     uint2 *jobs = reinterpret_cast<uint2 *>(sp + off);
@@ -864,8 +905,9 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     static long long *dbg_wg = nullptr;
     if (dbg && !dbg_wg) (void)hipMalloc(&dbg_wg, (size_t)65536 * 4 * sizeof(long long));
     if (dbg && dbg_wg) (void)hipMemsetAsync(dbg_wg, 0, (size_t)(groups < 65536 ? groups : 65536) * 4 * sizeof(long long), st);
-    constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2 + 4 * X3_MAX_TILES + 4 * 2 * X3_MAX_TILES + 64;   // 128 KB of tile ring / wave regions + tile flags + the waves' tile lists
-    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP>), X3_SCAN_LDS);
+    constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2 + 8 * X3_MAX_TILES + 8 * 2 * X3_MAX_TILES + 64;   // 128 KB of tile ring + tile flags + the waves' tile lists
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP, 4>), X3_SCAN_LDS);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP, 8>), X3_SCAN_LDS);
     // one workgroup per CU, items pulled from per-XCD queues (see the kernel)
     static int n_cus = 0;
     if (!n_cus) {
@@ -874,10 +916,13 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
         n_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess && v > 0) ? v : 256;
     }
     const int grid = groups < n_cus ? groups : n_cus / 8 * 8;
-    hipLaunchKernelGGL((match_x3_scan_kernel<CP>), dim3(grid), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, dbg_dev, dbg_wg);
+    if (x3_waves == 8)
+        hipLaunchKernelGGL((match_x3_scan_kernel<CP, 8>), dim3(grid), dim3(512), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, dbg_dev, dbg_wg);
+    else
+        hipLaunchKernelGGL((match_x3_scan_kernel<CP, 4>), dim3(grid), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, dbg_dev, dbg_wg);
     // sweep 2: four one-wave workgroups per CU pull the jobs sweep 1 posted (none posted: they exit at once)
     allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_sweep2_kernel<CP>), 4 * 32768);
-    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP>), dim3(n_cus), dim3(256), 4 * 32768, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, smax, tl, jobs, njobs, next_job, cnt, cand, dbg_dev);
+    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP>), dim3(n_cus), dim3(256), 4 * 32768, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, G, S, al_norm, ql_max, smax, tl, jobs, njobs, next_job, cnt, cand, dbg_dev);
     const size_t lds = (size_t)4 * (2 * CP + 2 * X3_SURV) * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
