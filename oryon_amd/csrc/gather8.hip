@@ -278,6 +278,9 @@ __device__ __forceinline__ void gather_q8_v3_tile(
         }
 #pragma unroll
         for (int part = 0; part < KPL / 64; ++part) {           // 64 channels per staging pass: slots 0-7 = hi halves, 8-15 = lo halves
+            // chunks that hold none of the map's C channels are not written at all (their values are zero and every reader of the hi / lo
+            // arrays skips them: match_x3.hip takes ceil(C / 64) live chunks) - a C = 32 map writes 128 + 128 bytes per row, not 1 KB
+            if (part * 64 >= C) continue;
             const int c0 = part * 64;
             WAVE_LDS_ORDER();
 #pragma unroll

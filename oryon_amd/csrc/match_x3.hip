@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void match_x3_split_anchors_kernel(const float
 __global__ __launch_bounds__(256) void match_x3_seed_kernel(const __half *__restrict__ ah, const __half *__restrict__ qh, int Cp, int cap_s,
                                                              int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q,
                                                              const int32_t *__restrict__ orig_idx, int orig_stride,
-                                                             const int32_t *__restrict__ sid_final, int cap_a, float *__restrict__ seed)
+                                                             const int32_t *__restrict__ sid_final, int cap_a, int kc, float *__restrict__ seed)
 {
     const int p = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void match_x3_seed_kernel(const __half *__rest
     const int r = lane >> 2, seg = lane & 3;
     const int q = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
     float s = 0.0f;
-    if (q < nq) {
+    if (q < nq && seg < kc) {                                   // (chunks beyond the map's channels are never written: zero by definition)
         const uint4 *ar = reinterpret_cast<const uint4 *>(ah + ((size_t)p * cap_s + row) * Cp) + seg * (Cp / 32);
         const uint4 *qr = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(qh + (size_t)p * cap_q * Cp) + x3_q_off(q, seg * 128));
         for (int i = 0; i < Cp / 32; ++i) {
@@ -131,13 +131,13 @@ __global__ __launch_bounds__(256) void match_x3_seed_kernel(const __half *__rest
 // grid: units (pair, query split) dealt to the 8 XCDs, T = cap_s / 256 anchor panels per unit; 4 waves x 64 anchors (two B-operand sets of hi +
 // lo rows = 256 registers: one workgroup per CU with the 512-register budget - with 32 anchors per wave every pair of ds_read_b128 fed only
 // 3 MFMAs and the LDS, not the matrix pipe, set the pace: 5.1 ms); tiles of 32 query rows (hi part 16 KB + lo part 16 KB, double-buffered)
-template <int CP, int WAVES>
+template <int CP, int WAVES, bool NARROW>
 __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot, char *__restrict__ smem, const __half *__restrict__ ah,
                                                    const __half *__restrict__ al, const __half *__restrict__ qh, const __half *__restrict__ ql, int B,
                                                    int cap_s, int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T, int S,
                                                    const float *__restrict__ al_norm, const float *__restrict__ ql_max,
                                                    const float *__restrict__ seed, float *__restrict__ smax, unsigned short *__restrict__ tl,
-                                                   uint2 *__restrict__ jobs, int32_t *__restrict__ njobs, int32_t *__restrict__ dbg,
+                                                   uint2 *__restrict__ jobs, int32_t *__restrict__ njobs, int kc, int32_t *__restrict__ dbg,
                                                    long long *__restrict__ dbg_wg)
 {
     constexpr int RB = CP * 2;                 // bytes per half row
@@ -278,8 +278,10 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
             for (int r = 0; r < 16; ++r) acc[ab][r] = 0.0f;
 #pragma unroll
         for (int s = 0; s < NKS; ++s)
+            if (!NARROW || s < 4 * kc) {                        // NARROW: k-steps of never-written chunks are skipped (zero by definition)
 #pragma unroll
-            for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], bh[ab][s], acc[ab], 0, 0, 0);
+                for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], bh[ab][s], acc[ab], 0, 0, 0);
+            }
         const int q0 = qt * ROWS + 4 * hi;
         int fl = 0;
 #pragma unroll
@@ -330,8 +332,10 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
             for (int s = 0; s < NKS; ++s) {
                 half8x nh = xh;
                 if (s + 1 < NKS) nh = rd(0, s + 1, tile);
+                if (!NARROW || s < 4 * kc) {                   // NARROW: channels beyond the live chunks are zero on both sides (wave-uniform)
 #pragma unroll
-                for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[ab][s], acc[ab], 0, 0, 0);
+                    for (int ab = 0; ab < NAB; ++ab) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[ab][s], acc[ab], 0, 0, 0);
+                }
                 xh = nh;
             }
             const int q0 = (qt_begin + it) * ROWS + 4 * hi;
@@ -431,7 +435,7 @@ __device__ __forceinline__ void match_x3_scan_item(const int xcd, const int slot
 // showed the dispatcher leaving most CUs empty after the first round (256 running, then 30-180).  So the grid is one workgroup per CU and
 // the workgroups pull items themselves: one queue per XCD (an item's two anchor panels and its query rows stay in that XCD's L2), in the
 // order the one-block-per-item grid used; a workgroup whose XCD has run dry takes items of the others.
-template <int CP, int WAVES>
+template <int CP, int WAVES, bool NARROW>
 __global__ __launch_bounds__(64 * WAVES, 1) void match_x3_scan_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
                                                                const __half *__restrict__ qh, const __half *__restrict__ ql, int B, int cap_s,
                                                                int cap_q, const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int T,
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void match_x3_scan_kernel(const __ha
                                                                const float *__restrict__ seed, float *__restrict__ smax,
                                                                unsigned short *__restrict__ tl, uint2 *__restrict__ jobs,
                                                                int32_t *__restrict__ njobs, int32_t *__restrict__ queue /*[8], zeroed*/,
-                                                               int items_per_xcd, int32_t *__restrict__ dbg, long long *__restrict__ dbg_wg)
+                                                               int items_per_xcd, int kc, int32_t *__restrict__ dbg, long long *__restrict__ dbg_wg)
 {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     __shared__ int item_s;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void match_x3_scan_kernel(const __ha
         __syncthreads();
         const int it = item_s;
         if (it < 0) return;
-        match_x3_scan_item<CP, WAVES>(it & 7, it >> 3, smem, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed, smax, tl, jobs, njobs, dbg, dbg_wg);
+        match_x3_scan_item<CP, WAVES, NARROW>(it & 7, it >> 3, smem, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed, smax, tl, jobs, njobs, kc, dbg, dbg_wg);
     }
 }
 
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void match_x3_scan_kernel(const __ha
 // split, <= 16 of its flagged tiles) - from the queue sweep 1 filled: hi / lo compensated products, rows scoring within the limit of the
 // anchor's maximum appended to its candidate list.  The limit comes from the maximum over ALL splits (sweep 1 has finished), so splits
 // away from the peak list nothing; several jobs can append to one list, so a lane reserves its entries with one atomic per tile.
-template <int CP>
+template <int CP, bool NARROW>
 __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *__restrict__ ah, const __half *__restrict__ al,
                                                                 const __half *__restrict__ qh, const __half *__restrict__ ql, int cap_s, int cap_q,
                                                                 const int32_t *__restrict__ n_c, const int32_t *__restrict__ n_q, int G, int S,
@@ -483,6 +487,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
                                                                 const float *__restrict__ smax, const unsigned short *__restrict__ tl,
                                                                 const uint2 *__restrict__ jobs, const int32_t *__restrict__ njobs,
                                                                 int32_t *__restrict__ next_job, int32_t *__restrict__ cnt, uint2 *__restrict__ cand,
+                                                                int kc /* live 64-channel chunks: ceil(C_true / 64); the rest of a row is zero */,
                                                                 int32_t *__restrict__ dbg)
 {
     constexpr int RB = CP * 2, ROWS = 32, PART = ROWS * RB, NKS = CP / 16, NAB = 2;
@@ -499,6 +504,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
     extern __shared__ __attribute__((aligned(256))) char smem2[];
     char *reg = smem2 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (NCH * CHB);
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    if constexpr (!NARROW) kc = CP / 64;                        // every chunk is live: the compiler sees a constant
     const int n_jobs = __atomic_load_n(njobs, __ATOMIC_RELAXED);
     // DMA source: lane L of instruction j lands at LDS (row j*8 + L/8, 16-byte slot L%8); slots are XOR-swizzled with (row >> 1) & 7 so
     // that the 16 lanes of a ds_read_b128 phase (rows r .. r+15 at one logical slot) cover all 64 banks
@@ -562,18 +568,19 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
         }
         if (dbg) { t_load += wall_clock64() - tj0; n_tiles_done += n_t; n_jobs_done += 1; }
         auto tile_at = [&](int i) { return qt_begin + (dense ? first + i : (int)(gl[i] & 0x3fffu)); };
-        auto issue2 = [&](int g) {                               // chunk g = (tile g / NCH of the job, k-chunk g % NCH)
-            const int qt = tile_at(g / NCH), c = g % NCH;
+        auto issue2 = [&](int g) {                               // chunk g = (tile g / kc of the job, k-chunk g % kc), into slot g % 4
+            const int ti = g / kc, c = g - ti * kc;
+            const int qt = tile_at(ti);
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
                 const char *qb = (part ? qlp : qhp) + (size_t)qt * PART + c * 4096;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + src2[j]),
-                                                     (__attribute__((address_space(3))) void *)(reg + c * CHB + part * (CHB / 2) + j * 1024), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(reg + (g & 3) * CHB + part * (CHB / 2) + j * 1024), 16, 0, 0);
             }
         };
-        const int n_g = n_t * NCH;
+        const int n_g = n_t * kc;                                 // narrow descriptors (C = 32 zero-padded to 256): only the live chunks travel
 #pragma unroll
         for (int d = 0; d < NCH - 1; ++d)
             if (d < n_g) issue2(d);
@@ -587,15 +594,16 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
                 for (int r = 0; r < 16; ++r) acc[ab][r] = 0.0f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const int g = i * NCH + c;
+                if (c < kc) {                                  // (wave-uniform; the dead chunks of a narrow row are zero)
+                const int g = i * kc + c;
                 const int rem = n_g - 1 - g;
                 // chunk g has landed when at most min(2, chunks left) later chunks are in flight (the candidate stores / atomics of earlier
                 // tiles only make the count conservative)
                 if (rem >= 2) X3_WAIT(2 * PERC); else if (rem == 1) X3_WAIT(PERC); else X3_WAIT(0);
                 __builtin_amdgcn_wave_barrier();
-                // slot (c + 3) % 4 held chunk g - 1, whose operand reads completed before its MFMAs were issued
+                // slot (g + 3) % 4 held chunk g - 1, whose operand reads completed before its MFMAs were issued
                 if (g + NCH - 1 < n_g) issue2(g + NCH - 1);
-                const char *cb = reg + c * CHB;
+                const char *cb = reg + (g & 3) * CHB;
 #pragma unroll
                 for (int s4 = 0; s4 < CH / 16; ++s4) {
                     const half8x xh = *reinterpret_cast<const half8x *>(cb + ko2[s4]);
@@ -618,6 +626,7 @@ __global__ __launch_bounds__(256, 1) void match_x3_sweep2_kernel(const __half *_
                         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bl[1][s], acc[1], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh[1][s], acc[1], 0, 0, 0);
                     }
+                }
                 }
             }
             const int q0 = qt * ROWS + 4 * hi;
@@ -733,8 +742,9 @@ __global__ __launch_bounds__(256) void match_x3_rescore_kernel(const float *__re
                 hits &= hits - 1;
                 const int jj = __shfl(qi, src);
                 const size_t qoff = (size_t)p * cap_q * Cp * 2 + x3_q_off(jj, lane * 8);          // bytes: lane l holds channels 4 l .. 4 l + 3
-                const uint2 h = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(qh) + qoff);
-                const uint2 lo_ = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(ql) + qoff);
+                const bool live_chunk = lane * 4 < C_true;                   // chunks beyond the map's channels are never written
+                const uint2 h = live_chunk ? *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(qh) + qoff) : make_uint2(0u, 0u);
+                const uint2 lo_ = live_chunk ? *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(ql) + qoff) : make_uint2(0u, 0u);
                 const __half2 h0 = *reinterpret_cast<const __half2 *>(&h.x), h1 = *reinterpret_cast<const __half2 *>(&h.y);
                 const __half2 l0 = *reinterpret_cast<const __half2 *>(&lo_.x), l1 = *reinterpret_cast<const __half2 *>(&lo_.y);
                 double v = a4[0] * ((double)__low2float(h0) + (double)__low2float(l0));
@@ -899,15 +909,17 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     const float *seed_arg = nullptr;
     if (use_seed && orig_idx && sid_final) {
         hipLaunchKernelGGL(match_x3_seed_kernel, dim3((cap_s + 3) / 4, B), dim3(256), 0, st, ah, qh, CP, cap_s, cap_q, n_c, n_q, orig_idx, orig_stride,
-                           sid_final, cap_a, seed);
+                           sid_final, cap_a, (C_true + 63) / 64, seed);
         seed_arg = seed;
     }
     static long long *dbg_wg = nullptr;
     if (dbg && !dbg_wg) (void)hipMalloc(&dbg_wg, (size_t)65536 * 4 * sizeof(long long));
     if (dbg && dbg_wg) (void)hipMemsetAsync(dbg_wg, 0, (size_t)(groups < 65536 ? groups : 65536) * 4 * sizeof(long long), st);
     constexpr int X3_SCAN_LDS = 4 * 2 * 32 * CP * 2 + 8 * X3_MAX_TILES + 8 * 2 * X3_MAX_TILES + 64;   // 128 KB of tile ring + tile flags + the waves' tile lists
-    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP, 4>), X3_SCAN_LDS);
-    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP, 8>), X3_SCAN_LDS);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP, 4, false>), X3_SCAN_LDS);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP, 8, false>), X3_SCAN_LDS);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP, 4, true>), X3_SCAN_LDS);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_scan_kernel<CP, 8, true>), X3_SCAN_LDS);
     // one workgroup per CU, items pulled from per-XCD queues (see the kernel)
     static int n_cus = 0;
     if (!n_cus) {
@@ -916,13 +928,21 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
         n_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess && v > 0) ? v : 256;
     }
     const int grid = groups < n_cus ? groups : n_cus / 8 * 8;
-    if (x3_waves == 8)
-        hipLaunchKernelGGL((match_x3_scan_kernel<CP, 8>), dim3(grid), dim3(512), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, dbg_dev, dbg_wg);
-    else
-        hipLaunchKernelGGL((match_x3_scan_kernel<CP, 4>), dim3(grid), dim3(256), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, dbg_dev, dbg_wg);
-    // sweep 2: four one-wave workgroups per CU pull the jobs sweep 1 posted (none posted: they exit at once)
-    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_sweep2_kernel<CP>), 4 * 32768);
-    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP>), dim3(n_cus), dim3(256), 4 * 32768, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, G, S, al_norm, ql_max, smax, tl, jobs, njobs, next_job, cnt, cand, dbg_dev);
+    const int kc = (C_true + 63) / 64;                          // live 64-channel chunks of a row (narrow maps are zero-padded to 256)
+#define X3_SCAN_LAUNCH(WV, NR)                                                                                                   \
+    hipLaunchKernelGGL((match_x3_scan_kernel<CP, WV, NR>), dim3(grid), dim3(64 * WV), X3_SCAN_LDS, st, ah, al, qh, ql, B, cap_s, cap_q, n_c, n_q, T, \
+                       S, al_norm, ql_max, seed_arg, smax, tl, jobs, njobs, queue, groups / 8, kc, dbg_dev, dbg_wg)
+    if (x3_waves == 8) { if (kc < 4) X3_SCAN_LAUNCH(8, true); else X3_SCAN_LAUNCH(8, false); }
+    else { if (kc < 4) X3_SCAN_LAUNCH(4, true); else X3_SCAN_LAUNCH(4, false); }
+#undef X3_SCAN_LAUNCH
+    // sweep 2: four independent waves per CU pull the jobs sweep 1 posted (none posted: they exit at once)
+#define X3_SWEEP2_LAUNCH(NR)                                                                                                     \
+    hipLaunchKernelGGL((match_x3_sweep2_kernel<CP, NR>), dim3(n_cus), dim3(256), 4 * 32768, st, ah, al, qh, ql, cap_s, cap_q, n_c, n_q, G, S, al_norm, \
+                       ql_max, smax, tl, jobs, njobs, next_job, cnt, cand, kc, dbg_dev)
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_sweep2_kernel<CP, true>), 4 * 32768);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&match_x3_sweep2_kernel<CP, false>), 4 * 32768);
+    if (kc < 4) X3_SWEEP2_LAUNCH(true); else X3_SWEEP2_LAUNCH(false);
+#undef X3_SWEEP2_LAUNCH
     const size_t lds = (size_t)4 * (2 * CP + 2 * X3_SURV) * sizeof(float);
     if (layout == ORYON_LAYOUT_NHWC)
         hipLaunchKernelGGL((match_x3_rescore_kernel<true>), dim3(cap_s / 4, B), dim3(256), lds, st, a_c, CP, cap_s, n_c, feat_q, C_true, HW, roi_q,
