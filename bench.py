@@ -677,10 +677,14 @@ def main():
         if rank == 0:
             hard = {"descriptors": "smooth rank-8 fields + 1-2 % noise (anchor map = query map + noise): the int8 bound settles every anchor's VALIDITY "
                                    "but cannot separate its near-ties, so the argmin of the <= 500 sampled anchors per pair comes from the second level: the "
-                                   "fp16x3 two-sweep scan of just those rows (K1x3, match_x3.hip) + the canonical fp32 chain on its few candidates "
+                                   "fp16x3 scan of just those rows (K1x3, match_x3.hip: seeded hi-only sweep, compensated products on the flagged "
+                                   "(64-anchor group, tile) jobs) + the canonical fp32 chain on its few candidates; the engine's K0 pass writes the "
+                                   "hi / lo rows itself once its feedback says the previous steps needed them (x3_prefetch) "
                                    "(ORYON_AMB_X3=0: exact fp32 scan against fp32 query rows materialised for the pair)",
                     "value": total * HARD_STEPS / float(hel.item()), "unit": "pairs/s", "ms_per_step": float(hel.item()) / HARD_STEPS * 1e3, "steps": HARD_STEPS,
                     "int8_undecided_fraction": float(engine._i8_frac), "int8_stage_skipped": bool(engine._i8_frac > engine.i8_max_undecided),
+                    "k0_passes_with_hi_lo_rows": (engine._native.x3_steps() if engine._native is not None else None),
+                    "fraction_of_headline": total * HARD_STEPS / float(hel.item()) / rec["value"],
                     "pairs_ok": int((hstatus[:total] == 0).sum())}
     # the other two stage sets of SURVEY 8(d), measured in this same run (short: 3 steps each) and carried in the same line; `value`
     # stays the configs[1] number (descriptors given)
