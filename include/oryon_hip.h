@@ -478,6 +478,38 @@ int oryon_pose_bop_errors(const double *pred_pose, const double *gt_pose, const 
                           const int32_t *pts_offset, const double *syms, const int32_t *sym_offset, int n_models, int max_syms,
                           const int32_t *model_of_pair, int max_points, double *workspace, double *out, void *stream);
 
+/* a5  StandardDecoder.forward (models/decoder.py:82-108) on the device, fp32 in / fp32 out, for the decoder the reference builds
+ *     (get_decoder, models/decoder.py:119-125: input_dim 128, decoder_dims [64, 32], extra_upsampling, guidance projections 256->32 and
+ *     128->16): three Up blocks (ConvTranspose2d 2x2 s2 -> cat guidance -> (conv3x3 - GroupNorm(C/16) - ReLU) x 2, :9-42), the two
+ *     guidance projections (conv3x3 + bias + ReLU, :66-72) and the 3x3 head (:80).  Replaces the cuDNN / MIOpen convolutions and the
+ *     separate GroupNorm / ReLU / cat / clone passes of the reference graph: every convolution is an implicit GEMM on the fp16 matrix
+ *     pipe with error-compensated (hi + lo) operands - fp32-grade, see csrc/decoder.hip - GroupNorm + ReLU are applied by the next
+ *     layer's loader, the statistics are reduced in a fixed order (bit-reproducible).
+ * Weights: DEVICE pointers to the module's fp32 parameters in torch layout (state-dict names in the comments); oryon_decoder_create packs
+ * them (a few small launches on `stream`, then one synchronise: the caller's tensors are not referenced afterwards). */
+typedef struct oryon_decoder oryon_decoder_t;
+typedef struct {
+    const float *gp_w[2], *gp_b[2];   /* decoder_guidance_projection.{0,1}.0.{weight,bias}: [32,256,3,3] [32]; [16,128,3,3] [16] */
+    const float *up_w[3], *up_b[3];   /* decoder{1,2,3}.up.{weight,bias}: [128,96,2,2] [96]; [64,48,2,2] [48]; [32,32,2,2] [32] */
+    const float *c1_w[3];             /* decoder{1,2,3}.conv.double_conv.0.weight: [64,128,3,3]; [32,64,3,3]; [32,32,3,3] */
+    const float *n1_g[3], *n1_b[3];   /* ....double_conv.1.{weight,bias}: [64]; [32]; [32] */
+    const float *c2_w[3];             /* ....double_conv.3.weight: [64,64,3,3]; [32,32,3,3]; [32,32,3,3] */
+    const float *n2_g[3], *n2_b[3];   /* ....double_conv.4.{weight,bias} */
+    const float *head_w, *head_b;     /* head.{weight,bias}: [1,32,3,3] [1] */
+} oryon_decoder_weights_t;
+int oryon_decoder_create(const oryon_decoder_weights_t *weights, oryon_decoder_t **handle, void *stream);
+void oryon_decoder_destroy(oryon_decoder_t *handle);
+/* x [n_img, 128, h, w] NCHW (= rearrange(fusion output, 'B C T H W -> (B T) C H W'), :93), g2 [n_img, 256, 2h, 2w], g3 [n_img, 128, 4h, 4w]
+ * NCHW (guidance[1:], :86), h % 8 == 0, w % 8 == 0 (the reference: 24 x 24) -> featmap [n_img, 32, 8h, 8w] NCHW, logits [n_img, 8h, 8w].
+ * workspace: oryon_decoder_workspace_bytes(n_img, h, w) bytes (0 = unsupported shape), 256-byte aligned, no other requirements; three
+ * activation buffers at the offsets oryon_decoder_workspace_layout reports (tests read intermediates there).
+ * stop_after: 0 = the whole module; k = 3 i + j (debug / tests): return after block i's cat buffer (j = 1), first (j = 2) or second
+ * (j = 3) convolution - raw NHWC outputs in buffers 0, 1, 2. */
+int64_t oryon_decoder_workspace_bytes(int n_img, int h, int w);
+int oryon_decoder_workspace_layout(int n_img, int h, int w, int64_t *offsets3);
+int oryon_decoder_forward(const oryon_decoder_t *handle, const float *x, const float *g2, const float *g3, int n_img, int h, int w,
+                          void *workspace, int64_t workspace_bytes, float *featmap, float *logits, int stop_after, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

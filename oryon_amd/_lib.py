@@ -25,6 +25,13 @@ class EngineConfig(ctypes.Structure):
                 ("round_f16", c_int), ("n_slots", c_int), ("overlap", c_int), ("gather_sets", c_int), ("reg_streams", c_int), ("reg_lag", c_int), ("screen", c_int), ("sample_first", c_int), ("x3_prefetch", c_int)]
 
 
+class DecoderWeights(ctypes.Structure):
+    """oryon_decoder_weights_t (include/oryon_hip.h): device pointers to StandardDecoder's fp32 parameters."""
+    _fields_ = [("gp_w", c_void_p * 2), ("gp_b", c_void_p * 2), ("up_w", c_void_p * 3), ("up_b", c_void_p * 3), ("c1_w", c_void_p * 3),
+                ("n1_g", c_void_p * 3), ("n1_b", c_void_p * 3), ("c2_w", c_void_p * 3), ("n2_g", c_void_p * 3), ("n2_b", c_void_p * 3),
+                ("head_w", c_void_p), ("head_b", c_void_p)]
+
+
 class PointDSCConfig(ctypes.Structure):
     _fields_ = [("in_dim", c_int), ("num_layers", c_int), ("num_channels", c_int), ("num_iterations", c_int),
                 ("ratio", c_float), ("inlier_threshold", c_float), ("sigma_d", c_float), ("k", c_int),
@@ -102,6 +109,11 @@ _PROTOS = {
     "oryon_engine_config_bytes": (c_size_t, []),
     "oryon_engine_host_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "oryon_engine_x3_steps": (c_int, [c_void_p, POINTER(c_int64)]),
+    "oryon_decoder_create": (c_int, [POINTER(DecoderWeights), POINTER(c_void_p), _P]),
+    "oryon_decoder_destroy": (None, [c_void_p]),
+    "oryon_decoder_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "oryon_decoder_workspace_layout": (c_int, [c_int, c_int, c_int, POINTER(c_int64)]),
+    "oryon_decoder_forward": (c_int, [c_void_p, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P, c_int, _P]),
     "oryon_pointdsc_create": (c_int, [POINTER(c_void_p), POINTER(PointDSCConfig)]),
     "oryon_pointdsc_destroy": (None, [c_void_p]),
     "oryon_pointdsc_load_param": (c_int, [c_void_p, c_char_p, _P, c_int64]),

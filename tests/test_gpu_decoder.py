@@ -1,0 +1,108 @@
+"""a5 on the device: StandardDecoder.forward through oryon_decoder_forward (csrc/decoder.hip) against (1) the torch fp32 module layer
+by layer on random inputs and (2) the outputs of the imported reference (tests/golden/g5_backbone.npz, models/decoder.py:82-108)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _decoder(seed):
+    from oracle import oryon_oracle as orc
+    from oryon_amd.backbone.fusion import StandardDecoder
+    dec = StandardDecoder("cpu", True, True, input_dim=128, decoder_dims=[64, 32]).eval()
+    dec.load_state_dict(orc.analytic_state_dict(dec.state_dict(), seed=seed), strict=True)
+    return dec.to("cuda")
+
+
+def _nhwc(buf, off, n, H, W, C):
+    return buf[off:off + n * H * W * C * 4].view(torch.float32).view(n, H, W, C).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 24, 24), (3, 8, 16)])
+def test_hip_decoder_layers_match_torch_fp32(n, h, w):
+    """Every intermediate the workspace exposes (cat buffers, raw convolution outputs) and both outputs against the torch modules run
+    in fp32 on the same device: <= 2e-5 of the tensor's largest magnitude (the fp16x3 products are ~2^-22 relative)."""
+    from oryon_amd.backbone import fusion
+    from oryon_amd.backbone.decoder_hip import HipDecoder
+    torch.backends.cudnn.allow_tf32 = False
+    torch.manual_seed(5)
+    dec = _decoder(7)
+    x = torch.randn(n, 128, h, w, device="cuda")
+    g2 = torch.randn(n, 256, 2 * h, 2 * w, device="cuda") * 2.0
+    g3 = torch.randn(n, 128, 4 * h, 4 * w, device="cuda") * 0.5 + 0.3
+    hip = HipDecoder(dec, x.device)
+    off = hip.layout(n, h, w)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    with torch.no_grad():
+        pg = [proj(g) for proj, g in zip(dec.decoder_guidance_projection, (g2, g3))] + [None]
+        y = x
+        H, W = h, w
+        for i, blk in enumerate((dec.decoder1, dec.decoder2, dec.decoder3)):
+            H, W = 2 * H, 2 * W
+            cat = blk.up(y)
+            if pg[i] is not None:
+                cat = torch.cat([cat, pg[i]], dim=1)
+            c1 = blk.conv.double_conv[0](cat)
+            c2 = blk.conv.double_conv[3](blk.conv.double_conv[2](blk.conv.double_conv[1](c1)))
+            y = blk.conv.double_conv[5](blk.conv.double_conv[4](c2))
+            for j, ref in ((1, cat), (2, c1), (3, c2)):
+                hip.forward(x, g2, g3, stop_after=3 * i + j)
+                torch.cuda.synchronize()
+                got = _nhwc(hip.workspace(n, h, w), off[j - 1], n, H, W, ref.shape[1])
+                assert rel(got, ref) < 2e-5, (i, j, rel(got, ref))
+        logits_ref = dec.head(y)
+        lg, fm = hip.forward(x, g2, g3)
+        assert rel(fm, y) < 2e-5 and rel(lg, logits_ref[:, 0]) < 2e-5, (rel(fm, y), rel(lg, logits_ref[:, 0]))
+        # the module switch routes StandardDecoder.forward through the same handle
+        fusion.enable_hip_decoder(True)
+        try:
+            lg2, fm2 = dec(x.view(n, 128, 1, h, w), [None, g2, g3])
+        finally:
+            fusion.enable_hip_decoder(False)
+        assert lg2.shape == (n, 1, 8 * h, 8 * w) and torch.equal(fm2, fm) and torch.equal(lg2[:, 0], lg)
+        lg3, fm3 = hip.forward(x, g2, g3)
+        assert torch.equal(fm3, fm) and torch.equal(lg3, lg)                    # fixed reduction order: bit-reproducible
+
+
+def test_hip_decoder_matches_reference_golden():
+    """The G5 fixture (fusion + decoder of the imported reference on hashed inputs / analytic weights): the decoder alone on the HIP path,
+    fed with the torch fusion output of the same test - <= 1e-4 relative, the north-star descriptor bar."""
+    from oracle import oryon_oracle as orc
+    from oryon_amd.backbone import fusion as F_
+    from oryon_amd.backbone.fusion import ImageTextFusion
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    g = np.load(os.path.join(GOLD, "g5_backbone.npz"))
+    dev = "cuda"
+    fusion = ImageTextFusion("cpu").eval()
+    fusion.load_state_dict(orc.analytic_state_dict(fusion.state_dict(), seed=3), strict=True)
+    fusion = fusion.to(dev)
+    decoder = _decoder(4)
+    B = 2
+    img = orc.hashed_tensor((B, 1024, 24, 24), 100, 0, 1.0).to(dev)
+    text = orc.hashed_tensor((B, 1, 80, 768), 101, 0, 1.0).to(dev)
+    guid = [orc.hashed_tensor((B, 512, 24, 24), 102, 0, 1.0).to(dev), orc.hashed_tensor((B, 256, 48, 48), 103, 0, 1.0).to(dev),
+            orc.hashed_tensor((B, 128, 96, 96), 104, 0, 1.0).to(dev)]
+    F_.enable_hip_decoder(True)
+    try:
+        with torch.no_grad():
+            feats = fusion(img, text, guid)
+            mask, featmap = decoder(feats, guid)
+        assert decoder.__dict__.get("_hip") is not None                         # the HIP path ran, not the torch modules
+    finally:
+        F_.enable_hip_decoder(False)
+    rel = lambda a, b: float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+    assert rel(mask[:, :, ::2, ::2].cpu().numpy(), g["mask"]) < 1e-4
+    assert rel(featmap[:, :, ::4, ::4].cpu().numpy(), g["featmap_sub"]) < 1e-4
+    assert rel(featmap.double().sum(dim=(2, 3)).cpu().numpy(), g["featmap_sum"]) < 1e-4
+    assert rel(featmap.double().abs().sum(dim=(2, 3)).cpu().numpy(), g["featmap_abs_sum"]) < 1e-5
+
+
+def test_hip_decoder_argument_checks():
+    from oryon_amd._lib import lib
+    assert lib().oryon_decoder_workspace_bytes(2, 24, 24) > 0
+    assert lib().oryon_decoder_workspace_bytes(2, 20, 24) == 0 and lib().oryon_decoder_workspace_bytes(0, 24, 24) == 0
