@@ -242,15 +242,17 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
         "value": total * steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "backbone_ms_per_step": bb_ms, "pairs_per_gpu": B, "pairs_ok": pairs_ok,
         "dtype": {"fp32": "f32 (PyTorch-ROCm fp32 GEMMs / convolutions, TF32-style shortcuts off)",
-                  "fp16x3": "f32 tensors; CLIP / Swin linears and the CLIP attention as error-compensated fp16x3 MFMA kernels (oryon_linear_f16x3, "
-                            "oryon_mha_f16x3: ~1e-6 relative, fp32-grade), fused fp32 LayerNorm / window attention, convolutions PyTorch-ROCm fp32",
+                  "fp16x3": "f32 tensors; CLIP / Swin / fusion linears and the CLIP attention as error-compensated fp16x3 MFMA kernels "
+                            "(oryon_linear_f16x3, oryon_mha_f16x3: ~1e-6 relative, fp32-grade), fused fp32 LayerNorm / window attention, the "
+                            "decoder as HIP implicit-GEMM convolutions on the same fp16x3 arithmetic (oryon_decoder_forward, csrc/decoder.hip); "
+                            "the remaining convolutions (patch embeddings, fusion's 7x7 / 3x3) PyTorch-ROCm fp32",
                   "bf16": "bf16 backbone GEMMs (autocast), f32 match+pose",
                   "bf16w": "bf16 backbone (weights + activations), f32 match+pose"}[backbone_dtype],
         "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
         "prompt_cache": "80-template text tower evaluated once (identical prompt set), as in eval of one object class",
         "roofline": {"bound": "mfma",
-                     "kernel": ("backbone GEMMs: oryon_linear_f16x3 / oryon_mha_f16x3 (fp32-equivalent FLOP/s against a third of the dense fp16 "
-                                "peak) + MIOpen convolutions" if backbone_dtype == "fp16x3" else
+                     "kernel": ("backbone GEMMs: oryon_linear_f16x3 / oryon_mha_f16x3 / dec_conv3x3_kernel (fp32-equivalent FLOP/s against a "
+                                "third of the dense fp16 peak) + the remaining MIOpen convolutions" if backbone_dtype == "fp16x3" else
                                 "backbone GEMMs / convolutions (hipBLASLt / MIOpen through PyTorch-ROCm)"),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None},
     }
@@ -692,7 +694,9 @@ def main():
     if not a.no_stage_sets:
         del inputs, engine
         torch.cuda.empty_cache()
-        for stage, bdt, label in (("decode", "fp32", "decode+match+pose"), ("full", "fp32", "full (feat+match+pose), fp32 torch linears"),
+        for stage, bdt, label in (("decode", "fp16x3", "decode+match+pose"),
+                                  ("decode", "fp32", "decode+match+pose, torch / MIOpen fp32 modules"),
+                                  ("full", "fp32", "full (feat+match+pose), fp32 torch linears"),
                                   ("full", "fp16x3", "full (feat+match+pose), fp16x3 linears")):
             r = run_stage_set(a, rank, world, dev, stage, steps=3, warmup=1, backbone_dtype=bdt)
             if rank == 0:

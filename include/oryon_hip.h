@@ -500,7 +500,8 @@ typedef struct {
 int oryon_decoder_create(const oryon_decoder_weights_t *weights, oryon_decoder_t **handle, void *stream);
 void oryon_decoder_destroy(oryon_decoder_t *handle);
 /* x [n_img, 128, h, w] NCHW (= rearrange(fusion output, 'B C T H W -> (B T) C H W'), :93), g2 [n_img, 256, 2h, 2w], g3 [n_img, 128, 4h, 4w]
- * NCHW (guidance[1:], :86), h % 8 == 0, w % 8 == 0 (the reference: 24 x 24) -> featmap [n_img, 32, 8h, 8w] NCHW, logits [n_img, 8h, 8w].
+ * (guidance[1:], :86; guidance_layout = ORYON_LAYOUT_NCHW, or ORYON_LAYOUT_NHWC for [n_img, 2h, 2w, 256] / [n_img, 4h, 4w, 128] - the Swin
+ * tower's own token layout, of which net.py:72-75 returns permuted views), h % 8 == 0, w % 8 == 0 (the reference: 24 x 24) -> featmap [n_img, 32, 8h, 8w] NCHW, logits [n_img, 8h, 8w].
  * workspace: oryon_decoder_workspace_bytes(n_img, h, w) bytes (0 = unsupported shape), 256-byte aligned, no other requirements; three
  * activation buffers at the offsets oryon_decoder_workspace_layout reports (tests read intermediates there).
  * stop_after: 0 = the whole module; k = 3 i + j (debug / tests): return after block i's cat buffer (j = 1), first (j = 2) or second
@@ -508,7 +509,7 @@ void oryon_decoder_destroy(oryon_decoder_t *handle);
 int64_t oryon_decoder_workspace_bytes(int n_img, int h, int w);
 int oryon_decoder_workspace_layout(int n_img, int h, int w, int64_t *offsets3);
 int oryon_decoder_forward(const oryon_decoder_t *handle, const float *x, const float *g2, const float *g3, int n_img, int h, int w,
-                          void *workspace, int64_t workspace_bytes, float *featmap, float *logits, int stop_after, void *stream);
+                          void *workspace, int64_t workspace_bytes, float *featmap, float *logits, int guidance_layout, int stop_after, void *stream);
 
 #ifdef __cplusplus
 }

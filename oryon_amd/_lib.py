@@ -113,7 +113,7 @@ _PROTOS = {
     "oryon_decoder_destroy": (None, [c_void_p]),
     "oryon_decoder_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "oryon_decoder_workspace_layout": (c_int, [c_int, c_int, c_int, POINTER(c_int64)]),
-    "oryon_decoder_forward": (c_int, [c_void_p, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P, c_int, _P]),
+    "oryon_decoder_forward": (c_int, [c_void_p, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P, _P, c_int, c_int, _P]),
     "oryon_pointdsc_create": (c_int, [POINTER(c_void_p), POINTER(PointDSCConfig)]),
     "oryon_pointdsc_destroy": (None, [c_void_p]),
     "oryon_pointdsc_load_param": (c_int, [c_void_p, c_char_p, _P, c_int64]),

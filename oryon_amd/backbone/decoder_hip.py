@@ -7,7 +7,7 @@ import torch
 from torch import Tensor
 
 from .. import _lib
-from ..ops import check, lib, ptr, stream_ptr
+from ..ops import LAYOUT_NCHW, LAYOUT_NHWC, check, lib, ptr, stream_ptr
 
 
 class HipDecoder:
@@ -67,11 +67,18 @@ class HipDecoder:
         """x [n,128,h,w], g2 [n,256,2h,2w], g3 [n,128,4h,4w] fp32 -> (logits [n,8h,8w], featmap [n,32,8h,8w])."""
         n, c, h, w = x.shape
         assert c == 128 and tuple(g2.shape) == (n, 256, 2 * h, 2 * w) and tuple(g3.shape) == (n, 128, 4 * h, 4 * w), (x.shape, g2.shape, g3.shape)
-        x, g2, g3 = (t.to(torch.float32).contiguous() for t in (x, g2, g3))
+        x = x.to(torch.float32).contiguous()
+        # the Swin tower hands out permuted views of its [n, H, W, C] token maps (backbone/swin.py::guidance_embeds): read them in place
+        nhwc = all(g.dtype == torch.float32 and g.permute(0, 2, 3, 1).is_contiguous() for g in (g2, g3))
+        if nhwc:
+            g2, g3 = g2.permute(0, 2, 3, 1), g3.permute(0, 2, 3, 1)              # the contiguous storage order
+        else:
+            g2, g3 = g2.to(torch.float32).contiguous(), g3.to(torch.float32).contiguous()
         ws = self.workspace(n, h, w)
         fm = torch.empty((n, 32, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
         lg = torch.empty((n, 8 * h, 8 * w), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            check(lib().oryon_decoder_forward(self._h, ptr(x), ptr(g2), ptr(g3), n, h, w, ptr(ws), ws.numel(), ptr(fm), ptr(lg), int(stop_after),
+            check(lib().oryon_decoder_forward(self._h, ptr(x), ptr(g2), ptr(g3), n, h, w, ptr(ws), ws.numel(), ptr(fm), ptr(lg),
+                                              LAYOUT_NHWC if nhwc else LAYOUT_NCHW, int(stop_after),
                                               stream_ptr(self.device)), "oryon_decoder_forward")
         return lg, fm

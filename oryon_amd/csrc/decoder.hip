@@ -33,6 +33,7 @@ constexpr int DEC_HALO = 18;                     // 16 + 2
 constexpr int DEC_PIX = DEC_HALO * DEC_HALO;     // 324 halo pixels per tile
 constexpr int DEC_PSTRIDE = 80;                  // bytes per pixel and plane: 32 halves + 16 bytes of padding
 constexpr int DEC_PLANE = DEC_PIX * DEC_PSTRIDE; // 25920 bytes per plane (hi, lo)
+constexpr int DEC_RING = 2;                      // steps of B fragments in flight per wave (divides 18)
 
 struct DecConv {
     const float *in;          // NHWC [n, H, W, in_cstride] (channels in_coff ..) or NCHW [n, cin, H, W]
@@ -90,17 +91,41 @@ __global__ void dec_pack_upconv_kernel(const float *__restrict__ w, int cin, int
     img[idx] = part ? lo : hi;
 }
 
-template <int NB, bool IN_NCHW, bool IN_GN>
-__global__ __launch_bounds__(256) void dec_conv3x3_kernel(const DecConv a)
+// WREG (single-slab convolutions, cin = 32, NB = 1 - decoder3's two and decoder2's second: half of the module's flops): the 36 weight
+// fragments live in 144 registers of every wave and the workgroups are persistent (grid = 2 per CU, items strided).  Fetched per tile
+// like the multi-slab variant does, the weights were 3.5x the bytes of the tile itself (4 waves x 36 KB from L2 per 41 KB tile).
+template <int NB, bool IN_NCHW, bool IN_GN, bool WREG = false>
+__global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3x3_kernel(const DecConv a, const int tiles, const int total)
 {
+    static_assert(!WREG || (NB == 1 && !IN_NCHW), "register-resident weights: one slab, one N block");
     __shared__ __attribute__((aligned(16))) char lds[2 * DEC_PLANE];
     __shared__ float red[4][NB * 2][2];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int tiles_x = a.W / 16;
-    const int tile = blockIdx.x, img = blockIdx.y;
-    const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
-    const int slabs = a.cin / 32;
+    const int slabs = WREG ? 1 : a.cin / 32;
+    const int li = lane & 31, kg = lane >> 5;
+    // byte offset of the lane's A piece for M block mb at tap (0, 0), k-step 0
+    int a_off[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) a_off[mb] = ((4 * wave + 2 * mb + (li >> 4)) * DEC_HALO + (li & 15)) * DEC_PSTRIDE + kg * 16;
 
+    // B fragments: a register ring RING steps deep (step = (tap, k-step), 18 per slab, consecutive in the image).  Fetched straight from
+    // global memory (L2-resident) they need ~0.5 us; one step ahead - what the compiler schedules by itself - left every step waiting
+    // for its weights (decoder3's convolutions: 0.49 ms, MFMA pipe 20 % busy).
+    constexpr int RING = DEC_RING;
+    const dh8 *wf0 = a.wimg + lane;
+    dh8 wb[WREG ? 18 : 1][2];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            wb[j][0] = wf0[(j * 2 + 0) * 64];
+            wb[j][1] = wf0[(j * 2 + 1) * 64];
+        }
+    }
+
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    const int img = item / tiles, tile = item % tiles;
+    const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
     dacc16 acc[2][NB];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -108,12 +133,16 @@ __global__ __launch_bounds__(256) void dec_conv3x3_kernel(const DecConv a)
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
-
-    const int li = lane & 31, kg = lane >> 5;
-    // byte offset of the lane's A piece for M block mb at tap (0, 0), k-step 0
-    int a_off[2];
+    dh8 rb[WREG ? 1 : RING][NB][2];
+    if constexpr (!WREG) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) a_off[mb] = ((4 * wave + 2 * mb + (li >> 4)) * DEC_HALO + (li & 15)) * DEC_PSTRIDE + kg * 16;
+        for (int j = 0; j < RING; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                rb[j][nb][0] = wf0[((j * NB + nb) * 2 + 0) * 64];
+                rb[j][nb][1] = wf0[((j * NB + nb) * 2 + 1) * 64];
+            }
+    }
 
     for (int s = 0; s < slabs; ++s) {
         __syncthreads();                                         // the previous slab's readers are done
@@ -136,7 +165,7 @@ __global__ __launch_bounds__(256) void dec_conv3x3_kernel(const DecConv a)
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
                 ok[pp] = pix < DEC_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 v[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[pp]) v[pp] = *reinterpret_cast<const float4 *>(a.in + (((size_t)img * a.H + gy) * a.W + gx) * a.in_cstride + a.in_coff + s * 32 + cq * 4);
+                if (ok[pp] && !(a.relu & 256)) v[pp] = *reinterpret_cast<const float4 *>(a.in + (((size_t)img * a.H + gy) * a.W + gx) * a.in_cstride + a.in_coff + s * 32 + cq * 4);
             }
 #pragma unroll
             for (int pp = 0; pp < 11; ++pp) {
@@ -188,29 +217,31 @@ __global__ __launch_bounds__(256) void dec_conv3x3_kernel(const DecConv a)
             }
         }
         __syncthreads();
-        const dh8 *wf = a.wimg + (size_t)s * (9 * 2 * NB * 2 * 64) + lane;
+        const dh8 *wf = wf0 + (size_t)(s * 18 + RING) * (NB * 2 * 64);          // the fragments RING steps ahead of this slab's step 0
+        if (!(a.relu & 512))
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int step = 0; step < 18; ++step) {
+            const int tap = step >> 1, ks = step & 1, slot = step % RING;
             const int toff = ((tap / 3) * DEC_HALO + (tap % 3)) * DEC_PSTRIDE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                dh8 bh[NB], bl[NB];
+            for (int mb = 0; mb < 2; ++mb) {
+                const dh8 ah = *reinterpret_cast<const dh8 *>(lds + a_off[mb] + toff + ks * 32);
+                const dh8 al = *reinterpret_cast<const dh8 *>(lds + DEC_PLANE + a_off[mb] + toff + ks * 32);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    bh[nb] = wf[(((tap * 2 + ks) * NB + nb) * 2 + 0) * 64];
-                    bl[nb] = wf[(((tap * 2 + ks) * NB + nb) * 2 + 1) * 64];
+                    const dh8 bh = WREG ? wb[WREG ? step : 0][0] : rb[WREG ? 0 : slot][nb][0];
+                    const dh8 bl = WREG ? wb[WREG ? step : 0][1] : rb[WREG ? 0 : slot][nb][1];
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mb][nb], 0, 0, 0);
                 }
+            }
+            if constexpr (WREG) continue;
+            // refill the slot with step + RING (the image is padded by RING steps: the last slab reads zeros nobody uses)
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    const dh8 ah = *reinterpret_cast<const dh8 *>(lds + a_off[mb] + toff + ks * 32);
-                    const dh8 al = *reinterpret_cast<const dh8 *>(lds + DEC_PLANE + a_off[mb] + toff + ks * 32);
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], acc[mb][nb], 0, 0, 0);
-                    }
-                }
+            for (int nb = 0; nb < NB; ++nb) {
+                rb[WREG ? 0 : slot][nb][0] = wf[((step * NB + nb) * 2 + 0) * 64];
+                rb[WREG ? 0 : slot][nb][1] = wf[((step * NB + nb) * 2 + 1) * 64];
             }
         }
     }
@@ -232,8 +263,8 @@ __global__ __launch_bounds__(256) void dec_conv3x3_kernel(const DecConv a)
                 s1 += v;
                 s2 = fmaf(v, v, s2);
                 v += bv;
-                if (a.relu) v = fmaxf(v, 0.0f);
-                if (co < a.cout) a.out[(((size_t)img * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co] = v;
+                if (a.relu & 1) v = fmaxf(v, 0.0f);
+                if (co < a.cout && !(a.relu & 1024)) a.out[(((size_t)img * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co] = v;
             }
         if (a.stats) {
             // group = 16 channels = the 16 lanes li & 16 .. of both k-group halves
@@ -255,29 +286,36 @@ __global__ __launch_bounds__(256) void dec_conv3x3_kernel(const DecConv a)
         if (t < NB * 2 * 2) {
             const int g = t >> 1, k = t & 1;
             const float v = (red[0][g][k] + red[1][g][k]) + (red[2][g][k] + red[3][g][k]);
-            a.stats[(((size_t)img * gridDim.x + tile) * (NB * 2) + g) * 2 + k] = v;
+            a.stats[(((size_t)img * tiles + tile) * (NB * 2) + g) * 2 + k] = v;
         }
     }
+    }   // items
 }
 
 // GroupNorm(cout / 16 groups, eps) folded into y = a x + b per (image, channel): partial sums of the tiles added in tile order in double
-__global__ void dec_gn_affine_kernel(const float *__restrict__ stats, int n_img, int tiles, int NG, const float *__restrict__ gamma,
-                                     const float *__restrict__ beta, double eps, double inv_count, float *__restrict__ affine)
+__global__ __launch_bounds__(64) void dec_gn_affine_kernel(const float *__restrict__ stats, int n_img, int tiles, int NG, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, double eps, double inv_count, float *__restrict__ affine)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_img * NG) return;
+    // one wave per (image, group): lane l adds tiles l, l + 64, .. in order, then a fixed butterfly - the same sum every run
+    const int idx = blockIdx.x, lane = threadIdx.x;
     const int img = idx / NG, g = idx % NG;
     double s1 = 0.0, s2 = 0.0;
-    for (int tl = 0; tl < tiles; ++tl) {
-        s1 += (double)stats[(((size_t)img * tiles + tl) * NG + g) * 2 + 0];
-        s2 += (double)stats[(((size_t)img * tiles + tl) * NG + g) * 2 + 1];
+    for (int tl = lane; tl < tiles; tl += 64) {
+        const float2 q = *reinterpret_cast<const float2 *>(stats + (((size_t)img * tiles + tl) * NG + g) * 2);
+        s1 += (double)q.x;
+        s2 += (double)q.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
     }
     const double mean = s1 * inv_count;
     double var = s2 * inv_count - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     const double rstd = 1.0 / sqrt(var + eps);
-    for (int c = 0; c < 16; ++c) {
-        const int ch = g * 16 + c;
+    if (lane < 16) {
+        const int ch = g * 16 + lane;
         const double sc = (double)gamma[ch] * rstd;
         affine[((size_t)img * NG * 16 + ch) * 2 + 0] = (float)sc;
         affine[((size_t)img * NG * 16 + ch) * 2 + 1] = (float)((double)beta[ch] - mean * sc);
@@ -426,7 +464,7 @@ constexpr int D_G[3] = {32, 16, 0};                       // projected guidance 
 constexpr int D_OUT[3] = {64, 32, 32};                    // decoder_dims + the extra upsampling block
 constexpr int D_GIN[2] = {256, 128};                      // Swin guidance channels
 
-inline int64_t conv_img_halves(int cin, int NB) { return (int64_t)(cin / 32) * 9 * 2 * NB * 2 * 64 * 8; }
+inline int64_t conv_img_halves(int cin, int NB) { return ((int64_t)(cin / 32) * 18 + DEC_RING) * NB * 2 * 64 * 8; }   // + RING steps of zeros
 inline int64_t up_img_halves(int cin, int nbp) { return (int64_t)(4 * nbp) * (cin / 16) * 2 * 64 * 8; }
 inline int nb_of(int cout) { return (cout + 31) / 32; }
 inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -449,7 +487,14 @@ WsLayout ws_layout(int n, int h, int w)
 template <int NB, bool IN_NCHW, bool IN_GN>
 void launch_conv(hipStream_t st, const DecConv &a, int n)
 {
-    hipLaunchKernelGGL((dec_conv3x3_kernel<NB, IN_NCHW, IN_GN>), dim3((a.H / 16) * (a.W / 16), n), dim3(256), 0, st, a);
+    const int tiles = (a.H / 16) * (a.W / 16), total = tiles * n;
+    if constexpr (NB == 1 && !IN_NCHW) {
+        if (a.cin == 32 && total > 512) {                   // single slab: persistent workgroups, weights in registers
+            hipLaunchKernelGGL((dec_conv3x3_kernel<1, false, IN_GN, true>), dim3(512), dim3(256), 0, st, a, tiles, total);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((dec_conv3x3_kernel<NB, IN_NCHW, IN_GN, false>), dim3(total), dim3(256), 0, st, a, tiles, total);
 }
 }  // namespace
 
@@ -550,14 +595,16 @@ int oryon_decoder_workspace_layout(int n_img, int h, int w, int64_t *offsets3)
 }
 
 int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float *g2, const float *g3, int n_img, int h, int w, void *workspace,
-                          int64_t workspace_bytes, float *featmap, float *logits, int stop_after, void *stream)
+                          int64_t workspace_bytes, float *featmap, float *logits, int guidance_layout, int stop_after, void *stream)
 {
+    ORYON_CHECK_ARG(guidance_layout == ORYON_LAYOUT_NCHW || guidance_layout == ORYON_LAYOUT_NHWC);
     ORYON_CHECK_ARG(d != nullptr && x != nullptr && g2 != nullptr && g3 != nullptr && workspace != nullptr);
     ORYON_CHECK_ARG(n_img > 0 && n_img < 65536 && h > 0 && w > 0 && h % 8 == 0 && w % 8 == 0);
     ORYON_CHECK_ARG(featmap != nullptr && logits != nullptr);
     const WsLayout L = ws_layout(n_img, h, w);
     ORYON_CHECK_ARG(workspace_bytes >= L.total);
     hipStream_t st = as_stream(stream);
+    static const int dbg = getenv("ORYON_DEC_DEBUG") ? atoi(getenv("ORYON_DEC_DEBUG")) : 0;      // probe switches (tools/r4_dec_ablate.py)
     char *ws = reinterpret_cast<char *>(workspace);
     float *R[3] = {reinterpret_cast<float *>(ws + L.R[0]), reinterpret_cast<float *>(ws + L.R[1]), reinterpret_cast<float *>(ws + L.R[2])};
     float *stats = reinterpret_cast<float *>(ws + L.stats);
@@ -591,8 +638,9 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
             // guidance projection: conv3x3 + bias + ReLU of the Swin map (NCHW, read in place) -> channels cup .. of the cat buffer
             DecConv a{};
             a.in = guid[i]; a.affine = nullptr; a.wimg = d->gp_img[i]; a.bias = d->gp_b[i]; a.out = cat; a.stats = nullptr;
-            a.H = H; a.W = W; a.cin = D_GIN[i]; a.in_cstride = 0; a.in_coff = 0; a.out_cstride = ccat; a.out_coff = cup; a.cout = D_G[i]; a.relu = 1;
-            launch_conv<1, true, false>(st, a, n_img);
+            a.H = H; a.W = W; a.cin = D_GIN[i]; a.in_cstride = D_GIN[i]; a.in_coff = 0; a.out_cstride = ccat; a.out_coff = cup; a.cout = D_G[i]; a.relu = 1;
+            if (guidance_layout == ORYON_LAYOUT_NHWC) launch_conv<1, false, false>(st, a, n_img);
+            else launch_conv<1, true, false>(st, a, n_img);
         }
         ORYON_CHECK_LAUNCH();
         if (stop_after == 3 * i + 1) return ORYON_OK;
@@ -600,10 +648,10 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
         {
             DecConv a{};
             a.in = cat; a.affine = nullptr; a.wimg = d->c1_img[i]; a.bias = nullptr; a.out = a1; a.stats = stats;
-            a.H = H; a.W = W; a.cin = ccat; a.in_cstride = ccat; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = 0;
+            a.H = H; a.W = W; a.cin = ccat; a.in_cstride = ccat; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = dbg;
             if (cout == 64) launch_conv<2, false, false>(st, a, n_img);
             else launch_conv<1, false, false>(st, a, n_img);
-            hipLaunchKernelGGL(dec_gn_affine_kernel, dim3(ceil_div(n_img * (cout / 16), 64)), dim3(64), 0, st, stats, n_img, tiles, cout / 16,
+            hipLaunchKernelGGL(dec_gn_affine_kernel, dim3(n_img * (cout / 16)), dim3(64), 0, st, stats, n_img, tiles, cout / 16,
                                d->n1_g[i], d->n1_b[i], 1e-5, 1.0 / ((double)H * W * 16), aff[2 * i]);
         }
         ORYON_CHECK_LAUNCH();
@@ -612,10 +660,10 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
         {
             DecConv a{};
             a.in = a1; a.affine = aff[2 * i]; a.wimg = d->c2_img[i]; a.bias = nullptr; a.out = b1; a.stats = stats;
-            a.H = H; a.W = W; a.cin = cout; a.in_cstride = cout; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = 0;
+            a.H = H; a.W = W; a.cin = cout; a.in_cstride = cout; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = dbg;
             if (cout == 64) launch_conv<2, false, true>(st, a, n_img);
             else launch_conv<1, false, true>(st, a, n_img);
-            hipLaunchKernelGGL(dec_gn_affine_kernel, dim3(ceil_div(n_img * (cout / 16), 64)), dim3(64), 0, st, stats, n_img, tiles, cout / 16,
+            hipLaunchKernelGGL(dec_gn_affine_kernel, dim3(n_img * (cout / 16)), dim3(64), 0, st, stats, n_img, tiles, cout / 16,
                                d->n2_g[i], d->n2_b[i], 1e-5, 1.0 / ((double)H * W * 16), aff[2 * i + 1]);
         }
         ORYON_CHECK_LAUNCH();

@@ -66,6 +66,10 @@ def test_hip_decoder_layers_match_torch_fp32(n, h, w):
         assert lg2.shape == (n, 1, 8 * h, 8 * w) and torch.equal(fm2, fm) and torch.equal(lg2[:, 0], lg)
         lg3, fm3 = hip.forward(x, g2, g3)
         assert torch.equal(fm3, fm) and torch.equal(lg3, lg)                    # fixed reduction order: bit-reproducible
+        # guidance maps as the Swin tower hands them out (permuted views of NHWC storage) are read in place: same values
+        g2v, g3v = (g.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for g in (g2, g3))
+        lg4, fm4 = hip.forward(x, g2v, g3v)
+        assert torch.equal(fm4, fm) and torch.equal(lg4, lg)
 
 
 def test_hip_decoder_matches_reference_golden():
@@ -87,15 +91,25 @@ def test_hip_decoder_matches_reference_golden():
     text = orc.hashed_tensor((B, 1, 80, 768), 101, 0, 1.0).to(dev)
     guid = [orc.hashed_tensor((B, 512, 24, 24), 102, 0, 1.0).to(dev), orc.hashed_tensor((B, 256, 48, 48), 103, 0, 1.0).to(dev),
             orc.hashed_tensor((B, 128, 96, 96), 104, 0, 1.0).to(dev)]
+    from oryon_amd.backbone import enable_fp16x3
+    rel = lambda a, b: float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
     F_.enable_hip_decoder(True)
     try:
         with torch.no_grad():
             feats = fusion(img, text, guid)
             mask, featmap = decoder(feats, guid)
         assert decoder.__dict__.get("_hip") is not None                         # the HIP path ran, not the torch modules
+        # the whole fast inference path (what bench.py's fp16x3 stage sets run): fusion linears on the fp16x3 kernel as well
+        enable_fp16x3(True)
+        with torch.no_grad():
+            feats_x3 = fusion(img, text, guid)
+            mask_x3, featmap_x3 = decoder(feats_x3, guid)
+        assert rel(feats_x3.cpu().numpy(), g["fusion_out"]) < 1e-4
+        assert rel(mask_x3[:, :, ::2, ::2].cpu().numpy(), g["mask"]) < 1e-4
+        assert rel(featmap_x3[:, :, ::4, ::4].cpu().numpy(), g["featmap_sub"]) < 1e-4
     finally:
+        enable_fp16x3(False)
         F_.enable_hip_decoder(False)
-    rel = lambda a, b: float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
     assert rel(mask[:, :, ::2, ::2].cpu().numpy(), g["mask"]) < 1e-4
     assert rel(featmap[:, :, ::4, ::4].cpu().numpy(), g["featmap_sub"]) < 1e-4
     assert rel(featmap.double().sum(dim=(2, 3)).cpu().numpy(), g["featmap_sum"]) < 1e-4

@@ -1,6 +1,7 @@
 """Round-4 probe: where do the 20 ms of the decode stage set go?  Times fusion and the decoder's blocks separately (HIP events, 128 images)."""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import oryon_amd
 oryon_amd.configure()
 from oryon_amd.net import Oryon, default_model_args
@@ -67,3 +68,20 @@ c = de.decoder3.conv.double_conv[0](u)
 timed("    decoder3.conv[1] GN", lambda: de.decoder3.conv.double_conv[1](c))
 timed("  dec.head", lambda: de.head(y3))
 timed("  featmap clone", lambda: y3.view(2 * B, 32, 192, 192).clone())
+
+# the HIP decoder (csrc/decoder.hip) on the same inputs
+from oryon_amd.backbone import fusion as F_
+F_.enable_hip_decoder(True)
+lg, fm = timed("decoder (HIP, oryon_decoder_forward)", lambda: de(x, enc[1]), n=5)
+F_.enable_hip_decoder(False)
+with torch.no_grad():
+    lg0, fm0 = de(x, enc[1])
+print("max rel diff featmap", float((fm - fm0).abs().max() / fm0.abs().max()), "logits", float((lg - lg0).abs().max() / lg0.abs().max()))
+
+from oryon_amd.backbone import enable_fp16x3
+enable_fp16x3(True)
+x3 = timed("fusion (fp16x3 linears)", lambda: fu(enc[0], prompt, enc[1]), n=5)
+timed("  swin pair (fp16x3)", lambda: fu.layers[0].swin_block(xx, app), n=5)
+timed("fusion + decoder (fast path)", lambda: de(fu(enc[0], prompt, enc[1]), enc[1]), n=5)
+enable_fp16x3(False)
+print("fusion fp16x3 vs fp32 max rel", float((x3 - x).abs().max() / x.abs().max()))
