@@ -511,6 +511,13 @@ int oryon_decoder_workspace_layout(int n_img, int h, int w, int64_t *offsets3);
 int oryon_decoder_forward(const oryon_decoder_t *handle, const float *x, const float *g2, const float *g3, int n_img, int h, int w,
                           void *workspace, int64_t workspace_bytes, float *featmap, float *logits, int guidance_layout, int stop_after, void *stream);
 
+/* a4  window attention of ImageTextFusion's guided Swin blocks (models/fusion.py:75-103 inside :173-213) on un-windowed tokens:
+ *     qk [B, H, W, 2C] fp32 (the q projection, then the k projection of [x | guidance]), v [B, H, W, C] fp32 -> out [B, H, W, C] fp32 =
+ *     roll(-shift) -> 12 x 12 windows -> softmax(q k^T / sqrt(32) + shift mask) v per head -> windows back -> roll(+shift), one kernel,
+ *     fp32 arithmetic.  head_dim 32 (C == heads * 32), window == 12, H % 12 == 0, W % 12 == 0 (the reference: 24 x 24, 4 heads). */
+int oryon_fusion_window_attention_f32(const float *qk, const float *v, int B, int H, int W, int C, int heads, int window, int shift,
+                                      float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

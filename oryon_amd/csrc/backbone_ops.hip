@@ -424,3 +424,102 @@ extern "C" int oryon_swin_window_attention_f32(const float *qkv, const float *pa
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// a4  window attention of ImageTextFusion's guided Swin blocks (models/fusion.py:75-103 WindowAttention.forward inside
+//     SwinTransformerBlock.forward :173-213): torch.roll(-shift) + window_partition + softmax(q k^T * hd^-0.5 + shift mask) v +
+//     window_reverse + torch.roll(+shift) as ONE kernel on un-windowed tokens - the q | k and v projections are per-token linears, so they
+//     run on the natural [B, H, W, .] order and nothing is permuted or copied around the attention (torch: 2 rolls, 2 window copies, 3
+//     head transposes, a scale, 2 batched GEMMs, a mask add and a softmax per block).  fp32 VALU arithmetic: one workgroup per (window,
+//     image, head), one query per thread, K and V rows of the head in LDS (read as broadcasts), scores in registers.
+template <int WS>
+__global__ __launch_bounds__(192) void fusion_window_attention_kernel(const float *__restrict__ qk, const float *__restrict__ v, int H, int W,
+                                                                      int C, int shift, float scale, float *__restrict__ out)
+{
+    constexpr int N = WS * WS, HD = 32;
+    static_assert(N <= 192, "one query per thread");
+    __shared__ __attribute__((aligned(16))) float Ks[N * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[N * HD];
+    __shared__ int labs[N];
+    const int t = threadIdx.x, head = blockIdx.z, b = blockIdx.y;
+    const int nwx = W / WS, wy = blockIdx.x / nwx, wx = blockIdx.x % nwx;
+    const bool active = t < N;
+    float q[HD];
+    int label = 0;
+    size_t tok = 0;
+    if (active) {
+        const int py = wy * WS + t / WS, px = wx * WS + t % WS;             // position in the rolled frame
+        const int sy = (py + shift) % H, sx = (px + shift) % W;             // torch.roll(x, -shift): rolled[p] = x[p + shift]
+        if (shift > 0) {                                                    // the regions of SwinTransformerBlock's img_mask (:155-163)
+            const int by = py < H - WS ? 0 : (py < H - shift ? 1 : 2);
+            const int bx = px < W - WS ? 0 : (px < W - shift ? 1 : 2);
+            label = by * 3 + bx;
+        }
+        labs[t] = label;
+        tok = ((size_t)b * H + sy) * W + sx;
+        const float4 *qs = reinterpret_cast<const float4 *>(qk + tok * 2 * C + head * HD);
+        const float4 *ks = reinterpret_cast<const float4 *>(qk + tok * 2 * C + C + head * HD);
+        const float4 *vs = reinterpret_cast<const float4 *>(v + tok * C + head * HD);
+#pragma unroll
+        for (int e = 0; e < HD / 4; ++e) {
+            const float4 a = qs[e];
+            q[4 * e + 0] = a.x * scale; q[4 * e + 1] = a.y * scale; q[4 * e + 2] = a.z * scale; q[4 * e + 3] = a.w * scale;
+            reinterpret_cast<float4 *>(Ks + t * HD)[e] = ks[e];
+            reinterpret_cast<float4 *>(Vs + t * HD)[e] = vs[e];
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float s[N];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < HD / 4; ++e) {
+            const float4 kk = reinterpret_cast<const float4 *>(Ks + j * HD)[e];
+            a0 = fmaf(q[4 * e + 0], kk.x, a0);
+            a1 = fmaf(q[4 * e + 1], kk.y, a1);
+            a0 = fmaf(q[4 * e + 2], kk.z, a0);
+            a1 = fmaf(q[4 * e + 3], kk.w, a1);
+        }
+        float sc = a0 + a1;
+        if (shift > 0 && labs[j] != label) sc += -100.0f;                   // the additive mask of :166-167
+        s[j] = sc;
+        m = fmaxf(m, sc);
+    }
+    float o[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) o[e] = 0.0f;
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float p = __expf(s[j] - m);
+        sum += p;
+#pragma unroll
+        for (int e = 0; e < HD / 4; ++e) {
+            const float4 vv = reinterpret_cast<const float4 *>(Vs + j * HD)[e];
+            o[4 * e + 0] = fmaf(p, vv.x, o[4 * e + 0]);
+            o[4 * e + 1] = fmaf(p, vv.y, o[4 * e + 1]);
+            o[4 * e + 2] = fmaf(p, vv.z, o[4 * e + 2]);
+            o[4 * e + 3] = fmaf(p, vv.w, o[4 * e + 3]);
+        }
+    }
+    const float inv = 1.0f / sum;
+    float4 *dst = reinterpret_cast<float4 *>(out + tok * C + head * HD);
+#pragma unroll
+    for (int e = 0; e < HD / 4; ++e) dst[e] = make_float4(o[4 * e] * inv, o[4 * e + 1] * inv, o[4 * e + 2] * inv, o[4 * e + 3] * inv);
+}
+
+extern "C" int oryon_fusion_window_attention_f32(const float *qk, const float *v, int B, int H, int W, int C, int heads, int window, int shift,
+                                                 float *out, void *stream)
+{
+    ORYON_CHECK_ARG(qk && v && out && B >= 0 && H > 0 && W > 0 && heads >= 1 && C == heads * 32);
+    ORYON_CHECK_ARG(window == 12 && H % window == 0 && W % window == 0 && shift >= 0 && shift < window);
+    ORYON_CHECK_ARG((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)out) & 15) == 0);
+    if (B == 0) return ORYON_OK;
+    hipLaunchKernelGGL(fusion_window_attention_kernel<12>, dim3((H / window) * (W / window), B, heads), dim3(192), 0, as_stream(stream), qk, v, H, W,
+                       C, shift, 1.0f / sqrtf(32.0f), out);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}

@@ -138,6 +138,21 @@ def swin_window_attention_f32(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t: 
 
 
 @_on_tensor_device
+def fusion_window_attention(qk: torch.Tensor, v: torch.Tensor, heads: int, window: int, shift: int) -> torch.Tensor:
+    """Shifted-window attention of ImageTextFusion's guided Swin blocks on un-windowed tokens: qk [B,H,W,2C] (q | k projections),
+    v [B,H,W,C] fp32 -> [B,H,W,C] fp32 (roll, windows, masked softmax attention, windows back, roll back in one kernel)."""
+    _lib.require_gpu(qk.device)
+    B, H, W, C2 = qk.shape
+    C = C2 // 2
+    assert qk.dtype == torch.float32 and v.dtype == torch.float32 and tuple(v.shape) == (B, H, W, C) and C2 == 2 * C
+    qk, v = qk.contiguous(), v.contiguous()
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=qk.device)
+    check(lib().oryon_fusion_window_attention_f32(ptr(qk), ptr(v), B, H, W, C, heads, window, shift, ptr(out), stream_ptr(qk.device)),
+          "oryon_fusion_window_attention_f32")
+    return out
+
+
+@_on_tensor_device
 def rgb_resize_bilinear(rgb_hwc: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
     """uint8 [n,HI,WI,3] -> fp32 [n,3,HO,WO] in [0,1] (K-1: /255., CHW, bilinear align_corners=False, fp64 arithmetic)."""
     _lib.require_gpu(rgb_hwc.device)

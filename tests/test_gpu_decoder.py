@@ -120,3 +120,34 @@ def test_hip_decoder_argument_checks():
     from oryon_amd._lib import lib
     assert lib().oryon_decoder_workspace_bytes(2, 24, 24) > 0
     assert lib().oryon_decoder_workspace_bytes(2, 20, 24) == 0 and lib().oryon_decoder_workspace_bytes(0, 24, 24) == 0
+
+
+@pytest.mark.parametrize("shift", [0, 6])
+def test_fusion_window_attention_matches_torch(shift):
+    """ops.fusion_window_attention (roll + 12 x 12 windows + masked softmax attention + un-window in one kernel) against the module's
+    torch path (models/fusion.py:75-103 inside :173-213) on random projections."""
+    from oryon_amd import ops
+    from oryon_amd.backbone.fusion import _GuidedSwinBlock, _to_windows, _from_windows
+    torch.manual_seed(3 + shift)
+    B, H, W, C, heads = 3, 24, 24, 128, 4
+    blk = _GuidedSwinBlock(C, C, (H, W), heads, 12, shift).to("cuda").eval()
+    q = torch.randn(B, H, W, C, device="cuda") * 2.0
+    k = torch.randn(B, H, W, C, device="cuda") * 2.0
+    v = torch.randn(B, H, W, C, device="cuda")
+    got = ops.fusion_window_attention(torch.cat([q, k], dim=-1), v, heads, 12, shift)
+
+    def win(t):
+        if shift > 0:
+            t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+        return _to_windows(t, 12)                                             # [nWB, N, C]
+    d = C // heads
+    qw, kw, vw = (win(t).view(-1, 144, heads, d).transpose(1, 2) for t in (q, k, v))
+    attn = (qw * d ** -0.5) @ kw.transpose(-2, -1)
+    if blk.attn_mask is not None:
+        nW = blk.attn_mask.shape[0]
+        attn = (attn.view(-1, nW, heads, 144, 144) + blk.attn_mask[None, :, None]).view(-1, heads, 144, 144)
+    o = (torch.softmax(attn, dim=-1) @ vw).transpose(1, 2).reshape(-1, 144, C)
+    o = _from_windows(o, 12, B, H, W)
+    if shift > 0:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    assert float((got - o).abs().max()) < 2e-5 * float(o.abs().max())
