@@ -3,6 +3,7 @@
 #   1. kernel-trace of `python bench.py` (default workload)                     -> <out>/kernel_stats.md + the printed JSON line
 #   2. separate --pmc passes (no trace domains besides --kernel-trace), restricted to the heavy kernels -> <out>/pmc_counters.md
 #   3. full (feat+match+pose) stage on the fp16x3 path: kernel trace + matrix-pipe counters -> <out>/full_stage_*.md
+#   4. decode stage set (fusion + decoder fast path): kernel trace + traffic / matrix-pipe counters of the decoder kernels -> <out>/decode_stage_*.md
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$R/gpurun_out/profiles}
@@ -41,4 +42,18 @@ python $R/tools/rocpd_summary.py $D/full_results.db --exclude "naive_conv|Im2d2C
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --kernel-trace --kernel-include-regex "linear_f16x3_stream|mha_x3" -d $P -o p -- python $R/bench.py --stages full --backbone-dtype fp16x3 --steps 1 --warmup 0 > /tmp/pmc_full.log 2>&1
   echo; python $R/tools/rocpd_summary.py $P/p_results.db | sed -n '/## PMC counters/,$p' | tail -n +3
 } > "$OUT/full_stage_pmc.md"
+# 4. the decode stage set (fusion + decoder on cached encodings, fast path: fp16x3 linears, HIP decoder, fused window attention):
+#    kernel trace of the stage run and the traffic / matrix-pipe counters of the decoder's kernels on tools/r4_fastpath.py (128 images)
+D=/tmp/prof_decode; rm -rf $D
+rocprofv3 --kernel-trace --stats -d $D -o dec -- python $R/bench.py --stages decode --backbone-dtype fp16x3 --steps 2 --warmup 1 > /tmp/decode.log 2>&1
+python $R/tools/rocpd_summary.py $D/dec_results.db --exclude "naive_conv|Im2d2Col|Col2Im2d" > "$OUT/decode_stage_kernel_stats.md"
+{
+  echo "# rocprofv3 PMC passes: tools/r4_fastpath.py (fusion + decoder fast path, 128 images), kernels /dec_conv3x3|dec_final|dec_upconv|fusion_window_attention/"
+  for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
+    P=/tmp/prof_pmc_dec; rm -rf $P
+    rocprofv3 --pmc $SET --kernel-trace --kernel-include-regex "dec_conv3x3|dec_final|dec_upconv|fusion_window_attention" -d $P -o p -- python $R/tools/r4_fastpath.py > /tmp/pmc_dec.log 2>&1
+    echo; echo "## pass: $SET"; echo
+    python $R/tools/rocpd_summary.py $P/p_results.db | sed -n '/## PMC counters/,$p' | tail -n +3
+  done
+} > "$OUT/decode_stage_pmc.md"
 ls -la "$OUT"
