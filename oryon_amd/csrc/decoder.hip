@@ -223,19 +223,24 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
         for (int step = 0; step < 18; ++step) {
             const int tap = step >> 1, ks = step & 1, slot = step % RING;
             const int toff = ((tap / 3) * DEC_HALO + (tap % 3)) * DEC_PSTRIDE;
+            // the three products of an accumulator are issued 2 NB MFMAs apart (every accumulator's chain is dependent: back to back
+            // they wait for each other's passes)
+            dh8 ah[2], al[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                const dh8 ah = *reinterpret_cast<const dh8 *>(lds + a_off[mb] + toff + ks * 32);
-                const dh8 al = *reinterpret_cast<const dh8 *>(lds + DEC_PLANE + a_off[mb] + toff + ks * 32);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const dh8 bh = WREG ? wb[WREG ? step : 0][0] : rb[WREG ? 0 : slot][nb][0];
-                    const dh8 bl = WREG ? wb[WREG ? step : 0][1] : rb[WREG ? 0 : slot][nb][1];
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mb][nb], 0, 0, 0);
-                }
+                ah[mb] = *reinterpret_cast<const dh8 *>(lds + a_off[mb] + toff + ks * 32);
+                al[mb] = *reinterpret_cast<const dh8 *>(lds + DEC_PLANE + a_off[mb] + toff + ks * 32);
             }
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const dh8 bh = WREG ? wb[WREG ? step : 0][0] : rb[WREG ? 0 : slot][nb][0];
+                        const dh8 bl = WREG ? wb[WREG ? step : 0][1] : rb[WREG ? 0 : slot][nb][1];
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(part == 0 ? al[mb] : ah[mb], part == 1 ? bl : bh, acc[mb][nb], 0, 0, 0);
+                    }
             if constexpr (WREG) continue;
             // refill the slot with step + RING (the image is padded by RING steps: the last slab reads zeros nobody uses)
 #pragma unroll
