@@ -128,8 +128,11 @@ __device__ __forceinline__ void gather_q8_v3_tile(
         const char *fb = reinterpret_cast<const char *>(feat + (size_t)m * C * HW);
         const unsigned voff = (unsigned)pix * 4u + (unsigned)seg * (unsigned)KPL * (unsigned)HW * 4u;
         if (tile_full) {
+            // buffer loads: the map as a raw buffer (base in SGPRs), the lane's pixel offset in ONE VGPR, the plane offset in an SGPR - no
+            // per-load address arithmetic on the VALU (as flat global loads the 256 addresses cost 256 v_lshl_add_u64 per tile)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(fb), 0, (int)((unsigned)C * (unsigned)HW * 4u), 0x00020000);
 #pragma unroll
-            for (int i = 0; i < KPL; ++i) VS(i, *reinterpret_cast<const float *>(fb + (size_t)i * HW * 4 + voff));
+            for (int i = 0; i < KPL; ++i) VS(i, __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, i * HW * 4, 0)));
         } else {
             // ragged tile (last rows of a map, or C < CP): every lane loads from a clamped, valid address; dead rows / channels are
             // zeroed afterwards.  The bounds go through opaque copies so that the compiler neither shares the 256 plane addresses
