@@ -43,6 +43,16 @@ def test_argument_validation_without_gpu():
     assert L.oryon_add_layernorm_bf16(None, None, None, None, 4, 1024, 1e-5, None, None, None) == -1
     assert L.oryon_swin_window_attention_bf16(None, None, None, 1, 7, 7, 128, 4, 0, None, None) == -1
     assert L.oryon_match_screened8_workspace_bytes(64, 256, 5120, 50176) > L.oryon_match_screened_workspace_bytes(64, 256, 5120) > 0
+    # round 4: the decoder handle and the fusion window attention
+    assert L.oryon_decoder_create(None, None, None) == -1
+    assert L.oryon_decoder_forward(None, None, None, None, 2, 24, 24, None, 0, None, None, 0, 0, None) == -1
+    assert L.oryon_decoder_workspace_bytes(128, 24, 24) == 3 * 128 * 192 * 192 * 32 * 4 + L.oryon_decoder_workspace_bytes(128, 24, 24) % (128 * 192 * 192 * 32 * 4)
+    assert L.oryon_decoder_workspace_bytes(128, 24, 20) == 0 and L.oryon_decoder_workspace_bytes(-1, 24, 24) == 0
+    import ctypes
+    off = (ctypes.c_int64 * 3)()
+    assert L.oryon_decoder_workspace_layout(2, 24, 24, off) == 0 and list(off) == [0, 2 * 192 * 192 * 32 * 4, 2 * 2 * 192 * 192 * 32 * 4]
+    assert L.oryon_decoder_workspace_layout(2, 24, 25, off) == -1
+    assert L.oryon_fusion_window_attention_f32(None, None, 1, 24, 24, 128, 4, 12, 0, None, None) == -1
 
 
 def test_no_cpu_fallback():
@@ -163,7 +173,8 @@ def test_hot_kernels_do_not_spill():
         pytest.skip("LLVM object tools not available")
     hot = ("match_mx6_screen_w4_kernelILi256ELi8E", "match_i8_screen_v2_kernelILi256E", "gather_q8_v3_kernelILi256ELi1ELb0ELi1E",
            "gather_q8_v3_kernelILi256ELi1ELb0ELi0E", "pdsc_attention_x3_img_kernel", "pdsc_pcn_qkv_x3_kernel", "pdsc_mlp3_x3_kernel",
-           "match_decide_lite_kernel", "match_resolve_selected_kernel")
+           "match_decide_lite_kernel", "match_resolve_selected_kernel", "dec_conv3x3_kernelILi1ELb0ELb1ELb1E", "dec_conv3x3_kernelILi2ELb0ELb0ELb0E",
+           "dec_final_kernel", "fusion_window_attention_kernel")
     seen = set()
     for k in rows:
         for h in hot:
