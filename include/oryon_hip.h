@@ -513,8 +513,8 @@ int oryon_decoder_forward(const oryon_decoder_t *handle, const float *x, const f
 
 /* a4  window attention of ImageTextFusion's guided Swin blocks (models/fusion.py:75-103 inside :173-213) on un-windowed tokens:
  *     qk [B, H, W, 2C] fp32 (the q projection, then the k projection of [x | guidance]), v [B, H, W, C] fp32 -> out [B, H, W, C] fp32 =
- *     roll(-shift) -> 12 x 12 windows -> softmax(q k^T / sqrt(32) + shift mask) v per head -> windows back -> roll(+shift), one kernel,
- *     fp32 arithmetic.  head_dim 32 (C == heads * 32), window == 12, H % 12 == 0, W % 12 == 0 (the reference: 24 x 24, 4 heads). */
+ *     roll(-shift) -> 12 x 12 windows -> softmax(q k^T / sqrt(32) + shift mask) v per head -> windows back -> roll(+shift), one kernel;
+ *     both products on the fp16 matrix pipe with error-compensated operands (fp32-grade, ~1e-6), fp32 softmax.  head_dim 32 (C == heads * 32), window == 12, H % 12 == 0, W % 12 == 0 (the reference: 24 x 24, 4 heads). */
 int oryon_fusion_window_attention_f32(const float *qk, const float *v, int B, int H, int W, int C, int heads, int window, int shift,
                                       float *out, void *stream);
 

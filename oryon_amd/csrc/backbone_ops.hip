@@ -430,85 +430,178 @@ extern "C" int oryon_swin_window_attention_f32(const float *qkv, const float *pa
 //     SwinTransformerBlock.forward :173-213): torch.roll(-shift) + window_partition + softmax(q k^T * hd^-0.5 + shift mask) v +
 //     window_reverse + torch.roll(+shift) as ONE kernel on un-windowed tokens - the q | k and v projections are per-token linears, so they
 //     run on the natural [B, H, W, .] order and nothing is permuted or copied around the attention (torch: 2 rolls, 2 window copies, 3
-//     head transposes, a scale, 2 batched GEMMs, a mask add and a softmax per block).  fp32 VALU arithmetic: one workgroup per (window,
-//     image, head), one query per thread, K and V rows of the head in LDS (read as broadcasts), scores in registers.
-template <int WS>
-__global__ __launch_bounds__(192) void fusion_window_attention_kernel(const float *__restrict__ qk, const float *__restrict__ v, int H, int W,
-                                                                      int C, int shift, float scale, float *__restrict__ out)
+//     head transposes, a scale, 2 batched GEMMs, a mask add and a softmax per block).
+// Both products run on the fp16 matrix pipe with error-compensated operands (a first version on the fp32 VALU - one query per thread, K / V
+// rows read from LDS as broadcasts - took 0.23 ms per call against 0.09 for this one).
+// One workgroup per (window, image, head), five waves; wave w owns queries 32 w .. 32 w + 31 (144 = 4.5 blocks, the rest is padding).
+// Everything is computed TRANSPOSED so that nothing has to change layout between the two products:
+//   S^T = K Q^T : A = K rows (M = keys, straight from global memory), B = Q rows (N = queries, scaled by hd^-0.5 first, as the module does)
+//                 -> a lane holds, for ITS query, the scores of 80 keys (16 per key block), its partner lane ^ 32 the other 80: the softmax
+//                 statistics are in-lane loops plus one cross-lane exchange;
+//   O^T = V^T P^T: B = P^T = the exponentials exactly where the accumulators left them (k-step ks = registers 8 (ks & 1) .. + 7 of key
+//                 block ks / 2), A = V^T from an LDS tile whose key axis is stored in that register order.
+// Operands are split hi + lo (fp16) and multiplied as lo.hi + hi.lo + hi.hi with fp32 accumulation, like every fp16x3 kernel here.
+typedef _Float16 fwa_h8 __attribute__((ext_vector_type(8)));
+typedef float fwa_acc __attribute__((ext_vector_type(16)));
+
+static __device__ __forceinline__ void fwa_split8(const float (&x)[8], fwa_h8 &hi, fwa_h8 &lo)
 {
-    constexpr int N = WS * WS, HD = 32;
-    static_assert(N <= 192, "one query per thread");
-    __shared__ __attribute__((aligned(16))) float Ks[N * HD];
-    __shared__ __attribute__((aligned(16))) float Vs[N * HD];
-    __shared__ int labs[N];
-    const int t = threadIdx.x, head = blockIdx.z, b = blockIdx.y;
-    const int nwx = W / WS, wy = blockIdx.x / nwx, wx = blockIdx.x % nwx;
-    const bool active = t < N;
-    float q[HD];
-    int label = 0;
-    size_t tok = 0;
-    if (active) {
-        const int py = wy * WS + t / WS, px = wx * WS + t % WS;             // position in the rolled frame
-        const int sy = (py + shift) % H, sx = (px + shift) % W;             // torch.roll(x, -shift): rolled[p] = x[p + shift]
-        if (shift > 0) {                                                    // the regions of SwinTransformerBlock's img_mask (:155-163)
-            const int by = py < H - WS ? 0 : (py < H - shift ? 1 : 2);
-            const int bx = px < W - WS ? 0 : (px < W - shift ? 1 : 2);
-            label = by * 3 + bx;
-        }
-        labs[t] = label;
-        tok = ((size_t)b * H + sy) * W + sx;
-        const float4 *qs = reinterpret_cast<const float4 *>(qk + tok * 2 * C + head * HD);
-        const float4 *ks = reinterpret_cast<const float4 *>(qk + tok * 2 * C + C + head * HD);
-        const float4 *vs = reinterpret_cast<const float4 *>(v + tok * C + head * HD);
 #pragma unroll
-        for (int e = 0; e < HD / 4; ++e) {
-            const float4 a = qs[e];
-            q[4 * e + 0] = a.x * scale; q[4 * e + 1] = a.y * scale; q[4 * e + 2] = a.z * scale; q[4 * e + 3] = a.w * scale;
-            reinterpret_cast<float4 *>(Ks + t * HD)[e] = ks[e];
-            reinterpret_cast<float4 *>(Vs + t * HD)[e] = vs[e];
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(x[e] - (float)h);
+    }
+}
+
+// slot of key j on the key axis of the V^T tile: k-step (j / 32) * 2 + (j % 32) / 16, lane half ((j % 16) % 8) / 4, element 4 ((j % 16) / 8) + j % 4
+// - the inverse of "register r of key block mb holds key 32 mb + 8 (r / 4) + 4 kg + r % 4"
+static __device__ __forceinline__ int fwa_slot(int j)
+{
+    const int jj = j & 31, u = jj & 15;
+    return ((j >> 5) * 2 + (jj >> 4)) * 16 + ((u & 7) >> 2) * 8 + 4 * (u >> 3) + (u & 3);
+}
+
+__global__ __launch_bounds__(320) void fusion_window_attention_x3_kernel(const float *__restrict__ qk, const float *__restrict__ v, int H, int W,
+                                                                         int C, int shift, float scale, float *__restrict__ out)
+{
+    constexpr int WS = 12, N = 144, NP = 160, HD = 32;
+    constexpr int VLD = 168;                                  // halves per V^T row (336 bytes: conflict-free 16-byte fragment reads)
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[HD * VLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[HD * VLD];
+    __shared__ int toks[NP];
+    __shared__ int labs[NP];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, kg = lane >> 5;
+    const int head = blockIdx.z, b = blockIdx.y;
+    const int nwx = W / WS, wy = blockIdx.x / nwx, wx = blockIdx.x % nwx;
+    if (t < NP) {
+        int tk = -1, lab = -1;
+        if (t < N) {
+            const int py = wy * WS + t / WS, px = wx * WS + t % WS;
+            const int sy = (py + shift) % H, sx = (px + shift) % W;
+            tk = (b * H + sy) * W + sx;
+            lab = 0;
+            if (shift > 0) {
+                const int by = py < H - WS ? 0 : (py < H - shift ? 1 : 2);
+                const int bx = px < W - WS ? 0 : (px < W - shift ? 1 : 2);
+                lab = by * 3 + bx;
+            }
         }
+        toks[t] = tk;
+        labs[t] = lab;
+    }
+    // the padded key slots of V^T are zero (their probabilities are zero too, but 0 x garbage is not)
+    for (int i = t; i < HD * 16; i += 320) {
+        const int d = i >> 4, sig = fwa_slot(N + (i & 15));
+        Vh[d * VLD + sig] = (_Float16)0.0f;
+        Vl[d * VLD + sig] = (_Float16)0.0f;
     }
     __syncthreads();
-    if (!active) return;
-    float s[N];
+    // V^T tile: key j -> slot sigma(j) (the order in which the accumulators of S^T hold the keys)
+    for (int i = t; i < N * 8; i += 320) {
+        const int j = i >> 3, dq = i & 7;
+        const float4 x = *reinterpret_cast<const float4 *>(v + (size_t)toks[j] * C + head * HD + dq * 4);
+        const int sig = fwa_slot(j);
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const _Float16 h = (_Float16)xv[c];
+            Vh[(dq * 4 + c) * VLD + sig] = h;
+            Vl[(dq * 4 + c) * VLD + sig] = (_Float16)(xv[c] - (float)h);
+        }
+    }
+    // Q fragments of the wave's query block (B operand: column = query, 8 dims per lane and k-step)
+    const int qn = wave * 32 + li;
+    const int qtok = toks[qn];
+    fwa_h8 qh[2], ql[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.0f;
+        if (qtok >= 0) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(qk + (size_t)qtok * 2 * C + head * HD + 16 * s + 8 * kg);
+            const float4 a1 = *reinterpret_cast<const float4 *>(qk + (size_t)qtok * 2 * C + head * HD + 16 * s + 8 * kg + 4);
+            x[0] = a0.x * scale; x[1] = a0.y * scale; x[2] = a0.z * scale; x[3] = a0.w * scale;
+            x[4] = a1.x * scale; x[5] = a1.y * scale; x[6] = a1.z * scale; x[7] = a1.w * scale;
+        }
+        fwa_split8(x, qh[s], ql[s]);
+    }
+    // S^T = K Q^T, key block by key block
+    fwa_acc sc[5];
+#pragma unroll
+    for (int mb = 0; mb < 5; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[mb][r] = 0.0f;
+        const int ktok = toks[mb * 32 + li];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = 0.0f;
+            if (ktok >= 0) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(qk + (size_t)ktok * 2 * C + C + head * HD + 16 * s + 8 * kg);
+                const float4 a1 = *reinterpret_cast<const float4 *>(qk + (size_t)ktok * 2 * C + C + head * HD + 16 * s + 8 * kg + 4);
+                x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+            }
+            fwa_h8 kh, kl;
+            fwa_split8(x, kh, kl);
+            sc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sc[mb], 0, 0, 0);
+            sc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sc[mb], 0, 0, 0);
+            sc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sc[mb], 0, 0, 0);
+        }
+    }
+    // mask + softmax statistics of the lane's query: register r of key block mb = key 32 mb + 8 (r / 4) + 4 kg + r % 4
+    const int qlab = labs[qn];
     float m = -3.0e38f;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        float a0 = 0.0f, a1 = 0.0f;
+    for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
-        for (int e = 0; e < HD / 4; ++e) {
-            const float4 kk = reinterpret_cast<const float4 *>(Ks + j * HD)[e];
-            a0 = fmaf(q[4 * e + 0], kk.x, a0);
-            a1 = fmaf(q[4 * e + 1], kk.y, a1);
-            a0 = fmaf(q[4 * e + 2], kk.z, a0);
-            a1 = fmaf(q[4 * e + 3], kk.w, a1);
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * mb + 8 * (r >> 2) + 4 * kg + (r & 3);
+            const int klab = labs[j];
+            float s = sc[mb][r];
+            if (klab < 0) s = -3.0e38f;                                    // padding
+            else if (klab != qlab) s += -100.0f;                           // the additive shift mask (models/fusion.py:166-167)
+            sc[mb][r] = s;
+            m = fmaxf(m, s);
         }
-        float sc = a0 + a1;
-        if (shift > 0 && labs[j] != label) sc += -100.0f;                   // the additive mask of :166-167
-        s[j] = sc;
-        m = fmaxf(m, sc);
-    }
-    float o[HD];
-#pragma unroll
-    for (int e = 0; e < HD; ++e) o[e] = 0.0f;
+    m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.0f;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const float p = __expf(s[j] - m);
-        sum += p;
+    for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
-        for (int e = 0; e < HD / 4; ++e) {
-            const float4 vv = reinterpret_cast<const float4 *>(Vs + j * HD)[e];
-            o[4 * e + 0] = fmaf(p, vv.x, o[4 * e + 0]);
-            o[4 * e + 1] = fmaf(p, vv.y, o[4 * e + 1]);
-            o[4 * e + 2] = fmaf(p, vv.z, o[4 * e + 2]);
-            o[4 * e + 3] = fmaf(p, vv.w, o[4 * e + 3]);
+        for (int r = 0; r < 16; ++r) {
+            const float p = sc[mb][r] > -1.0e38f ? __expf(sc[mb][r] - m) : 0.0f;
+            sc[mb][r] = p;
+            sum += p;
         }
-    }
-    const float inv = 1.0f / sum;
-    float4 *dst = reinterpret_cast<float4 *>(out + tok * C + head * HD);
+    sum += __shfl_xor(sum, 32);
+    __syncthreads();                                                        // the V^T tile is complete
+    // O^T = V^T P^T: ten k-steps of 16 keys
+    fwa_acc o;
 #pragma unroll
-    for (int e = 0; e < HD / 4; ++e) dst[e] = make_float4(o[4 * e] * inv, o[4 * e + 1] * inv, o[4 * e + 2] * inv, o[4 * e + 3] * inv);
+    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = sc[ks >> 1][8 * (ks & 1) + e];
+        fwa_h8 ph, pl;
+        fwa_split8(x, ph, pl);
+        const fwa_h8 vh = *reinterpret_cast<const fwa_h8 *>(Vh + li * VLD + ks * 16 + kg * 8);
+        const fwa_h8 vl = *reinterpret_cast<const fwa_h8 *>(Vl + li * VLD + ks * 16 + kg * 8);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+    }
+    if (qn < N) {
+        const float inv = 1.0f / sum;
+        float *dst = out + (size_t)qtok * C + head * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)                                         // registers 4 g .. 4 g + 3 = dims 8 g + 4 kg + 0..3
+            *reinterpret_cast<float4 *>(dst + 8 * g + 4 * kg) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+    }
 }
 
 extern "C" int oryon_fusion_window_attention_f32(const float *qk, const float *v, int B, int H, int W, int C, int heads, int window, int shift,
@@ -518,7 +611,7 @@ extern "C" int oryon_fusion_window_attention_f32(const float *qk, const float *v
     ORYON_CHECK_ARG(window == 12 && H % window == 0 && W % window == 0 && shift >= 0 && shift < window);
     ORYON_CHECK_ARG((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)out) & 15) == 0);
     if (B == 0) return ORYON_OK;
-    hipLaunchKernelGGL(fusion_window_attention_kernel<12>, dim3((H / window) * (W / window), B, heads), dim3(192), 0, as_stream(stream), qk, v, H, W,
+    hipLaunchKernelGGL(fusion_window_attention_x3_kernel, dim3((H / window) * (W / window), B, heads), dim3(320), 0, as_stream(stream), qk, v, H, W,
                        C, shift, 1.0f / sqrtf(32.0f), out);
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
                 ok[pp] = pix < DEC_PIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 v[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[pp] && !(a.relu & 256)) v[pp] = *reinterpret_cast<const float4 *>(a.in + (((size_t)img * a.H + gy) * a.W + gx) * a.in_cstride + a.in_coff + s * 32 + cq * 4);
+                if (ok[pp]) v[pp] = *reinterpret_cast<const float4 *>(a.in + (((size_t)img * a.H + gy) * a.W + gx) * a.in_cstride + a.in_coff + s * 32 + cq * 4);
             }
 #pragma unroll
             for (int pp = 0; pp < 11; ++pp) {
@@ -218,7 +218,6 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
         }
         __syncthreads();
         const dh8 *wf = wf0 + (size_t)(s * 18 + RING) * (NB * 2 * 64);          // the fragments RING steps ahead of this slab's step 0
-        if (!(a.relu & 512))
 #pragma unroll
         for (int step = 0; step < 18; ++step) {
             const int tap = step >> 1, ks = step & 1, slot = step % RING;
@@ -268,8 +267,8 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
                 s1 += v;
                 s2 = fmaf(v, v, s2);
                 v += bv;
-                if (a.relu & 1) v = fmaxf(v, 0.0f);
-                if (co < a.cout && !(a.relu & 1024)) a.out[(((size_t)img * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co] = v;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if (co < a.cout) a.out[(((size_t)img * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co] = v;
             }
         if (a.stats) {
             // group = 16 channels = the 16 lanes li & 16 .. of both k-group halves
@@ -609,7 +608,6 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
     const WsLayout L = ws_layout(n_img, h, w);
     ORYON_CHECK_ARG(workspace_bytes >= L.total);
     hipStream_t st = as_stream(stream);
-    static const int dbg = getenv("ORYON_DEC_DEBUG") ? atoi(getenv("ORYON_DEC_DEBUG")) : 0;      // probe switches (tools/r4_dec_ablate.py)
     char *ws = reinterpret_cast<char *>(workspace);
     float *R[3] = {reinterpret_cast<float *>(ws + L.R[0]), reinterpret_cast<float *>(ws + L.R[1]), reinterpret_cast<float *>(ws + L.R[2])};
     float *stats = reinterpret_cast<float *>(ws + L.stats);
@@ -653,7 +651,7 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
         {
             DecConv a{};
             a.in = cat; a.affine = nullptr; a.wimg = d->c1_img[i]; a.bias = nullptr; a.out = a1; a.stats = stats;
-            a.H = H; a.W = W; a.cin = ccat; a.in_cstride = ccat; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = dbg;
+            a.H = H; a.W = W; a.cin = ccat; a.in_cstride = ccat; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = 0;
             if (cout == 64) launch_conv<2, false, false>(st, a, n_img);
             else launch_conv<1, false, false>(st, a, n_img);
             hipLaunchKernelGGL(dec_gn_affine_kernel, dim3(n_img * (cout / 16)), dim3(64), 0, st, stats, n_img, tiles, cout / 16,
@@ -665,7 +663,7 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
         {
             DecConv a{};
             a.in = a1; a.affine = aff[2 * i]; a.wimg = d->c2_img[i]; a.bias = nullptr; a.out = b1; a.stats = stats;
-            a.H = H; a.W = W; a.cin = cout; a.in_cstride = cout; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = dbg;
+            a.H = H; a.W = W; a.cin = cout; a.in_cstride = cout; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = 0;
             if (cout == 64) launch_conv<2, false, true>(st, a, n_img);
             else launch_conv<1, false, true>(st, a, n_img);
             hipLaunchKernelGGL(dec_gn_affine_kernel, dim3(n_img * (cout / 16)), dim3(64), 0, st, stats, n_img, tiles, cout / 16,

@@ -140,7 +140,8 @@ def swin_window_attention_f32(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t: 
 @_on_tensor_device
 def fusion_window_attention(qk: torch.Tensor, v: torch.Tensor, heads: int, window: int, shift: int) -> torch.Tensor:
     """Shifted-window attention of ImageTextFusion's guided Swin blocks on un-windowed tokens: qk [B,H,W,2C] (q | k projections),
-    v [B,H,W,C] fp32 -> [B,H,W,C] fp32 (roll, windows, masked softmax attention, windows back, roll back in one kernel)."""
+    v [B,H,W,C] fp32 -> [B,H,W,C] fp32 (roll, windows, masked softmax attention, windows back, roll back in one kernel; fp16x3 MFMA products,
+    fp32-grade)."""
     _lib.require_gpu(qk.device)
     B, H, W, C2 = qk.shape
     C = C2 // 2

@@ -174,7 +174,7 @@ def test_hot_kernels_do_not_spill():
     hot = ("match_mx6_screen_w4_kernelILi256ELi8E", "match_i8_screen_v2_kernelILi256E", "gather_q8_v3_kernelILi256ELi1ELb0ELi1E",
            "gather_q8_v3_kernelILi256ELi1ELb0ELi0E", "pdsc_attention_x3_img_kernel", "pdsc_pcn_qkv_x3_kernel", "pdsc_mlp3_x3_kernel",
            "match_decide_lite_kernel", "match_resolve_selected_kernel", "dec_conv3x3_kernelILi1ELb0ELb1ELb1E", "dec_conv3x3_kernelILi2ELb0ELb0ELb0E",
-           "dec_final_kernel", "fusion_window_attention_kernel")
+           "dec_final_kernel", "fusion_window_attention_x3_kernel")
     seen = set()
     for k in rows:
         for h in hot:

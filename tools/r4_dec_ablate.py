@@ -1,5 +1,7 @@
-"""Round-4 probe: phase ablation of the decoder's conv3x3 kernels (ORYON_DEC_DEBUG bit 256 = no tile loads, 512 = no MFMA loop,
-1024 = no output stores).  Run once per mask: ORYON_DEC_DEBUG=<mask> python tools/r4_dec_ablate.py"""
+"""Round-4 probe: the HIP decoder's time up to a given stage (`stop_after` of oryon_decoder_forward: 7 = block 3's cat buffer, 8 / 9 = its first
+/ second convolution, 0 = the whole module), 128 images.  The phase ablation recorded in DESIGN.md (no tile loads / no MFMA loop / no output
+stores) used temporary switches inside dec_conv3x3_kernel (commit "Decoder: persistent register-weight variant ..."); they are not in the
+library any more - no switch of the shipped kernels changes results."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import oryon_amd
