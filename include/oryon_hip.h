@@ -90,7 +90,8 @@ int oryon_add_layernorm_f32(const float *x, const float *delta, const float *gam
  *     out     [B, H, W, C] bf16;  C == heads * 32, heads <= 8, 0 <= shift < 7 (torchvision passes 0 or 3) */
 int oryon_swin_window_attention_bf16(const void *qkv, const void *pad_qkv, const float *bias_t, int B, int H, int W, int C, int heads,
                                      int shift, void *out, void *stream);
-/* the same kernel on fp32 tensors (fp32 evaluation of the guidance tower; arithmetic identical, no rounding at the ends) */
+/* the same operation on fp32 tensors (fp32 evaluation of the guidance tower): both products on the fp16 matrix pipe with error-compensated
+ * operands (fp32-grade, ~1e-6 relative; round 4 - the fp32-VALU form of the bf16 kernel took twice as long), fp32 bias / mask / softmax */
 int oryon_swin_window_attention_f32(const float *qkv, const float *pad_qkv, const float *bias_t, int B, int H, int W, int C, int heads,
                                     int shift, float *out, void *stream);
 

@@ -409,21 +409,6 @@ extern "C" int oryon_swin_window_attention_bf16(const void *qkv, const void *pad
     return ORYON_OK;
 }
 
-extern "C" int oryon_swin_window_attention_f32(const float *qkv, const float *pad_qkv, const float *bias_t, int B, int H, int W, int C,
-                                               int heads, int shift, float *out, void *stream)
-{
-    ORYON_CHECK_ARG(qkv && pad_qkv && bias_t && out && B >= 0 && H > 0 && W > 0 && heads >= 1 && heads <= 8 && C == heads * SWIN_HD);
-    ORYON_CHECK_ARG(shift >= 0 && shift < SWIN_WS);
-    ORYON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)pad_qkv | (uintptr_t)out) & 15) == 0);
-    if (B == 0) return ORYON_OK;
-    const int nwy = (H + SWIN_WS - 1) / SWIN_WS, nwx = (W + SWIN_WS - 1) / SWIN_WS;
-    const size_t lds = (size_t)heads * SWIN_WAVE_FLOATS * sizeof(float);
-    allow_dynamic_lds(reinterpret_cast<const void *>(swin_window_attention_kernel<float>), 8 * SWIN_WAVE_FLOATS * (int)sizeof(float));
-    hipLaunchKernelGGL(swin_window_attention_kernel<float>, dim3(nwy * nwx, B), dim3(64 * heads), lds, as_stream(stream), qkv, pad_qkv, bias_t,
-                       H, W, C, shift, out);
-    ORYON_CHECK_LAUNCH();
-    return ORYON_OK;
-}
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // a4  window attention of ImageTextFusion's guided Swin blocks (models/fusion.py:75-103 WindowAttention.forward inside
@@ -613,6 +598,169 @@ extern "C" int oryon_fusion_window_attention_f32(const float *qk, const float *v
     if (B == 0) return ORYON_OK;
     hipLaunchKernelGGL(fusion_window_attention_x3_kernel, dim3((H / window) * (W / window), B, heads), dim3(320), 0, as_stream(stream), qk, v, H, W,
                        C, shift, 1.0f / sqrtf(32.0f), out);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+// The Swin guidance tower's shifted-window attention (torchvision shifted_window_attention, window 7, head dim 32) on the fp16 matrix pipe for
+// the fp32 evaluation - the same transposed scheme as fusion_window_attention_x3_kernel: one workgroup per (window, image, head), two waves of
+// 32 queries (49 tokens = 1.5 blocks), S^T = K Q^T + relative-position bias + shift mask, in-lane softmax, O^T = V^T P^T.  Padding tokens (the
+// map is padded to a multiple of 7 before the roll) carry q | k | v = the Linear's bias (`pad_qkv`) and take part as keys; their outputs are
+// cropped.  The VALU kernel above (one query per lane, fp32 fmaf) took 1.2-2.4 ms per call on the tower's 96 x 96 / 48 x 48 maps.
+__global__ __launch_bounds__(128) void swin_window_attention_x3_kernel(const float *__restrict__ qkv, const float *__restrict__ pad_qkv,
+                                                                      const float *__restrict__ bias_t, int H, int W, int C, int shift,
+                                                                      float *__restrict__ out)
+{
+    constexpr int WS = SWIN_WS, N = SWIN_N, NP = 64, HD = SWIN_HD;
+    constexpr int VLD = 72;                                   // halves per V^T row (144 bytes)
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[HD * VLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[HD * VLD];
+    __shared__ int toks[NP];                                  // >= 0: token, -2: padding token, -1: no token (slots 49..63)
+    __shared__ int labs[NP];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, kg = lane >> 5;
+    const int head = blockIdx.z, b = blockIdx.y;
+    const int Hp = (H + WS - 1) / WS * WS, Wp = (W + WS - 1) / WS * WS;
+    const int nwx = Wp / WS, wy = blockIdx.x / nwx, wx = blockIdx.x % nwx;
+    if (t < NP) {
+        int tk = -1, lab = -1;
+        if (t < N) {
+            const int py = wy * WS + t / WS, px = wx * WS + t % WS;                          // rolled, padded frame
+            const int sy = (py + shift) % Hp, sx = (px + shift) % Wp;
+            tk = (sy < H && sx < W) ? (b * H + sy) * W + sx : -2;
+            lab = 0;
+            if (shift > 0) {
+                const int by = py < Hp - WS ? 0 : (py < Hp - shift ? 1 : 2);
+                const int bx = px < Wp - WS ? 0 : (px < Wp - shift ? 1 : 2);
+                lab = by * 3 + bx;
+            }
+        }
+        toks[t] = tk;
+        labs[t] = lab;
+    }
+    for (int i = t; i < HD * (NP - N); i += 128) {                                          // zero the unused key slots of V^T
+        const int d = i / (NP - N), sig = fwa_slot(N + i % (NP - N));
+        Vh[d * VLD + sig] = (_Float16)0.0f;
+        Vl[d * VLD + sig] = (_Float16)0.0f;
+    }
+    __syncthreads();
+    auto row = [&](int tk) { return tk >= 0 ? qkv + (size_t)tk * 3 * C : pad_qkv; };
+    for (int i = t; i < N * 8; i += 128) {
+        const int j = i >> 3, dq = i & 7;
+        const float4 x = *reinterpret_cast<const float4 *>(row(toks[j]) + 2 * C + head * HD + dq * 4);
+        const int sig = fwa_slot(j);
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const _Float16 h = (_Float16)xv[c];
+            Vh[(dq * 4 + c) * VLD + sig] = h;
+            Vl[(dq * 4 + c) * VLD + sig] = (_Float16)(xv[c] - (float)h);
+        }
+    }
+    const int qn = wave * 32 + li;
+    const int qtok = toks[qn];
+    const float scale = 0.17677669529663687f;                                                // 32^-0.5
+    fwa_h8 qh[2], ql[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.0f;
+        if (qtok != -1) {
+            const float *src = row(qtok) + head * HD + 16 * s + 8 * kg;
+            const float4 a0 = *reinterpret_cast<const float4 *>(src), a1 = *reinterpret_cast<const float4 *>(src + 4);
+            x[0] = a0.x * scale; x[1] = a0.y * scale; x[2] = a0.z * scale; x[3] = a0.w * scale;
+            x[4] = a1.x * scale; x[5] = a1.y * scale; x[6] = a1.z * scale; x[7] = a1.w * scale;
+        }
+        fwa_split8(x, qh[s], ql[s]);
+    }
+    fwa_acc sc[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[mb][r] = 0.0f;
+        const int ktok = toks[mb * 32 + li];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = 0.0f;
+            if (ktok != -1) {
+                const float *src = row(ktok) + C + head * HD + 16 * s + 8 * kg;
+                const float4 a0 = *reinterpret_cast<const float4 *>(src), a1 = *reinterpret_cast<const float4 *>(src + 4);
+                x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+            }
+            fwa_h8 kh, kl;
+            fwa_split8(x, kh, kl);
+            sc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sc[mb], 0, 0, 0);
+            sc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sc[mb], 0, 0, 0);
+            sc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sc[mb], 0, 0, 0);
+        }
+    }
+    // relative-position bias (bias_t[head][key][query]: 32 consecutive queries per load), shift mask, softmax of the lane's query
+    const int qlab = labs[qn];
+    const float *bt = bias_t + (size_t)head * N * N + (qn < N ? qn : 0);
+    float m = -3.0e38f;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * mb + 8 * (r >> 2) + 4 * kg + (r & 3);
+            const int klab = labs[j];
+            float s = -3.0e38f;
+            if (klab >= 0) {
+                s = sc[mb][r] + bt[j * N];
+                if (klab != qlab) s -= 100.0f;
+            }
+            sc[mb][r] = s;
+            m = fmaxf(m, s);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = sc[mb][r] > -1.0e38f ? expf(sc[mb][r] - m) : 0.0f;
+            sc[mb][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32);
+    __syncthreads();
+    fwa_acc o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = sc[ks >> 1][8 * (ks & 1) + e];
+        fwa_h8 ph, pl;
+        fwa_split8(x, ph, pl);
+        const fwa_h8 vh = *reinterpret_cast<const fwa_h8 *>(Vh + li * VLD + ks * 16 + kg * 8);
+        const fwa_h8 vl = *reinterpret_cast<const fwa_h8 *>(Vl + li * VLD + ks * 16 + kg * 8);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+    }
+    if (qtok >= 0) {                                                                         // padding tokens are cropped away
+        const float inv = 1.0f / sum;
+        float *dst = out + (size_t)qtok * C + head * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(dst + 8 * g + 4 * kg) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+    }
+}
+
+extern "C" int oryon_swin_window_attention_f32(const float *qkv, const float *pad_qkv, const float *bias_t, int B, int H, int W, int C,
+                                               int heads, int shift, float *out, void *stream)
+{
+    ORYON_CHECK_ARG(qkv && pad_qkv && bias_t && out && B >= 0 && H > 0 && W > 0 && heads >= 1 && heads <= 8 && C == heads * SWIN_HD);
+    ORYON_CHECK_ARG(shift >= 0 && shift < SWIN_WS);
+    ORYON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)pad_qkv | (uintptr_t)out) & 15) == 0);
+    if (B == 0) return ORYON_OK;
+    const int nwy = (H + SWIN_WS - 1) / SWIN_WS, nwx = (W + SWIN_WS - 1) / SWIN_WS;
+    hipLaunchKernelGGL(swin_window_attention_x3_kernel, dim3(nwy * nwx, B, heads), dim3(128), 0, as_stream(stream), qkv, pad_qkv, bias_t, H, W, C,
+                       shift, out);
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }
