@@ -592,7 +592,7 @@ __global__ __launch_bounds__(320) void fusion_window_attention_x3_kernel(const f
 extern "C" int oryon_fusion_window_attention_f32(const float *qk, const float *v, int B, int H, int W, int C, int heads, int window, int shift,
                                                  float *out, void *stream)
 {
-    ORYON_CHECK_ARG(qk && v && out && B >= 0 && H > 0 && W > 0 && heads >= 1 && C == heads * 32);
+    ORYON_CHECK_ARG(qk && v && out && B >= 0 && B < 65536 && H > 0 && W > 0 && heads >= 1 && heads <= 64 && C == heads * 32);
     ORYON_CHECK_ARG(window == 12 && H % window == 0 && W % window == 0 && shift >= 0 && shift < window);
     ORYON_CHECK_ARG((((uintptr_t)qk | (uintptr_t)v | (uintptr_t)out) & 15) == 0);
     if (B == 0) return ORYON_OK;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(128) void swin_window_attention_x3_kernel(const flo
 extern "C" int oryon_swin_window_attention_f32(const float *qkv, const float *pad_qkv, const float *bias_t, int B, int H, int W, int C,
                                                int heads, int shift, float *out, void *stream)
 {
-    ORYON_CHECK_ARG(qkv && pad_qkv && bias_t && out && B >= 0 && H > 0 && W > 0 && heads >= 1 && heads <= 8 && C == heads * SWIN_HD);
+    ORYON_CHECK_ARG(qkv && pad_qkv && bias_t && out && B >= 0 && B < 65536 && H > 0 && W > 0 && heads >= 1 && heads <= 8 && C == heads * SWIN_HD);
     ORYON_CHECK_ARG(shift >= 0 && shift < SWIN_WS);
     ORYON_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)pad_qkv | (uintptr_t)out) & 15) == 0);
     if (B == 0) return ORYON_OK;
