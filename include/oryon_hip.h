@@ -519,6 +519,15 @@ int oryon_decoder_forward(const oryon_decoder_t *handle, const float *x, const f
 int oryon_fusion_window_attention_f32(const float *qk, const float *v, int B, int H, int W, int C, int heads, int window, int shift,
                                       float *out, void *stream);
 
+/* a4  the two convolutions of ImageTextFusion on its 24 x 24 maps (models/fusion.py:562 + :595-600: conv1 7x7 pad 3 on the cost volume;
+ *     :566-570 + :614-615: guidance_projection 3x3 pad 1 + ReLU) as implicit GEMMs on the fp16 matrix pipe with error-compensated operands
+ *     (fp32-grade).  x [n, 24, 24, cin] fp32 NHWC -> y [n, 24, 24, cout] fp32 NHWC = act(conv(x, w) + bias); ksize 3 or 7 (stride 1, padding
+ *     ksize / 2), cout % 64 == 0, cin % 4 == 0.  `image`: the weights packed once by oryon_conv24_pack_f16x3 from torch's [cout, cin, k, k]
+ *     layout into oryon_conv24_image_bytes(cout, cin, ksize) bytes (0 = unsupported shape). */
+int64_t oryon_conv24_image_bytes(int cout, int cin, int ksize);
+int oryon_conv24_pack_f16x3(const float *w, int cout, int cin, int ksize, void *image, void *stream);
+int oryon_conv24_f16x3(const float *x, int n, int cin, const void *image, const float *bias, int cout, int ksize, int relu, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,9 @@ _PROTOS = {
     "oryon_engine_host_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "oryon_engine_x3_steps": (c_int, [c_void_p, POINTER(c_int64)]),
     "oryon_fusion_window_attention_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "oryon_conv24_image_bytes": (c_int64, [c_int, c_int, c_int]),
+    "oryon_conv24_pack_f16x3": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "oryon_conv24_f16x3": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
     "oryon_decoder_create": (c_int, [POINTER(DecoderWeights), POINTER(c_void_p), _P]),
     "oryon_decoder_destroy": (None, [c_void_p]),
     "oryon_decoder_workspace_bytes": (c_int64, [c_int, c_int, c_int]),

@@ -54,7 +54,7 @@ static __device__ __forceinline__ void split_h(float v, _Float16 &hi, _Float16 &
 // Weight image of a 3x3 convolution (torch layout w[cout, cin, 3, 3]): fragment ((((slab * 9 + tap) * 2 + kstep) * NB + nb) * 2 + part),
 // 64 lanes x 8 halves each: lane l holds output channel nb * 32 + (l & 31), input channels slab * 32 + kstep * 16 + (l >> 5) * 8 + 0..7 -
 // the B operand of v_mfma_f32_32x32x16_f16.  part 0 = hi halves, 1 = lo halves.  Channels beyond cout are zero columns.
-__global__ void dec_pack_conv3x3_kernel(const float *__restrict__ w, int cout, int cin, int NB, _Float16 *__restrict__ img, int64_t total)
+__global__ void dec_pack_conv3x3_kernel(const float *__restrict__ w, int cout, int cin, int NB, _Float16 *__restrict__ img, int64_t total, int T = 9)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -62,11 +62,11 @@ __global__ void dec_pack_conv3x3_kernel(const float *__restrict__ w, int cout, i
     int64_t rest = idx >> 10;
     const int nb = rest % NB; rest /= NB;
     const int ks = rest & 1; rest >>= 1;
-    const int tap = rest % 9;
-    const int s = rest / 9;
+    const int tap = rest % T;
+    const int s = rest / T;
     const int n = nb * 32 + (lane & 31), c = s * 32 + ks * 16 + (lane >> 5) * 8 + e;
     float v = 0.0f;
-    if (n < cout && c < cin) v = w[((size_t)n * cin + c) * 9 + tap];
+    if (n < cout && c < cin) v = w[((size_t)n * cin + c) * T + tap];
     _Float16 hi, lo;
     split_h(v, hi, lo);
     img[idx] = part ? lo : hi;
@@ -444,6 +444,140 @@ __global__ __launch_bounds__(256) void dec_final_kernel(const float *__restrict_
     logits[((size_t)img * H + gy) * W + gx] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// a4  the two convolutions of ImageTextFusion on its 24 x 24 maps (models/fusion.py:562 / :595-600 conv1 = 7x7 on the cost volume, 80 -> 128;
+//     :566-570 / :614-615 guidance_projection = 3x3 + ReLU on the Swin map, 512 -> 128), same arithmetic as dec_conv3x3_kernel.  The maps are
+//     too small to tile (576 pixels = 18 M blocks): one workgroup = one WHOLE image x 64 output channels, nine waves of two M blocks, the
+//     zero-padded halo map of a 32-channel slab as hi / lo planes in LDS (108 KB for 3x3, 144 KB for 7x7), weights per (tap, k-step) straight
+//     from global memory one tap ahead (all nine waves ask for the same fragments: L1 hits).  NHWC in, NHWC out.
+struct FusConv {
+    const float *in;          // [n, 24, 24, cin]
+    const dh8 *wimg;          // fragments ((((slab * T + tap) * 2 + kstep) * (cout / 32) + nb) * 2 + part)
+    const float *bias;        // [cout] or NULL
+    float *out;               // [n, 24, 24, cout]
+    int cin, cout, relu;
+};
+
+template <int KS>
+__global__ __launch_bounds__(576) void fus_conv24_kernel(const FusConv a)
+{
+    constexpr int S = 24, PAD = KS / 2, HWP = S + 2 * PAD, HP = HWP * HWP, T = KS * KS;
+    constexpr int PLANE = HP * DEC_PSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char flds[];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, kg = lane >> 5;
+    const int groups = a.cout / 64, nbt = a.cout / 32;
+    const int img = blockIdx.x / groups, nb0 = (blockIdx.x % groups) * 2;
+    const int slabs = (a.cin + 31) / 32;
+    dacc16 acc[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+    int a_off[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int p = (wave * 2 + mb) * 32 + li;
+        a_off[mb] = ((p / S) * HWP + p % S) * DEC_PSTRIDE + kg * 16;        // halo coordinates of the pixel at tap (0, 0)
+    }
+    const dh8 *wf = a.wimg + lane;
+    auto frag = [&](int step, int nb, int part) { return wf[(((size_t)step * nbt + nb0 + nb) * 2 + part) * 64]; };
+    for (int s = 0; s < slabs; ++s) {
+        __syncthreads();
+        {
+            const int p8 = t >> 3, cq = t & 7;
+            const bool cok = s * 32 + cq * 4 < a.cin;
+            constexpr int PASSES = (HP + 71) / 72;
+#pragma unroll 1
+            for (int p0 = 0; p0 < PASSES; p0 += 5) {
+                float4 v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int pix = (p0 + j) * 72 + p8;
+                    const int gy = pix / HWP - PAD, gx = pix % HWP - PAD;
+                    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p0 + j < PASSES && pix < HP && cok && gy >= 0 && gy < S && gx >= 0 && gx < S)
+                        v[j] = *reinterpret_cast<const float4 *>(a.in + (((size_t)img * S + gy) * S + gx) * a.cin + s * 32 + cq * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int pix = (p0 + j) * 72 + p8;
+                    if (p0 + j >= PASSES || pix >= HP) continue;
+                    dh4 hi, lo;
+                    _Float16 h, l;
+                    split_h(v[j].x, h, l); hi[0] = h; lo[0] = l;
+                    split_h(v[j].y, h, l); hi[1] = h; lo[1] = l;
+                    split_h(v[j].z, h, l); hi[2] = h; lo[2] = l;
+                    split_h(v[j].w, h, l); hi[3] = h; lo[3] = l;
+                    *reinterpret_cast<dh4 *>(flds + pix * DEC_PSTRIDE + cq * 8) = hi;
+                    *reinterpret_cast<dh4 *>(flds + PLANE + pix * DEC_PSTRIDE + cq * 8) = lo;
+                }
+            }
+        }
+        __syncthreads();
+        dh8 cur[2][2][2], nxt[2][2][2];                        // [k-step][N block][hi | lo] of one tap
+        const int step0 = s * T * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                cur[ks][nb][0] = frag(step0 + ks, nb, 0);
+                cur[ks][nb][1] = frag(step0 + ks, nb, 1);
+            }
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+            // the next tap's fragments (the image is padded by one tap: the last prefetch of the last slab reads zeros nobody uses)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    nxt[ks][nb][0] = frag(step0 + (tap + 1) * 2 + ks, nb, 0);
+                    nxt[ks][nb][1] = frag(step0 + (tap + 1) * 2 + ks, nb, 1);
+                }
+            const int toff = ((tap / KS) * HWP + tap % KS) * DEC_PSTRIDE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                dh8 ah[2], al[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    ah[mb] = *reinterpret_cast<const dh8 *>(flds + a_off[mb] + toff + ks * 32);
+                    al[mb] = *reinterpret_cast<const dh8 *>(flds + PLANE + a_off[mb] + toff + ks * 32);
+                }
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(part == 0 ? al[mb] : ah[mb], cur[ks][nb][part == 1 ? 1 : 0],
+                                                                                 acc[mb][nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    cur[ks][nb][0] = nxt[ks][nb][0];
+                    cur[ks][nb][1] = nxt[ks][nb][1];
+                }
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int co = (nb0 + nb) * 32 + li;
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = (wave * 2 + mb) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
+                float v = acc[mb][nb][r] + bv;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                a.out[((size_t)img * S * S + p) * a.cout + co] = v;
+            }
+    }
+}
+
 }  // namespace oryon
 
 using namespace oryon;
@@ -676,6 +810,49 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
     }
     hipLaunchKernelGGL(dec_final_kernel, dim3((H / 8) * (W / 32), n_img), dim3(256), 0, st, prev, prev_aff, H, W, d->head_w, d->head_b, featmap,
                        logits);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+static inline int64_t conv24_image_halves(int cout, int cin, int ksize)
+{
+    return ((int64_t)((cin + 31) / 32) * ksize * ksize + 1) * 2 * (cout / 32) * 2 * 64 * 8;          // + one tap of zeros (the prefetch reads ahead)
+}
+
+int64_t oryon_conv24_image_bytes(int cout, int cin, int ksize)
+{
+    if (cout <= 0 || cout % 64 || cin <= 0 || cin % 4 || (ksize != 3 && ksize != 7)) return 0;
+    return conv24_image_halves(cout, cin, ksize) * 2;
+}
+
+int oryon_conv24_pack_f16x3(const float *w, int cout, int cin, int ksize, void *image, void *stream)
+{
+    ORYON_CHECK_ARG(w != nullptr && image != nullptr && oryon_conv24_image_bytes(cout, cin, ksize) > 0);
+    const int64_t total = conv24_image_halves(cout, cin, ksize);
+    hipLaunchKernelGGL(dec_pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, cout, cin, cout / 32,
+                       reinterpret_cast<_Float16 *>(image), total, ksize * ksize);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}
+
+int oryon_conv24_f16x3(const float *x, int n, int cin, const void *image, const float *bias, int cout, int ksize, int relu, float *y, void *stream)
+{
+    ORYON_CHECK_ARG(x != nullptr && image != nullptr && y != nullptr && n >= 0 && oryon_conv24_image_bytes(cout, cin, ksize) > 0);
+    ORYON_CHECK_ARG((int64_t)n * (cout / 64) < 2147483647LL);
+    ORYON_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)image) & 15) == 0);
+    if (n == 0) return ORYON_OK;
+    FusConv a{};
+    a.in = x; a.wimg = reinterpret_cast<const dh8 *>(image); a.bias = bias; a.out = y; a.cin = cin; a.cout = cout; a.relu = relu ? 1 : 0;
+    const dim3 grid((unsigned)(n * (cout / 64)));
+    if (ksize == 3) {
+        constexpr int dyn = 2 * 26 * 26 * DEC_PSTRIDE;
+        allow_dynamic_lds(reinterpret_cast<const void *>(&fus_conv24_kernel<3>), dyn);
+        hipLaunchKernelGGL(fus_conv24_kernel<3>, grid, dim3(576), dyn, as_stream(stream), a);
+    } else {
+        constexpr int dyn = 2 * 30 * 30 * DEC_PSTRIDE;
+        allow_dynamic_lds(reinterpret_cast<const void *>(&fus_conv24_kernel<7>), dyn);
+        hipLaunchKernelGGL(fus_conv24_kernel<7>, grid, dim3(576), dyn, as_stream(stream), a);
+    }
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

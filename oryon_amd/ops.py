@@ -137,6 +137,52 @@ def swin_window_attention_f32(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t: 
     return out
 
 
+_conv24_images: dict = {}
+
+
+def _conv24_image(weight: torch.Tensor) -> torch.Tensor:
+    """Packed fp16 hi / lo fragment image of a conv weight [cout, cin, k, k], made once per live tensor and in-place version."""
+    key = id(weight)
+    hit = _conv24_images.get(key)
+    if hit is not None and (hit[0]() is not weight or hit[1] != (weight._version, weight.data_ptr(), tuple(weight.shape))):
+        hit = None
+    if hit is None:
+        cout, cin, k, _ = weight.shape
+        nbytes = int(lib().oryon_conv24_image_bytes(cout, cin, k))
+        if nbytes <= 0:
+            raise _lib.OryonError(f"oryon_conv24_f16x3: unsupported weight shape {tuple(weight.shape)}")
+        w = weight.detach().to(torch.float32).contiguous()
+        img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        check(lib().oryon_conv24_pack_f16x3(ptr(w), cout, cin, k, ptr(img), stream_ptr(w.device)), "oryon_conv24_pack_f16x3")
+        if len(_conv24_images) > 64:
+            _conv24_images.clear()
+        ref = weakref.ref(weight, lambda _r, k_=key: _conv24_images.pop(k_, None))
+        hit = _conv24_images[key] = (ref, (weight._version, weight.data_ptr(), tuple(weight.shape)), img)
+    return hit[2]
+
+
+def conv24_supported(x_nhwc: torch.Tensor, weight: torch.Tensor) -> bool:
+    return (x_nhwc.is_cuda and x_nhwc.dtype == torch.float32 and x_nhwc.dim() == 4
+            and tuple(x_nhwc.shape[1:3]) == (24, 24) and weight.dim() == 4 and weight.shape[2] == weight.shape[3] and weight.shape[2] in (3, 7)
+            and weight.shape[0] % 64 == 0 and weight.shape[1] % 4 == 0 and x_nhwc.shape[3] == weight.shape[1])
+
+
+@_on_tensor_device
+def conv24_f16x3(x_nhwc: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False) -> torch.Tensor:
+    """act(conv2d(x, weight, bias, stride 1, padding k // 2)) for 24 x 24 maps: x [n,24,24,cin] fp32 NHWC, weight [cout,cin,k,k] (torch
+    layout, k = 3 or 7) -> [n,24,24,cout] fp32 NHWC (ImageTextFusion's conv1 / guidance_projection; fp16x3 MFMA products, fp32-grade).
+    Inference only: no autograd graph is recorded."""
+    dev = _lib.require_gpu(x_nhwc.device)
+    assert conv24_supported(x_nhwc, weight), (x_nhwc.shape, weight.shape)
+    x = x_nhwc.contiguous()
+    n, cout, cin, k = x.shape[0], weight.shape[0], weight.shape[1], weight.shape[2]
+    img = _conv24_image(weight)
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    y = torch.empty((n, 24, 24, cout), dtype=torch.float32, device=dev)
+    check(lib().oryon_conv24_f16x3(ptr(x), n, cin, ptr(img), ptr(b), cout, k, int(relu), ptr(y), stream_ptr(dev)), "oryon_conv24_f16x3")
+    return y
+
+
 @_on_tensor_device
 def fusion_window_attention(qk: torch.Tensor, v: torch.Tensor, heads: int, window: int, shift: int) -> torch.Tensor:
     """Shifted-window attention of ImageTextFusion's guided Swin blocks on un-windowed tokens: qk [B,H,W,2C] (q | k projections),

@@ -53,6 +53,9 @@ def test_argument_validation_without_gpu():
     assert L.oryon_decoder_workspace_layout(2, 24, 24, off) == 0 and list(off) == [0, 2 * 192 * 192 * 32 * 4, 2 * 2 * 192 * 192 * 32 * 4]
     assert L.oryon_decoder_workspace_layout(2, 24, 25, off) == -1
     assert L.oryon_fusion_window_attention_f32(None, None, 1, 24, 24, 128, 4, 12, 0, None, None) == -1
+    assert L.oryon_conv24_image_bytes(128, 512, 3) == (16 * 9 + 1) * 2 * 4 * 2 * 1024 and L.oryon_conv24_image_bytes(128, 80, 7) == (3 * 49 + 1) * 2 * 4 * 2 * 1024
+    assert L.oryon_conv24_image_bytes(96, 80, 7) == 0 and L.oryon_conv24_image_bytes(128, 80, 5) == 0
+    assert L.oryon_conv24_f16x3(None, 1, 80, None, None, 128, 7, 0, None, None) == -1
 
 
 def test_no_cpu_fallback():

@@ -151,3 +151,22 @@ def test_fusion_window_attention_matches_torch(shift):
     if shift > 0:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
     assert float((got - o).abs().max()) < 2e-5 * float(o.abs().max())
+
+
+@pytest.mark.parametrize("k,cin,cout,relu", [(3, 512, 128, True), (7, 80, 128, False), (3, 36, 64, False)])
+def test_conv24_matches_torch(k, cin, cout, relu):
+    """oryon_conv24_f16x3 (ImageTextFusion's conv1 / guidance_projection shapes, models/fusion.py:562-570, and a ragged cin) against
+    F.conv2d in fp32: <= 2e-5 of the output's maximum."""
+    from oryon_amd import ops
+    torch.backends.cudnn.allow_tf32 = False
+    torch.manual_seed(k + cin)
+    n = 3
+    x = torch.randn(n, 24, 24, cin, device="cuda")
+    w = torch.randn(cout, cin, k, k, device="cuda") * (3.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, device="cuda") * 0.1
+    got = ops.conv24_f16x3(x, w, b, relu=relu)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=k // 2)
+    ref = torch.relu(ref) if relu else ref
+    err = float((got.permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+    assert torch.equal(got, ops.conv24_f16x3(x, w, b, relu=relu))
