@@ -211,6 +211,40 @@ def test_oryon_forward_gpu_equals_cpu_and_prompt_cache():
 
 
 @pytest.mark.gpu
+def test_oryon_forward_fast_path_matches_the_fp32_modules():
+    """The whole fast inference path of Oryon.forward (backbone.enable_fp16x3: fp16x3 linears / attentions in both towers and the fusion
+    module, whole-map HIP convolutions and fused window attention in fusion, the HIP decoder) against the torch / MIOpen fp32 evaluation
+    of the same module on the same device: descriptor maps and mask logits <= 1e-4 relative, the north-star descriptor bar."""
+    from oryon_amd.backbone import enable_fp16x3
+    from oryon_amd.backbone.clip import CLIPConfig
+    from oryon_amd.net import Oryon, default_model_args
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    cfg = CLIPConfig.vit_l14_336()
+    cfg.v_layers, cfg.t_layers = 2, 2
+    torch.manual_seed(1)
+    net = Oryon(default_model_args(), "cuda", clip_cfg=cfg).eval()
+    B = 2
+    gen = torch.Generator().manual_seed(4)
+    toks = torch.randint(1, 49000, (1, 80, 77), generator=gen)
+    toks[..., 11] = 49407
+    toks[..., 12:] = 0
+    xs = {"anchor": {"rgb": torch.rand(B, 3, 224, 224, generator=gen).cuda()}, "query": {"rgb": torch.rand(B, 3, 224, 224, generator=gen).cuda()},
+          "prompt_tokens": toks.expand(B, 80, 77).contiguous()}
+    with torch.no_grad():
+        ref = net(xs)
+        enable_fp16x3(True)
+        try:
+            out = net(xs)
+            assert net.decoder.__dict__.get("_hip") is not None                 # the HIP decoder ran
+        finally:
+            enable_fp16x3(False)
+    for k in ("featmap_a", "featmap_q", "mask_a", "mask_q"):
+        err = float((out[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-4, (k, err)
+
+
+@pytest.mark.gpu
 def test_fp16x3_linear_and_clip_tower_match_fp32():
     """B4 (oryon_linear_f16x3): the error-compensated fp16x3 linear against an fp64 reference (must be at least as accurate as torch's
     fp32 linear), ragged M, fused QuickGELU; and the CLIP image tower evaluated with it against the fp32 torch evaluation: patch tokens
