@@ -179,6 +179,8 @@ def conv24_f16x3(x_nhwc: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
     img = _conv24_image(weight)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
     y = torch.empty((n, 24, 24, cout), dtype=torch.float32, device=dev)
+    if n == 0:
+        return y
     check(lib().oryon_conv24_f16x3(ptr(x), n, cin, ptr(img), ptr(b), cout, k, int(relu), ptr(y), stream_ptr(dev)), "oryon_conv24_f16x3")
     return y
 
@@ -194,6 +196,8 @@ def fusion_window_attention(qk: torch.Tensor, v: torch.Tensor, heads: int, windo
     assert qk.dtype == torch.float32 and v.dtype == torch.float32 and tuple(v.shape) == (B, H, W, C) and C2 == 2 * C
     qk, v = qk.contiguous(), v.contiguous()
     out = torch.empty((B, H, W, C), dtype=torch.float32, device=qk.device)
+    if B == 0:
+        return out
     check(lib().oryon_fusion_window_attention_f32(ptr(qk), ptr(v), B, H, W, C, heads, window, shift, ptr(out), stream_ptr(qk.device)),
           "oryon_fusion_window_attention_f32")
     return out
