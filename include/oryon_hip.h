@@ -528,6 +528,18 @@ int64_t oryon_conv24_image_bytes(int cout, int cin, int ksize);
 int oryon_conv24_pack_f16x3(const float *w, int cout, int cin, int ksize, void *image, void *stream);
 int oryon_conv24_f16x3(const float *x, int n, int cin, const void *image, const float *bias, int cout, int ksize, int relu, float *y, void *stream);
 
+/* a4  the class-aggregation layer of the fusion module's aggregator (models/fusion.py:300-332 around the LinearAttention of :240-266) for the
+ *     reference's single prompt axis (T = 1) on 24 x 24 maps with 128 channels, 4 heads, 6 x 6 pooling, 128-wide text guidance: AvgPool ->
+ *     LayerNorm -> q | k from [tokens | text guidance], v -> elu + 1 linear attention -> residual -> LayerNorm -> MLP 128 -> 512 -> 128 (ReLU)
+ *     -> residual -> bilinear upsampling (align_corners) -> residual on the map, one kernel, fp32 arithmetic.
+ *     x [B, 24, 24, 128] fp32 NHWC, text_guidance [B, 128] fp32 -> out [B, 24, 24, 128] fp32 NHWC.  Weights: device pointers, torch layouts
+ *     (norm1 / norm2: [128]; attention.q / .k: [128, 256] + [128]; attention.v: [128, 128] + [128]; MLP.0: [512, 128] + [512]; MLP.2: [128, 512] + [128]). */
+typedef struct {
+    const float *ln1_w, *ln1_b, *wq, *bq, *wk, *bk, *wv, *bv, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+} oryon_fusion_class_weights_t;
+int oryon_fusion_class_layer_f32(const float *x, const float *text_guidance, const oryon_fusion_class_weights_t *weights, int B, float *out,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

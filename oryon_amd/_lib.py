@@ -32,6 +32,11 @@ class DecoderWeights(ctypes.Structure):
                 ("head_w", c_void_p), ("head_b", c_void_p)]
 
 
+class FusionClassWeights(ctypes.Structure):
+    """oryon_fusion_class_weights_t (include/oryon_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "wq", "bq", "wk", "bk", "wv", "bv", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
 class PointDSCConfig(ctypes.Structure):
     _fields_ = [("in_dim", c_int), ("num_layers", c_int), ("num_channels", c_int), ("num_iterations", c_int),
                 ("ratio", c_float), ("inlier_threshold", c_float), ("sigma_d", c_float), ("k", c_int),
@@ -110,6 +115,7 @@ _PROTOS = {
     "oryon_engine_host_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "oryon_engine_x3_steps": (c_int, [c_void_p, POINTER(c_int64)]),
     "oryon_fusion_window_attention_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "oryon_fusion_class_layer_f32": (c_int, [_P, _P, POINTER(FusionClassWeights), c_int, _P, _P]),
     "oryon_conv24_image_bytes": (c_int64, [c_int, c_int, c_int]),
     "oryon_conv24_pack_f16x3": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "oryon_conv24_f16x3": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),

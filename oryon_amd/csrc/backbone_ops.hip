@@ -764,3 +764,191 @@ extern "C" int oryon_swin_window_attention_f32(const float *qkv, const float *pa
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// a4  the class-aggregation layer of ImageTextFusion's aggregator (models/fusion.py:300-332 ClassTransformerLayer around :240-266
+//     LinearAttention) for the reference's single prompt axis (T = 1) on 24 x 24 maps: AvgPool 6x6 -> LayerNorm -> q | k from
+//     [tokens | text guidance], v -> elu + 1 linear attention over the T axis -> residual -> LayerNorm -> MLP (128 -> 512 -> 128, ReLU) ->
+//     residual -> bilinear upsampling (align_corners) back to 24 x 24 -> residual on the map.  torch runs ~40 launch-bound passes over
+//     [B * 16, 1, 128] tensors (0.42 ms per layer at 128 images); here one workgroup per image does all of it in fp32 on the VALU (the
+//     layer is 0.2 MFLOP per token: nothing for the matrix pipe), weights streamed from L2, activations in LDS.  NHWC in, NHWC out.
+struct FusClassW {
+    const float *ln1_w, *ln1_b, *wq, *bq, *wk, *bk, *wv, *bv, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+};
+
+__global__ __launch_bounds__(256) void fusion_class_layer_kernel(const float *__restrict__ x, const float *__restrict__ tg, const FusClassW w,
+                                                                 float *__restrict__ out)
+{
+    constexpr int S = 24, C = 128, NT = 16, PC = 6, HID = 512;
+    extern __shared__ __attribute__((aligned(16))) float cl[];
+    float *ys = cl;                       // [16][128]  pooled tokens, later the layer's token output
+    float *xs = ys + NT * C;              // [16][256]  LayerNorm output | text guidance
+    float *qs = xs + NT * 2 * C;          // [16][128]
+    float *ks = qs + NT * C;              // [16][128]
+    float *vs = ks + NT * C;              // [16][128]
+    float *hs = vs + NT * C;              // [16][512]
+    float *fs = hs + NT * HID;            // [16][4]
+    const int t = threadIdx.x, j = t & 127, half = t >> 7, b = blockIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    const float *xb = x + (size_t)b * S * S * C;
+    // P0: 6 x 6 average pooling (nn.AvgPool2d: sum / 36)
+#pragma unroll 1
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const int cell = half * 8 + c8, cy = cell >> 2, cx = cell & 3;
+        float s = 0.0f;
+#pragma unroll
+        for (int py = 0; py < PC; ++py)
+#pragma unroll
+            for (int px = 0; px < PC; ++px) s += xb[((cy * PC + py) * S + cx * PC + px) * C + j];
+        ys[cell * C + j] = s / 36.0f;
+    }
+    __syncthreads();
+    auto layer_norm = [&](const float *src, const float *lw, const float *lb) {     // 4 tokens per wave, 2 channels per lane -> xs[tok][0..127]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tok = wave * 4 + i;
+            const float a0 = src[tok * C + lane], a1 = src[tok * C + lane + 64];
+            float s = a0 + a1;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            const float mean = s * (1.0f / C);
+            const float d0 = a0 - mean, d1 = a1 - mean;
+            float q = d0 * d0 + d1 * d1;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+            const float rstd = 1.0f / sqrt_rn(q * (1.0f / C) + 1e-5f);
+            xs[tok * 2 * C + lane] = d0 * rstd * lw[lane] + lb[lane];
+            xs[tok * 2 * C + lane + 64] = d1 * rstd * lw[lane + 64] + lb[lane + 64];
+        }
+    };
+    layer_norm(ys, w.ln1_w, w.ln1_b);
+    if (t < C) {
+        const float g = tg[(size_t)b * C + t];
+#pragma unroll
+        for (int tok = 0; tok < NT; ++tok) xs[tok * 2 * C + C + t] = g;
+    }
+    __syncthreads();
+    // P2: q, k (256 inputs), v (128 inputs) for output channel j and the thread's 8 tokens
+    {
+        float aq[8], ak[8], av[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { aq[i] = 0.0f; ak[i] = 0.0f; av[i] = 0.0f; }
+        const float4 *rq = reinterpret_cast<const float4 *>(w.wq + (size_t)j * 2 * C), *rk = reinterpret_cast<const float4 *>(w.wk + (size_t)j * 2 * C);
+        const float4 *rv = reinterpret_cast<const float4 *>(w.wv + (size_t)j * C);
+#pragma unroll 2
+        for (int k4 = 0; k4 < 2 * C / 4; ++k4) {
+            const float4 a = rq[k4], c = rk[k4];
+            const float4 d = k4 < C / 4 ? rv[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 xv = *reinterpret_cast<const float4 *>(xs + (half * 8 + i) * 2 * C + k4 * 4);
+                aq[i] = fmaf(a.w, xv.w, fmaf(a.z, xv.z, fmaf(a.y, xv.y, fmaf(a.x, xv.x, aq[i]))));
+                ak[i] = fmaf(c.w, xv.w, fmaf(c.z, xv.z, fmaf(c.y, xv.y, fmaf(c.x, xv.x, ak[i]))));
+                av[i] = fmaf(d.w, xv.w, fmaf(d.z, xv.z, fmaf(d.y, xv.y, fmaf(d.x, xv.x, av[i]))));
+            }
+        }
+        const float bq = w.bq[j], bk = w.bk[j], bv = w.bv[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tok = half * 8 + i;
+            const float q = aq[i] + bq, k = ak[i] + bk;
+            qs[tok * C + j] = q > 0.0f ? q + 1.0f : expf(q);                  // elu(x) + 1
+            ks[tok * C + j] = k > 0.0f ? k + 1.0f : expf(k);
+            vs[tok * C + j] = av[i] + bv;                                      // / T with T = 1
+        }
+    }
+    __syncthreads();
+    // P3: T = 1: out = q (k v^T) / (q . k + eps) = v * (q . k) / (q . k + eps) per head (4 heads of 32)
+    if (t < NT * 4) {
+        const int tok = t >> 2, h = t & 3;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s = fmaf(qs[tok * C + h * 32 + d], ks[tok * C + h * 32 + d], s);
+        fs[t] = s * (1.0f / (s + 1e-6f));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int tok = half * 8 + i;
+        ys[tok * C + j] += vs[tok * C + j] * fs[tok * 4 + (j >> 5)];
+    }
+    __syncthreads();
+    layer_norm(ys, w.ln2_w, w.ln2_b);
+    __syncthreads();
+    // P5: hidden = relu(W1 n + b1): outputs j, j + 128, j + 256, j + 384
+    {
+        float ah[4][8];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ah[o][i] = 0.0f;
+#pragma unroll 1
+        for (int k4 = 0; k4 < C / 4; ++k4) {
+            float4 wv4[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) wv4[o] = reinterpret_cast<const float4 *>(w.w1 + (size_t)(j + o * C) * C)[k4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 xv = *reinterpret_cast<const float4 *>(xs + (half * 8 + i) * 2 * C + k4 * 4);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) ah[o][i] = fmaf(wv4[o].w, xv.w, fmaf(wv4[o].z, xv.z, fmaf(wv4[o].y, xv.y, fmaf(wv4[o].x, xv.x, ah[o][i]))));
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float bb = w.b1[j + o * C];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hs[(half * 8 + i) * HID + j + o * C] = fmaxf(ah[o][i] + bb, 0.0f);
+        }
+    }
+    __syncthreads();
+    {
+        float ao[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ao[i] = 0.0f;
+        const float4 *r2 = reinterpret_cast<const float4 *>(w.w2 + (size_t)j * HID);
+#pragma unroll 2
+        for (int k4 = 0; k4 < HID / 4; ++k4) {
+            const float4 a = r2[k4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 hv = *reinterpret_cast<const float4 *>(hs + (half * 8 + i) * HID + k4 * 4);
+                ao[i] = fmaf(a.w, hv.w, fmaf(a.z, hv.z, fmaf(a.y, hv.y, fmaf(a.x, hv.x, ao[i]))));
+            }
+        }
+        const float bb = w.b2[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ys[(half * 8 + i) * C + j] += ao[i] + bb;
+    }
+    __syncthreads();
+    // P7: bilinear upsampling 4 x 4 -> 24 x 24 with align_corners = True (torch: src = dst * (in - 1) / (out - 1)) + the residual on the map
+    float *ob = out + (size_t)b * S * S * C;
+    const float sc = 3.0f / 23.0f;
+#pragma unroll 1
+    for (int p = half * (S * S / 2); p < (half + 1) * (S * S / 2); ++p) {
+        const int py = p / S, px = p % S;
+        const float fy = sc * (float)py, fx = sc * (float)px;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < 3 ? 1 : 0), x1 = x0 + (x0 < 3 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        const float v = hy * (hx * ys[(y0 * 4 + x0) * C + j] + lx * ys[(y0 * 4 + x1) * C + j]) +
+                        ly * (hx * ys[(y1 * 4 + x0) * C + j] + lx * ys[(y1 * 4 + x1) * C + j]);
+        ob[(size_t)p * C + j] = xb[(size_t)p * C + j] + v;
+    }
+}
+
+extern "C" int oryon_fusion_class_layer_f32(const float *x, const float *text_guidance, const oryon_fusion_class_weights_t *wts, int B, float *out,
+                                            void *stream)
+{
+    ORYON_CHECK_ARG(x && text_guidance && wts && out && B >= 0);
+    ORYON_CHECK_ARG(wts->ln1_w && wts->ln1_b && wts->wq && wts->bq && wts->wk && wts->bk && wts->wv && wts->bv && wts->ln2_w && wts->ln2_b && wts->w1 &&
+                    wts->b1 && wts->w2 && wts->b2);
+    ORYON_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)wts->wq | (uintptr_t)wts->wk | (uintptr_t)wts->wv | (uintptr_t)wts->w1 | (uintptr_t)wts->w2) & 15) == 0);
+    if (B == 0) return ORYON_OK;
+    FusClassW w{wts->ln1_w, wts->ln1_b, wts->wq, wts->bq, wts->wk, wts->bk, wts->wv, wts->bv, wts->ln2_w, wts->ln2_b, wts->w1, wts->b1, wts->w2, wts->b2};
+    constexpr int dyn = (16 * 128 * 4 + 16 * 256 + 16 * 512 + 64) * 4;
+    allow_dynamic_lds(reinterpret_cast<const void *>(&fusion_class_layer_kernel), dyn);
+    hipLaunchKernelGGL(fusion_class_layer_kernel, dim3(B), dim3(256), dyn, as_stream(stream), x, text_guidance, w, out);
+    ORYON_CHECK_LAUNCH();
+    return ORYON_OK;
+}

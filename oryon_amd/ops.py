@@ -137,6 +137,26 @@ def swin_window_attention_f32(qkv: torch.Tensor, pad_qkv: torch.Tensor, bias_t: 
     return out
 
 
+@_on_tensor_device
+def fusion_class_layer(x_nhwc: torch.Tensor, text_guidance: torch.Tensor, params) -> torch.Tensor:
+    """The class-aggregation layer of ImageTextFusion for T = 1 (see oryon_fusion_class_layer_f32): x [B,24,24,128] fp32 NHWC, text_guidance
+    [B,128], params = the 14 fp32 parameter tensors (norm1 w/b, q w/b, k w/b, v w/b, norm2 w/b, MLP.0 w/b, MLP.2 w/b) -> [B,24,24,128]."""
+    dev = _lib.require_gpu(x_nhwc.device)
+    B = x_nhwc.shape[0]
+    assert x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[1:]) == (24, 24, 128) and tuple(text_guidance.shape) == (B, 128)
+    x, tg = x_nhwc.contiguous(), text_guidance.to(torch.float32).contiguous()
+    out = torch.empty_like(x)
+    if B == 0:
+        return out
+    ps = [p.detach().to(torch.float32).contiguous() for p in params]
+    shapes = [(128,), (128,), (128, 256), (128,), (128, 256), (128,), (128, 128), (128,), (128,), (128,), (512, 128), (512,), (128, 512), (128,)]
+    assert [tuple(p.shape) for p in ps] == shapes, [tuple(p.shape) for p in ps]
+    w = _lib.FusionClassWeights(*[ptr(p) for p in ps])
+    import ctypes
+    check(lib().oryon_fusion_class_layer_f32(ptr(x), ptr(tg), ctypes.byref(w), B, ptr(out), stream_ptr(dev)), "oryon_fusion_class_layer_f32")
+    return out
+
+
 _conv24_images: dict = {}
 
 

@@ -191,3 +191,29 @@ def test_new_entries_handle_empty_and_single_batches():
     with torch.no_grad():
         lg0, fm0 = dec(x.view(1, 128, 1, 24, 24), [None, g2, g3])
     assert float((fm - fm0).abs().max() / fm0.abs().max()) < 2e-5 and float((lg - lg0[:, 0]).abs().max() / lg0.abs().max()) < 2e-5
+
+
+def test_fusion_class_layer_matches_torch():
+    """oryon_fusion_class_layer_f32 (AvgPool -> LayerNorm -> guided linear attention over T = 1 -> MLP -> bilinear upsampling -> residuals,
+    models/fusion.py:300-332) against the torch module: <= 1e-5 of the output's maximum."""
+    from oracle import oryon_oracle as orc
+    from oryon_amd.backbone import fusion as F_
+    torch.manual_seed(11)
+    layer = F_._ClassLayer(128, 128, 4, (6, 6)).eval()
+    layer.load_state_dict(orc.analytic_state_dict(layer.state_dict(), seed=5), strict=True)
+    layer = layer.to("cuda")
+    B = 5
+    x = torch.randn(B, 24, 24, 128, device="cuda").permute(0, 3, 1, 2).unsqueeze(2)          # [B,128,1,24,24] on NHWC storage
+    g = torch.randn(B, 1, 128, device="cuda")
+    with torch.no_grad():
+        ref = layer(x, g)
+        F_.FP16X3_LINEAR = True
+        try:
+            got = layer(x, g)
+        finally:
+            F_.FP16X3_LINEAR = False
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+    # the update itself (output minus the residual map) to the same bar relative to ITS size
+    du, dr = got - x, ref - x
+    assert float((du - dr).abs().max() / dr.abs().max()) < 1e-4
