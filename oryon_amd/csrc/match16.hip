@@ -1979,7 +1979,7 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     if (fmt == 1) {
         const uint8_t *a6 = reinterpret_cast<const uint8_t *>(a_i8), *q6 = reinterpret_cast<const uint8_t *>(q_i8);
         profile_begin(st, screen_mx6_name(C));
-        launch_screen_mx6(C, groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2);
+        launch_screen_mx6(C, groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2, C_true);
         profile_end(st);
     } else {
     profile_begin(st, C == 256 ? screen8_name<256>() : screen8_name<512>());

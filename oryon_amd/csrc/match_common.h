@@ -34,6 +34,6 @@ void match_x3_scatter_ovf(int B, int cap_s, const int32_t *n_ovf, const int32_t 
 const char *screen_mx6_name(int C);
 // screen_mx6.hip: K1s6 launch (C = 256 / 512); groups / T as sized for 256-anchor panels by the caller
 void launch_screen_mx6(int C, int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q,
-                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2);
+                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int C_true);
 
 }  // namespace oryon

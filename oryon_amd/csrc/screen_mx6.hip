@@ -231,7 +231,9 @@ __device__ __forceinline__ void mx6_static_for(F &&f)
 }
 
 // C_pad = 512: WAVES = 4, one wave per SIMD (192 code + 8 exponent registers of stationary operands), 2 x 64 KB of dynamic LDS
-template <int CP, int WAVES>
+// KL = live k-steps of 64 channels (round 4: narrow maps - the reference's own C = 32 - are zero-padded to the 256-channel rows; their dead
+// k-steps hold zero codes and contribute exactly 0, so they are simply not multiplied: same results, a quarter of the MFMAs at C <= 64)
+template <int CP, int WAVES, int KL = CP / 64>
 __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_screen_w4_kernel(
     const uint8_t *__restrict__ a6, const uint8_t *__restrict__ q6, int B, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
     const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2,
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
 #pragma unroll
         for (int w = 0; w < NKS / 4; ++w) sc[w] = 0;
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
+        for (int s = 0; s < KL; ++s) {
             const i32x4 lo = *reinterpret_cast<const i32x4 *>(arow + 64 * s), up = *reinterpret_cast<const i32x4 *>(arow + 64 * s + 16);
             breg[ab][s] = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, -1, -1);   // the fp6 format reads six dwords
             sc[s >> 2] |= ((unsigned)up[2] & 0xffu) << (8 * (s & 3));
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
 
     i32x8 areg[NKS];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, 0u);
+    for (int s = 0; s < KL; ++s) areg[s] = rd(s, 0, 0u);
     f32x16s acc[NAB];
 #pragma unroll
     for (int ab = 0; ab < NAB; ++ab)
@@ -372,14 +374,14 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
             reduce_block(acc[2], sid23, 2);
             reduce_block(acc[3], sid23, 3);
             // (the reductions read acc[2..3] before the second half overwrites them: program order)
-            mx6_static_for<0, NKS>([&](auto SC) { mfma(acc[0], 0, SC); mfma(acc[1], 1, SC); });
+            mx6_static_for<0, KL>([&](auto SC) { mfma(acc[0], 0, SC); mfma(acc[1], 1, SC); });
 #pragma unroll
-            for (int i = 0; i < 2 * NKS; ++i) {
+            for (int i = 0; i < 2 * KL; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 16 / NKS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16 / KL, 0);
             }
             // second half: this block for 2 / 3 while the VALU reduces what 0 / 1 just finished; next A operand behind its last use
-            mx6_static_for<0, NKS>([&](auto SC) {
+            mx6_static_for<0, KL>([&](auto SC) {
                 constexpr int s_ = decltype(SC)::value;
                 mfma(acc[2], 2, SC); mfma(acc[3], 3, SC);
                 if (qb + 1 < NQB) areg[s_] = rd(s_, qb + 1, tile);
@@ -387,9 +389,9 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
             reduce_block(acc[0], sid, 0);
             reduce_block(acc[1], sid, 1);
 #pragma unroll
-            for (int i = 0; i < 2 * NKS; ++i) {
+            for (int i = 0; i < 2 * KL; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 16 / NKS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16 / KL, 0);
                 if (qb + 1 < NQB && (i & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
             sid01 = sid;
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
         __syncthreads();
         buf ^= 1;
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
+        for (int s = 0; s < KL; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
     }
     (void)sid01;
     reduce_block(acc[2], sid23, 2);
@@ -469,7 +471,7 @@ static int mx6_var()
 namespace {
 template <int CP>
 void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q, const int32_t *n_a,
-                       const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
+                       const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int kl = 0)
 {
     // C_pad 256: 512-anchor panels (8 waves; `groups` was sized for 256-anchor panels, T of them per unit).  C_pad 512: the stationary
     // operand is 128 registers, so 4 waves per workgroup and one workgroup per CU (512 registers per wave), as the int8 kernel
@@ -491,6 +493,13 @@ void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, c
             const int g8 = groups / T * T8;
             if (dbg && !dbg_wg) (void)hipMalloc(&dbg_wg, (size_t)65536 * 4 * sizeof(long long));
             if (dbg && dbg_wg && g8 <= 65536) (void)hipMemsetAsync(dbg_wg, 0, (size_t)g8 * 4 * sizeof(long long), st);
+            if (kl == 1)
+                hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 8, 1>), dim3(g8), dim3(512), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, T8, S,
+                                   ws_max, ws_i1, ws_m2, (dbg && g8 <= 65536) ? dbg_wg : nullptr);
+            else if (kl == 2)
+                hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 8, 2>), dim3(g8), dim3(512), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, T8, S,
+                                   ws_max, ws_i1, ws_m2, (dbg && g8 <= 65536) ? dbg_wg : nullptr);
+            else
             hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 8>), dim3(g8), dim3(512), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, T8, S,
                                ws_max, ws_i1, ws_m2, (dbg && g8 <= 65536) ? dbg_wg : nullptr);
             if (dbg && dbg_wg && g8 <= 65536) mx6_debug_report(dbg_wg, g8, st);
@@ -524,9 +533,11 @@ const char *screen_mx6_name(int C)
 }
 
 void launch_screen_mx6(int C, int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q,
-                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
+                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int C_true)
 {
-    if (C == 256) launch_screen_mx6_t<256>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, ws_max, ws_i1, ws_m2);
+    // live k-steps of narrow maps (1 for C <= 64, 2 for C <= 128; otherwise all four): see match_mx6_screen_w4_kernel
+    const int kl = (C == 256 && C_true > 0 && C_true <= 64) ? 1 : (C == 256 && C_true > 0 && C_true <= 128) ? 2 : 0;
+    if (C == 256) launch_screen_mx6_t<256>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, ws_max, ws_i1, ws_m2, kl);
     else launch_screen_mx6_t<512>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, ws_max, ws_i1, ws_m2);
 }
 

@@ -139,6 +139,19 @@ def test_default_route_cfg4_size_2_pairs_vs_oracle():
         _check_pair(b, p, got, P)
 
 
+@pytest.mark.parametrize("C", [32, 96])
+def test_default_route_narrow_descriptors_vs_oracle(C):
+    """The reference's own descriptor width (C = 32 @ 192 x 192, configs/config.yaml:34-35) and a width with two live 64-channel k-steps:
+    K0 zero-pads the rows to 256 channels, the MX-fp6 screen multiplies only the live k-steps (match_mx6_screen_w4_kernel<256, 8, KL>),
+    K1x3 touches only the live chunks - and everything still equals the oracle's exact fp32 scan."""
+    from oryon_amd.synth import make_pair
+    pairs = [make_pair(90 + C + i, 192, 192, C, device="cuda") for i in range(3)]
+    got, P = _run_default_engine(pairs, first_key=90 + C)
+    assert got["dominant"].startswith("match_mx6_screen"), got["dominant"]
+    for b, p in enumerate(pairs):
+        _check_pair(b, p, got, P)
+
+
 def test_default_route_smooth_fields_take_the_second_level_vs_oracle():
     """Smooth rank-8 descriptor fields (+ 2 % noise): the MX-fp6 bound settles validity but cannot separate an anchor's near-ties, so the
     argmin of the sampled anchors comes from K1x3 (fp16x3 two-sweep scan + fp64-refined filter + canonical fp32 chain) - and must still be
