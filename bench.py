@@ -697,7 +697,8 @@ def main():
         for stage, bdt, label in (("decode", "fp16x3", "decode+match+pose"),
                                   ("decode", "fp32", "decode+match+pose, torch / MIOpen fp32 modules"),
                                   ("full", "fp32", "full (feat+match+pose), fp32 torch linears"),
-                                  ("full", "fp16x3", "full (feat+match+pose), fp16x3 linears")):
+                                  ("full", "fp16x3", "full (feat+match+pose), fp16x3 linears"),
+                                  ("full", "bf16w", "full (feat+match+pose), bf16 backbone (weights + activations) - NOT fp32-grade: for the record only")):
             r = run_stage_set(a, rank, world, dev, stage, steps=3, warmup=1, backbone_dtype=bdt)
             if rank == 0:
                 stage_recs[label] = r
