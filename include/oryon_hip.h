@@ -8,7 +8,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller owns all buffers;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are asynchronous on
- *     it, never synchronise, never allocate (except oryon_pointdsc_create/_finalize);
+ *     it, never synchronise, never allocate (except the handle constructors: oryon_pointdsc_create/_finalize,
+ *     oryon_engine_create, oryon_decoder_create - the last one also waits for its packing launches once);
  *   - return value: ORYON_OK or a negative ORYON_ERR_*; nothing throws; oryon_last_error() gives text;
  *   - per-pair outcomes (no mask / no correspondences) are DATA, reported in `status` arrays with the
  *     reference's own failure semantics (pipeline.py:335-350), not error codes;
