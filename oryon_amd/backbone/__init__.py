@@ -14,5 +14,8 @@ def enable_fp16x3(flag: bool = True, guard: bool = False) -> None:
     ops.X3_GUARD = bool(flag and guard)
     clip.FP16X3_LINEAR = bool(flag)
     fusion.FP16X3_LINEAR = bool(flag)           # guided Swin blocks' linears + the CLIP 1x1 projection of ImageTextFusion
-    fusion.HIP_DECODER = bool(flag)             # StandardDecoder.forward through oryon_decoder_forward (csrc/decoder.hip)
+    # the fusion / decoder kernels that split activations to fp16 themselves (window attention, whole-map convolutions, class layers, the
+    # decoder) have no range check of their own: in guard mode they stay on the torch fp32 modules
+    fusion.FUSED_KERNELS = bool(flag and not guard)
+    fusion.HIP_DECODER = bool(flag and not guard)   # StandardDecoder.forward through oryon_decoder_forward (csrc/decoder.hip)
     swin.FUSED_F32_ATTENTION = bool(flag)

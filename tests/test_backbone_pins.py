@@ -357,6 +357,22 @@ def test_add_layernorm_f32_matches_fp64():
 
 
 @pytest.mark.gpu
+def test_fp16x3_guard_mode_keeps_the_unguarded_fused_kernels_off():
+    """enable_fp16x3(True, guard=True) is the validation mode for a first run with a real checkpoint: the linears check their operands
+    against the float16 range; the kernels that split activations themselves (fusion's attention / convolutions / class layers, the
+    decoder) have no such check and therefore stay on the torch fp32 modules in that mode."""
+    from oryon_amd.backbone import enable_fp16x3, fusion
+    try:
+        enable_fp16x3(True, guard=True)
+        assert fusion.FP16X3_LINEAR and not fusion.FUSED_KERNELS and not fusion.HIP_DECODER
+        enable_fp16x3(True)
+        assert fusion.FP16X3_LINEAR and fusion.FUSED_KERNELS and fusion.HIP_DECODER
+    finally:
+        enable_fp16x3(False)
+    assert not (fusion.FP16X3_LINEAR or fusion.FUSED_KERNELS or fusion.HIP_DECODER)
+
+
+@pytest.mark.gpu
 def test_fp16x3_guard_catches_operands_outside_the_float16_range():
     """enable_fp16x3(True, guard=True): an activation beyond float16's range would split into inf silently; the guard evaluates that
     layer with torch's fp32 linear instead (counted), in-range layers still take the kernel; an out-of-range weight is refused."""

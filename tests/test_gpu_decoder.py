@@ -207,11 +207,11 @@ def test_fusion_class_layer_matches_torch():
     g = torch.randn(B, 1, 128, device="cuda")
     with torch.no_grad():
         ref = layer(x, g)
-        F_.FP16X3_LINEAR = True
+        F_.FP16X3_LINEAR = F_.FUSED_KERNELS = True
         try:
             got = layer(x, g)
         finally:
-            F_.FP16X3_LINEAR = False
+            F_.FP16X3_LINEAR = F_.FUSED_KERNELS = False
     assert got.shape == ref.shape
     assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
     # the update itself (output minus the residual map) to the same bar relative to ITS size
