@@ -356,7 +356,6 @@ def test_add_layernorm_f32_matches_fp64():
             assert e < 5e-6 and e <= 2.0 * e32 + 1e-7, (rows, D, e, e32)
 
 
-@pytest.mark.gpu
 def test_fp16x3_guard_mode_keeps_the_unguarded_fused_kernels_off():
     """enable_fp16x3(True, guard=True) is the validation mode for a first run with a real checkpoint: the linears check their operands
     against the float16 range; the kernels that split activations themselves (fusion's attention / convolutions / class layers, the
