@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <set>
@@ -42,6 +43,16 @@ void profile_end(hipStream_t st);
             return ORYON_ERR_HIP;                                                       \
         }                                                                               \
     } while (0)
+
+// Development switches.  The SHIPPED library (make all) reads no environment variable: dev_env_* return their defaults.  The dev build
+// (make dev -> liboryon_hip_dev.so, -DORYON_DEV; what the A/B scripts under tools/ load) reads them.
+#ifdef ORYON_DEV
+static inline int dev_env_int(const char *name, int dflt) { const char *s = getenv(name); return s ? atoi(s) : dflt; }
+static inline bool dev_env_set(const char *name) { return getenv(name) != nullptr; }
+#else
+static inline int dev_env_int(const char *, int dflt) { return dflt; }
+static inline bool dev_env_set(const char *) { return false; }
+#endif
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -403,7 +403,7 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
     // development aid (tools/ablate_native.sh): ORYON_ENGINE_ABLATE bit 0 / 1 / 2 leaves out K0's gathers / the matcher / the registration
     // once every buffer set has been filled by a complete step - the following steps then time the REST of the pipeline on stale buffers
     // (identical inputs every step, as in bench.py).  Never set in production: results are those of an earlier step.
-    static const int ablate_env = getenv("ORYON_ENGINE_ABLATE") ? atoi(getenv("ORYON_ENGINE_ABLATE")) : 0;
+    static const int ablate_env = dev_env_int("ORYON_ENGINE_ABLATE", 0);
     const int ablate = e->n_submit >= (int64_t)(c.n_slots + c.gather_sets) ? ablate_env : 0;
     // ---- K0 on the gather stream
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[0], sg));

@@ -479,6 +479,189 @@ __global__ __launch_bounds__(256, (CP / LPR > 128 ? 1 : 2)) void gather_q8_v3_ga
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K0v4 (round 5): the MX-fp6 pass over channel-planar maps with the 256 channels of a 64-row tile SPLIT OVER THE FOUR WAVES of a
+// workgroup.  K0v3 keeps a row's 256 raw values in one lane: 512 registers, one wave per SIMD, ~800 v_accvgpr moves per tile, and a
+// wave's loads, its 255-step norm chain and its conversions run one after the other with nobody to hide them.  Here wave w owns
+// channels [64 w, 64 w + 64) = two 32-channel blocks of the tile's 64 rows (lane = row): 64 raw values per lane in the four
+// 16-float tuples the fp6 conversion consumes, < 128 registers, four workgroups (16 waves) per CU, so one workgroup's loads fly
+// under another's arithmetic.
+//   * canonical norm: the k-ordered fmaf chain is handed from wave to wave through LDS (wave w continues from wave w - 1's partial
+//     sum): the accumulation order is k = 0 ... 255 as before, so d - and with it every fp32 unit row - is bit for bit K0v3's;
+//   * block exponents, codes, the measured error: per block exactly the arithmetic of K0v3 (FMT = 1); the row's error sum is formed
+//     from the per-block (sum, exponent) pairs in block order by one wave, i.e. the same fmaf chain;
+//   * stores: the tile's 64 x 256-byte mx6 rows are assembled in a 16 KB LDS stage (the same XOR swizzle) and leave as ONE
+//     contiguous 16 KB run; the fp32 anchor rows (WANT32) go through wave-private stages as in K0v3.
+// Reference: utils/pcd.py:184-193 (the gather), :28-29 (the normalisation inside cosine_similarity).
+constexpr int G4_STAGE = 16384;                 // 64 rows x 256 B
+constexpr int G4_HAND = 4 * 64 * 4;             // chain hand-off [wave][row]
+constexpr int G4_TERMS = 2 * 8 * 64 * 4;        // (block error sum, block exponent) [block][row]
+constexpr int G4_LDS = G4_STAGE + G4_HAND + G4_TERMS;
+constexpr int G4_STAGE32 = 4096;              // per wave, WANT32 only: 64 rows x 64 B
+
+template <bool WANT32>
+__global__ __launch_bounds__(256, 4) void gather_mx6_v4_kernel(
+    const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride, const int32_t *__restrict__ count,
+    int rows_cap, int n_maps, int chunk_tiles, int chunks_per_map, uint8_t *__restrict__ out8, unsigned *__restrict__ eps_max,
+    float *__restrict__ norm, float *__restrict__ out32, int round_f16)
+{
+    extern __shared__ __attribute__((aligned(256))) char lds4[];
+    char *stage = lds4;
+    float *hand = reinterpret_cast<float *>(lds4 + G4_STAGE);
+    float *term_be = reinterpret_cast<float *>(lds4 + G4_STAGE + G4_HAND);
+    int *term_e = reinterpret_cast<int *>(lds4 + G4_STAGE + G4_HAND + G4_TERMS / 2);
+
+    const int bid = (int)blockIdx.x;
+    const int xcd = bid & 7, pos = bid >> 3;
+    const int unit = (pos / chunk_tiles) * 8 + xcd;
+    if (unit >= n_maps * chunks_per_map) return;
+    const int m = unit / chunks_per_map;
+    const int tile = (unit % chunks_per_map) * chunk_tiles + pos % chunk_tiles;
+    const int n = count[m];
+    const int n_fill = (n + 255) / 256 * 256;                 // rows [n, n_fill) are written as zero rows
+    const int row0 = tile * 64;
+    if (row0 >= n_fill || row0 >= rows_cap) return;           // workgroup-uniform: no barrier is skipped by part of a workgroup
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int my_row = row0 + lane;
+    const bool live = my_row < n;
+    const int pix = live ? roi[(size_t)m * roi_stride + my_row] : 0;
+    const bool tile_full = (row0 + 64 <= n) && (C == 256);    // workgroup-uniform
+
+    RowRegs<64, 1> R;                                         // local channel i = global channel 64 wave + i
+    const char *fb = reinterpret_cast<const char *>(feat + (size_t)m * C * HW);
+    if (tile_full) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(fb), 0, (int)((unsigned)C * (unsigned)HW * 4u), 0x00020000);
+        const int s0 = wave * 64 * HW * 4;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) R.set(i, __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pix * 4, s0 + i * HW * 4, 0)));
+    } else {
+        int hw_b = HW, c_b = C;
+        asm volatile("" : "+s"(hw_b), "+s"(c_b));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int kb = wave * 64 + 32 * b;
+            if (kb < c_b) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    int k = kb + i;
+                    k = k < c_b ? k : c_b - 1;
+                    R.set(32 * b + i, *reinterpret_cast<const float *>(fb + (size_t)k * hw_b * 4 + (unsigned)pix * 4u));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) R.set(32 * b + i, 0.0f);
+            }
+        }
+        int c_c = C;
+        asm volatile("" : "+s"(c_c));
+#pragma unroll
+        for (int i = 0; i < 64; ++i) R.set(i, (live && (wave * 64 + i < c_c)) ? R.get(i) : 0.0f);
+    }
+    if (round_f16) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) R.set(i, __half2float(__float2half_rn(R.get(i))));
+    }
+
+    // canonical norm: the chain passes through the four waves in channel order
+    float acc = 0.0f;
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            if (w > 0) acc = hand[(w - 1) * 64 + lane];
+            acc = chain_sq<64>(R, acc);
+            hand[w * 64 + lane] = acc;
+        }
+        __syncthreads();
+    }
+    float d = sqrt_rn(hand[3 * 64 + lane]);
+    d = d < 1e-8f ? 1e-8f : d;
+    if (wave == 3 && norm) norm[(size_t)m * rows_cap + my_row] = d;
+
+    if constexpr (WANT32) {
+        // canonical unit rows, k-permuted inside groups of 8 (position 8g + 4h + j holds k = 8g + 2j + h): this wave's 64 channels in four
+        // passes of 16 through a wave-private 4 KB stage (64 rows x 64 B), out as 16 rows x 64 bytes per store instruction.  (A 16 KB
+        // stage per wave - K0v3's - would leave room for two workgroups per CU only.)
+        char *st32 = lds4 + G4_LDS + wave * G4_STAGE32;
+        float *o32 = out32 + ((size_t)m * rows_cap + row0) * 256 + 64 * wave;
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+            WAVE_LDS_ORDER();
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int g = 2 * p4 + (sl >> 1), hh = sl & 1;
+                float4 q;
+                q.x = __fdiv_rn(R.get(8 * g + 0 + hh), d);
+                q.y = __fdiv_rn(R.get(8 * g + 2 + hh), d);
+                q.z = __fdiv_rn(R.get(8 * g + 4 + hh), d);
+                q.w = __fdiv_rn(R.get(8 * g + 6 + hh), d);
+                *reinterpret_cast<float4 *>(st32 + lane * 64 + ((sl ^ ((lane >> 1) & 3)) << 4)) = q;
+            }
+            WAVE_LDS_ORDER();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = j * 16 + (lane >> 2), sl = lane & 3;
+                const float4 q = *reinterpret_cast<const float4 *>(st32 + t * 64 + ((sl ^ ((t >> 1) & 3)) << 4));
+                *reinterpret_cast<float4 *>(o32 + (size_t)t * 256 + 16 * p4 + sl * 4) = q;
+            }
+        }
+    }
+
+    // MX-fp6 slots of this wave's two blocks (arithmetic of K0v3, FMT = 1)
+    const float rd = __fdiv_rn(1.0f, d);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int gb = 2 * wave + b;
+        float bm = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) bm = fmaxf(bm, fabsf(R.get(32 * b + i)));
+        const float r = __fdiv_rn(bm, d) * (1.0f / 7.5f);
+        int e = r > 0.0f ? ilogbf(r) + 1 : -40;
+        if (r > 0.0f && ldexpf(1.0f, e - 1) >= r) e -= 1;
+        e = e < -40 ? -40 : (e > 8 ? 8 : e);
+        const float rde = rd * ldexpf(1.0f, -e);
+        R.t[2 * b] *= rde;
+        R.t[2 * b + 1] *= rde;
+        const f32x16g ev = R.t[2 * b], od = R.t[2 * b + 1];
+        const u32x6g c = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 1.0f);
+        const f32x32g back = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(c, 1.0f);
+        float be = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d0 = ev[i] - back[2 * i], d1 = od[i] - back[2 * i + 1];
+            be = __fmaf_rn(d0, d0, be);
+            be = __fmaf_rn(d1, d1, be);
+        }
+        term_be[gb * 64 + lane] = be;
+        term_e[gb * 64 + lane] = e;
+        *reinterpret_cast<uint4 *>(stage + stage_addr(lane, 2 * gb, 256)) = make_uint4(c[0], c[1], c[2], c[3]);
+        *reinterpret_cast<uint4 *>(stage + stage_addr(lane, 2 * gb + 1, 256)) = make_uint4(c[4], c[5], (unsigned)(e + 127), 0u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    {
+        char *o8 = reinterpret_cast<char *>(out8) + ((size_t)m * rows_cap + row0) * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = j * 256 + (int)threadIdx.x;
+            const uint4 q = *reinterpret_cast<const uint4 *>(stage + stage_addr(f >> 4, f & 15, 256));
+            *reinterpret_cast<uint4 *>(o8 + (size_t)f * 16) = q;
+        }
+    }
+    if (wave == 0) {
+        // |e|_2 of the row: the per-block sums in block order, the very chain K0v3 runs in one lane
+        float err2 = 0.0f;
+#pragma unroll
+        for (int gb = 0; gb < 8; ++gb) err2 = __fmaf_rn(term_be[gb * 64 + lane], ldexpf(1.0f, 2 * term_e[gb * 64 + lane]), err2);
+        float er = live ? sqrt_rn(err2) * 1.00002f + 3e-7f : 0.0f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) er = fmaxf(er, __shfl_xor(er, off));
+        if (lane == 0 && er > 0.0f) atomicMax(&eps_max[m], __float_as_uint(er));
+    }
+}
+
 }  // namespace oryon
 
 using namespace oryon;
@@ -520,6 +703,27 @@ int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, c
                      float *out32, int lanes_per_row, int round_f16, hipStream_t st, int fmt, void *aux)
 {
     const int lpr = C_pad == 512 ? 2 : (lanes_per_row == 2 ? 2 : 1);
+    // K0v4 (round 5): the MX-fp6 pass over wide channel-planar maps; everything else (narrow maps, channels_last, C_pad 512, the
+    // device-gated fall-back passes) stays on K0v3
+    static const int v4 = dev_env_int("ORYON_K0V4", 1);
+    if (fmt == 1 && v4 && C_pad == 256 && C > 128 && layout == ORYON_LAYOUT_NCHW && !map_enable && lanes_per_row != 2) {
+        const int T = (rows_cap + 63) / 64;
+        const int chunks_per_map = n_maps >= 8 ? 1 : (8 + n_maps - 1) / n_maps;
+        const int chunk_tiles = (T + chunks_per_map - 1) / chunks_per_map;
+        const int units = n_maps * chunks_per_map;
+        const int groups = ((units + 7) / 8) * 8 * chunk_tiles;
+        if (out32) {
+            auto k4 = gather_mx6_v4_kernel<true>;
+            allow_dynamic_lds(reinterpret_cast<const void *>(k4), G4_LDS + 4 * G4_STAGE32);
+            hipLaunchKernelGGL(k4, dim3(groups), dim3(256), G4_LDS + 4 * G4_STAGE32, st, feat, C, HW, roi, roi_stride, count, rows_cap, n_maps,
+                               chunk_tiles, chunks_per_map, reinterpret_cast<uint8_t *>(out8), reinterpret_cast<unsigned *>(eps), norm, out32, round_f16);
+        } else {
+            auto k4 = gather_mx6_v4_kernel<false>;
+            hipLaunchKernelGGL(k4, dim3(groups), dim3(256), G4_LDS, st, feat, C, HW, roi, roi_stride, count, rows_cap, n_maps, chunk_tiles,
+                               chunks_per_map, reinterpret_cast<uint8_t *>(out8), reinterpret_cast<unsigned *>(eps), norm, out32, round_f16);
+        }
+        return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+    }
 #define G8(CPV, LPRV, FMTV)                                                                                                    \
     do {                                                                                                                       \
         if (layout == ORYON_LAYOUT_NHWC) launch_g8<CPV, LPRV, true, FMTV>(st, feat, n_maps, C, HW, roi, roi_stride, count, map_enable, rows_cap, out8, scale, eps, norm, out32, round_f16); \
@@ -558,7 +762,7 @@ extern "C" int oryon_gather_q8(const float *feat, int n_maps, int C, int HW, int
     if (n_maps == 0) return ORYON_OK;
     hipStream_t st = as_stream(stream);
     ORYON_CHECK_HIP(hipMemsetAsync(eps_max, 0, (size_t)n_maps * sizeof(float), st));
-    static const int lpr_env = getenv("ORYON_GATHER8_LPR") ? atoi(getenv("ORYON_GATHER8_LPR")) : 1;
+    static const int lpr_env = dev_env_int("ORYON_GATHER8_LPR", 1);
     const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad, out_i8, slice_scale,
                                     eps_max, row_norm, out_f32, lpr_env, round_f16, st, 0, nullptr);
     if (rc) { set_error("oryon_gather_q8: launch failed"); return rc; }
@@ -576,7 +780,7 @@ extern "C" int oryon_gather_mx6(const float *feat, int n_maps, int C, int HW, in
     if (n_maps == 0) return ORYON_OK;
     hipStream_t st = as_stream(stream);
     ORYON_CHECK_HIP(hipMemsetAsync(err_max, 0, (size_t)n_maps * sizeof(float), st));
-    static const int lpr_env = getenv("ORYON_GATHER8_LPR") ? atoi(getenv("ORYON_GATHER8_LPR")) : 1;
+    static const int lpr_env = dev_env_int("ORYON_GATHER8_LPR", 1);
     const int rc = gather_q8_launch(feat, n_maps, C, HW, layout, roi, roi_stride, count, nullptr, rows_cap, C_pad,
                                     reinterpret_cast<int8_t *>(out_mx6), nullptr, err_max, row_norm, out_f32, lpr_env, round_f16, st, 1, nullptr);
     if (rc) { set_error("oryon_gather_mx6: launch failed"); return rc; }

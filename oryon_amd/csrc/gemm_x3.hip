@@ -484,7 +484,7 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
     ORYON_CHECK_ARG(K % GX_BK == 0 && act >= 0 && act <= 2);
     ORYON_CHECK_ARG(N % GX_BN == 0 || (N % 128 == 0 && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)));   // half-wide last column tile: stream kernel only
     if (M == 0) return ORYON_OK;
-    static const int variant = getenv("ORYON_GEMM_X3_VARIANT") ? atoi(getenv("ORYON_GEMM_X3_VARIANT")) : 2;      // dev: 1 = small-tile kernel
+    static const int variant = dev_env_int("ORYON_GEMM_X3_VARIANT", 2);      // dev: 1 = small-tile kernel
     if ((variant != 1 || N % GX_BN != 0) && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)) {
         const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
         const int sup_n = (tiles_n + 7) / 8;

@@ -495,7 +495,7 @@ extern "C" int oryon_match_f32(const float *a_hat, const float *q_hat, int B, in
     else if (C == 64) LAUNCH_REGB(64);
     else if (C == 128) LAUNCH_REGB(128);
     else if (C == 256) {
-        static const int var = getenv("ORYON_MATCH_VARIANT") ? atoi(getenv("ORYON_MATCH_VARIANT")) : 0;
+        static const int var = dev_env_int("ORYON_MATCH_VARIANT", 0);
 #define LAUNCH_VAR(V) hipLaunchKernelGGL((match_f32_regb_kernel<256, V>), dim3(groups_regb), dim3(MATCH_THREADS), 0, st, a_hat, q_hat, B, cap_a, cap_q, n_a, n_q, threshold, T, S, min_dist, argmin, valid, ws_dist, ws_idx, nullptr, nullptr)
         switch (var) {
             case 1: LAUNCH_VAR(1); break; case 2: LAUNCH_VAR(2); break; case 3: LAUNCH_VAR(3); break; case 4: LAUNCH_VAR(4); break;

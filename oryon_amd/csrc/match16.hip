@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void match_scatter8_kernel(int cap_a, const in
 
 static int pick_split16(int B, int T)
 {
-    static const int target = getenv("ORYON_SCREEN_WGS") ? atoi(getenv("ORYON_SCREEN_WGS")) : 8192;     // timing experiments only
+    static const int target = dev_env_int("ORYON_SCREEN_WGS", 8192);     // timing experiments only
     int S = (target + B * T - 1) / (B * T);
     if (S < 1) S = 1;
     if (S > 16) S = 16;
@@ -1116,8 +1116,8 @@ extern "C" int oryon_match_screened(const float *a_hat, const float *q_hat, cons
 #define LAUNCH16_AMB(CPV)                                                                                                 \
     launch_screen<CPV, 1>(groups, st, w.a16c, q16, B, cap_a, cap_q, w.n_amb, n_q, T, S, valid_cut, w.amb_max, w.cnt, w.cand, 1,        \
                           w.amb_idx, nullptr, nullptr)
-    static const int var16 = getenv("ORYON_MATCH16_VARIANT") ? atoi(getenv("ORYON_MATCH16_VARIANT")) : 0;
-    static const bool two_pass = getenv("ORYON_SCREEN_TWOPASS") != nullptr;
+    static const int var16 = dev_env_int("ORYON_MATCH16_VARIANT", 0);
+    static const bool two_pass = dev_env_set("ORYON_SCREEN_TWOPASS");
     const float *m_final = nullptr;
     if (two_pass || var16) {
 #define LAUNCH16V(V) hipLaunchKernelGGL((match_f16_screen_kernel<256, 0, V>), dim3(groups), dim3(256), 0, st, a16, q16, B, cap_a, cap_q, n_a, n_q, T, S, valid_cut, w.ws_max, w.cnt, w.cand, S, nullptr, w.ws_i1, w.ws_m2)
@@ -1203,9 +1203,9 @@ Screen8Ws carve_screen8(void *base, int B, int C, int cap_a, int cap_q, int S)
 template <int CP>
 const char *screen8_name()
 {
-    const int variant = getenv("ORYON_SCREEN8_VARIANT") ? atoi(getenv("ORYON_SCREEN8_VARIANT")) : 2;
-    const int ablate = getenv("ORYON_SCREEN8_ABLATE") ? atoi(getenv("ORYON_SCREEN8_ABLATE")) : 0;
-    const int waves = getenv("ORYON_SCREEN8_WAVES") ? atoi(getenv("ORYON_SCREEN8_WAVES")) : 8;
+    const int variant = dev_env_int("ORYON_SCREEN8_VARIANT", 2);
+    const int ablate = dev_env_int("ORYON_SCREEN8_ABLATE", 0);
+    const int waves = dev_env_int("ORYON_SCREEN8_WAVES", 8);
     if (variant == 1) return CP == 256 ? "match_i8_screen_kernel<256>" : "match_i8_screen_kernel<512>";
     if (ablate && CP == 256) return "match_i8_screen_v2_kernel<256, ABLATED> (timing ablation: results are wrong)";
     if (waves == 8 && CP == 256) return "match_i8_screen_v2_kernel<256, 0, 8>";
@@ -1217,21 +1217,21 @@ void launch_screen8(int groups, hipStream_t st, const int8_t *a8, const int8_t *
                     const int32_t *n_a, const int32_t *n_q, int T, int S, float *ws_max, int32_t *ws_i1, float *ws_m2)
 {
     constexpr size_t dyn = 2 * screen8_tile_bytes(CP) > 65536 ? 2 * screen8_tile_bytes(CP) : 0;
-    static const int variant = getenv("ORYON_SCREEN8_VARIANT") ? atoi(getenv("ORYON_SCREEN8_VARIANT")) : 2;
+    static const int variant = dev_env_int("ORYON_SCREEN8_VARIANT", 2);
     if (variant == 1) {                 // round-1 loop (kept for A/B timing)
         if (dyn) allow_dynamic_lds(reinterpret_cast<const void *>(&match_i8_screen_kernel<CP>), (int)dyn);
         hipLaunchKernelGGL((match_i8_screen_kernel<CP>), dim3(groups), dim3(256), dyn, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S,
                            ws_max, ws_i1, ws_m2);
         return;
     }
-    static const int ablate = getenv("ORYON_SCREEN8_ABLATE") ? atoi(getenv("ORYON_SCREEN8_ABLATE")) : 0;
+    static const int ablate = dev_env_int("ORYON_SCREEN8_ABLATE", 0);
     if (ablate && CP == 256) {
 #define ABL(V) case V: hipLaunchKernelGGL((match_i8_screen_v2_kernel<256, V>), dim3(groups), dim3(256), 0, st, a8, q8, q_scale, B, cap_a, cap_q, n_a, n_q, T, S, ws_max, ws_i1, ws_m2); break
         switch (ablate) { ABL(1); ABL(2); ABL(3); default: ABL(8); }
 #undef ABL
         return;
     }
-    static const int waves = getenv("ORYON_SCREEN8_WAVES") ? atoi(getenv("ORYON_SCREEN8_WAVES")) : 8;
+    static const int waves = dev_env_int("ORYON_SCREEN8_WAVES", 8);
     if (waves == 8 && CP == 256) {
         const int T8 = (cap_a + 511) / 512;
         hipLaunchKernelGGL((match_i8_screen_v2_kernel<256, 0, 8>), dim3(groups / T * T8), dim3(512), 0, st, a8, q8, q_scale, B, cap_a, cap_q, n_a,
@@ -1386,7 +1386,7 @@ extern "C" int oryon_match_screened8_raw(const float *a_hat, const int8_t *a_i8,
                        w.ws_max, w.ws_i1, w.ws_m2, w.m_final, w.cnt, w.cand, w.n_amb, w.amb_idx, a_scale, nullptr, q_eps_max, cut0,
                        sqrtf((float)C_true), (float)C_true, a_i8, q_i8, q_scale);
     ORYON_CHECK_LAUNCH();
-    static const int resc_l = getenv("ORYON_RESCORE_LANES") ? atoi(getenv("ORYON_RESCORE_LANES")) : 2;
+    static const int resc_l = dev_env_int("ORYON_RESCORE_LANES", 2);
 #define RESCORE_RAW(LV, NHWCV)                                                                                                 \
     hipLaunchKernelGGL((match_rescore_raw_kernel<LV, NHWCV>), dim3(cap_a / (256 / LV), B), dim3(256), 0, st, a_hat, feat_q, C_true, HW, \
                        roi_q, roi_stride, q_norm, C, cap_a, cap_q, n_a, n_q, threshold, w.m_final, w.cnt, w.cand, min_dist, argmin,  \
@@ -1974,7 +1974,7 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     // second level for the sampled anchors no screen can separate: fp16x3 two-sweep scan (K1x3, match_x3.hip; C_pad 256) instead of the
     // exact fp32 scan - same results, hard-descriptor step 9.8 -> 8.5 ms; ~30 us of empty launches per step when no anchor needs it.
     // ORYON_AMB_X3=0 keeps the exact scan (the tests run both settings).
-    static const bool x3_env = !getenv("ORYON_AMB_X3") || atoi(getenv("ORYON_AMB_X3")) != 0;
+    static const bool x3_env = dev_env_int("ORYON_AMB_X3", 1) != 0;
     const int use_x3 = (x3_env && C == 256 && !force_eager) ? 1 : 0;
     if (fmt == 1) {
         const uint8_t *a6 = reinterpret_cast<const uint8_t *>(a_i8), *q6 = reinterpret_cast<const uint8_t *>(q_i8);

@@ -850,7 +850,7 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
 {
     constexpr int CP = 256;
     // sweep 1 as 8-wave workgroups (512 anchors, two waves per SIMD) unless ORYON_X3_WAVES=4 (256 anchors, one wave per SIMD)
-    static const int x3_waves = (getenv("ORYON_X3_WAVES") && atoi(getenv("ORYON_X3_WAVES")) == 4) ? 4 : 8;
+    static const int x3_waves = (dev_env_int("ORYON_X3_WAVES", 8) == 4) ? 4 : 8;
     const int T = (cap_s + 64 * x3_waves - 1) / (64 * x3_waves);
     const int G = T * x3_waves;                                  // 64-anchor groups per (pair, split)
     const int S = 8;
@@ -897,7 +897,7 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
     }
     hipLaunchKernelGGL(match_x3_split_anchors_kernel, dim3(64, B), dim3(256), 0, st, a_c, CP, cap_s, n_c, ah, al, al_norm);
     const int groups = ((B * S + 7) / 8) * 8 * T;
-    static const bool dbg = getenv("ORYON_X3_DEBUG") != nullptr;          // development aid: list statistics of this call on stderr
+    static const bool dbg = dev_env_set("ORYON_X3_DEBUG");          // development aid: list statistics of this call on stderr
     int32_t *dbg_dev = nullptr;
     if (dbg) {
         dbg_dev = reinterpret_cast<int32_t *>(seed + (size_t)B * cap_s + 64);         // in the scratch's 8 KB of slack
@@ -905,7 +905,7 @@ int match_x3_resolve(const float *a_c, const int32_t *n_c, int cap_s, const floa
         (void)hipMemsetAsync(dbg_dev + 8, 0xff, 8, st);
     }
     // seeds of the running maxima from the screen's winning slices (ORYON_X3_SEED=0: the round-3 scan, for A/B timing; same results)
-    static const bool use_seed = !getenv("ORYON_X3_SEED") || atoi(getenv("ORYON_X3_SEED")) != 0;
+    static const bool use_seed = dev_env_int("ORYON_X3_SEED", 1) != 0;
     const float *seed_arg = nullptr;
     if (use_seed && orig_idx && sid_final) {
         hipLaunchKernelGGL(match_x3_seed_kernel, dim3((cap_s + 3) / 4, B), dim3(256), 0, st, ah, qh, CP, cap_s, cap_q, n_c, n_q, orig_idx, orig_stride,

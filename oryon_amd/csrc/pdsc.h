@@ -71,7 +71,7 @@ struct PdscWorkspace {
 // key splits of the attention launch: aim at >= 2 workgroups per CU (512), never more splits than 64-key tiles
 inline int pdsc_attention_splits(int B, int n_cap)
 {
-    static const int forced = getenv("ORYON_PDSC_ATT_SPLITS") ? atoi(getenv("ORYON_PDSC_ATT_SPLITS")) : 0;
+    static const int forced = dev_env_int("ORYON_PDSC_ATT_SPLITS", 0);
     const int blocks = B * (n_cap / 128);
     int ks = forced ? forced : (256 + blocks - 1) / blocks;     // one workgroup per CU is enough once tile t+1 is prefetched
     const int tiles = n_cap / 64;

@@ -2171,7 +2171,7 @@ static int launch_linear(bool relu, bool resid, const float *X, int ldx, size_t 
                          const int32_t *n_rows, hipStream_t st)
 {
     dim3 grid(n_cap / LIN_ROWS, ceil_div(N, LIN_COLS), B), block(256);
-    static const bool x3 = getenv("ORYON_PDSC_FP32_MFMA") == nullptr;
+    static const bool x3 = !dev_env_set("ORYON_PDSC_FP32_MFMA");
     if (x3 && K % LIN_BK == 0 && ldx % 2 == 0) {
         if (relu && !resid) hipLaunchKernelGGL((pdsc_linear_x3_kernel<true, false>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
         else if (!relu && resid) hipLaunchKernelGGL((pdsc_linear_x3_kernel<false, true>), grid, block, 0, st, X, ldx, xb, W, bias, R, ldr, rb, Y, ldy, yb, K, N, n_rows);
@@ -2212,20 +2212,20 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
     hipLaunchKernelGGL(pdsc_sc_kernel, dim3(n_cap / 128, n_cap / ATT_KT, B), dim3(256), 0, st, src, tgt, n_rows, n_cap, inv_sigma2, ws.sc);
     for (int l = 0; l < M.cfg.num_layers; ++l) {
         const PdscLayer &L = M.layers[l];
-        static const bool x3 = getenv("ORYON_PDSC_FP32_MFMA") == nullptr;     // fp16x3 unless the pure-fp32 kernels are asked for
-        static const bool fused_pq = !getenv("ORYON_PDSC_FUSED_PQ") || atoi(getenv("ORYON_PDSC_FUSED_PQ")) != 0;       // dev: 0 = two launches
-        static const bool att_img = !getenv("ORYON_PDSC_ATT_IMG") || atoi(getenv("ORYON_PDSC_ATT_IMG")) != 0;           // dev: 0 = fp32 K / V
+        static const bool x3 = !dev_env_set("ORYON_PDSC_FP32_MFMA");     // fp16x3 unless the pure-fp32 kernels are asked for
+        static const bool fused_pq = dev_env_int("ORYON_PDSC_FUSED_PQ", 1) != 0;       // dev: 0 = two launches
+        static const bool att_img = dev_env_int("ORYON_PDSC_ATT_IMG", 1) != 0;           // dev: 0 = fp32 K / V
         bool use_img = false;
         // round 4: fc_message of layer l - 1 and PointCN + q|k|v of layer l came as ONE launch at the end of the previous iteration
-        static const bool fuse_chain = !getenv("ORYON_PDSC_FUSED_CHAIN") || atoi(getenv("ORYON_PDSC_FUSED_CHAIN")) != 0;     // dev: 0 = separate launches
-        static const bool fuse_att = !getenv("ORYON_PDSC_FUSED_ATT") || atoi(getenv("ORYON_PDSC_FUSED_ATT")) != 0;           // dev: 0 = attention as its own launch
+        static const bool fuse_chain = dev_env_int("ORYON_PDSC_FUSED_CHAIN", 1) != 0;     // dev: 0 = separate launches
+        static const bool fuse_att = dev_env_int("ORYON_PDSC_FUSED_ATT", 1) != 0;           // dev: 0 = attention as its own launch
         const bool chain_ok = C == 128 && x3 && fused_pq && fuse_chain && n_cap % 256 == 0 && ws.att_splits == 1 && ws.kv_img != nullptr && att_img &&
-                              (!getenv("ORYON_PDSC_FUSED_MLP") || atoi(getenv("ORYON_PDSC_FUSED_MLP")) != 0) &&
-                              (!getenv("ORYON_PDSC_WAVES") || atoi(getenv("ORYON_PDSC_WAVES")) == 8);
+                              (dev_env_int("ORYON_PDSC_FUSED_MLP", 1) != 0) &&
+                              (dev_env_int("ORYON_PDSC_WAVES", 8) == 8);
         // K / V images alternate between two buffers when the attention is part of the one-launch-per-layer kernel (its workgroups write
         // layer l + 1's tiles while others still read layer l's)
         const bool att_chain = chain_ok && fuse_att && ws.kv_img2 != nullptr && L.mlp_img_p &&
-                               (!getenv("ORYON_PDSC_ATT8") || atoi(getenv("ORYON_PDSC_ATT8")) != 0);
+                               (dev_env_int("ORYON_PDSC_ATT8", 1) != 0);
         char *kv_cur = (att_chain && (l & 1)) ? ws.kv_img2 : ws.kv_img, *kv_nxt = (att_chain && !(l & 1)) ? ws.kv_img2 : ws.kv_img;
         if (l > 0 && chain_ok && L.pq_img && M.layers[l - 1].mlp_img) {
             use_img = true;                                            // (launched at the end of the previous iteration)
@@ -2234,7 +2234,7 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
             // PointCN (conv + BN + ReLU, BN folded) and the q | k | v projections in one launch
             // 8-wave workgroups (256 points): the same 128 KB of weights feed twice the points and the launch occupies half the CUs with
             // two waves per SIMD - latency-bound kernels lose nothing, and K0 / the other registration stream find free CUs beside them
-            static const int pw = getenv("ORYON_PDSC_WAVES") ? atoi(getenv("ORYON_PDSC_WAVES")) : 8;
+            static const int pw = dev_env_int("ORYON_PDSC_WAVES", 8);
             const bool w8 = pw == 8 && n_cap % 256 == 0;
             if (w8) allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_pcn_qkv_x3_kernel<8>), 2 * PDSC_PQ_CHUNK_BYTES);
             else allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_pcn_qkv_x3_kernel<4>), 2 * PDSC_PQ_CHUNK_BYTES);
@@ -2274,7 +2274,7 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         }
         const int KS = ws.att_splits;
         dim3 ag(n_cap / ATT_Q, KS, B);
-        static const bool att8 = !getenv("ORYON_PDSC_ATT8") || atoi(getenv("ORYON_PDSC_ATT8")) != 0;       // 0: the 4-wave attention kernel
+        static const bool att8 = dev_env_int("ORYON_PDSC_ATT8", 1) != 0;       // 0: the 4-wave attention kernel
         if (C == 128 && x3 && use_img && att8) {
             allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_attention_x3_img8_kernel<128>), 2 * PDSC_KV_TILE_BYTES);
             hipLaunchKernelGGL((pdsc_attention_x3_img8_kernel<128>), dim3(n_cap / ATT_Q, 1, (B + 7) / 8 * 8), dim3(512), 2 * PDSC_KV_TILE_BYTES, st,
@@ -2296,7 +2296,7 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
                                n_rows, n_cap, C, KS, B, ws.msg);
         if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
         // fc_message: C -> C/2 -> C/2 -> C, residual onto the PointCN output
-        static const bool fused_mlp = !getenv("ORYON_PDSC_FUSED_MLP") || atoi(getenv("ORYON_PDSC_FUSED_MLP")) != 0;   // dev: 0 = three launches
+        static const bool fused_mlp = dev_env_int("ORYON_PDSC_FUSED_MLP", 1) != 0;   // dev: 0 = three launches
         if (chain_ok && L.mlp_img && l + 1 < M.cfg.num_layers && M.layers[l + 1].pq_img) {
             const PdscLayer &N = M.layers[l + 1];
             constexpr int FZ_LDS = PDSC_MLP_IMG_BYTES + PDSC_PQ_CHUNK_BYTES;
@@ -2307,7 +2307,7 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
             continue;
         }
         if (C == 128 && x3 && fused_mlp && L.mlp_img) {
-            static const int mw = getenv("ORYON_PDSC_WAVES") ? atoi(getenv("ORYON_PDSC_WAVES")) : 8;
+            static const int mw = dev_env_int("ORYON_PDSC_WAVES", 8);
             if (mw == 8 && n_cap % 256 == 0) {
                 allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_mlp3_x3_kernel<8>), PDSC_MLP_IMG_BYTES);
                 hipLaunchKernelGGL(pdsc_mlp3_x3_kernel<8>, dim3(n_cap / 256, B), dim3(512), PDSC_MLP_IMG_BYTES, st, ws.msg, ws.feat1, L.mlp_img, L.b_m1,

@@ -648,7 +648,7 @@ int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float
         dist_pre = ws.seed_dist;
     }
     // 1: the one-wave-per-seed kernel (same results; 91 vs 100 us per 64 registrations in the kernel trace, no difference in the step: not the default)
-    static const bool knn_wave = getenv("ORYON_PDSC_KNN_WAVE") && atoi(getenv("ORYON_PDSC_KNN_WAVE")) != 0;
+    static const bool knn_wave = dev_env_int("ORYON_PDSC_KNN_WAVE", 0) != 0;
     if (knn_wave && dist_pre && n_cap <= 1024 && k <= 63) {
         const size_t shw = ((size_t)k * (128 + 4) + (size_t)k * 6) * sizeof(float);
         if (n_cap <= 512)

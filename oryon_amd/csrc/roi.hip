@@ -558,7 +558,7 @@ extern "C" int oryon_gather_normalise_f32(const float *feat, int n_maps, int C, 
     ORYON_CHECK_ARG(rows_cap > 0 && rows_cap % GN_ROWS == 0);
     if (n_maps == 0) return ORYON_OK;
     if (C_pad <= 512) {
-        static const int rows_env = getenv("ORYON_GATHER_ROWS") ? atoi(getenv("ORYON_GATHER_ROWS")) : 0;
+        static const int rows_env = dev_env_int("ORYON_GATHER_ROWS", 0);
         const int rows = rows_env ? rows_env : 32;
         const size_t sh = ((size_t)C_pad * (rows + 1) + 64) * sizeof(float);
 #define LAUNCH_G2(NLV, RV)                                                                                                 \

@@ -464,7 +464,7 @@ static void mx6_debug_report(const long long *dbg_dev, int groups, hipStream_t s
 static int mx6_var()
 {
     // 0: default; 1: diagnostic build of the 8-wave loop (wrong results); 2: the first 8-wave kernel at C_pad 256; 3: 4-wave workgroups
-    static const int var = getenv("ORYON_MX6_VAR") ? atoi(getenv("ORYON_MX6_VAR")) : 0;
+    static const int var = dev_env_int("ORYON_MX6_VAR", 0);
     return var;
 }
 
@@ -488,7 +488,7 @@ void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, c
     if constexpr (CP == 256) {
         if (var == 0) {                                          // default: 8 waves x 128 anchors (1024-anchor panels, one workgroup per CU)
             const int T8 = (cap_a + 1023) / 1024;
-            static const bool dbg = getenv("ORYON_MX6_DEBUG") != nullptr;
+            static const bool dbg = dev_env_set("ORYON_MX6_DEBUG");
             static long long *dbg_wg = nullptr;
             const int g8 = groups / T * T8;
             if (dbg && !dbg_wg) (void)hipMalloc(&dbg_wg, (size_t)65536 * 4 * sizeof(long long));

@@ -8,6 +8,15 @@ if ROOT not in sys.path:
 
 
 import oryon_amd  # noqa: E402
+from oryon_amd import _lib as _oryon_lib  # noqa: E402
+
+# The shipped library reads no environment variable.  Variant-vs-variant tests re-run themselves in a child interpreter against the
+# DEVELOPMENT build (`make dev`: liboryon_hip_dev.so, the same sources with the ORYON_* kernel-variant switches compiled in); the child is
+# told so with ORYON_TEST_DEV_LIB=1 - test infrastructure only, the product never looks at it.
+DEV_LIB_PATH = os.path.join(os.path.dirname(_oryon_lib.LIB_PATH), "liboryon_hip_dev.so")
+if os.environ.get("ORYON_TEST_DEV_LIB") == "1":
+    assert os.path.exists(DEV_LIB_PATH), "liboryon_hip_dev.so missing: run `make -C oryon_amd/csrc dev` (or __graft_entry__.build())"
+    _oryon_lib.LIB_PATH = DEV_LIB_PATH
 
 oryon_amd.configure()        # hardware queues for the step engine's streams, before any test initialises HIP
 

@@ -175,7 +175,7 @@ def test_hot_kernels_do_not_spill():
     if not rows:
         pytest.skip("LLVM object tools not available")
     hot = ("match_mx6_screen_w4_kernelILi256ELi8E", "match_i8_screen_v2_kernelILi256E", "gather_q8_v3_kernelILi256ELi1ELb0ELi1E",
-           "gather_q8_v3_kernelILi256ELi1ELb0ELi0E", "pdsc_attention_x3_img_kernel", "pdsc_pcn_qkv_x3_kernel", "pdsc_mlp3_x3_kernel",
+           "gather_q8_v3_kernelILi256ELi1ELb0ELi0E", "gather_mx6_v4_kernelILb0E", "gather_mx6_v4_kernelILb1E", "pdsc_attention_x3_img_kernel", "pdsc_pcn_qkv_x3_kernel", "pdsc_mlp3_x3_kernel",
            "match_decide_lite_kernel", "match_resolve_selected_kernel", "dec_conv3x3_kernelILi1ELb0ELb1ELb1E", "dec_conv3x3_kernelILi2ELb0ELb0ELb0E",
            "dec_final_kernel", "fusion_window_attention_x3_kernel")
     seen = set()
@@ -185,6 +185,24 @@ def test_hot_kernels_do_not_spill():
                 seen.add(h)
                 assert k["scratch"] == 0, f"{k['name']}: {k['spill']} spilled registers, {k['scratch']} B of scratch per lane"
     assert seen == set(hot), sorted(set(hot) - seen)
+
+
+def test_shipped_library_reads_no_environment_variable():
+    """liboryon_hip.so has no switch that changes (or skips) what it computes - no ORYON_* name among its strings and no
+    import of getenv; the development build (make dev), which the variant-vs-variant tests and tools/ load explicitly, is where they live."""
+    import re, subprocess
+    from oryon_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "oryon_hip.h")).read()
+    names = sorted(set(m.decode() for m in re.findall(rb"ORYON_[A-Z0-9_]{3,}", blob)))
+    names = [n for n in names if n not in header]            # enum constants of the C ABI appear in argument-check messages
+    assert names == [], names
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert not re.search(r"\bgetenv\b", nm.stdout), "liboryon_hip.so imports getenv"
+    dev = os.path.join(os.path.dirname(_lib.LIB_PATH), "liboryon_hip_dev.so")
+    if os.path.exists(dev):
+        assert b"ORYON_AMB_X3" in open(dev, "rb").read()
 
 
 def test_engine_config_struct_matches_the_library():

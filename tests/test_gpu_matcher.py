@@ -684,7 +684,7 @@ def test_lazy_corrs_with_the_exact_second_level():
     import os, subprocess, sys
     if os.environ.get("ORYON_AMB_X3") == "0":
         pytest.skip("already the child run")
-    env = dict(os.environ, ORYON_AMB_X3="0")
+    env = dict(os.environ, ORYON_AMB_X3="0", ORYON_TEST_DEV_LIB="1")       # the switch exists in the development build only
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k", "test_lazy_corrs and not second_level"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -9,6 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _devlib  # noqa: E402,F401  (the development library: ORYON_* switches are live)
 import bench  # noqa: E402
 import oryon_amd
 oryon_amd.configure()
