@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
     for (int nb = 0; nb < NB; ++nb) {
         const int co = nb * 32 + li;
         const float bv = (a.bias && co < a.cout) ? a.bias[co] : 0.0f;
-        float s1 = 0.0f, s2 = 0.0f;
+        float s1 = 0.0f;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -265,19 +265,28 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
                 const int gy = y0 + 4 * wave + 2 * mb + (m >> 4), gx = x0 + (m & 15);
                 float v = acc[mb][nb][r];
                 s1 += v;
-                s2 = fmaf(v, v, s2);
                 v += bv;
                 if (a.relu) v = fmaxf(v, 0.0f);
                 if (co < a.cout) a.out[(((size_t)img * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co] = v;
             }
         if (a.stats) {
-            // group = 16 channels = the 16 lanes li & 16 .. of both k-group halves
+            // GroupNorm statistics without cancellation: (sum, sum of squared deviations from the WAVE's own group mean) per wave, merged
+            // below and in dec_gn_affine_kernel with the parallel-variance formula - E[x^2] - mean^2 in fp32 loses the variance as soon as
+            // |mean| >> std (trained activations with a DC offset).  group = 16 channels = the 16 lanes li & 16 .. of both k-group halves
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                s1 += __shfl_xor(s1, off);
-                s2 += __shfl_xor(s2, off);
-            }
+            for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off);
             s1 += __shfl_xor(s1, 32);
+            const float mu = s1 * (1.0f / 1024.0f);                // 16 channels x 64 pixels of this wave's two M blocks
+            float s2 = 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dv = acc[mb][nb][r] - mu;
+                    s2 = fmaf(dv, dv, s2);
+                }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) s2 += __shfl_xor(s2, off);
             s2 += __shfl_xor(s2, 32);
             if ((lane & 47) == 0) {                              // lanes 0 and 16
                 red[wave][nb * 2 + (lane >> 4)][0] = s1;
@@ -287,10 +296,21 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
     }
     if (a.stats) {
         __syncthreads();
-        if (t < NB * 2 * 2) {
-            const int g = t >> 1, k = t & 1;
-            const float v = (red[0][g][k] + red[1][g][k]) + (red[2][g][k] + red[3][g][k]);
-            a.stats[(((size_t)img * tiles + tile) * (NB * 2) + g) * 2 + k] = v;
+        if (t < NB * 2) {
+            // the tile's (sum, M2) from its four waves' (sum, M2): M2 = sum M2_w + 1024 sum (mean_w - mean_tile)^2
+            const int g = t;
+            const float sum = (red[0][g][0] + red[1][g][0]) + (red[2][g][0] + red[3][g][0]);
+            const float mt = sum * (1.0f / 4096.0f);
+            float m2 = (red[0][g][1] + red[1][g][1]) + (red[2][g][1] + red[3][g][1]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float dm = red[w][g][0] * (1.0f / 1024.0f) - mt;
+                m2 = fmaf(1024.0f * dm, dm, m2);
+            }
+            float2 o;
+            o.x = sum;
+            o.y = m2;
+            *reinterpret_cast<float2 *>(a.stats + (((size_t)img * tiles + tile) * (NB * 2) + g) * 2) = o;
         }
     }
     }   // items
@@ -303,19 +323,21 @@ __global__ __launch_bounds__(64) void dec_gn_affine_kernel(const float *__restri
     // one wave per (image, group): lane l adds tiles l, l + 64, .. in order, then a fixed butterfly - the same sum every run
     const int idx = blockIdx.x, lane = threadIdx.x;
     const int img = idx / NG, g = idx % NG;
-    double s1 = 0.0, s2 = 0.0;
+    // tile partials are (sum, M2 about the tile's own mean) of 4096 values each; merged in double with the parallel-variance formula
+    double s1 = 0.0;
+    for (int tl = lane; tl < tiles; tl += 64) s1 += (double)stats[(((size_t)img * tiles + tl) * NG + g) * 2];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s1 += __shfl_xor(s1, off);
+    const double mean = s1 * inv_count;
+    double m2 = 0.0;
     for (int tl = lane; tl < tiles; tl += 64) {
         const float2 q = *reinterpret_cast<const float2 *>(stats + (((size_t)img * tiles + tl) * NG + g) * 2);
-        s1 += (double)q.x;
-        s2 += (double)q.y;
+        const double dm = (double)q.x * (1.0 / 4096.0) - mean;
+        m2 += (double)q.y + 4096.0 * dm * dm;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        s1 += __shfl_xor(s1, off);
-        s2 += __shfl_xor(s2, off);
-    }
-    const double mean = s1 * inv_count;
-    double var = s2 * inv_count - mean * mean;
+    for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off);
+    double var = m2 * inv_count;
     var = var < 0.0 ? 0.0 : var;
     const double rstd = 1.0 / sqrt(var + eps);
     if (lane < 16) {

@@ -229,6 +229,15 @@ class MatchPoseEngine:
             elif len(out) > 4:
                 # views of a `keep` step (more than pose / status / n_valid / n_lifted): the caller may read them whenever it likes
                 self._native.reads_pending[slot] = True
+            else:
+                # result views of an ordinary step: pose / status live in the slot's PROTECTED block (the engine orders their next
+                # overwrite after the caller's stream), the two counters do not (include/oryon_hip.h, "slot lifetime") - a view of them
+                # read asynchronously n_slots steps later would race with the matcher / lift of the step that re-uses the slot.  They
+                # leave as copies (2 x B int32, queued here behind the step), and the event below marks where those reads end.
+                for k in ("n_valid", "n_lifted"):
+                    if isinstance(out.get(k), Tensor):
+                        out[k] = out[k].clone()
+                queued = True
             if queued and self._native.reads_pending[slot] is not True:
                 # reads of the slot's unprotected buffers now sit on the caller's stream: remember where they end.  If they have
                 # completed by the time the slot comes round again (the usual case, n_slots steps later) nothing needs ordering

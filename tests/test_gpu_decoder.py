@@ -67,7 +67,7 @@ def test_hip_decoder_layers_match_torch_fp32(n, h, w):
         if (h, w) == (24, 24):
             assert lg2.shape == (n, 1, 8 * h, 8 * w) and torch.equal(fm2, fm) and torch.equal(lg2[:, 0], lg)
         else:
-            assert lg2.shape == (n, 1, 192, 192) and dec.__dict__.get("_hip") is None
+            assert lg2.shape == (n, 1, 192, 192) and not fusion._fast_cache(dec).get("hip")
         lg3, fm3 = hip.forward(x, g2, g3)
         assert torch.equal(fm3, fm) and torch.equal(lg3, lg)                    # fixed reduction order: bit-reproducible
         # guidance maps as the Swin tower hands them out (permuted views of NHWC storage) are read in place: same values
@@ -102,7 +102,7 @@ def test_hip_decoder_matches_reference_golden():
         with torch.no_grad():
             feats = fusion(img, text, guid)
             mask, featmap = decoder(feats, guid)
-        assert decoder.__dict__.get("_hip") is not None                         # the HIP path ran, not the torch modules
+        assert F_._fast_cache(decoder).get("hip")                         # the HIP path ran, not the torch modules
         # the whole fast inference path (what bench.py's fp16x3 stage sets run): fusion linears on the fp16x3 kernel as well
         enable_fp16x3(True)
         with torch.no_grad():
@@ -217,3 +217,61 @@ def test_fusion_class_layer_matches_torch():
     # the update itself (output minus the residual map) to the same bar relative to ITS size
     du, dr = got - x, ref - x
     assert float((du - dr).abs().max() / dr.abs().max()) < 1e-4
+
+
+def test_hip_decoder_groupnorm_with_a_large_dc_offset():
+    """GroupNorm statistics from E[x^2] - mean^2 in fp32 lose the variance once |mean| >> std.  The tile partials are now
+    (sum, M2 about the tile mean) merged with the parallel-variance formula: a decoder whose up-convolution biases put a DC offset of
+    ~100 standard deviations on every convolution output must still agree with the torch fp32 modules (Welford-style GroupNorm)."""
+    from oryon_amd.backbone.decoder_hip import HipDecoder
+    torch.backends.cudnn.allow_tf32 = False
+    torch.manual_seed(9)
+    dec = _decoder(11)
+    with torch.no_grad():
+        for blk in (dec.decoder1, dec.decoder2, dec.decoder3):
+            blk.up.bias += 40.0                                                # every conv1 input channel rides on +40
+            for j in (0, 3):
+                blk.conv.double_conv[j].weight[:, :, 1, 1] += 2.0              # centre taps with a non-zero sum: the offset survives the
+                                                                               # convolution, the zero padding does not modulate it
+    n, h, w_ = 2, 24, 24
+    x = torch.randn(n, 128, h, w_, device="cuda") * 0.1
+    g2 = torch.randn(n, 256, 2 * h, 2 * w_, device="cuda")
+    g3 = torch.randn(n, 128, 4 * h, 4 * w_, device="cuda")
+    with torch.no_grad():
+        pg = [proj(g) for proj, g in zip(dec.decoder_guidance_projection, (g2, g3))]
+        c1 = dec.decoder1.conv.double_conv[0](torch.cat([dec.decoder1.up(x), pg[0]], dim=1))
+        grp = c1.view(n, 4, 16, -1)
+        ratio = float((grp.mean(dim=(2, 3)).abs() / grp.std(dim=(2, 3))).min())
+        assert ratio > 30, ratio                                               # the regime the fix is for
+        logits_ref, fm_ref = dec(x.view(n, 128, 1, h, w_), [None, g2, g3])
+        lg, fm = HipDecoder(dec, x.device).forward(x, g2, g3)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert rel(fm, fm_ref) < 1e-4 and rel(lg, logits_ref[:, 0]) < 1e-4, (rel(fm, fm_ref), rel(lg, logits_ref[:, 0]))
+
+
+def test_modules_copy_and_pickle_after_the_fast_path_ran():
+    """the fast path's caches (HipDecoder handle, q | k weights, clip_conv view) no longer live in module.__dict__ -
+    a decoder / fusion module that ran it deep-copies, pickles and torch.save()s, and the copy builds its own handle."""
+    import copy, io, pickle
+    from oryon_amd.backbone import fusion as F_
+    dec = _decoder(4)
+    x = torch.randn(1, 128, 1, 24, 24, device="cuda")
+    g2, g3 = torch.randn(1, 256, 48, 48, device="cuda"), torch.randn(1, 128, 96, 96, device="cuda")
+    F_.enable_hip_decoder(True)
+    try:
+        with torch.no_grad():
+            lg, fm = dec(x, [None, g2, g3])
+            assert F_._fast_cache(dec).get("hip")
+            dec2 = copy.deepcopy(dec)
+            blob = pickle.dumps(dec)
+            buf = io.BytesIO()
+            torch.save(dec, buf)
+            assert not F_._fast_cache(dec2).get("hip")                         # nothing travelled with the copy
+            lg2, fm2 = dec2(x, [None, g2, g3])
+            assert F_._fast_cache(dec2)["hip"] is not F_._fast_cache(dec)["hip"]
+            assert torch.equal(fm2, fm) and torch.equal(lg2, lg)
+            dec3 = pickle.loads(blob)
+            lg3, fm3 = dec3(x, [None, g2, g3])
+            assert torch.equal(fm3, fm)
+    finally:
+        F_.enable_hip_decoder(False)
