@@ -373,11 +373,12 @@ int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const floa
  * overlap: 0 = everything on the caller's stream (no engine streams), 1 = match on an engine stream, registration on one stream
  *          per slot, 2 = additionally K0 on its own stream (n_slots >= 2 for overlap >= 1).
  * Per-pair results live in the arena: oryon_engine_buffer gives offset / size of a slot's named buffer ("pose" [B,16] fp32,
- *          "status_out" [B] i32, "n_valid", "n_lift", "n_a", "n_q", "n_und" [B] i32, "corrs" [B,n_cap,4] i32, "pcd_a", "pcd_q"
+ *          "status_out", "n_valid_out", "n_lift_out" [B] i32, "n_valid", "n_lift", "n_a", "n_q", "n_und" [B] i32, "corrs" [B,n_cap,4] i32, "pcd_a", "pcd_q"
  *          [B,n_cap,3] fp32, "roi_a", "roi_q" [B,FH*FW] i32, "min_dist", "argmin", "valid" [B,cap_a], ...); a slot's buffers are valid
  *          from oryon_engine_wait(slot) until the n_slots-th next submit.
- *          Slot lifetime, precisely: that submit orders the overwrite of "pose" / "status_out" after everything queued on
- *          caller_stream before it, whatever inputs_resident says.  K0 and the matcher overwrite the slot's OTHER buffers (ROI lists,
+ *          Slot lifetime, precisely: that submit orders the overwrite of "pose" / "status_out" / "n_valid_out" / "n_lift_out" (the
+ *          protected block: written on the registration stream; the last two are the step's "n_valid" / "n_lift" copied there) after
+ *          everything queued on caller_stream before it, whatever inputs_resident says.  K0 and the matcher overwrite the slot's OTHER buffers (ROI lists,
  *          counts, matcher outputs, correspondences, lifted points) without waiting for caller_stream when inputs_resident != 0: a
  *          caller that may still have reads of those queued when the slot comes round again passes inputs_resident = 0 for that submit.
  *          "corrs" rows >= the pair's n_sel are undefined (a re-used slot keeps an earlier step's rows there; K2 reads n_sel rows).

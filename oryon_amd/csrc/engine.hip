@@ -52,6 +52,7 @@ struct SlotBuf {
     int32_t *n_lift;
     float *pose;
     int32_t *status_out;
+    int32_t *n_valid_out, *n_lift_out;      // copies of n_valid / n_lift made on the registration stream: part of the slot's protected block
     void *pdsc_ws;
     size_t base, bytes;                        // offset of the slot in the arena
 };
@@ -196,6 +197,8 @@ int carve_engine(const oryon_engine_config_t &c, const oryon_pointdsc_t *solver,
         TAKE(n_lift, int32_t, B);
         TAKE(pose, float, B * 16);
         TAKE(status_out, int32_t, B);
+        TAKE(n_valid_out, int32_t, B);
+        TAKE(n_lift_out, int32_t, B);
 #undef TAKE
         b.pdsc_ws = take("pdsc_ws", L.pdsc_ws_bytes);
         b.bytes = off - b.base;
@@ -222,6 +225,18 @@ int check_cfg(const oryon_engine_config_t *c)
 }  // namespace
 
 // sizeof(oryon_engine_config_t) as this library was built: bindings in other languages check their mirror of the struct against it
+namespace oryon {
+__global__ void engine_counts_kernel(const int32_t *__restrict__ n_valid, const int32_t *__restrict__ n_lift, int B,
+                                     int32_t *__restrict__ n_valid_out, int32_t *__restrict__ n_lift_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        n_valid_out[i] = n_valid[i];
+        n_lift_out[i] = n_lift[i];
+    }
+}
+}  // namespace oryon
+
 extern "C" size_t oryon_engine_config_bytes(void) { return sizeof(oryon_engine_config_t); }
 
 extern "C" size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver)
@@ -531,6 +546,9 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[6], sr));
     if (!(ablate & 4) && (rc = oryon_pointdsc_register(e->solver, b.pcd_a, b.pcd_q, b.n_lift, B, e->L.n_cap, b.status, b.pdsc_ws, e->L.pdsc_ws_bytes,
                                                        b.pose, nullptr, b.status_out, sr))) return rc;
+    // the two per-pair counters a caller reads with the pose: copied on the registration stream (which is always ordered after the
+    // caller's stream) into the slot's protected block, so that result views of them stay valid for the slot's whole lifetime
+    hipLaunchKernelGGL(engine_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, sr, b.n_valid, b.n_lift, B, b.n_valid_out, b.n_lift_out);
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[7], sr));
     if (c.overlap >= 1) ORYON_CHECK_HIP(hipEventRecord(e->ev_done[slot], sr));
     e->used[slot] = true;

@@ -96,6 +96,103 @@ __global__ __launch_bounds__(256) void pdsc_seed_rank_kernel(const float *__rest
     if (t == 0) n_seeds[b] = S;
 }
 
+// Round 5: K5 as ONE launch - one 16-wave workgroup per pair (n_cap <= 2048).  Two threads per row walk half of the j range each
+// with the pair's (x, y, z, score) quadruples in LDS (one broadcast ds_read_b128 per test); `|s_i - s_j| >= R` is tested on the SQUARED
+// distance against x0 = the smallest float whose correctly rounded root reaches R (found once per workgroup; sqrt is monotone, so the
+// outcome is the one sqrt_rn(d2) >= R gives) - no square root in the O(n^2) loop.  The ranking is RANK COUNTING:
+// rank_i = #{j : key_j > key_i, or key_j == key_i and j < i} is the position of row i in "descending by key, ties by ascending index"
+// - the order of the 45-barrier bitonic sort it replaces - and rows with rank < S are the seeds.  22.4 + 12.4 us -> one launch.
+// Reference: PointDSC.py:199-217 (pick_seeds).
+__global__ __launch_bounds__(1024) void pdsc_seeds_fused_kernel(const float *__restrict__ src, const float *__restrict__ conf,
+                                                                 const int32_t *__restrict__ n_rows, int n_cap, float radius, int S_cap,
+                                                                 float ratio, float *__restrict__ key_out, int32_t *__restrict__ seeds,
+                                                                 int32_t *__restrict__ n_seeds)
+{
+    extern __shared__ float sm[];
+    float4 *pt = reinterpret_cast<float4 *>(sm);           // [n_cap] x, y, z, score
+    float *key = sm + 4 * n_cap;                           // [n_cap]
+    __shared__ float s_x0;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int n = n_rows[b];
+    int S = (int)((double)n * (double)ratio);
+    S = S < S_cap ? S : S_cap;
+    for (int i = t; i < n; i += 1024) {
+        float4 q;
+        q.x = src[((size_t)b * n_cap + i) * 3 + 0];
+        q.y = src[((size_t)b * n_cap + i) * 3 + 1];
+        q.z = src[((size_t)b * n_cap + i) * 3 + 2];
+        q.w = conf[(size_t)b * n_cap + i];
+        pt[i] = q;
+    }
+    if (t == 0) {
+        // smallest float x0 with sqrt_rn(x0) >= radius: within a few ulps of radius^2
+        float x = radius * radius;
+        for (int u = 0; u < 4; ++u) x = __uint_as_float(__float_as_uint(x) - 1u);
+        while (!(sqrt_rn(x) >= radius)) x = __uint_as_float(__float_as_uint(x) + 1u);
+        s_x0 = x;
+    }
+    __syncthreads();
+    const float x0 = s_x0;
+    // thread -> (row i = t & 511 (+ 512, ..), half of the j range = t >> 9, wave-uniform).  The j side of the NMS test comes through the
+    // SCALAR cache (src / conf of row j: uniform addresses -> s_load, SGPR operands), the j side of the ranking out of a register by
+    // v_readlane: no LDS instruction in either inner loop.  (Measured: a same-address ds_read_b128 / b64 does not broadcast - ~64 LDS
+    // cycles per wave instruction; with the (x, y, z, score) quadruples read that way this kernel took 105-118 us.)
+    int *part_ok = reinterpret_cast<int *>(key + n_cap);           // [2][n_cap] per-half verdicts, then per-half rank counts
+    const int part = __builtin_amdgcn_readfirstlane(t >> 9);
+    const int lane = t & 63;
+    const int per = (n + 1) / 2, j0 = part * per, j1 = (j0 + per < n) ? j0 + per : n;
+    const float *sp = src + (size_t)b * n_cap * 3, *cp = conf + (size_t)b * n_cap;
+    for (int base = 0; base < n; base += 512) {
+        const int i = base + (t & 511);
+        const float4 me = i < n ? pt[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bool lm = true;
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float ox = sp[3 * (j + u)], oy = sp[3 * (j + u) + 1], oz = sp[3 * (j + u) + 2], ow = cp[j + u];
+                const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                lm = lm & ((me.w >= ow) | (d2 >= x0));
+            }
+        }
+        for (; j < j1; ++j) {
+            const float ox = sp[3 * j], oy = sp[3 * j + 1], oz = sp[3 * j + 2], ow = cp[j];
+            const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            lm = lm & ((me.w >= ow) | (d2 >= x0));
+        }
+        if (i < n) part_ok[part * n_cap + i] = lm ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const float kv = pt[i].w * ((part_ok[i] & part_ok[n_cap + i]) ? 1.0f : 0.0f);
+        key[i] = kv;
+        key_out[(size_t)b * n_cap + i] = kv;
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 512) {
+        const int i = base + (t & 511);
+        const float ki = i < n ? key[i] : 0.0f;
+        int rank = 0;
+        for (int jb = j0; jb < j1; jb += 64) {
+            const float kreg = (jb + lane < j1) ? key[jb + lane] : -INFINITY;      // -inf: neither greater than nor equal to any key
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                const float kj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kreg), u));
+                rank += ((kj > ki) | ((kj == ki) & (jb + u < i))) ? 1 : 0;
+            }
+        }
+        if (i < n) part_ok[part * n_cap + i] = rank;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const int rank = part_ok[i] + part_ok[n_cap + i];
+        if (rank < S) seeds[(size_t)b * S_cap + rank] = i;
+    }
+    if (t == 0) n_seeds[b] = S;
+}
+
 // ------------------------------------------------------------------------------------------------ K6 + K7a
 // One workgroup per (seed, pair): feature-space kNN of the seed row, then the k x k compatibility matrix
 //   M_ab = clamp(1 - (1 - f_a.f_b)/sigma^2, 0) * clamp(1 - (|s_a-s_b| - |t_a-t_b|)^2/sigma_d^2, 0),  M_aa = 0.
@@ -136,6 +233,62 @@ __global__ __launch_bounds__(256) void pdsc_seed_dist_kernel(const float *__rest
             acc = fmaf(f.w, row[4 * c4 + 3], acc);
         }
         dist[((size_t)b * S_cap + s) * n_cap + j] = 2.0f - 2.0f * acc;
+    }
+}
+
+// Round 5: the same distances on the fp32 matrix pipe.  v_mfma_f32_32x32x2_f32 accumulates its two k values one after the other
+// into each output element, i.e. it IS the k-ordered fmaf chain (the property the exact matcher K1 rests on, match.hip): D[row, seed]
+// comes out bit for bit as pdsc_seed_dist_kernel computes it, at 64 MFMAs per 32 x 32 tile instead of 128 dependent VALU fmas per
+// element.  Workgroup = 64 rows of a pair; wave w = (row half w & 1, seed tiles w >> 1, + 2, ..); seed features in LDS, rows padded
+// to 129 floats (a lane's seed = its column: conflict-free).  39.5 -> ~10 us per 64 registrations.
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void pdsc_seed_dist_mfma_kernel(const float *__restrict__ feat_n, const int32_t *__restrict__ n_rows, int n_cap,
+                                                                   const int32_t *__restrict__ seeds, const int32_t *__restrict__ n_seeds,
+                                                                   int S_cap, float *__restrict__ dist /*[B,S_cap,n_cap]*/)
+{
+    constexpr int C = 128, FS = C + 1;
+    extern __shared__ float fs[];           // [S_pad][129]
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = n_rows[b], S = n_seeds[b];
+    if ((int)blockIdx.x * 64 >= n || S <= 0) return;
+    const int tiles = (S + 31) / 32;
+    const float *F = feat_n + (size_t)b * n_cap * C;
+    for (int e = t; e < tiles * 32 * C; e += 256) {
+        const int sd = e / C, c = e % C;
+        fs[sd * FS + c] = sd < S ? F[(size_t)seeds[(size_t)b * S_cap + sd] * C + c] : 0.0f;
+    }
+    const int half = lane >> 5, col = lane & 31;
+    const int j = blockIdx.x * 64 + (wave & 1) * 32 + col;          // this lane's A row (rows >= n are zero rows of feat_n)
+    float a[C / 2];                                                  // the row's values k = 2 step + half
+    {
+        const float4 *rp = reinterpret_cast<const float4 *>(F + (size_t)j * C);
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            const float4 v = rp[q];
+            a[2 * q] = half ? v.y : v.x;
+            a[2 * q + 1] = half ? v.w : v.z;
+        }
+    }
+    __syncthreads();
+    for (int st = wave >> 1; st < tiles; st += 2) {
+        f32x16s acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const float *bp = fs + (st * 32 + col) * FS + half;
+#pragma unroll
+        for (int step = 0; step < C / 2; ++step) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step], bp[2 * step], acc, 0, 0, 0);
+        const int sd = st * 32 + col;                                // the lane's column = seed
+        if (sd < S) {
+            float *dp = dist + ((size_t)b * S_cap + sd) * n_cap + blockIdx.x * 64 + (wave & 1) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r0 = 8 * g + 4 * half;                     // rows r0 .. r0 + 3 of the tile
+                float4 o;
+                o.x = 2.0f - 2.0f * acc[4 * g + 0];
+                o.y = 2.0f - 2.0f * acc[4 * g + 1];
+                o.z = 2.0f - 2.0f * acc[4 * g + 2];
+                o.w = 2.0f - 2.0f * acc[4 * g + 3];
+                *reinterpret_cast<float4 *>(dp + r0) = o;
+            }
+        }
     }
 }
 
@@ -443,6 +596,155 @@ __global__ __launch_bounds__(64) void pdsc_power_kernel(const int32_t *__restric
     }
 }
 
+// Round 5: K6b + K7a + K7b as ONE launch per registration (C = 128, n_cap <= 1024): one workgroup per (seed, pair) takes the seed's
+// feature distances from pdsc_seed_dist_kernel, selects the k + 1 nearest rows with a WAVE-LEVEL bitonic top-64 - every lane holds EPT
+// (key, row) pairs as 64-bit composites; the 64-element lists are sorted in registers (shuffles, no barrier), merged pairwise by
+// min(a_i, b_63-i) + a 6-stage bitonic merge, across the four waves through LDS with two barriers - i.e. ascending distance, ties by
+// row index: the order of the 45-barrier bitonic sort of all n_cap rows it replaces, hence the same neighbours; then builds the k x k
+// compatibility matrix in LDS and runs the power iteration on it (wave 0; M never goes to memory).  Replaces pdsc_knn_matrix_kernel +
+// pdsc_power_kernel.  Reference: common.py:48-69 (knn), PointDSC.py:257-281 (compatibility), :338-358 (power iteration).
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
+{
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// one compare-exchange stage of a 64-lane bitonic network: lanes whose `keep_min` is set keep the smaller of (own, partner)
+__device__ __forceinline__ unsigned long long bitonic_cx(unsigned long long x, int stride, bool keep_min)
+{
+    const unsigned long long p = shfl_xor_u64(x, stride);
+    const bool lt = x < p;
+    return (lt == keep_min) ? x : p;
+}
+// full sort of one value per lane (21 stages); desc: descending order
+__device__ __forceinline__ unsigned long long wave_sort64(unsigned long long x, int lane, bool desc)
+{
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const bool up = (((lane & size) == 0) || size == 64) != desc;
+            x = bitonic_cx(x, stride, ((lane & stride) == 0) == up);
+        }
+    return x;
+}
+// a bitonic sequence (one value per lane) -> sorted (6 stages)
+__device__ __forceinline__ unsigned long long wave_merge64(unsigned long long x, int lane, bool desc)
+{
+#pragma unroll
+    for (int stride = 32; stride > 0; stride >>= 1) x = bitonic_cx(x, stride, ((lane & stride) == 0) != desc);
+    return x;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(256) void pdsc_hyp_fused_kernel(const float *__restrict__ feat_n, const float *__restrict__ src,
+                                                              const float *__restrict__ tgt, const int32_t *__restrict__ n_rows, int n_cap,
+                                                              const float *__restrict__ dist_pre /* [B,S_cap,n_cap] */,
+                                                              const int32_t *__restrict__ n_seeds,
+                                                              int S_cap, int k_cfg, float inv_sigma2, float inv_sigma_d2,
+                                                              int32_t *__restrict__ knn_out, float *__restrict__ M_out, int n_batch)
+{
+    constexpr int C = 128;
+    static_assert(EPT == 2 || EPT == 4, "lists per wave");
+    extern __shared__ float sm[];
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int b = (lin / 8 / (int)gridDim.x) * 8 + (lin & 7), s = (lin / 8) % (int)gridDim.x;
+    if (b >= n_batch || s >= n_seeds[b]) return;
+    const int n = n_rows[b];
+    const int k = k_cfg < n - 1 ? k_cfg : n - 1;
+    unsigned long long *lists = reinterpret_cast<unsigned long long *>(sm);     // [4][64] the waves' sorted 64-lists
+    float *kf = sm + 512;                                          // [k_cfg][C + 4]
+    float *kc = kf + k_cfg * (C + 4);                              // [k_cfg][6]
+    int *kidx = reinterpret_cast<int *>(kc + k_cfg * 6);           // [KNN_MAX_K]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *F = feat_n + (size_t)b * n_cap * C;
+    const float *dp = dist_pre + ((size_t)b * S_cap + s) * n_cap;
+    {
+        // list e of wave w = rows [(w EPT + e) 64, + 64); order-preserving keys (no NaN / -0.0 among 2 - 2 dot), absent rows last
+        unsigned long long x[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int j = (wave * EPT + e) * 64 + lane;
+            unsigned kx = 0xffffffffu;
+            if (j < n) {
+                const unsigned bits = __float_as_uint(dp[j]);
+                kx = (bits >> 31) ? ~bits : (bits | 0x80000000u);
+                kx = kx == 0xffffffffu ? 0xfffffffeu : kx;
+            }
+            x[e] = ((unsigned long long)kx << 32) | (unsigned)j;
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) x[e] = wave_sort64(x[e], lane, (e & 1) != 0);          // even lists ascending, odd descending
+        // pairwise: the 64 smallest of (asc, desc) = lane-wise minimum, a bitonic sequence
+        unsigned long long y;
+        if constexpr (EPT == 4) {
+            unsigned long long y0 = x[0] < x[1] ? x[0] : x[1], y1 = x[2] < x[3] ? x[2] : x[3];
+            y0 = wave_merge64(y0, lane, false);
+            y1 = wave_merge64(y1, lane, true);
+            y = y0 < y1 ? y0 : y1;
+        } else {
+            y = x[0] < x[1] ? x[0] : x[1];
+        }
+        y = wave_merge64(y, lane, false);                              // this wave's 64 smallest, ascending
+        lists[wave * 64 + lane] = y;
+        __syncthreads();
+        if ((wave & 1) == 0) {
+            const unsigned long long o = lists[(wave + 1) * 64 + 63 - lane];
+            y = wave_merge64(y < o ? y : o, lane, false);
+        }
+        __syncthreads();
+        if (wave == 2) lists[2 * 64 + lane] = y;
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long o = lists[2 * 64 + 63 - lane];
+            y = wave_merge64(y < o ? y : o, lane, false);
+            // rank 0 (the row itself, or its duplicate with the smallest index) is dropped; ranks 1..k are the neighbours (common.py:68)
+            if (lane >= 1 && lane <= k) kidx[lane - 1] = (int)(unsigned)y;
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < k * (C / 4); e += 256) {
+        const int a = e / (C / 4), c4 = e % (C / 4);
+        *reinterpret_cast<float4 *>(kf + a * (C + 4) + 4 * c4) = reinterpret_cast<const float4 *>(F + (size_t)kidx[a] * C)[c4];
+    }
+    for (int e = t; e < k * 3; e += 256) {
+        const int a = e / 3, d = e % 3;
+        kc[a * 6 + d] = src[((size_t)b * n_cap + kidx[a]) * 3 + d];
+        kc[a * 6 + 3 + d] = tgt[((size_t)b * n_cap + kidx[a]) * 3 + d];
+    }
+    if (t < k) knn_out[((size_t)b * S_cap + s) * k_cfg + t] = kidx[t];
+    __syncthreads();
+    float *Mo = M_out + ((size_t)b * S_cap + s) * k_cfg * k_cfg;
+    for (int e = t; e < k; e += 256) Mo[e * k_cfg + e] = 0.0f;
+    const int n_pairs = k * (k - 1) / 2;
+    for (int e = t; e < n_pairs; e += 256) {
+        int a = (int)((2.0f * k - 1.0f - sqrt_rn((2.0f * k - 1.0f) * (2.0f * k - 1.0f) - 8.0f * (float)e)) * 0.5f);
+        while (a > 0 && a * (2 * k - a - 1) / 2 > e) --a;
+        while ((a + 1) * (2 * k - a - 2) / 2 <= e) ++a;
+        const int c2 = a + 1 + (e - a * (2 * k - a - 1) / 2);
+        float dot = 0.0f;
+        const float4 *fa = reinterpret_cast<const float4 *>(kf + a * (C + 4)), *fb = reinterpret_cast<const float4 *>(kf + c2 * (C + 4));
+#pragma unroll 8
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const float4 x = fa[c4], y = fb[c4];
+            dot = fmaf(x.x, y.x, dot);
+            dot = fmaf(x.y, y.y, dot);
+            dot = fmaf(x.z, y.z, dot);
+            dot = fmaf(x.w, y.w, dot);
+        }
+        float fm = 1.0f - (1.0f - dot) * inv_sigma2;
+        fm = fm > 0.0f ? fm : 0.0f;
+        const float *pa = kc + a * 6, *pb = kc + c2 * 6;
+        const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+        const float ex = pa[3] - pb[3], ey = pa[4] - pb[4], ez = pa[5] - pb[5];
+        const float df = sqrt_rn(dx * dx + dy * dy + dz * dz) - sqrt_rn(ex * ex + ey * ey + ez * ez);
+        float smv = 1.0f - df * df * inv_sigma_d2;
+        smv = smv > 0.0f ? smv : 0.0f;
+        const float v = fm * smv;
+        Mo[a * k_cfg + c2] = v;
+        Mo[c2 * k_cfg + a] = v;
+    }
+}
+
 __global__ __launch_bounds__(64) void pdsc_seed_solve_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
                                                               const int32_t *__restrict__ n_rows, int n_cap,
                                                               const int32_t *__restrict__ n_seeds, int S_cap, int k_cfg,
@@ -624,6 +926,12 @@ __global__ __launch_bounds__(256) void pdsc_refine_kernel(const float *__restric
 int pdsc_run_seeds(const PdscModel &M, const float *src, const float *conf, const int32_t *n_rows, int B, int n_cap, int S_cap,
                    int32_t *seeds, int32_t *n_seeds, float *key_scratch /* [B,n_cap] */, hipStream_t st)
 {
+    static const bool fused_seeds = dev_env_int("ORYON_PDSC_FUSED_SEEDS", 1) != 0;      // dev build: 0 = keys + bitonic rank kernels
+    if (fused_seeds && n_cap <= 2048) {
+        hipLaunchKernelGGL(pdsc_seeds_fused_kernel, dim3(B), dim3(1024), (size_t)7 * n_cap * sizeof(float), st, src, conf, n_rows, n_cap,
+                           M.cfg.nms_radius, S_cap, M.cfg.ratio, key_scratch, seeds, n_seeds);
+        return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
+    }
     size_t P = 256;
     while (P < (size_t)n_cap) P <<= 1;
     hipLaunchKernelGGL(pdsc_seed_keys_kernel, dim3(n_cap / 64, B), dim3(256), (size_t)4 * n_cap * sizeof(float), st, src, conf, n_rows, n_cap,
@@ -641,6 +949,31 @@ int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float
     size_t P = 256;
     while (P < (size_t)n_cap) P <<= 1;
     const size_t sh1 = (2 * P + C + (size_t)KNN_MAX_K * (C + 4) + KNN_MAX_K * 6 + KNN_MAX_K) * sizeof(float);
+    const int nit = M.cfg.num_iterations < HYP_MAX_IT ? M.cfg.num_iterations : HYP_MAX_IT;
+    // round 5: distances + kNN (rank counting) + compatibility matrix + power iteration in ONE launch (0 = the separate kernels, dev build)
+    static const bool fused_hyp = dev_env_int("ORYON_PDSC_FUSED_HYP", 1) != 0;
+    if (fused_hyp && C == 128 && n_cap <= 1024 && k <= KNN_MAX_K - 1 && (size_t)S_cap * 128 * sizeof(float) <= 64 * 1024) {
+        static const bool dist_mfma = dev_env_int("ORYON_PDSC_DIST_MFMA", 1) != 0;          // dev build: 0 = the VALU kernel
+        if (dist_mfma) {
+            const size_t shd = (size_t)((S_cap + 31) / 32 * 32) * 129 * sizeof(float);
+            allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_seed_dist_mfma_kernel), (int)shd);
+            hipLaunchKernelGGL(pdsc_seed_dist_mfma_kernel, dim3(n_cap / 64, B), dim3(256), shd, st, feat_n, n_rows, n_cap, seeds, n_seeds, S_cap,
+                               ws.seed_dist);
+        } else
+        hipLaunchKernelGGL((pdsc_seed_dist_kernel<128>), dim3(n_cap / 64, B), dim3(256), (size_t)S_cap * 128 * sizeof(float), st, feat_n, n_rows,
+                           n_cap, seeds, n_seeds, S_cap, ws.seed_dist);
+        const int ept = n_cap <= 512 ? 2 : 4;
+        const size_t shf = ((size_t)512 + (size_t)k * (C + 4) + k * 6 + KNN_MAX_K) * sizeof(float);
+        const dim3 grid(S_cap, (B + 7) / 8 * 8);
+        if (ept == 2)
+            hipLaunchKernelGGL(pdsc_hyp_fused_kernel<2>, grid, dim3(256), shf, st, feat_n, src, tgt, n_rows, n_cap, ws.seed_dist, n_seeds, S_cap, k,
+                               1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, B);
+        else
+            hipLaunchKernelGGL(pdsc_hyp_fused_kernel<4>, grid, dim3(256), shf, st, feat_n, src, tgt, n_rows, n_cap, ws.seed_dist, n_seeds, S_cap, k,
+                               1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, B);
+        if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
+        hipLaunchKernelGGL(pdsc_power_kernel, dim3(S_cap, B), dim3(64), 0, st, n_rows, n_seeds, S_cap, k, nit, ws.Mmat, ws.v_hist, ws.close_hist);
+    } else {
     const float *dist_pre = nullptr;
     if (C == 128 && (size_t)S_cap * 128 * sizeof(float) <= 64 * 1024) {
         hipLaunchKernelGGL((pdsc_seed_dist_kernel<128>), dim3(n_cap / 64, B), dim3(256), (size_t)S_cap * 128 * sizeof(float), st, feat_n, n_rows,
@@ -661,8 +994,8 @@ int pdsc_run_hypotheses(const PdscModel &M, const PdscWorkspace &ws, const float
     hipLaunchKernelGGL(pdsc_knn_matrix_kernel, dim3(S_cap, (B + 7) / 8 * 8), dim3(256), sh1, st, feat_n, src, tgt, n_rows, n_cap, C, seeds,
                        n_seeds, S_cap, k, 1.0f / (M.sigma * M.sigma), 1.0f / (M.sigma_d * M.sigma_d), ws.knn, ws.Mmat, dist_pre, B);
     if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
-    const int nit = M.cfg.num_iterations < HYP_MAX_IT ? M.cfg.num_iterations : HYP_MAX_IT;
     hipLaunchKernelGGL(pdsc_power_kernel, dim3(S_cap, B), dim3(64), 0, st, n_rows, n_seeds, S_cap, k, nit, ws.Mmat, ws.v_hist, ws.close_hist);
+    }
     hipLaunchKernelGGL(pdsc_seed_solve_kernel, dim3(S_cap, B), dim3(64), 0, st, src, tgt, n_rows, n_cap, n_seeds, S_cap, k, nit,
                        M.cfg.inlier_threshold, ws.knn, ws.v_hist, ws.close_hist, seed_T, fitness);
     hipLaunchKernelGGL(pdsc_seed_select_kernel, dim3(B), dim3(256), 0, st, src, tgt, n_rows, n_cap, n_seeds, S_cap, M.cfg.inlier_threshold,

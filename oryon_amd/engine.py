@@ -59,6 +59,7 @@ class NativeStep:
     _SLOT_VIEWS = {  # name -> (dtype, shape builder)
         "pose": (torch.float32, lambda g: (g["B"], 4, 4)), "status_out": (torch.int32, lambda g: (g["B"],)),
         "n_valid": (torch.int32, lambda g: (g["B"],)), "n_lift": (torch.int32, lambda g: (g["B"],)),
+        "n_valid_out": (torch.int32, lambda g: (g["B"],)), "n_lift_out": (torch.int32, lambda g: (g["B"],)),
         "n_a": (torch.int32, lambda g: (g["B"],)), "n_q": (torch.int32, lambda g: (g["B"],)), "n_und": (torch.int32, lambda g: (g["B"],)),
         "n_sel": (torch.int32, lambda g: (g["B"],)), "status": (torch.int32, lambda g: (g["B"],)),
         "roi_a": (torch.int32, lambda g: (g["B"], g["HW"])), "roi_q": (torch.int32, lambda g: (g["B"], g["HW"])),
@@ -225,19 +226,11 @@ class MatchPoseEngine:
                 for k, v in list(out.items()):           # the slot buffers are re-used n_slots steps later: hand out copies
                     if isinstance(v, Tensor):
                         out[k] = v.clone()
-                queued = True
+                # pose / status / n_valid / n_lifted come out of the protected block: only a `keep` step's extra buffers need the event
+                queued = queued or len(out) > 4
             elif len(out) > 4:
                 # views of a `keep` step (more than pose / status / n_valid / n_lifted): the caller may read them whenever it likes
                 self._native.reads_pending[slot] = True
-            else:
-                # result views of an ordinary step: pose / status live in the slot's PROTECTED block (the engine orders their next
-                # overwrite after the caller's stream), the two counters do not (include/oryon_hip.h, "slot lifetime") - a view of them
-                # read asynchronously n_slots steps later would race with the matcher / lift of the step that re-uses the slot.  They
-                # leave as copies (2 x B int32, queued here behind the step), and the event below marks where those reads end.
-                for k in ("n_valid", "n_lifted"):
-                    if isinstance(out.get(k), Tensor):
-                        out[k] = out[k].clone()
-                queued = True
             if queued and self._native.reads_pending[slot] is not True:
                 # reads of the slot's unprotected buffers now sit on the caller's stream: remember where they end.  If they have
                 # completed by the time the slot comes round again (the usual case, n_slots steps later) nothing needs ordering
@@ -344,8 +337,10 @@ class MatchPoseEngine:
         slot = nat.submit(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key, keep, resident)
         # the engine's streams read the inputs asynchronously: the result dict keeps them alive until `finish` has ordered the caller's
         # stream after the step (an input freed earlier could be handed to a new tensor and overwritten while the step still reads it)
-        out = dict(pose=nat.view(slot, "pose"), status=nat.view(slot, "status_out"), n_valid=nat.view(slot, "n_valid"),
-                   n_lifted=nat.view(slot, "n_lift"), _native_slot=slot,
+        # all four are views of the slot's PROTECTED block (the engine orders their next overwrite after the caller's stream): the two
+        # counters are the registration stream's copies of the matcher's n_valid / the lift's n_lift, not the unprotected originals
+        out = dict(pose=nat.view(slot, "pose"), status=nat.view(slot, "status_out"), n_valid=nat.view(slot, "n_valid_out"),
+                   n_lifted=nat.view(slot, "n_lift_out"), _native_slot=slot,
                    _inputs=(feat_a, feat_q, mask_a, mask_q, depth_a, depth_q, cam_a, cam_q, pair_key))
         if keep:
             for k in ("roi_a", "roi_q", "n_a", "n_q", "min_dist", "argmin", "valid", "corrs", "pcd_a", "pcd_q"):
