@@ -343,6 +343,9 @@ def main():
                          "allocation per step); python: the per-call schedule of oryon_amd/engine.py (torch streams, ~40 torch allocations per step)")
     ap.add_argument("--screen", choices=["mx6", "int8"], default="mx6",
                     help="screening operands of the native engine's lazy matcher: MX-fp6 (v_mfma_scale_f32_32x32x64_f8f6f4, default) or int8")
+    ap.add_argument("--input-sets", type=int, default=4,
+                    help="distinct sets of B synthetic pairs (descriptor maps, masks, depths, poses AND pair keys) the timed steps rotate through: "
+                         "step k runs on set k %% N, so no step re-reads the maps its predecessor left in the Infinity Cache / L2 (VERDICT r04)")
     ap.add_argument("--no-stage-sets", action="store_true",
                     help="skip the 'decode+match+pose' and 'full' stage sets that the default run measures after the headline")
     ap.add_argument("--collation-selftest", action="store_true",
@@ -374,37 +377,49 @@ def main():
     B, H, C = a.batch, a.size, a.channels
     if a.stages in ("full", "decode"):
         return bench_full(a, rank, world, dev)
-    inputs = make_inputs(B, H, C, first=rank * B, dev=dev)
-    if a.layout == "nhwc":
-        inputs["feat_a"] = inputs["feat_a"].contiguous(memory_format=torch.channels_last)
-        inputs["feat_q"] = inputs["feat_q"].contiguous(memory_format=torch.channels_last)
+    # N distinct input sets: set s holds the global pairs [s * world * B, (s + 1) * world * B), this rank its block of B of them
+    n_sets = max(1, a.input_sets)
+    total = B * world
+    sets = []
+    for s_ in range(n_sets):
+        d_ = make_inputs(B, H, C, first=s_ * total + rank * B, dev=dev)
+        if a.layout == "nhwc":
+            d_["feat_a"] = d_["feat_a"].contiguous(memory_format=torch.channels_last)
+            d_["feat_q"] = d_["feat_q"].contiguous(memory_format=torch.channels_last)
+        d_["cam"] = d_["cam"].reshape(B, 9).to(torch.float32).contiguous()     # the C ABI's type: fp32 [B,9] (pipeline.py:434-435 + lift_pcd)
+        d_["key"] = torch.arange(s_ * total + rank * B, s_ * total + rank * B + B, dtype=torch.int64, device=dev)
+        sets.append(d_)
+    inputs = sets[0]
     engine = MatchPoseEngine(build_solver(dev), MatchPoseConfig(dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1,
                                                                 match_mode=a.match_mode, sample_first=a.sample_first),
                              overlap_registration=not a.no_overlap, overlap_gather=a.overlap_gather and not a.no_overlap,
                              native=a.engine == "native", result_views=True)
     engine.native_timing = True           # HIP events around the three sections and the screening kernel of every native step
     engine.native_geometry["screen"] = 1 if a.screen == "mx6" else 0
-    key = torch.arange(rank * B, rank * B + B, dtype=torch.int64, device=dev)
-    total = B * world
-    # the C ABI's input types, made once: fp32 [B,9] intrinsics (the reference's float64 [B,3,3] rounded, as pipeline.py:434-435 + lift_pcd do)
-    inputs["cam"] = inputs["cam"].reshape(B, 9).to(torch.float32).contiguous()
-    host = {"submit_s": 0.0, "submits": 0}
+    key = inputs["key"]
+    host = {"submit_s": 0.0, "submits": 0, "rot": 0, "set_of": {}, "last_set": 0}
 
-    def submit(keep=False):
+    def submit(keep=False, which=None):
+        idx_ = host["rot"] % n_sets if which is None else which
+        d_ = sets[idx_]
+        if which is None:
+            host["rot"] += 1
         t_ = time.perf_counter()
-        out = engine.run(inputs["feat_a"], inputs["feat_q"], inputs["mask_a"], inputs["mask_q"], inputs["depth_a"],
-                         inputs["depth_q"], inputs["cam"], inputs["cam"], key, keep=keep, inputs_resident=True)
+        out = engine.run(d_["feat_a"], d_["feat_q"], d_["mask_a"], d_["mask_q"], d_["depth_a"],
+                         d_["depth_q"], d_["cam"], d_["cam"], d_["key"], keep=keep, inputs_resident=True)
         host["submit_s"] += time.perf_counter() - t_
         host["submits"] += 1
+        host["set_of"][id(out)] = idx_                      # (not a key of `out`: the engine tells keep steps from ordinary ones by its size)
         return out
 
     def collect(out):
+        host["last_set"] = host["set_of"].pop(id(out), host["last_set"])
         engine.finish(out)
         pose, status = gather_poses(out["pose"], out["status"], total)
         return out, pose, status
 
     def step(keep=False):
-        return collect(submit(keep))
+        return collect(submit(keep, which=0))          # the sanity / checksum step: always input set 0
 
     def run_steps(n):
         """n complete steps; with overlap the registration of step k runs on a second stream under the matching of step k+1
@@ -602,6 +617,8 @@ def main():
                 "descriptor_layout": "NCHW contiguous fp32 (as Oryon.forward returns them)" if a.layout == "nchw" else "channels_last (NHWC storage) fp32",
                 "match_mode": a.match_mode + ((" (MX-fp6 MFMA screen with a proven bound, exact fp32 re-scoring of the sampled anchors' candidates; anchors the bound cannot settle are resolved exactly: outputs identical to the fp32 scan)" if native is not None and engine.native_geometry.get("screen", 0) == 1 else " (int8-MFMA pre-screen, fp16-MFMA screening of the undecided anchors, exact fp32 re-scoring: outputs identical to the fp32 scan)") if use_i8 else " (fp16-MFMA screening, exact fp32 re-scoring: outputs identical to the fp32 scan)" if screened else ""),
                 "sample_first": a.sample_first or None,
+                "input_sets": f"{n_sets} distinct sets of {B} pairs per GPU (maps, masks, depths, poses, pair keys), step k runs on set k % {n_sets}; "
+                              "sanity / pose_sha256 on set 0",
                 "pairs_per_gpu": B, "global_pairs": total, "parallelism": f"pairs sharded over {world} GPU(s), all_gather of poses",
                 "pipelining": ("none" if a.no_overlap else "registration of step k on a second HIP stream under the matching of step k+1"
                                + ("; K0 (ROI + gather) of step k+1 on a third stream under the screening / registration of step k"
@@ -646,6 +663,7 @@ def main():
         if rank == 0:
             smine = sout["pose"].cpu()
             sok = sout["status"].cpu() == 0
+            gt = sets[host["last_set"]]["pose_gt"].to(torch.float32)          # the input set the last step ran on
             sfirst = {"schedule": "matcher on a uniformly random 1024-anchor subset per pair first (>= 500 valid rows there give an identically "
                                   "distributed sample of the 500 correspondences); pairs that come up short are redone on all anchors, gated on "
                                   "the device.  NOT the headline: the default route settles the validity of all <= 5000 anchors like the reference",
@@ -658,13 +676,14 @@ def main():
     # cannot separate the candidates
     hard = None
     if not a.no_stage_sets and (H, C) == (224, 256):
-        gen = torch.Generator(device=dev).manual_seed(77 + rank)
         yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=dev), torch.linspace(0, 1, H, device=dev), indexing="ij")
         coef = torch.stack([torch.ones_like(xx), xx, yy, xx * yy, torch.sin(3 * xx), torch.cos(3 * yy), torch.sin(7 * yy), torch.cos(5 * xx)])
-        basis = torch.randn((B, C, coef.shape[0]), generator=gen, device=dev)
-        inputs["feat_q"].copy_(torch.einsum("bck,khw->bchw", basis, coef))
-        inputs["feat_q"].add_(0.02 * torch.randn(inputs["feat_q"].shape, generator=gen, device=dev))
-        inputs["feat_a"].copy_(inputs["feat_q"]).add_(0.01 * torch.randn(inputs["feat_a"].shape, generator=gen, device=dev))
+        for s_, d_ in enumerate(sets):                # every input set gets its own smooth fields (same rotation as the headline)
+            gen = torch.Generator(device=dev).manual_seed(77 + rank + 1000 * s_)
+            basis = torch.randn((B, C, coef.shape[0]), generator=gen, device=dev)
+            d_["feat_q"].copy_(torch.einsum("bck,khw->bchw", basis, coef))
+            d_["feat_q"].add_(0.02 * torch.randn(d_["feat_q"].shape, generator=gen, device=dev))
+            d_["feat_a"].copy_(d_["feat_q"]).add_(0.01 * torch.randn(d_["feat_a"].shape, generator=gen, device=dev))
         torch.cuda.synchronize()                      # the gather stream reads the maps as soon as a step is submitted: finish rewriting them first
         engine.collect_i8_stats = True                # report the int8 stage's undecided fraction on these inputs (asynchronous, no sync)
         run_steps(3)                                  # lets the asynchronous statistics arrive
@@ -688,18 +707,18 @@ def main():
                     "k0_passes_with_hi_lo_rows": (engine._native.x3_steps() if engine._native is not None else None),
                     "fraction_of_headline": total * HARD_STEPS / float(hel.item()) / rec["value"],
                     "pairs_ok": int((hstatus[:total] == 0).sum())}
-    # the other two stage sets of SURVEY 8(d), measured in this same run (short: 3 steps each) and carried in the same line; `value`
+    # the other two stage sets of SURVEY 8(d), measured in this same run (10 steps each) and carried in the same line; `value`
     # stays the configs[1] number (descriptors given)
     stage_recs = {}
     if not a.no_stage_sets:
-        del inputs, engine
+        del inputs, engine, sets
         torch.cuda.empty_cache()
         for stage, bdt, label in (("decode", "fp16x3", "decode+match+pose"),
                                   ("decode", "fp32", "decode+match+pose, torch / MIOpen fp32 modules"),
                                   ("full", "fp32", "full (feat+match+pose), fp32 torch linears"),
                                   ("full", "fp16x3", "full (feat+match+pose), fp16x3 linears"),
                                   ("full", "bf16w", "full (feat+match+pose), bf16 backbone (weights + activations) - NOT fp32-grade: for the record only")):
-            r = run_stage_set(a, rank, world, dev, stage, steps=3, warmup=1, backbone_dtype=bdt)
+            r = run_stage_set(a, rank, world, dev, stage, steps=10, warmup=2, backbone_dtype=bdt)
             if rank == 0:
                 stage_recs[label] = r
     if rank == 0:
