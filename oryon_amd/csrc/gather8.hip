@@ -500,12 +500,13 @@ constexpr int G4_TERMS = 2 * 8 * 64 * 4;        // (block error sum, block expon
 constexpr int G4_LDS = G4_STAGE + G4_HAND + G4_TERMS;
 constexpr int G4_STAGE32 = 4096;              // per wave, WANT32 only: 64 rows x 64 B
 
-template <bool WANT32>
-__global__ __launch_bounds__(256, 4) void gather_mx6_v4_kernel(
+template <bool WANT32, bool X3 = false>
+__global__ __launch_bounds__(256, X3 ? 3 : 4) void gather_mx6_v4_kernel(
     const float *__restrict__ feat, int C, int HW, const int32_t *__restrict__ roi, int roi_stride, const int32_t *__restrict__ count,
     int rows_cap, int n_maps, int chunk_tiles, int chunks_per_map, uint8_t *__restrict__ out8, unsigned *__restrict__ eps_max,
-    float *__restrict__ norm, float *__restrict__ out32, int round_f16)
+    float *__restrict__ norm, float *__restrict__ out32, int round_f16, void *__restrict__ aux = nullptr, unsigned *__restrict__ lo_max = nullptr)
 {
+    static_assert(!(WANT32 && X3), "the hi / lo rows are a query-side product");
     extern __shared__ __attribute__((aligned(256))) char lds4[];
     char *stage = lds4;
     float *hand = reinterpret_cast<float *>(lds4 + G4_STAGE);
@@ -609,7 +610,60 @@ __global__ __launch_bounds__(256, 4) void gather_mx6_v4_kernel(
         }
     }
 
-    // MX-fp6 slots of this wave's two blocks (arithmetic of K0v3, FMT = 1)
+    if constexpr (X3) {
+        // FMT = 3 (the engine's K0 pass when recent steps needed the second level): besides the mx6 slots, the canonical unit row
+        // u = RN(x / d) as error-compensated float16 halves hi = half(u), lo = half(u - hi) for K1x3 (match_x3.hip) - layout of K0v3:
+        // tiles of 32 rows, inside a tile the four 64-channel chunks one after the other, hi array then lo array in `aux`.  This
+        // wave's chunk is chunk `wave`; it leaves in four passes (block 0 hi, lo, block 1 hi, lo) of 64 bytes per row through the
+        // wave-private 4 KB stage, 16 rows x 64 B per store instruction.  The unit values replace the raw ones in place (the fp6
+        // conversion below then works on them, as K0v3's FMT = 3 does).
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            R.set(i, __fdiv_rn(R.get(i), d));
+            if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+        }
+        float lo2 = 0.0f;
+        if (wave * 64 < C) {                                            // chunks beyond the map's channels are not written (readers skip them)
+            constexpr size_t HB = 512;                                  // bytes per half row
+            char *st16 = lds4 + G4_LDS + wave * G4_STAGE32;
+            char *ob[2];
+            ob[0] = reinterpret_cast<char *>(aux) + ((size_t)m * rows_cap + row0) * HB + wave * 4096;
+            ob[1] = ob[0] + (size_t)n_maps * rows_cap * HB;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int blk = pass >> 1, lo_pass = pass & 1;
+                WAVE_LDS_ORDER();
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    unsigned w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float u0 = R.get(32 * blk + 8 * sl + 2 * j), u1 = R.get(32 * blk + 8 * sl + 2 * j + 1);
+                        const __half h0 = __float2half_rn(u0), h1 = __float2half_rn(u1);
+                        if (lo_pass) {
+                            const float d0 = u0 - __half2float(h0), d1 = u1 - __half2float(h1);      // exact: hi is u rounded to 11 bits
+                            const __half l0 = __float2half_rn(d0), l1 = __float2half_rn(d1);
+                            w[j] = (unsigned)__half_as_ushort(l0) | ((unsigned)__half_as_ushort(l1) << 16);
+                            lo2 += fmaf(d0, d0, d1 * d1);                                               // |lo| <= |d| (1 + 2^-11)
+                        } else {
+                            w[j] = (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16);
+                        }
+                    }
+                    *reinterpret_cast<uint4 *>(st16 + lane * 64 + ((sl ^ ((lane >> 1) & 3)) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                WAVE_LDS_ORDER();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = j * 16 + (lane >> 2), sl = lane & 3;
+                    const uint4 q = *reinterpret_cast<const uint4 *>(st16 + t * 64 + ((sl ^ ((t >> 1) & 3)) << 4));
+                    *reinterpret_cast<uint4 *>(ob[lo_pass] + (size_t)(t >> 5) * (32 * HB) + (t & 31) * 128 + blk * 64 + sl * 16) = q;
+                }
+            }
+        }
+        reinterpret_cast<float *>(lds4 + G4_LDS + 4 * G4_STAGE32)[wave * 64 + lane] = lo2;       // per-wave partial |u - hi|^2 of the row
+    }
+
+    // MX-fp6 slots of this wave's two blocks (arithmetic of K0v3, FMT = 1; FMT = 3: on the unit values)
     const float rd = __fdiv_rn(1.0f, d);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -617,11 +671,11 @@ __global__ __launch_bounds__(256, 4) void gather_mx6_v4_kernel(
         float bm = 0.0f;
 #pragma unroll
         for (int i = 0; i < 32; ++i) bm = fmaxf(bm, fabsf(R.get(32 * b + i)));
-        const float r = __fdiv_rn(bm, d) * (1.0f / 7.5f);
+        const float r = (X3 ? bm : __fdiv_rn(bm, d)) * (1.0f / 7.5f);
         int e = r > 0.0f ? ilogbf(r) + 1 : -40;
         if (r > 0.0f && ldexpf(1.0f, e - 1) >= r) e -= 1;
         e = e < -40 ? -40 : (e > 8 ? 8 : e);
-        const float rde = rd * ldexpf(1.0f, -e);
+        const float rde = (X3 ? 1.0f : rd) * ldexpf(1.0f, -e);
         R.t[2 * b] *= rde;
         R.t[2 * b + 1] *= rde;
         const f32x16g ev = R.t[2 * b], od = R.t[2 * b + 1];
@@ -659,6 +713,12 @@ __global__ __launch_bounds__(256, 4) void gather_mx6_v4_kernel(
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) er = fmaxf(er, __shfl_xor(er, off));
         if (lane == 0 && er > 0.0f) atomicMax(&eps_max[m], __float_as_uint(er));
+        if constexpr (X3) {
+            // largest |u - hi|_2^2 of the map's rows (K1x3's first sweep multiplies hi parts only); dead rows are zero rows
+            const float *lp = reinterpret_cast<const float *>(lds4 + G4_LDS + 4 * G4_STAGE32);
+            const float lo2 = ((lp[lane] + lp[64 + lane]) + lp[128 + lane]) + lp[192 + lane];
+            if (lo_max && lo2 > 0.0f && __float_as_uint(lo2) > __atomic_load_n(&lo_max[m], __ATOMIC_RELAXED)) atomicMax(&lo_max[m], __float_as_uint(lo2));
+        }
     }
 }
 
@@ -706,21 +766,30 @@ int gather_q8_launch(const float *feat, int n_maps, int C, int HW, int layout, c
     // K0v4 (round 5): the MX-fp6 pass over wide channel-planar maps; everything else (narrow maps, channels_last, C_pad 512, the
     // device-gated fall-back passes) stays on K0v3
     static const int v4 = dev_env_int("ORYON_K0V4", 1);
-    if (fmt == 1 && v4 && C_pad == 256 && C > 128 && layout == ORYON_LAYOUT_NCHW && !map_enable && lanes_per_row != 2) {
+    if ((fmt == 1 || (fmt == 3 && aux && scale && !out32)) && v4 && C_pad == 256 && C > 128 && layout == ORYON_LAYOUT_NCHW && !map_enable &&
+        (lanes_per_row != 2 || fmt == 3)) {
         const int T = (rows_cap + 63) / 64;
         const int chunks_per_map = n_maps >= 8 ? 1 : (8 + n_maps - 1) / n_maps;
         const int chunk_tiles = (T + chunks_per_map - 1) / chunks_per_map;
         const int units = n_maps * chunks_per_map;
         const int groups = ((units + 7) / 8) * 8 * chunk_tiles;
-        if (out32) {
+        if (fmt == 3) {
+            auto k4 = gather_mx6_v4_kernel<false, true>;
+            constexpr int X3_LDS = G4_LDS + 4 * G4_STAGE32 + 1024;
+            hipLaunchKernelGGL(k4, dim3(groups), dim3(256), X3_LDS, st, feat, C, HW, roi, roi_stride, count, rows_cap, n_maps, chunk_tiles,
+                               chunks_per_map, reinterpret_cast<uint8_t *>(out8), reinterpret_cast<unsigned *>(eps), norm, out32, round_f16, aux,
+                               reinterpret_cast<unsigned *>(scale));
+        } else if (out32) {
             auto k4 = gather_mx6_v4_kernel<true>;
             allow_dynamic_lds(reinterpret_cast<const void *>(k4), G4_LDS + 4 * G4_STAGE32);
             hipLaunchKernelGGL(k4, dim3(groups), dim3(256), G4_LDS + 4 * G4_STAGE32, st, feat, C, HW, roi, roi_stride, count, rows_cap, n_maps,
-                               chunk_tiles, chunks_per_map, reinterpret_cast<uint8_t *>(out8), reinterpret_cast<unsigned *>(eps), norm, out32, round_f16);
+                               chunk_tiles, chunks_per_map, reinterpret_cast<uint8_t *>(out8), reinterpret_cast<unsigned *>(eps), norm, out32, round_f16,
+                               nullptr, nullptr);
         } else {
             auto k4 = gather_mx6_v4_kernel<false>;
             hipLaunchKernelGGL(k4, dim3(groups), dim3(256), G4_LDS, st, feat, C, HW, roi, roi_stride, count, rows_cap, n_maps, chunk_tiles,
-                               chunks_per_map, reinterpret_cast<uint8_t *>(out8), reinterpret_cast<unsigned *>(eps), norm, out32, round_f16);
+                               chunks_per_map, reinterpret_cast<uint8_t *>(out8), reinterpret_cast<unsigned *>(eps), norm, out32, round_f16,
+                               nullptr, nullptr);
         }
         return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
     }

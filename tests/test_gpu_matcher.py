@@ -83,11 +83,21 @@ def test_nn_correspondences_dropin(name):
     assert out.dtype == torch.int64 and tuple(out.shape) == (500, 4) and out.device.type == "cuda"
     got = out.cpu().numpy()
     ref = g["sampled_corrs"]
-    if np.array_equal(got, ref):
+    if np.array_equal(got, ref):                    # the case on every fixture (tools/r5_loose_diag.py: 0 differing rows on all nine)
         return
-    # only rows whose argmin is a sub-1e-6 near-tie in the reference may differ
-    diff = np.any(got != ref, axis=1)
-    assert diff.mean() < 0.02, f"{diff.sum()} of 500 sampled rows differ"
+    # Anything else must be explained row by row: the sampled ANCHORS are the reference's (same valid set, same RNG draws), and a row may
+    # name another query pixel only if that pixel is an exact-arithmetic near-tie of the reference's choice (|d(got) - d(ref)| < 1e-6 in
+    # float64: the reference's own fp32 rounding decides such rows)
+    assert np.array_equal(got[:, :2], ref[:, :2]), "a sampled anchor differs from the reference's"
+    f1, f2 = g["feats1"].astype(np.float64), g["feats2"].astype(np.float64)
+    for r in np.nonzero(np.any(got != ref, axis=1))[0]:
+        a = f1[:, got[r, 0], got[r, 1]]
+        a = a / max(np.linalg.norm(a), 1e-8)
+        d = []
+        for y, x in ((got[r, 2], got[r, 3]), (ref[r, 2], ref[r, 3])):
+            q = f2[:, y, x]
+            d.append(0.5 * (1.0 - a @ (q / max(np.linalg.norm(q), 1e-8))))
+        assert abs(d[0] - d[1]) < 1e-6, f"row {r}: distances {d[0]:.9f} (HIP) vs {d[1]:.9f} (reference) are not a near-tie"
 
 
 @pytest.mark.parametrize("C,H,W,seed", [(32, 40, 40, 1), (256, 24, 24, 2), (96, 31, 37, 3), (1, 16, 16, 4), (33, 20, 20, 5)])

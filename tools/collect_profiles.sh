@@ -12,8 +12,9 @@ cd /tmp
 python $R/bench.py --no-cpu-baseline --no-stage-sets > "$OUT/bench_line.json" 2> /tmp/bench.err
 D=/tmp/prof_trace; rm -rf $D
 rocprofv3 --kernel-trace --stats -d $D -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-sets > /tmp/trace.log 2>&1
-python $R/tools/rocpd_summary.py $D/bench_results.db > "$OUT/kernel_stats.md"
-RX='mx6_screen|screen_v2_kernel|gather_q8_v3|pdsc_attention|match_decide|match_resolve|pdsc_linear|pdsc_pcn_qkv|pdsc_mlp3'
+python $R/tools/rocpd_summary.py $D/bench_results.db --after "distribution_elementwise|index_elementwise" > "$OUT/kernel_stats.md"
+python $R/tools/rocpd_summary.py $D/bench_results.db > "$OUT/kernel_stats_whole_run.md"
+RX='mx6_screen|screen_v2_kernel|gather_q8_v3|gather_mx6_v4|pdsc_att|match_decide|match_resolve|pdsc_linear|pdsc_pcn_qkv|pdsc_mlp3|pdsc_hyp|pdsc_seed'
 {
   echo "# rocprofv3 PMC passes: bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap (2 engine passes, B=64), kernels /$RX/"
   for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \

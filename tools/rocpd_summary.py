@@ -3,25 +3,35 @@
 (the same content as `--stats` CSV output): calls, total / average / min / max duration, share.
 Optionally also dumps PMC counter sums per kernel.
 
-    python tools/rocpd_summary.py gpurun_out/prof/bench_results.db [--exclude REGEX] > profiles/r01_bench_kernel_stats.md
-"""
+    python tools/rocpd_summary.py gpurun_out/prof/bench_results.db [--exclude REGEX] [--after REGEX] > profiles/r01_bench_kernel_stats.md
+
+--after REGEX: only dispatches that START after the last dispatch matching REGEX has ended (round 5: bench.py's input generation is
+torch RNG kernels and ~2000 copies; `--after distribution_elementwise` leaves the engine's steps, so that the per-step copy / fill
+counts can be read off)."""
 import re
 import sqlite3
 import sys
 
 
-def main(path, exclude=None):
+def main(path, exclude=None, after=None):
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
+    where = ""
+    if after:
+        ends = [e for n, e in c.execute(f"select {name_col}, end from kernels") if re.search(after, n)]
+        if ends:
+            where = f" where start > {max(ends)}"
     rows = c.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                     f"from kernels group by {name_col} order by 3 desc").fetchall()
+                     f"from kernels{where} group by {name_col} order by 3 desc").fetchall()
     dropped = 0.0
     if exclude:
         dropped = sum(r[2] for r in rows if re.search(exclude, r[0])) / 1e6
         rows = [r for r in rows if not re.search(exclude, r[0])]
     total = sum(r[2] for r in rows) or 1
     print(f"# rocprofv3 kernel-trace summary of `{path.split('/')[-1]}`\n")
+    if where:
+        print(f"(only dispatches after the last one matching /{after}/ - the run's set-up - had ended)\n")
     if exclude:
         print(f"(kernels matching /{exclude}/ left out: {dropped:.1f} ms in total - one-off library auto-tuning launches of the warm-up pass)\n")
     print("| kernel | calls | total ms | avg us | min us | max us | % of GPU time |")
@@ -44,4 +54,5 @@ def main(path, exclude=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "--exclude" else None)
+    opt = dict(zip(sys.argv[2::2], sys.argv[3::2]))
+    main(sys.argv[1], opt.get("--exclude"), opt.get("--after"))
