@@ -448,6 +448,13 @@ int oryon_engine_x3_steps(const oryon_engine_t *handle, int64_t *n_steps);
  *     into the epilogue.
  *     K % 32 == 0, N % 256 == 0 (N % 128 == 0 when K >= 64), N * K < 2^30, |values| < 65504. */
 int oryon_split_f16x3(const float *x, int64_t n, void *hi_f16, void *lo_f16, void *stream);
+/* Range check of the fp16x3 path (round 5): every fp16x3 kernel of this library (B4 linear, B5 attention, the Swin / fusion window
+ * attentions, the 24 x 24 and decoder convolutions) ORs 1 into a per-device flag word when one of its raw accumulators is not a finite
+ * value below 60000 in magnitude - which is what an operand beyond float16's range (|x| >= 65520: hi = inf) produces in every product it
+ * enters, and what an output that the NEXT kernel could not split looks like.  oryon_x3_range_flag copies the flag to *value_out after
+ * everything queued on `stream` (synchronises that stream: call it once per forward, not per layer) and clears it when reset != 0.
+ * The Python towers (oryon_amd.net.Oryon.forward) re-evaluate a forward whose flag came back set with the fp32 torch modules. */
+int oryon_x3_range_flag(int *value_out, int reset, void *stream);
 int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,
                        void *stream);
 

@@ -75,6 +75,7 @@ _PROTOS = {
     "oryon_match_corrs_i8": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                                      _P, _P, c_float, c_int, c_int, c_int, c_uint64, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P,
                                      c_size_t, _P]),
+    "oryon_x3_range_flag": (c_int, [POINTER(c_int), c_int, _P]),
     "oryon_gather_mx6": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "oryon_match_corrs_mx6": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int,
                                       _P, _P, c_float, c_int, c_int, c_int, c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P,

@@ -43,6 +43,7 @@ struct DecConv {
     float *out;               // NHWC [n, H, W, out_cstride], channels out_coff .. out_coff + cout - 1
     float *stats;             // [n, tiles, cout / 16, 2] partial (sum, sum of squares) of the raw outputs, or NULL
     int H, W, cin, in_cstride, in_coff, out_cstride, out_coff, cout, relu;
+    unsigned *range_flag;     // per-device flag word (common.h: x3_range_flag), or NULL
 };
 
 static __device__ __forceinline__ void split_h(float v, _Float16 &hi, _Float16 &lo)
@@ -293,6 +294,18 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
                 red[wave][nb * 2 + (lane >> 4)][1] = s2;
             }
         }
+        if constexpr (!WREG) if (a.range_flag && co < a.cout) {
+            // range flag (common.h): the pre-activation values of this block once more, after the stores.  Not in the single-slab
+            // persistent instantiations (WREG: 36 weight fragments resident, 248-252 registers - the check spilled 8-15 of them): their
+            // inputs are the up-convolution's outputs (checked there) and GroupNorm-normalised maps, i.e. in range by construction,
+            // and their raw outputs are only ever consumed through the next GroupNorm (fp32 statistics).
+            unsigned mg = 0u;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mg = max(mg, x3_mag(acc[mb][nb][r] + bv));
+            x3_raise(a.range_flag, mg);
+        }
     }
     if (a.stats) {
         __syncthreads();
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(64) void dec_gn_affine_kernel(const float *__restri
 template <int KS, bool IN_NCHW, bool IN_GN>
 __global__ __launch_bounds__(256) void dec_upconv_kernel(const float *__restrict__ in, const float *__restrict__ affine, int Hin, int Win,
                                                          int in_cstride, const dh8 *__restrict__ wimg, const float *__restrict__ bias,
-                                                         float *__restrict__ out, int out_cstride, int cout, int nbp)
+                                                         float *__restrict__ out, int out_cstride, int cout, int nbp, unsigned *__restrict__ range_flag)
 {
     constexpr int CIN = KS * 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, kg = lane >> 5;
@@ -393,6 +406,7 @@ __global__ __launch_bounds__(256) void dec_upconv_kernel(const float *__restrict
         }
     }
     const int Hout = 2 * Hin, Wout = 2 * Win;
+    unsigned x3m = 0u;
     for (int nb = 0; nb < 4 * nbp; ++nb) {
         dacc16 acc;
 #pragma unroll
@@ -413,8 +427,10 @@ __global__ __launch_bounds__(256) void dec_upconv_kernel(const float *__restrict
             const int m = 8 * (r >> 2) + 4 * kg + (r & 3);
             const int q = p0 + m, y = q / Win, x = q % Win;
             out[(((size_t)img * Hout + 2 * y + (dydx >> 1)) * Wout + 2 * x + (dydx & 1)) * out_cstride + co] = acc[r] + bv;
+            x3m = max(x3m, x3_mag(acc[r] + bv));
         }
     }
+    x3_raise(range_flag, x3m);
 }
 
 // Last layer: GroupNorm + ReLU of decoder3's second convolution, the descriptor map as NCHW fp32 (models/decoder.py:98: the clone that
@@ -478,6 +494,7 @@ struct FusConv {
     const float *bias;        // [cout] or NULL
     float *out;               // [n, 24, 24, cout]
     int cin, cout, relu;
+    unsigned *range_flag;     // per-device flag word (common.h), or NULL
 };
 
 template <int KS>
@@ -584,6 +601,7 @@ __global__ __launch_bounds__(576) void fus_conv24_kernel(const FusConv a)
                 }
         }
     }
+    unsigned x3m = 0u;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int co = (nb0 + nb) * 32 + li;
@@ -594,10 +612,12 @@ __global__ __launch_bounds__(576) void fus_conv24_kernel(const FusConv a)
             for (int r = 0; r < 16; ++r) {
                 const int p = (wave * 2 + mb) * 32 + 8 * (r >> 2) + 4 * kg + (r & 3);
                 float v = acc[mb][nb][r] + bv;
+                x3m = max(x3m, x3_mag(v));
                 if (a.relu) v = fmaxf(v, 0.0f);
                 a.out[((size_t)img * S * S + p) * a.cout + co] = v;
             }
     }
+    if (a.range_flag) x3_raise(a.range_flag, x3m);
 }
 
 }  // namespace oryon
@@ -764,6 +784,7 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
     const WsLayout L = ws_layout(n_img, h, w);
     ORYON_CHECK_ARG(workspace_bytes >= L.total);
     hipStream_t st = as_stream(stream);
+    unsigned *rflag = x3_range_flag();
     char *ws = reinterpret_cast<char *>(workspace);
     float *R[3] = {reinterpret_cast<float *>(ws + L.R[0]), reinterpret_cast<float *>(ws + L.R[1]), reinterpret_cast<float *>(ws + L.R[2])};
     float *stats = reinterpret_cast<float *>(ws + L.stats);
@@ -782,13 +803,13 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
             const dim3 grid((unsigned)ceil_div(H * W / 32, 4), n_img);
             if (i == 0)
                 hipLaunchKernelGGL((dec_upconv_kernel<8, true, false>), grid, dim3(256), 0, st, prev, prev_aff, H, W, cin, d->up_img[i], d->up_b[i],
-                                   cat, ccat, cup, nbp);
+                                   cat, ccat, cup, nbp, rflag);
             else if (i == 1)
                 hipLaunchKernelGGL((dec_upconv_kernel<4, false, true>), grid, dim3(256), 0, st, prev, prev_aff, H, W, cin, d->up_img[i], d->up_b[i],
-                                   cat, ccat, cup, nbp);
+                                   cat, ccat, cup, nbp, rflag);
             else
                 hipLaunchKernelGGL((dec_upconv_kernel<2, false, true>), grid, dim3(256), 0, st, prev, prev_aff, H, W, cin, d->up_img[i], d->up_b[i],
-                                   cat, ccat, cup, nbp);
+                                   cat, ccat, cup, nbp, rflag);
         }
         H *= 2;
         W *= 2;
@@ -796,6 +817,7 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
         if (D_G[i] > 0) {
             // guidance projection: conv3x3 + bias + ReLU of the Swin map (NCHW, read in place) -> channels cup .. of the cat buffer
             DecConv a{};
+            a.range_flag = rflag;
             a.in = guid[i]; a.affine = nullptr; a.wimg = d->gp_img[i]; a.bias = d->gp_b[i]; a.out = cat; a.stats = nullptr;
             a.H = H; a.W = W; a.cin = D_GIN[i]; a.in_cstride = D_GIN[i]; a.in_coff = 0; a.out_cstride = ccat; a.out_coff = cup; a.cout = D_G[i]; a.relu = 1;
             if (guidance_layout == ORYON_LAYOUT_NHWC) launch_conv<1, false, false>(st, a, n_img);
@@ -806,6 +828,7 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
         // conv1 (raw output + GroupNorm partial sums)
         {
             DecConv a{};
+            a.range_flag = rflag;
             a.in = cat; a.affine = nullptr; a.wimg = d->c1_img[i]; a.bias = nullptr; a.out = a1; a.stats = stats;
             a.H = H; a.W = W; a.cin = ccat; a.in_cstride = ccat; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = 0;
             if (cout == 64) launch_conv<2, false, false>(st, a, n_img);
@@ -818,6 +841,7 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
         // conv2 on relu(GN(conv1))
         {
             DecConv a{};
+            a.range_flag = rflag;
             a.in = a1; a.affine = aff[2 * i]; a.wimg = d->c2_img[i]; a.bias = nullptr; a.out = b1; a.stats = stats;
             a.H = H; a.W = W; a.cin = cout; a.in_cstride = cout; a.in_coff = 0; a.out_cstride = cout; a.out_coff = 0; a.cout = cout; a.relu = 0;
             if (cout == 64) launch_conv<2, false, true>(st, a, n_img);
@@ -864,6 +888,7 @@ int oryon_conv24_f16x3(const float *x, int n, int cin, const void *image, const 
     ORYON_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)image) & 15) == 0);
     if (n == 0) return ORYON_OK;
     FusConv a{};
+    a.range_flag = x3_range_flag();
     a.in = x; a.wimg = reinterpret_cast<const dh8 *>(image); a.bias = bias; a.out = y; a.cin = cin; a.cout = cout; a.relu = relu ? 1 : 0;
     const dim3 grid((unsigned)(n * (cout / 64)));
     if (ksize == 3) {

@@ -46,7 +46,8 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo)
 template <int ACT>
 __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const float *__restrict__ A, int M, int K, const __half *__restrict__ Whi,
                                                                const __half *__restrict__ Wlo, const float *__restrict__ bias, int N,
-                                                               float *__restrict__ C, int tiles_m, int tiles_n, int sup_n, int sup_rows, int sup_cols)
+                                                               float *__restrict__ C, int tiles_m, int tiles_n, int sup_n, int sup_rows, int sup_cols,
+                                                               unsigned *__restrict__ range_flag)
 {
     __shared__ __attribute__((aligned(16))) __half sAh[GX_BM * GX_LD], sAl[GX_BM * GX_LD], sWh[GX_BN * GX_LD], sWl[GX_BN * GX_LD];
     // block -> (tile_m, tile_n): XCD x (= blockIdx % 8) owns every 8th 8x8 super-tile
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const float *__res
         }
     }
     // epilogue: lane owns column l31 of each 32x32 block and rows (r & 3) + 8 (r >> 2) + 4 kh
+    unsigned mag = 0u;                                   // range flag (common.h): largest magnitude among the raw accumulators of live rows
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int n = n0 + wn * 128 + b * 32 + l31;
@@ -146,11 +148,13 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const float *__res
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 float v = acc[a][b][r] + bv;
+                if (m < M) mag = max(mag, x3_mag(v));             // pre-activation: what a later split would see is bounded by it
                 if (ACT == 1) v = v * (1.0f / (1.0f + __expf(-1.702f * v)));
                 if (ACT == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                 if (m < M) C[(size_t)m * N + n] = v;
             }
     }
+    x3_raise(range_flag, mag);
 }
 
 constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 32;
@@ -185,7 +189,8 @@ template <int ACT>
 __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float *__restrict__ A, int M, int K, const __half *__restrict__ Whi,
                                                                   const __half *__restrict__ Wlo, const float *__restrict__ bias, int N,
                                                                   float *__restrict__ C, int tiles_m, int tiles_n, int sup_n, int sup_rows,
-                                                                  int sup_cols, int n_slots)
+                                                                  int sup_cols, int n_slots,
+                                                                       unsigned *__restrict__ range_flag)
 {
     extern __shared__ __attribute__((aligned(1024))) char g2_lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, kh = lane >> 5;
@@ -436,12 +441,22 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
                     }
                 }
         }
+        // range flag (common.h): accumulator + bias of the tile's live rows and columns, on the accumulators' way back to zero
+        {
+            unsigned mag = 0u;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+                for (int r = 0; r < 16; ++r) {
+                    const bool row_in = mrow + a * 32 + (r & 3) + 8 * (r >> 2) < M;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+                    for (int b = 0; b < 4; ++b) {
+                        if (cols_in && row_in) mag = max(mag, x3_mag(acc[a][b][r] + bv[b]));      // pre-activation value
+                        acc[a][b][r] = 0.0f;
+                    }
+                }
+            x3_raise(range_flag, mag);
+        }
         if (nslot < 0) break;
         m0 = nm0; n0 = nn0;
         nslot = next_valid(nslot + (int)gridDim.x, nm0, nn0);
@@ -504,7 +519,7 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
     do {                                                                                                                            \
         allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<ACT>), 2 * G2_STAGE);                           \
         hipLaunchKernelGGL((linear_f16x3_stream_kernel<ACT>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2, bias, N, C, \
-                           tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots);                                                   \
+                           tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots, x3_range_flag());                                  \
     } while (0)
         if (act == 2) ORYON_LAUNCH_STREAM(2);
         else if (act == 1) ORYON_LAUNCH_STREAM(1);
@@ -523,11 +538,11 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
     hipStream_t st = as_stream(stream);
     const __half *wh = static_cast<const __half *>(W_hi), *wl = static_cast<const __half *>(W_lo);
     if (act == 2)
-        hipLaunchKernelGGL((linear_f16x3_kernel<2>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols);
+        hipLaunchKernelGGL((linear_f16x3_kernel<2>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, x3_range_flag());
     else if (act == 1)
-        hipLaunchKernelGGL((linear_f16x3_kernel<1>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols);
+        hipLaunchKernelGGL((linear_f16x3_kernel<1>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, x3_range_flag());
     else
-        hipLaunchKernelGGL((linear_f16x3_kernel<0>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols);
+        hipLaunchKernelGGL((linear_f16x3_kernel<0>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, x3_range_flag());
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

@@ -29,6 +29,37 @@ void profile_end(hipStream_t st)
 }
 }  // namespace oryon
 
+namespace oryon {
+unsigned *x3_range_flag()
+{
+    static std::mutex mu;
+    static unsigned *flags[64] = {nullptr};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!flags[dev]) {
+        if (hipMalloc(reinterpret_cast<void **>(&flags[dev]), 256) != hipSuccess) return nullptr;
+        (void)hipMemset(flags[dev], 0, 256);
+    }
+    return flags[dev];
+}
+}  // namespace oryon
+
+extern "C" int oryon_x3_range_flag(int *value_out, int reset, void *stream)
+{
+    ORYON_CHECK_ARG(value_out);
+    unsigned *f = oryon::x3_range_flag();
+    if (!f) { oryon::set_error("oryon_x3_range_flag: no device memory for the flag"); return ORYON_ERR_HIP; }
+    hipStream_t st = oryon::as_stream(stream);
+    unsigned v = 0;
+    ORYON_CHECK_HIP(hipMemcpyAsync(&v, f, sizeof(v), hipMemcpyDeviceToHost, st));
+    if (reset) ORYON_CHECK_HIP(hipMemsetAsync(f, 0, sizeof(unsigned), st));
+    ORYON_CHECK_HIP(hipStreamSynchronize(st));
+    *value_out = (int)v;
+    return ORYON_OK;
+}
+
 extern "C" const char *oryon_dominant_kernel(void) { return oryon::g_dominant; }
 
 extern "C" int oryon_profile_events(void *start_event, void *stop_event)

@@ -161,7 +161,22 @@ class Oryon(nn.Module):
     def get_guidance_embeds(self, img: Tensor) -> List[Tensor]:
         return guidance_embeds(self.guidance_backbone, img.clone())
 
+    x3_range_fallbacks = 0          # forwards re-evaluated with the fp32 modules because the fp16x3 range flag came back set
+
     def forward(self, xs: dict) -> Dict[str, Tensor]:
+        out = self._forward(xs)
+        from . import backbone
+        t = out["featmap_a"]
+        if t.is_cuda and not torch.is_grad_enabled() and backbone.fp16x3_enabled():
+            # one 4-byte read-back per forward: did any fp16x3 kernel see a value its float16 split cannot hold (|x| >= 65504)?
+            from . import ops
+            if ops.x3_range_flag(t.device, reset=True):
+                Oryon.x3_range_fallbacks += 1
+                with backbone.fp16x3_disabled():
+                    out = self._forward(xs)
+        return out
+
+    def _forward(self, xs: dict) -> Dict[str, Tensor]:
         rgb_a = xs["anchor"]["rgb"].to(self.device)
         rgb_q = xs["query"]["rgb"].to(self.device)
         if "prompt_tokens" in xs:

@@ -4,6 +4,7 @@ Every wrapper takes torch CUDA tensors, allocates outputs with torch (plumbing) 
 kernel on the current torch stream.  Nothing here computes: the arithmetic lives in liboryon_hip.so."""
 from __future__ import annotations
 
+import ctypes
 import functools
 import weakref
 from typing import Optional, Tuple
@@ -678,6 +679,16 @@ _x3_weights = {}
 X3_GUARD = False
 X3_LIMIT = 60000.0            # below float16's 65504 with room for the rounding of `hi`
 x3_guard_fallbacks = 0        # layers evaluated by torch because an operand left the float16 range (guard mode)
+
+
+def x3_range_flag(device=None, reset: bool = True) -> bool:
+    """oryon_x3_range_flag: True when an fp16x3 kernel on `device` saw an out-of-range / non-finite pre-activation output since the
+    last reset.  Synchronises the device's current stream: call once per forward."""
+    dev = _lib.require_gpu(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
+    v = ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        check(lib().oryon_x3_range_flag(ctypes.byref(v), int(bool(reset)), stream_ptr(dev)), "oryon_x3_range_flag")
+    return v.value != 0
 
 
 def _split_weight_f16x3(weight: torch.Tensor):

@@ -356,19 +356,89 @@ def test_add_layernorm_f32_matches_fp64():
             assert e < 5e-6 and e <= 2.0 * e32 + 1e-7, (rows, D, e, e32)
 
 
-def test_fp16x3_guard_mode_keeps_the_unguarded_fused_kernels_off():
-    """enable_fp16x3(True, guard=True) is the validation mode for a first run with a real checkpoint: the linears check their operands
-    against the float16 range; the kernels that split activations themselves (fusion's attention / convolutions / class layers, the
-    decoder) have no such check and therefore stay on the torch fp32 modules in that mode."""
-    from oryon_amd.backbone import enable_fp16x3, fusion
+def test_fp16x3_switches_and_the_fallback_context():
+    """enable_fp16x3 switches every fast-path flag together - since round 5 the fused kernels stay ON in guard mode too (they carry the
+    device-side range flag) - and fp16x3_disabled() restores exactly what was set."""
+    from oryon_amd import ops
+    from oryon_amd.backbone import enable_fp16x3, fp16x3_disabled, fp16x3_enabled, fusion
     try:
         enable_fp16x3(True, guard=True)
-        assert fusion.FP16X3_LINEAR and not fusion.FUSED_KERNELS and not fusion.HIP_DECODER
+        assert fusion.FP16X3_LINEAR and fusion.FUSED_KERNELS and fusion.HIP_DECODER and ops.X3_GUARD and fp16x3_enabled()
+        with fp16x3_disabled():
+            assert not fp16x3_enabled() and not ops.X3_GUARD
+        assert fusion.FP16X3_LINEAR and fusion.FUSED_KERNELS and fusion.HIP_DECODER and ops.X3_GUARD
         enable_fp16x3(True)
-        assert fusion.FP16X3_LINEAR and fusion.FUSED_KERNELS and fusion.HIP_DECODER
+        assert fusion.FP16X3_LINEAR and fusion.FUSED_KERNELS and fusion.HIP_DECODER and not ops.X3_GUARD
     finally:
         enable_fp16x3(False)
-    assert not (fusion.FP16X3_LINEAR or fusion.FUSED_KERNELS or fusion.HIP_DECODER)
+    assert not (fusion.FP16X3_LINEAR or fusion.FUSED_KERNELS or fusion.HIP_DECODER or fp16x3_enabled())
+
+
+@pytest.mark.gpu
+def test_fp16x3_device_range_flag():
+    """oryon_x3_range_flag (round 5): the fp16x3 linear / convolution kernels raise a per-device flag when a pre-activation output is not a
+    finite value below 60000 - in-range calls leave it clear; an activation beyond float16's range (hi = inf), a NaN, and an output that
+    merely grows past the limit each set it; reading with reset clears it."""
+    from oryon_amd import ops
+    torch.manual_seed(0)
+    w = torch.randn(256, 128, device="cuda") * 0.05
+    b = torch.randn(256, device="cuda")
+    x = torch.randn(300, 128, device="cuda")
+    with torch.no_grad():
+        ops.x3_range_flag(x.device, reset=True)
+        ops.linear_f16x3(x, w, b)
+        ops.linear_f16x3(x, w, b, gelu=True)
+        assert ops.x3_range_flag(x.device) is False
+        xb = x.clone(); xb[299, 5] = 7.0e4                          # splits into hi = inf: every output of that row is inf / NaN
+        y = ops.linear_f16x3(xb, w, b)
+        assert not torch.isfinite(y[299]).all() and torch.isfinite(y[:299]).all()
+        assert ops.x3_range_flag(x.device) is True and ops.x3_range_flag(x.device) is False        # read + reset
+        xn = x.clone(); xn[0, 0] = float("nan")
+        ops.linear_f16x3(xn, w, b, quick_gelu=True)
+        assert ops.x3_range_flag(x.device) is True
+        ops.linear_f16x3(x * 3.0e3, w * 40.0, b)                    # operands in range, outputs ~1e5: the NEXT split could not hold them
+        assert ops.x3_range_flag(x.device) is True
+        # the 24 x 24 convolution and the decoder raise it the same way
+        xc = torch.randn(1, 24, 24, 64, device="cuda")
+        wc = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+        ops.conv24_f16x3(xc, wc, None)
+        assert ops.x3_range_flag(x.device) is False
+        xc[0, 3, 3, 1] = 1.0e5
+        ops.conv24_f16x3(xc, wc, None)
+        assert ops.x3_range_flag(x.device) is True
+
+
+@pytest.mark.gpu
+def test_oryon_forward_falls_back_to_fp32_when_the_range_flag_is_raised():
+    """Oryon.forward on the fast path reads the flag once per forward; with a decoder weight blown up so that an up-convolution output
+    leaves float16's range the forward is evaluated again with the torch fp32 modules: same result as enable_fp16x3(False), counted."""
+    from oryon_amd.backbone import enable_fp16x3
+    from oryon_amd.backbone.clip import CLIPConfig
+    from oryon_amd.net import Oryon, default_model_args
+    torch.manual_seed(3)
+    net = Oryon(default_model_args(), "cuda", clip_cfg=CLIPConfig(v_layers=1, t_layers=1)).eval()
+    gen = torch.Generator().manual_seed(0)
+    toks = torch.randint(1, 49000, (1, 80, 77), generator=gen)
+    toks[..., 10] = 49407
+    toks[..., 11:] = 0
+    xs = {"anchor": {"rgb": torch.rand(1, 3, 224, 224, generator=gen).cuda()}, "query": {"rgb": torch.rand(1, 3, 224, 224, generator=gen).cuda()},
+          "prompt_tokens": toks.cuda()}
+    with torch.no_grad():
+        enable_fp16x3(True)
+        try:
+            n0 = Oryon.x3_range_fallbacks
+            fast = net(xs)
+            assert Oryon.x3_range_fallbacks == n0                  # random-init network: everything in range, no fallback
+            net.decoder.decoder1.up.bias += 9.0e4                   # the first up-convolution now outputs ~9e4: beyond the next split
+            out = net(xs)
+            assert Oryon.x3_range_fallbacks == n0 + 1
+        finally:
+            enable_fp16x3(False)
+        ref = net(xs)
+    assert all(torch.isfinite(v).all() for v in out.values())
+    for k in ref:                                                  # two fp32 library evaluations (MIOpen picks its algorithms per call): equal to round-off
+        torch.testing.assert_close(out[k], ref[k], rtol=1e-5, atol=1e-5 * float(ref[k].abs().max()))
+    assert torch.isfinite(fast["featmap_a"]).all()
 
 
 @pytest.mark.gpu
