@@ -13,6 +13,7 @@ python $R/bench.py --no-cpu-baseline --no-stage-sets > "$OUT/bench_line.json" 2>
 D=/tmp/prof_trace; rm -rf $D
 rocprofv3 --kernel-trace --stats -d $D -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-sets > /tmp/trace.log 2>&1
 python $R/tools/rocpd_summary.py $D/bench_results.db --after "distribution_elementwise|index_elementwise" > "$OUT/kernel_stats.md"
+python $R/tools/rocpd_summary.py $D/bench_results.db --between "match_mx6_screen_w4" > "$OUT/kernel_stats_steps_only.md"
 python $R/tools/rocpd_summary.py $D/bench_results.db > "$OUT/kernel_stats_whole_run.md"
 RX='mx6_screen|screen_v2_kernel|gather_q8_v3|gather_mx6_v4|pdsc_att|match_decide|match_resolve|pdsc_linear|pdsc_pcn_qkv|pdsc_mlp3|pdsc_hyp|pdsc_seed'
 {

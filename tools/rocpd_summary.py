@@ -5,6 +5,8 @@ Optionally also dumps PMC counter sums per kernel.
 
     python tools/rocpd_summary.py gpurun_out/prof/bench_results.db [--exclude REGEX] [--after REGEX] > profiles/r01_bench_kernel_stats.md
 
+--between REGEX: only dispatches between the first and the last dispatch matching REGEX (e.g. the screen kernel: whole steps of the
+pipeline, nothing of the set-up); the header then says how many matching dispatches span the window.
 --after REGEX: only dispatches that START after the last dispatch matching REGEX has ended (round 5: bench.py's input generation is
 torch RNG kernels and ~2000 copies; `--after distribution_elementwise` leaves the engine's steps, so that the per-step copy / fill
 counts can be read off)."""
@@ -13,7 +15,7 @@ import sqlite3
 import sys
 
 
-def main(path, exclude=None, after=None):
+def main(path, exclude=None, after=None, between=None):
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
@@ -22,6 +24,12 @@ def main(path, exclude=None, after=None):
         ends = [e for n, e in c.execute(f"select {name_col}, end from kernels") if re.search(after, n)]
         if ends:
             where = f" where start > {max(ends)}"
+    n_between = 0
+    if between:
+        marks = [(st_, e) for n, st_, e in c.execute(f"select {name_col}, start, end from kernels") if re.search(between, n)]
+        if len(marks) >= 2:
+            n_between = len(marks)
+            where = f" where start >= {min(m[0] for m in marks)} and start < {max(m[0] for m in marks)}"
     rows = c.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                      f"from kernels{where} group by {name_col} order by 3 desc").fetchall()
     dropped = 0.0
@@ -30,7 +38,9 @@ def main(path, exclude=None, after=None):
         rows = [r for r in rows if not re.search(exclude, r[0])]
     total = sum(r[2] for r in rows) or 1
     print(f"# rocprofv3 kernel-trace summary of `{path.split('/')[-1]}`\n")
-    if where:
+    if n_between:
+        print(f"(only dispatches from the first to the last one matching /{between}/: {n_between - 1} whole periods of that kernel, i.e. steps of the pipeline)\n")
+    elif where:
         print(f"(only dispatches after the last one matching /{after}/ - the run's set-up - had ended)\n")
     if exclude:
         print(f"(kernels matching /{exclude}/ left out: {dropped:.1f} ms in total - one-off library auto-tuning launches of the warm-up pass)\n")
@@ -55,4 +65,4 @@ def main(path, exclude=None, after=None):
 
 if __name__ == "__main__":
     opt = dict(zip(sys.argv[2::2], sys.argv[3::2]))
-    main(sys.argv[1], opt.get("--exclude"), opt.get("--after"))
+    main(sys.argv[1], opt.get("--exclude"), opt.get("--after"), opt.get("--between"))
