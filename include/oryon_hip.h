@@ -405,7 +405,8 @@ typedef struct {
     int round_f16;           /* the reference's half-descriptor branch (utils/pcd.py:195-197) */
     int n_slots;             /* result slots: a step's results stay readable until the n_slots-th next submit (6; <= 8) */
     int overlap;             /* see above (2) */
-    int gather_sets;         /* K0 output sets: K0 may run this many steps ahead of the matcher minus one (3; <= 4, <= n_slots) */
+    int gather_sets;         /* K0 output sets: K0 may run this many steps ahead of the matcher minus one (<= 4, <= n_slots).  2 is the Python binding's
+                                default since round 5: a third set adds 3.4 ms of queueing to a step's latency (14.1 -> 10.7 ms at cfg2) and no throughput */
     int reg_streams;         /* registration streams the steps alternate over (2; <= 4) */
     int reg_lag;             /* > 0: the matcher of step k waits for the registration of step k - reg_lag (< n_slots); 0 = never (default) */
     int screen;              /* 0 = int8 screen (oryon_gather_q8 + oryon_match_corrs_i8), 1 = MX-fp6 screen (oryon_gather_mx6 +

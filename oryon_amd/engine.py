@@ -69,7 +69,7 @@ class NativeStep:
     }
 
     def __init__(self, solver: PointDSC, cfg: "MatchPoseConfig", key: Tuple, dev: torch.device, overlap: int, n_slots: int = 6,
-                 gather_sets: int = 3, reg_streams: int = 2, reg_lag: int = 0, screen: int = 1, x3_prefetch: int = 1):
+                 gather_sets: int = 2, reg_streams: int = 2, reg_lag: int = 0, screen: int = 1, x3_prefetch: int = 1):
         B, C, FH, FW, HA, WA, HQ, WQ, layout = key
         self.key, self.dev = key, dev
         if overlap >= 2:
@@ -194,7 +194,7 @@ class MatchPoseEngine:
         self.result_views = result_views
         self._native: Optional[NativeStep] = None
         self._inflight: Dict[int, Dict[str, Tensor]] = {}       # slot -> result dict of the native step that last used it
-        self.native_geometry = dict(n_slots=6, gather_sets=3, reg_streams=2, reg_lag=0, screen=1, x3_prefetch=1)      # NativeStep's pipeline depth (see oryon_engine_config_t)
+        self.native_geometry = dict(n_slots=6, gather_sets=2, reg_streams=2, reg_lag=0, screen=1, x3_prefetch=1)      # NativeStep's pipeline depth (see oryon_engine_config_t)
         self.native_timing = False          # bracket the sections of every native step with HIP events (NativeStep.timing)
         self._reg_stream = None
         self.reg_streams = 2
