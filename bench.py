@@ -39,6 +39,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Pe
 PEAK_F16_MFMA_TFLOPS = 2500.0      # same table, "Peak BF16/FP16 MFMA" dense
 PEAK_I8_MFMA_TOPS = 5000.0         # dense INT8 = 2x the 16-bit rate (same table: FP8 ~5 PF dense; i8 32x32x32 measured 4.4 POP/s)
 PEAK_FP6_MFMA_TFLOPS = 10000.0     # same table, "Peak FP6/FP4 MFMA ~10 PF dense" (MX block-scaled only; 32x32x64 measured 8.9 PF/s)
+BARE_FP6_32x32x64_TFLOPS = 5320.0     # measured: bare loop of v_mfma_scale_f32_32x32x64_f8f6f4 (fp6 e2m3, random bits), power-limited (profiles/r05_mfma_mx_rates.md)
 PEAK_HBM_BYTES = 8.0e12            # same guide: HBM3E 8 TB/s
 METRIC = "image-pairs/sec end-to-end (feat+match+reg) @224², C=256; ADD(-S) parity"
 
@@ -639,6 +640,10 @@ def main():
                 "unshared": (None if unshared_ms is None else
                              {"avg_launch_ms": unshared_ms, "achieved": flops / (unshared_ms * 1e-3) / 1e12,
                               "frac": flops / (unshared_ms * 1e-3) / 1e12 / peak,
+                              # what a bare register-resident loop of the same instruction sustains on this part under its power limit
+                              # (tools/probe_mfma_mx_rates.hip, profiles/r05_mfma_mx_rates.md: fp6 e2m3 32x32x64, random operand bits)
+                              "frac_of_bare_loop_rate": (flops / (unshared_ms * 1e-3) / 1e12 / BARE_FP6_32x32x64_TFLOPS) if "mx6" in dispatched else None,
+                              "bare_loop_tflops": BARE_FP6_32x32x64_TFLOPS if "mx6" in dispatched else None,
                               "measured": "same events, 5 steps of a serial engine (one stream, nothing beside the kernel) in this run: the "
                                           "figure a rocprofv3 kernel trace of this command shows, since the profiler serialises the queues"}),
             },
