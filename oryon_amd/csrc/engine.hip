@@ -549,6 +549,7 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
     // the two per-pair counters a caller reads with the pose: copied on the registration stream (which is always ordered after the
     // caller's stream) into the slot's protected block, so that result views of them stay valid for the slot's whole lifetime
     hipLaunchKernelGGL(engine_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, sr, b.n_valid, b.n_lift, B, b.n_valid_out, b.n_lift_out);
+    ORYON_CHECK_LAUNCH();
     if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[7], sr));
     if (c.overlap >= 1) ORYON_CHECK_HIP(hipEventRecord(e->ev_done[slot], sr));
     e->used[slot] = true;
