@@ -359,7 +359,9 @@ int oryon_pointdsc_refine(oryon_pointdsc_t *handle, const float *src, const floa
  * The whole batched step as ONE call (round 3): what the per-sample loop of FPM_Pipeline.test_step does for every pair of a batch
  * (pipeline.py:313-355: is_detection_valid -> get_featmap_corrs [utils/pcd.py:177-216] -> get_pose [pipeline.py:429-472:
  * scale / validate / lift, get_pointdsc_pose]), for B pairs, enqueued from C++ on streams and events the engine owns, over a
- * persistent arena the caller hands over once.  oryon_engine_submit issues, without allocating or synchronising,
+ * persistent arena the caller hands over once (the streams come from a per-device pool that lives as long as the process: every engine of
+ * a process runs on the same four streams, so a re-created engine keeps the hardware queues of the first).  oryon_engine_submit issues,
+ * without allocating or synchronising,
  *     gather stream : oryon_roi_compact x2, oryon_roi_subsample, oryon_gather_q8 x2                       (K0)
  *     match stream  : oryon_match_corrs_i8, oryon_lift_pairs                                               (K1s8 + K1b, K2)
  *     reg stream    : oryon_pointdsc_register                                                              (K3-K10)
@@ -440,6 +442,11 @@ int oryon_engine_elapsed(oryon_engine_t *handle, int64_t step_a, int event_a, in
 int oryon_engine_host_stats(const oryon_engine_t *handle, int64_t *n_submit, double *submit_ms_total, double *submit_ms_last);
 /* number of submits so far whose K0 pass wrote the hi / lo rows (cfg.x3_prefetch) */
 int oryon_engine_x3_steps(const oryon_engine_t *handle, int64_t *n_steps);
+/* the engine's own feedback, for callers that want the statistic without queueing reads of slot buffers (round 5): sums of the newest
+ * COMPLETED step's per-pair counts of anchors the screen left to the second level ("n_und") and of anchors ("n_a") - the pinned-memory
+ * copies the x3_prefetch decision is made from (MX-fp6 screen only).  *step = that step's submit index, -1 when none has completed yet.
+ * Never waits: an event query per slot. */
+int oryon_engine_feedback(oryon_engine_t *handle, int64_t *step, int64_t *n_undecided, int64_t *n_anchors);
 
 /* B4  error-compensated fp16x3 linear layer for the frozen fp32 towers (CLIP ViT-L/14@336, Swin) of Oryon.forward
  *     (net.py:142-167, models/vlm.py:43-61; the reference evaluates them with fp32 torch linears):

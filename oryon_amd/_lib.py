@@ -115,6 +115,7 @@ _PROTOS = {
     "oryon_engine_config_bytes": (c_size_t, []),
     "oryon_engine_host_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "oryon_engine_x3_steps": (c_int, [c_void_p, POINTER(c_int64)]),
+    "oryon_engine_feedback": (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "oryon_fusion_window_attention_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "oryon_fusion_class_layer_f32": (c_int, [_P, _P, POINTER(FusionClassWeights), c_int, _P, _P]),
     "oryon_conv24_image_bytes": (c_int64, [c_int, c_int, c_int]),

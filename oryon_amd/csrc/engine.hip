@@ -247,6 +247,29 @@ extern "C" size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, con
     return L.bytes;
 }
 
+namespace oryon {
+// The engine's HIP streams come from a per-device pool that lives as long as the process (round 5).  The runtime places a stream on one
+// of its GPU_MAX_HW_QUEUES hardware queues when the stream is created, and which queues a NEW set lands on differs from build to
+// build: the same hard cfg2 step ran 5.45 ms on the first engine of a process and 6.4 ms on the third (streams destroyed and re-created
+// in between: two of the new ones shared a queue).  Engines of one process therefore share one set of streams - they do not run
+// concurrently (a second engine's steps simply queue behind the first's), and none of them destroys a stream.
+struct StreamPool { hipStream_t sm = nullptr, sg = nullptr, sr[MAX_REG_STREAMS] = {nullptr, nullptr, nullptr, nullptr}; };
+static hipError_t pooled_stream(hipStream_t *slot_in_pool)
+{
+    if (*slot_in_pool) return hipSuccess;
+    return hipStreamCreateWithFlags(slot_in_pool, hipStreamNonBlocking);
+}
+static StreamPool &stream_pool()
+{
+    static std::mutex mu;
+    static StreamPool pools[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    return pools[(dev >= 0 && dev < 64) ? dev : 0];
+}
+}  // namespace oryon
+
 extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,
                                    size_t arena_bytes)
 {
@@ -276,8 +299,9 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     e->host_ns_total = e->host_ns_last = 0.0;
     hipError_t err = hipSuccess;
     auto ok = [&](hipError_t x) { if (err == hipSuccess) err = x; };
-    if (cfg->overlap >= 1) ok(hipStreamCreateWithFlags(&e->sm, hipStreamNonBlocking));
-    if (cfg->overlap >= 2) ok(hipStreamCreateWithFlags(&e->sg, hipStreamNonBlocking));
+    StreamPool &pool = stream_pool();
+    if (cfg->overlap >= 1) { ok(pooled_stream(&pool.sm)); e->sm = pool.sm; }
+    if (cfg->overlap >= 2) { ok(pooled_stream(&pool.sg)); e->sg = pool.sg; }
     for (int s = 0; s < MAX_REG_STREAMS; ++s) e->sr[s] = nullptr;
     e->n_reg_streams = cfg->reg_streams;
     for (int s = 0; s < MAX_SLOTS; ++s) {
@@ -289,7 +313,7 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
         for (int i = 0; i < 8; ++i) e->tev[r][i] = nullptr;
     }
     for (int s = 0; s < e->n_reg_streams; ++s)
-        if (cfg->overlap >= 1) ok(hipStreamCreateWithFlags(&e->sr[s], hipStreamNonBlocking));
+        if (cfg->overlap >= 1) { ok(pooled_stream(&pool.sr[s])); e->sr[s] = pool.sr[s]; }
     for (int s = 0; s < cfg->n_slots; ++s) {
         for (hipEvent_t *ev : {&e->ev_inputs[s], &e->ev_gathered[s], &e->ev_matched[s], &e->ev_done[s]})
             ok(hipEventCreateWithFlags(ev, hipEventDisableTiming));
@@ -319,8 +343,9 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
 extern "C" void oryon_engine_destroy(oryon_engine_t *e)
 {
     if (!e) return;
+    // the streams belong to the process-wide pool: drained here, never destroyed
     for (int s = 0; s < MAX_REG_STREAMS; ++s)
-        if (e->sr[s]) { (void)hipStreamSynchronize(e->sr[s]); (void)hipStreamDestroy(e->sr[s]); }
+        if (e->sr[s]) (void)hipStreamSynchronize(e->sr[s]);
     for (int s = 0; s < MAX_SLOTS; ++s) {
         for (hipEvent_t ev : {e->ev_inputs[s], e->ev_gathered[s], e->ev_matched[s], e->ev_done[s]})
             if (ev) (void)hipEventDestroy(ev);
@@ -328,8 +353,8 @@ extern "C" void oryon_engine_destroy(oryon_engine_t *e)
     for (int r = 0; r < TIMING_RING; ++r)
         for (int i = 0; i < 8; ++i)
             if (e->tev[r][i]) (void)hipEventDestroy(e->tev[r][i]);
-    if (e->sm) { (void)hipStreamSynchronize(e->sm); (void)hipStreamDestroy(e->sm); }
-    if (e->sg) { (void)hipStreamSynchronize(e->sg); (void)hipStreamDestroy(e->sg); }
+    if (e->sm) (void)hipStreamSynchronize(e->sm);
+    if (e->sg) (void)hipStreamSynchronize(e->sg);
     for (int s = 0; s < MAX_SLOTS; ++s)
         if (e->ev_fb[s]) (void)hipEventDestroy(e->ev_fb[s]);
     if (e->fb_host) (void)hipHostFree(e->fb_host);
@@ -572,6 +597,26 @@ extern "C" int oryon_engine_host_stats(const oryon_engine_t *e, int64_t *n_submi
     if (n_submit) *n_submit = e->n_submit;
     if (submit_ms_total) *submit_ms_total = e->host_ns_total * 1e-6;
     if (submit_ms_last) *submit_ms_last = e->host_ns_last * 1e-6;
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_feedback(oryon_engine_t *e, int64_t *step, int64_t *n_undecided, int64_t *n_anchors)
+{
+    ORYON_CHECK_ARG(e && step && n_undecided && n_anchors);
+    *step = -1;
+    *n_undecided = *n_anchors = 0;
+    if (!e->fb_host) return ORYON_OK;
+    const int B = e->cfg.B;
+    int best = -1;
+    for (int s = 0; s < e->cfg.n_slots; ++s)
+        if (e->fb_step[s] >= 0 && (best < 0 || e->fb_step[s] > e->fb_step[best]) && hipEventQuery(e->ev_fb[s]) == hipSuccess) best = s;
+    if (best < 0) return ORYON_OK;
+    const int32_t *h = e->fb_host + (size_t)best * 2 * B;
+    int64_t und = 0, all = 0;
+    for (int i = 0; i < B; ++i) { und += h[i]; all += h[B + i]; }
+    *step = e->fb_step[best];
+    *n_undecided = und;
+    *n_anchors = all;
     return ORYON_OK;
 }
 

@@ -61,6 +61,13 @@ def run(n):
     eng.finish(prev)
 
 
+if os.environ.get("ENG_STATS"):
+    eng.collect_i8_stats = True
+if os.environ.get("ENG_SF_TOGGLE"):
+    eng.cfg.sample_first = 1024
+    run(8)
+    torch.cuda.synchronize()
+    eng.cfg.sample_first = 0
 if os.environ.get("ENG_SIDE_STREAM"):
     _side = torch.cuda.Stream()
     torch.cuda.set_stream(_side)          # the caller's stream is not the legacy default stream: blocking streams do not synchronise with it
