@@ -253,7 +253,7 @@ namespace oryon {
 // build: the same hard cfg2 step ran 5.45 ms on the first engine of a process and 6.4 ms on the third (streams destroyed and re-created
 // in between: two of the new ones shared a queue).  Engines of one process therefore share one set of streams - they do not run
 // concurrently (a second engine's steps simply queue behind the first's), and none of them destroys a stream.
-struct StreamPool { hipStream_t sm = nullptr, sg = nullptr, sr[MAX_REG_STREAMS] = {nullptr, nullptr, nullptr, nullptr}; };
+struct StreamPool { hipStream_t all[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
 static hipError_t pooled_stream(hipStream_t *slot_in_pool)
 {
     if (*slot_in_pool) return hipSuccess;
@@ -300,8 +300,16 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     hipError_t err = hipSuccess;
     auto ok = [&](hipError_t x) { if (err == hipSuccess) err = x; };
     StreamPool &pool = stream_pool();
-    if (cfg->overlap >= 1) { ok(pooled_stream(&pool.sm)); e->sm = pool.sm; }
-    if (cfg->overlap >= 2) { ok(pooled_stream(&pool.sg)); e->sg = pool.sg; }
+    // Which of the pool's 8 consecutively created streams serve as match / gather / registration 0 / registration 1.  The runtime gives
+    // the first streams of a process one hardware queue each, in creation order, and the placement matters far more than one would
+    // think (cfg2 step, same box, `tools/engine_timeline.py`, two runs each): 0123 (creation order, rounds 3-4) 3.46 ms; 2301 3.33-3.34;
+    // 2345 3.34-3.38; 2453 / 2534 / 4523 3.42-3.47; 5670 3.7-3.8; 1357 3.9; 0246 4.07; 3210 / 3456 4.1-4.2 ms.  The two best have the
+    // match stream on the pool's third and the gather stream on its fourth queue.  (dev build: ORYON_ENGINE_ROLES = four digits)
+    static const int roles = dev_env_int("ORYON_ENGINE_ROLES", 2301);
+    const int r_m = roles / 1000 % 10, r_g = roles / 100 % 10, r_r0 = roles / 10 % 10, r_r1 = roles % 10;
+    for (int i = 0; i < 8; ++i) ok(pooled_stream(&pool.all[i]));
+    if (cfg->overlap >= 1) e->sm = pool.all[r_m & 7];
+    if (cfg->overlap >= 2) e->sg = pool.all[r_g & 7];
     for (int s = 0; s < MAX_REG_STREAMS; ++s) e->sr[s] = nullptr;
     e->n_reg_streams = cfg->reg_streams;
     for (int s = 0; s < MAX_SLOTS; ++s) {
@@ -313,7 +321,7 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
         for (int i = 0; i < 8; ++i) e->tev[r][i] = nullptr;
     }
     for (int s = 0; s < e->n_reg_streams; ++s)
-        if (cfg->overlap >= 1) { ok(pooled_stream(&pool.sr[s])); e->sr[s] = pool.sr[s]; }
+        if (cfg->overlap >= 1) e->sr[s] = pool.all[(s == 0 ? r_r0 : s == 1 ? r_r1 : (r_r1 + s - 1)) & 7];
     for (int s = 0; s < cfg->n_slots; ++s) {
         for (hipEvent_t *ev : {&e->ev_inputs[s], &e->ev_gathered[s], &e->ev_matched[s], &e->ev_done[s]})
             ok(hipEventCreateWithFlags(ev, hipEventDisableTiming));
