@@ -321,7 +321,7 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
         for (int i = 0; i < 8; ++i) e->tev[r][i] = nullptr;
     }
     for (int s = 0; s < e->n_reg_streams; ++s)
-        if (cfg->overlap >= 1) e->sr[s] = pool.all[(s == 0 ? r_r0 : s == 1 ? r_r1 : (r_r1 + s - 1)) & 7];
+        if (cfg->overlap >= 1) e->sr[s] = pool.all[(s == 0 ? r_r0 : s == 1 ? r_r1 : 2 + s) & 7];      // a third / fourth registration stream: pool streams 4, 5
     for (int s = 0; s < cfg->n_slots; ++s) {
         for (hipEvent_t *ev : {&e->ev_inputs[s], &e->ev_gathered[s], &e->ev_matched[s], &e->ev_done[s]})
             ok(hipEventCreateWithFlags(ev, hipEventDisableTiming));
