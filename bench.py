@@ -152,6 +152,16 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
     B, H = a.batch, 224
     torch.manual_seed(4321 + rank)
     model = Oryon(default_model_args(), dev).eval()
+    clip_values = backbone_dtype == "fp16x3-clipload"
+    if clip_values:
+        # the reference's CLIPEncoder holds the OpenAI checkpoint as `clip.load` builds it - fp16 Linear / Conv / in_proj / projection
+        # tensors - widened with `.to(torch.float32)` and frozen (models/vlm.py:19-29): every weight IS an fp16 value.  Random-init
+        # weights of that kind here; the fp16x3 linear then needs two products instead of three (same results bit for bit).
+        backbone_dtype = "fp16x3"
+        with torch.no_grad():
+            for p_ in model.vlm.clip_model.parameters():
+                if p_.dim() >= 2:
+                    p_.copy_(p_.half().float())
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
     rgb_a = torch.rand((B, 3, H, H), generator=gen, device=dev)
     rgb_q = torch.rand((B, 3, H, H), generator=gen, device=dev)
@@ -233,7 +243,8 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
     flops_backbone = B * 2 * (5.7e9 if decode_only else 0.39e12)
     # fp16x3: every fp32 multiply-add is three fp16 MFMA multiply-adds, so the fp32-equivalent rate is priced against a third of the
     # dense fp16 peak (the towers' linears, attention and the Swin linears run there; the convolutions still run on the fp32 pipe)
-    peak = {"fp32": PEAK_FP32_MFMA_TFLOPS, "fp16x3": PEAK_F16_MFMA_TFLOPS / 3.0}.get(backbone_dtype, PEAK_F16_MFMA_TFLOPS)
+    # (fp16x3-clipload: the CLIP linears - 0.9 of the FLOPs - take two products; priced against half the fp16 peak)
+    peak = {"fp32": PEAK_FP32_MFMA_TFLOPS, "fp16x3": PEAK_F16_MFMA_TFLOPS / (2.0 if clip_values else 3.0)}.get(backbone_dtype, PEAK_F16_MFMA_TFLOPS)
     achieved = flops_backbone / (bb_ms * 1e-3) / 1e12
     return {
         "metric": ("image-pairs/sec (decode+match+reg): fusion + decoder on cached CLIP / Swin encodings (-> C=32 @192x192), then match + pose"
@@ -249,11 +260,14 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
                             "the remaining convolutions (patch embeddings, fusion's 7x7 / 3x3) PyTorch-ROCm fp32",
                   "bf16": "bf16 backbone GEMMs (autocast), f32 match+pose",
                   "bf16w": "bf16 backbone (weights + activations), f32 match+pose"}[backbone_dtype],
-        "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)",
+        "data": "synthetic RGB-D, random-init weights of the reference architecture (no checkpoints / network)" +
+                ("; the CLIP tower's weights rounded to fp16 values in fp32 storage, as `clip.load` + `.to(torch.float32)` leaves the "
+                 "reference's frozen CLIPEncoder (models/vlm.py:19-29)" if clip_values else ""),
         "prompt_cache": "80-template text tower evaluated once (identical prompt set), as in eval of one object class",
         "roofline": {"bound": "mfma",
                      "kernel": ("backbone GEMMs: oryon_linear_f16x3 / oryon_mha_f16x3 / dec_conv3x3_kernel (fp32-equivalent FLOP/s against a "
-                                "third of the dense fp16 peak) + the remaining MIOpen convolutions" if backbone_dtype == "fp16x3" else
+                                "third of the dense fp16 peak" + (" - here half: fp16-valued CLIP weights have no low half, two products" if clip_values else "") +
+                                ") + the remaining MIOpen convolutions" if backbone_dtype == "fp16x3" else
                                 "backbone GEMMs / convolutions (hipBLASLt / MIOpen through PyTorch-ROCm)"),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None},
     }
@@ -322,7 +336,7 @@ def main():
                          "forward on cached CLIP / Swin encodings, then match + pose (SURVEY 8d 'decode+match+pose'); full: random-init "
                          "CLIP ViT-L/14@336 + Swin-B + fusion + decoder forward on 224x224 RGB (-> C=32 @192x192, the reference's own "
                          "shapes), then match + pose - a separate stage set, never mixed into the headline")
-    ap.add_argument("--backbone-dtype", choices=["fp32", "fp16x3", "bf16", "bf16w"], default="fp32",
+    ap.add_argument("--backbone-dtype", choices=["fp32", "fp16x3", "fp16x3-clipload", "bf16", "bf16w"], default="fp32",
                     help="fp32 | bf16 (autocast over fp32 weights) | bf16w (weights converted to bf16 once)")
     ap.add_argument("--no-overlap-gather", dest="overlap_gather", action="store_false",
                     help="keep the K0 gather of step k+1 on the main stream (default: on its own stream, under the screening / registration of "
@@ -722,6 +736,7 @@ def main():
                                   ("decode", "fp32", "decode+match+pose, torch / MIOpen fp32 modules"),
                                   ("full", "fp32", "full (feat+match+pose), fp32 torch linears"),
                                   ("full", "fp16x3", "full (feat+match+pose), fp16x3 linears"),
+                                  ("full", "fp16x3-clipload", "full (feat+match+pose), fp16x3 linears, CLIP weights fp16-valued as `clip.load` leaves them"),
                                   ("full", "bf16w", "full (feat+match+pose), bf16 backbone (weights + activations) - NOT fp32-grade: for the record only")):
             r = run_stage_set(a, rank, world, dev, stage, steps=10, warmup=2, backbone_dtype=bdt)
             if rank == 0:

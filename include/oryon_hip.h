@@ -454,7 +454,10 @@ int oryon_engine_feedback(oryon_engine_t *handle, int64_t *step, int64_t *n_unde
  *     with every product accumulated as Ahi*Whi + Ahi*Wlo + Alo*Whi on the fp16 matrix pipe (fp32 accumulate): ~2^-22 relative, i.e.
  *     fp32-grade results at ~3x the fp32-MFMA rate.  act: 0 = none, 1 = QuickGELU x*sigmoid(1.702x) (CLIP), 2 = GELU x*Phi(x) with erf (Swin's nn.GELU), fused
  *     into the epilogue.
- *     K % 32 == 0, N % 256 == 0 (N % 128 == 0 when K >= 64), N * K < 2^30, |values| < 65504. */
+ *     K % 32 == 0, N % 256 == 0 (N % 128 == 0 when K >= 64), N * K < 2^30, |values| < 65504.
+ *     W_lo == NULL (K >= 64 only) declares that every weight IS an fp16 value (its low half would be all zeros: what `clip.load` leaves in
+ *     the reference's CLIPEncoder, models/vlm.py:19-22 - an fp16 checkpoint widened to fp32): the Ahi*Wlo products are left out, two
+ *     instead of three MFMAs per product, results bit-identical to passing a zero W_lo. */
 int oryon_split_f16x3(const float *x, int64_t n, void *hi_f16, void *lo_f16, void *stream);
 /* Range check of the fp16x3 path (round 5): every fp16x3 kernel of this library (B4 linear, B5 attention, the Swin / fusion window
  * attentions, the 24 x 24 and decoder convolutions) ORs 1 into a per-device flag word when one of its raw accumulators is not a finite

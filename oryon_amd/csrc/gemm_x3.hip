@@ -185,7 +185,10 @@ constexpr int G2_STAGE = 2 * G2_A_BYTES + 2 * G2_W_BYTES;                       
 // tools/probe_mfma_peak.hip; LDS reads at twice this kernel's rate cost that loop nothing).
 struct G3Frags { h8 ah[2], wh[4]; };           // the hi halves are double-buffered; the lo halves (al, wl) are re-read in place
 
-template <int ACT>
+// WEX ("weights exact"): every weight is exactly representable in fp16 (W_lo would be all zeros - what `clip.load` leaves in the
+// reference's CLIPEncoder, models/vlm.py:19-22: an fp16 checkpoint widened to fp32): the a_hi * w_lo term, its fragments and its DMA
+// are left out - 16 instead of 24 MFMAs per k-step, bit-identical results (the omitted products are exact zeros).
+template <int ACT, bool WEX>
 __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float *__restrict__ A, int M, int K, const __half *__restrict__ Whi,
                                                                   const __half *__restrict__ Wlo, const float *__restrict__ bias, int N,
                                                                   float *__restrict__ C, int tiles_m, int tiles_n, int sup_n, int sup_rows,
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
     const int a_row0 = t >> 3, a_c4 = t & 7;
     const float *a_tile;
     unsigned a_src[4];
-    const int w_piece0 = (wave_u * 4) & 15;
+    const int w_piece0 = WEX ? wave_u * 2 : (wave_u * 4) & 15;
     const char *w_mat;
     auto set_load_tile = [&](int lm0, int ln0) {
         a_tile = A + (size_t)lm0 * K;
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
         // N % 128 == 0: the last column tile may be half wide; the waves whose 64 weight rows fall past N re-read the tile's first rows
         // (their products land in accumulators that are never stored)
         const int w_row = ln0 + w_piece0 * 16 < N ? ln0 + w_piece0 * 16 : ln0;
-        w_mat = reinterpret_cast<const char *>(wave_u < 4 ? Whi : Wlo) + ((size_t)w_row * K) * 2;
+        w_mat = reinterpret_cast<const char *>(WEX || wave_u < 4 ? Whi : Wlo) + ((size_t)w_row * K) * 2;
     };
     set_load_tile(m0, n0);
     const unsigned a_dst = (unsigned)(a_row0 * 64 + ((((a_c4 >> 1) ^ ((a_row0 >> 2) & 3)) << 4) | ((a_c4 & 1) << 3)));   // + 4096 i
@@ -256,13 +259,14 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
 #pragma unroll
         for (int i = 0; i < 4; ++i) storeA1(stage, i);
     };
-    // weight tiles by LDS-DMA: wave w issues pieces 4 w .. 4 w + 3 of the 32 (16 Whi + 16 Wlo pieces of 16 rows x 64 bytes)
+    // weight tiles by LDS-DMA: wave w issues pieces 4 w .. 4 w + 3 of the 32 (16 Whi + 16 Wlo pieces of 16 rows x 64 bytes);
+    // WEX: pieces 2 w, 2 w + 1 of the 16 Whi pieces
     const unsigned w_src = (unsigned)(((size_t)(lane >> 2) * K + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);       // row = lane / 4 (+ 16 j)
     auto dmaW = [&](int k0, int stage) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < (WEX ? 2 : 4); ++j) {
             const char *src = w_mat + (size_t)j * 16 * K * 2 + (size_t)k0 * 2 + w_src;
-            char *dst = g2_lds + stage * G2_STAGE + 2 * G2_A_BYTES + (wave_u < 4 ? 0 : G2_W_BYTES) + (w_piece0 + j) * 1024;
+            char *dst = g2_lds + stage * G2_STAGE + 2 * G2_A_BYTES + (WEX || wave_u < 4 ? 0 : G2_W_BYTES) + (w_piece0 + j) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
@@ -309,6 +313,35 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
         G3_SB;
         al[1] = G3_RD(pa + G2_A_BYTES + 2048);
         G3_SB;
+        if constexpr (WEX) {
+            G3_MFMA(cur.ah[0], cur.wh[0], 0, 0);
+            G3_SB;
+            mid(0);
+            G3_SB;
+            G3_MFMA(cur.ah[0], cur.wh[1], 0, 1);
+            G3_SB;
+            G3_MFMA(cur.ah[0], cur.wh[2], 0, 2);
+            G3_SB;
+            mid(1);
+            G3_SB;
+            G3_MFMA(cur.ah[0], cur.wh[3], 0, 3);
+            G3_SB;
+            mid(2);
+            G3_SB;
+            G3_MFMA(cur.ah[1], cur.wh[0], 1, 0);
+            G3_SB;
+            G3_MFMA(cur.ah[1], cur.wh[1], 1, 1);
+            G3_SB;
+            mid(3);
+            G3_SB;
+            G3_MFMA(cur.ah[1], cur.wh[2], 1, 2);
+            G3_SB;
+            tail();                                  // after the last mid(): it reloads the registers the mids store from
+            G3_SB;
+            G3_MFMA(cur.ah[1], cur.wh[3], 1, 3);
+            G3_SB;
+            return;
+        }
         G3_MFMA(cur.ah[0], wl[0], 0, 0);
         G3_SB;
         mid(0);
@@ -371,7 +404,8 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
     storeA(0);
     gloadA(G2_BK);
     dmaW(G2_BK, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 // k-tile 0's 4 DMAs; k-tile 1's 4 loads + 4 DMAs may stay in flight
+    if constexpr (WEX) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // k-tile 0's DMAs; k-tile 1's 4 loads + 2 DMAs may stay in flight
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // k-tile 0's 4 DMAs; k-tile 1's 4 loads + 4 DMAs may stay in flight
     __syncthreads();
     G3Frags f0, f1;
     {
@@ -379,7 +413,10 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
 #pragma unroll
         for (int a = 0; a < 2; ++a) { f0.ah[a] = G3_RD(pa + a * 2048); al[a] = G3_RD(pa + G2_A_BYTES + a * 2048); }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { f0.wh[b] = G3_RD(pw + b * 2048); wl[b] = G3_RD(pw + G2_W_BYTES + b * 2048); }
+        for (int b = 0; b < 4; ++b) {
+            f0.wh[b] = G3_RD(pw + b * 2048);
+            if constexpr (!WEX) wl[b] = G3_RD(pw + G2_W_BYTES + b * 2048);
+        }
     }
 
     int g = 0;                                                        // running k-tile count of this workgroup: stage = g & 1
@@ -495,12 +532,14 @@ extern "C" int oryon_split_f16x3(const float *x, int64_t n, void *hi, void *lo, 
 extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act,
                                   float *C, void *stream)
 {
-    ORYON_CHECK_ARG(A && W_hi && W_lo && C && M >= 0 && K > 0 && N > 0);
+    ORYON_CHECK_ARG(A && W_hi && C && M >= 0 && K > 0 && N > 0);
+    // W_lo == NULL: the weights are exactly representable in fp16 (stream-kernel shapes only)
+    ORYON_CHECK_ARG(W_lo || (K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)));
     ORYON_CHECK_ARG(K % GX_BK == 0 && act >= 0 && act <= 2);
     ORYON_CHECK_ARG(N % GX_BN == 0 || (N % 128 == 0 && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)));   // half-wide last column tile: stream kernel only
     if (M == 0) return ORYON_OK;
     static const int variant = dev_env_int("ORYON_GEMM_X3_VARIANT", 2);      // dev: 1 = small-tile kernel
-    if ((variant != 1 || N % GX_BN != 0) && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)) {
+    if ((variant != 1 || N % GX_BN != 0 || !W_lo) && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)) {
         const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
         const int sup_n = (tiles_n + 7) / 8;
         const int sup_cols = (tiles_n + sup_n - 1) / sup_n;
@@ -515,15 +554,19 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
         if (grid > n_slots) grid = n_slots;
         hipStream_t st2 = as_stream(stream);
         const __half *wh2 = static_cast<const __half *>(W_hi), *wl2 = static_cast<const __half *>(W_lo);
-#define ORYON_LAUNCH_STREAM(ACT)                                                                                                    \
+#define ORYON_LAUNCH_STREAM(ACT, WEX)                                                                                               \
     do {                                                                                                                            \
-        allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<ACT>), 2 * G2_STAGE);                           \
-        hipLaunchKernelGGL((linear_f16x3_stream_kernel<ACT>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2, bias, N, C, \
-                           tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots, x3_range_flag());                                  \
+        allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<ACT, WEX>), 2 * G2_STAGE);                      \
+        hipLaunchKernelGGL((linear_f16x3_stream_kernel<ACT, WEX>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2, bias, N, \
+                           C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots, x3_range_flag());                                \
     } while (0)
-        if (act == 2) ORYON_LAUNCH_STREAM(2);
-        else if (act == 1) ORYON_LAUNCH_STREAM(1);
-        else ORYON_LAUNCH_STREAM(0);
+        if (!wl2) {
+            if (act == 2) ORYON_LAUNCH_STREAM(2, true);
+            else if (act == 1) ORYON_LAUNCH_STREAM(1, true);
+            else ORYON_LAUNCH_STREAM(0, true);
+        } else if (act == 2) ORYON_LAUNCH_STREAM(2, false);
+        else if (act == 1) ORYON_LAUNCH_STREAM(1, false);
+        else ORYON_LAUNCH_STREAM(0, false);
 #undef ORYON_LAUNCH_STREAM
         ORYON_CHECK_LAUNCH();
         return ORYON_OK;

@@ -678,6 +678,7 @@ _x3_weights = {}
 # that layer with torch's fp32 linear when the split would overflow; weights are checked once, when they are split.
 X3_GUARD = False
 X3_LIMIT = 60000.0            # below float16's 65504 with room for the rounding of `hi`
+X3_EXACT_WEIGHTS = True       # use the two-product kernel for weights whose fp16 split has no low half (results are bit-identical)
 x3_guard_fallbacks = 0        # layers evaluated by torch because an operand left the float16 range (guard mode)
 
 
@@ -706,6 +707,12 @@ def _split_weight_f16x3(weight: torch.Tensor):
         hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
         lo = torch.empty(w.shape, dtype=torch.float16, device=w.device)
         check(lib().oryon_split_f16x3(ptr(w), w.numel(), ptr(hi), ptr(lo), stream_ptr(w.device)), "oryon_split_f16x3")
+        # A weight that IS an fp16 value in every element (what `clip.load` leaves in the reference's CLIPEncoder - an fp16 checkpoint
+        # widened with `.to(torch.float32)`, models/vlm.py:19-22 - and what every frozen layer of a checkpoint fine-tuned from it still
+        # holds) has an all-zero low half: the kernel then leaves out the a_hi * w_lo products (W_lo = NULL; 16 instead of 24 MFMAs per
+        # k-step, bit-identical results).  One device read-back per weight and version, here, never per call.
+        if X3_EXACT_WEIGHTS and w.shape[1] >= 64 and not bool(lo.any()):
+            lo = None
         if len(_x3_weights) > 4096:
             _x3_weights.clear()
         ref = weakref.ref(weight, lambda _r, k=key: _x3_weights.pop(k, None))
@@ -739,7 +746,7 @@ def linear_f16x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     hi, lo = _split_weight_f16x3(weight)
     out = torch.empty((x2.shape[0], N), dtype=torch.float32, device=dev)
     b = None if bias is None else bias.detach().to(torch.float32).contiguous()
-    check(lib().oryon_linear_f16x3(ptr(x2), x2.shape[0], K, ptr(hi), ptr(lo), ptr(b), N, 2 if gelu else (1 if quick_gelu else 0), ptr(out),
+    check(lib().oryon_linear_f16x3(ptr(x2), x2.shape[0], K, ptr(hi), ptr(lo) if lo is not None else None, ptr(b), N, 2 if gelu else (1 if quick_gelu else 0), ptr(out),
                                    stream_ptr(dev)), "oryon_linear_f16x3")
     return out.view(*x.shape[:-1], N)
 

@@ -245,6 +245,46 @@ def test_oryon_forward_fast_path_matches_the_fp32_modules():
 
 
 @pytest.mark.gpu
+def test_fp16x3_linear_with_fp16_exact_weights_is_bit_identical():
+    """Weights that are fp16 values in fp32 storage (what `clip.load(...)` + `.to(torch.float32)` leaves in the reference's CLIPEncoder,
+    models/vlm.py:19-22) have an all-zero low half: ops.linear_f16x3 detects that once per weight and passes W_lo = NULL - the kernel
+    variant without the a_hi * w_lo products.  Its results equal the three-product kernel's bit for bit, for every activation, ragged
+    M and the half-wide last column tile; a weight with ONE element off the fp16 grid takes the three-product kernel."""
+    from oryon_amd import ops
+    dev = "cuda"
+    torch.set_grad_enabled(False)
+    g = torch.Generator(device=dev).manual_seed(5)
+    for M, K, N, act in ((577 * 3, 1024, 3072, None), (1000, 1024, 4096, "quick"), (130, 4096, 1024, None), (1, 64, 256, None),
+                         (1500, 128, 384, "erf"), (700, 512, 128, None)):
+        x = torch.randn(M, K, generator=g, device=dev) * 3.0
+        w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).half().float()
+        b = torch.randn(N, generator=g, device=dev)
+        kw = dict(quick_gelu=act == "quick", gelu=act == "erf")
+        hi, lo = ops._split_weight_f16x3(w)
+        assert lo is None and torch.equal(hi.float(), w)
+        got = ops.linear_f16x3(x, w, b, **kw)
+        ops.X3_EXACT_WEIGHTS = False
+        try:
+            w3 = w.clone()
+            assert ops._split_weight_f16x3(w3)[1] is not None
+            ref = ops.linear_f16x3(x, w3, b, **kw)
+        finally:
+            ops.X3_EXACT_WEIGHTS = True
+        assert torch.equal(got, ref), (M, K, N, act, float((got - ref).abs().max()))
+        r64 = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        if act == "erf":
+            r64 = torch.nn.functional.gelu(r64)
+        elif act:
+            r64 = r64 * torch.sigmoid(1.702 * r64)
+        assert float((got.double() - r64).abs().max()) / float(r64.abs().max()) < 5e-6
+    w = (torch.randn(256, 128, generator=g, device=dev)).half().float()
+    w[17, 5] += 2.0 ** -14                        # off the fp16 grid
+    assert ops._split_weight_f16x3(w)[1] is not None
+    w32 = torch.randn(256, 32, generator=g, device=dev).half().float()          # K = 32: the small-tile kernel keeps its (zero) low half
+    assert ops._split_weight_f16x3(w32)[1] is not None
+
+
+@pytest.mark.gpu
 def test_fp16x3_linear_and_clip_tower_match_fp32():
     """B4 (oryon_linear_f16x3): the error-compensated fp16x3 linear against an fp64 reference (must be at least as accurate as torch's
     fp32 linear), ragged M, fused QuickGELU; and the CLIP image tower evaluated with it against the fp32 torch evaluation: patch tokens
