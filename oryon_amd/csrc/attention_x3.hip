@@ -10,6 +10,7 @@
 //   qkv [N, L, 3*Dm] fp32 = the in_proj output (q | k | v, head h at columns h*64 .. h*64+63 of each third), out [N, L, Dm] fp32.
 // One workgroup = 128 queries of one (image, head); 4 waves x 32 queries.
 #include <hip/hip_fp16.h>
+#include <type_traits>
 #include "common.h"
 
 namespace oryon {
@@ -26,12 +27,50 @@ __device__ __forceinline__ void mha_split(float x, _Float16 &hi, _Float16 &lo)
     lo = (_Float16)(x - (float)hi);
 }
 
-__global__ __launch_bounds__(256) void mha_x3_kernel(const float *__restrict__ qkv, int L, int Dm, float scale, float *__restrict__ out, int n_qblk,
-                                                     int heads, int n_units)
+// Round 5 rework of the loop around the same arithmetic (results bit-identical to the round-2 kernel): the ISA of that kernel spent ~790
+// VALU-class instructions per 64-key tile and wave against 48 MFMAs (1536 matrix-pipe cycles), a quarter of them 64-bit address arithmetic
+// and per-load `key < L` branches of the 16 scalar V loads, another quarter v_accvgpr moves of a spilled prefetch set.  Now: wave-uniform
+// 64-bit bases in SGPRs + one 32-bit lane offset (saddr loads); predicates only in the ONE ragged tile (rows clamped instead of zeroed -
+// their scores are masked to -inf, p = 0 exactly, so any finite K / V row gives the same result); the second 32-key half of the last
+// tile (L = 577: one valid key of 64) and the waves of the last query block that hold no query at all are skipped; the accumulators are
+// rescaled only when some lane's running maximum moved.
+template <bool RAGGED>
+__device__ __forceinline__ void mha_fetch(const float *__restrict__ kbase, const float *__restrict__ vbase, unsigned rs, int j0, int L,
+                                          unsigned krow0, unsigned kc4, unsigned vkey0, unsigned vch, float4 (&kv)[4], float (&vv)[16])
+{
+    if constexpr (!RAGGED) {
+        const float *kp = kbase + (size_t)j0 * rs, *vp = vbase + (size_t)j0 * rs;           // wave-uniform
+        const unsigned koff = krow0 * rs + 4u * kc4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kv[i] = *reinterpret_cast<const float4 *>(kp + (koff + (unsigned)(16 * i) * rs));
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vv[o * 8 + e] = vp[(unsigned)(32 * o + 8 * (e >> 2) + (e & 3)) * rs + vch];
+    } else {
+        const unsigned last = (unsigned)(L - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned row = (unsigned)j0 + krow0 + 16u * i;
+            row = row < last ? row : last;
+            kv[i] = *reinterpret_cast<const float4 *>(kbase + ((size_t)row * rs + 4u * kc4));
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned key = (unsigned)j0 + vkey0 + (unsigned)(32 * o + 8 * (e >> 2) + (e & 3));
+                key = key < last ? key : last;
+                vv[o * 8 + e] = vbase[((size_t)key - vkey0) * rs + vch];                    // vbase already holds this wave's key phase
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void mha_x3_kernel(const float *__restrict__ qkv, int L, int Dm, float scale, float *__restrict__ out,
+                                                        int n_qblk, int heads, int n_units)
 {
     constexpr int C = MHA_D, CB = C / 32, NS = C / 16;
-    constexpr int KF4 = MHA_KT * (C / 4) / 256;          // 4 float4 of K per thread and tile
-    constexpr int VPT = MHA_KT * C / 256, VOCT = VPT / 8, GROUPS = 256 / C;
+    static_assert(C == 64 && MHA_KT == 64, "fetch / land index maps are written for 64 x 64 tiles and 256 threads");
     __shared__ __attribute__((aligned(16))) _Float16 Kh[MHA_KT * MHA_KLD], Kl[MHA_KT * MHA_KLD];
     __shared__ __attribute__((aligned(16))) _Float16 Vh[MHA_KT * C], Vl[MHA_KT * C];
     // XCD-aware block map (1-D grid): the query blocks of one (image, head) read the same K / V rows, so they get linear ids that are equal
@@ -40,50 +79,39 @@ __global__ __launch_bounds__(256) void mha_x3_kernel(const float *__restrict__ q
     const int unit = (lin / 8 / n_qblk) * 8 + (lin & 7);
     if (unit >= n_units) return;
     const int img = unit / heads, head = unit % heads, q0 = ((lin / 8) % n_qblk) * MHA_Q;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
-    const size_t rs = (size_t)3 * Dm;                    // row stride of qkv
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned rs = 3u * (unsigned)Dm;               // row stride of qkv (floats)
     const float *base = qkv + (size_t)img * L * rs + head * C;
     const int qrow = q0 + wave * 32 + l31;
     const int qsafe = qrow < L ? qrow : L - 1;
+    const bool wave_live = q0 + wave * 32 < L;           // wave-uniform: a wave without a single query only helps landing the tiles
 
-    float4 kv[KF4];
-    float vv[VPT];
-    const int vch = t % C, vgrp = t / C;
-    auto fetch = [&](int j0) {
-#pragma unroll
-        for (int i = 0; i < KF4; ++i) {
-            const int e = t + 256 * i, row = e / (C / 4), c4 = e % (C / 4);
-            kv[i] = j0 + row < L ? *reinterpret_cast<const float4 *>(base + (size_t)(j0 + row) * rs + Dm + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int o = 0; o < VOCT; ++o) {
-            const int oct = vgrp + GROUPS * o;           // octet index = (kb*2 + t2)*2 + h
-            const int kb = oct >> 2, t2 = (oct >> 1) & 1, h = oct & 1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int key = j0 + kb * 32 + 16 * t2 + 8 * (e >> 2) + 4 * h + (e & 3);
-                vv[o * 8 + e] = key < L ? base[(size_t)key * rs + 2 * Dm + vch] : 0.0f;
-            }
-        }
-    };
+    // K tile: float4 e = t + 256 i -> row t / 16 + 16 i, columns 4 (t % 16) ..; V tile: octet (wave + 4 o) of channel `lane` = keys
+    // 32 o + 16 ((wave >> 1) & 1) + 4 (wave & 1) + 8 (e >> 2) + (e & 3) - the MFMA k-slot order of the P registers
+    float4 kv[4];
+    float vv[16];
+    const unsigned krow0 = (unsigned)t >> 4, kc4 = (unsigned)t & 15u, vch = (unsigned)lane;
+    const unsigned vkey0 = (unsigned)(16 * ((wave >> 1) & 1) + 4 * (wave & 1));
+    const float *kbase = base + Dm, *vbase = base + 2 * Dm + (size_t)vkey0 * rs;
     auto land = [&]() {
 #pragma unroll
-        for (int i = 0; i < KF4; ++i) {
-            const int e = t + 256 * i, row = e / (C / 4), c4 = e % (C / 4);
+        for (int i = 0; i < 4; ++i) {
+            const int row = (int)krow0 + 16 * i;
             union { _Float16 h[4]; uint2 u; } ph, pl;
             mha_split(kv[i].x, ph.h[0], pl.h[0]); mha_split(kv[i].y, ph.h[1], pl.h[1]);
             mha_split(kv[i].z, ph.h[2], pl.h[2]); mha_split(kv[i].w, ph.h[3], pl.h[3]);
-            *reinterpret_cast<uint2 *>(Kh + row * MHA_KLD + 4 * c4) = ph.u;
-            *reinterpret_cast<uint2 *>(Kl + row * MHA_KLD + 4 * c4) = pl.u;
+            *reinterpret_cast<uint2 *>(Kh + row * MHA_KLD + 4 * (int)kc4) = ph.u;
+            *reinterpret_cast<uint2 *>(Kl + row * MHA_KLD + 4 * (int)kc4) = pl.u;
         }
 #pragma unroll
-        for (int o = 0; o < VOCT; ++o) {
-            const int oct = vgrp + GROUPS * o;
+        for (int o = 0; o < 2; ++o) {
+            const int oct = wave + 4 * o;
             union { _Float16 h[8]; uint4 u; } ph, pl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) mha_split(vv[o * 8 + e], ph.h[e], pl.h[e]);
-            *reinterpret_cast<uint4 *>(Vh + ((size_t)oct * C + vch) * 8) = ph.u;
-            *reinterpret_cast<uint4 *>(Vl + ((size_t)oct * C + vch) * 8) = pl.u;
+            *reinterpret_cast<uint4 *>(Vh + ((size_t)oct * C + lane) * 8) = ph.u;
+            *reinterpret_cast<uint4 *>(Vl + ((size_t)oct * C + lane) * 8) = pl.u;
         }
     };
 
@@ -111,21 +139,19 @@ __global__ __launch_bounds__(256) void mha_x3_kernel(const float *__restrict__ q
         for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
-    fetch(0);
-    for (int j0 = 0; j0 < L; j0 += MHA_KT) {
-        __syncthreads();
-        land();
-        __syncthreads();
-        if (j0 + MHA_KT < L) fetch(j0 + MHA_KT);
-        af32x16 s[2];
+    // one 64-key tile (NKB = 2) or its first 32 keys only (NKB = 1: the rest of the last tile lies beyond L)
+    auto tile = [&](auto nkb_tag, auto ragged_tag, int j0) {
+        constexpr int NKB = decltype(nkb_tag)::value;
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        af32x16 s[NKB];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < NKB; ++kb) {
                 const ahalf8 ah = *reinterpret_cast<const ahalf8 *>(Kh + (kb * 32 + l31) * MHA_KLD + 16 * s_ + 8 * hi);
                 const ahalf8 al = *reinterpret_cast<const ahalf8 *>(Kl + (kb * 32 + l31) * MHA_KLD + 16 * s_ + 8 * hi);
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s_], s[kb], 0, 0, 0);
@@ -134,23 +160,32 @@ __global__ __launch_bounds__(256) void mha_x3_kernel(const float *__restrict__ q
             }
         }
         float m_tile = -INFINITY;
-        const bool ragged = j0 + MHA_KT > L;             // only the last tile holds keys >= L
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = s[kb][r];
-                if (ragged && j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) v = -INFINITY;
-                s[kb][r] = v;
+                if constexpr (RAGGED) {
+                    if (j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) v = -INFINITY;
+                    s[kb][r] = v;
+                }
                 m_tile = fmaxf(m_tile, v);
             }
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
         const float m_new = fmaxf(m_run, m_tile);
-        const float alpha = __expf(m_run - m_new);
-        float l_tile = 0.0f;
-        ahalf8 ph[2][2], pl[2][2];
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0ull) {      // some lane's maximum moved: rescale (alpha is exactly 1 elsewhere)
+            const float alpha = __expf(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
+            m_run = m_new;
+        }
+        float l_tile = 0.0f;
+        ahalf8 ph[NKB][2], pl[NKB][2];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __expf(s[kb][r] - m_new);
@@ -160,14 +195,9 @@ __global__ __launch_bounds__(256) void mha_x3_kernel(const float *__restrict__ q
                 ph[kb][r >> 3][r & 7] = h_;
                 pl[kb][r >> 3][r & 7] = l_;
             }
-        l_run = l_run * alpha + l_tile;
-        m_run = m_new;
+        l_run += l_tile;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 const int oct = (kb * 2 + t2) * 2 + hi;
@@ -180,6 +210,25 @@ __global__ __launch_bounds__(256) void mha_x3_kernel(const float *__restrict__ q
                     acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kb][t2], acc_o[cb], 0, 0, 0);
                 }
             }
+    };
+
+    auto fetch = [&](int j) {
+        if (j + MHA_KT <= L) mha_fetch<false>(kbase, vbase, rs, j, L, krow0, kc4, vkey0, vch, kv, vv);
+        else mha_fetch<true>(kbase, vbase, rs, j, L, krow0, kc4, vkey0, vch, kv, vv);
+    };
+    // (tried: two tile buffers with the next tile's split placed after the QK^T MFMAs and one barrier per tile - 0.88 vs 0.87 ms, the
+    // compiler keeps the split's VALU behind the MFMA block whatever sched_group_barrier asks for)
+    fetch(0);
+    for (int j0 = 0; j0 < L; j0 += MHA_KT) {
+        __syncthreads();
+        land();
+        __syncthreads();
+        const int jn = j0 + MHA_KT;
+        if (jn < L) fetch(jn);
+        if (!wave_live) continue;
+        if (jn <= L) tile(std::integral_constant<int, 2>{}, std::false_type{}, j0);
+        else if (j0 + 32 < L) tile(std::integral_constant<int, 2>{}, std::true_type{}, j0);
+        else tile(std::integral_constant<int, 1>{}, std::true_type{}, j0);
     }
     const float l_all = l_run + __shfl_xor(l_run, 32);
     if (qrow >= L) return;
