@@ -468,6 +468,13 @@ int oryon_split_f16x3(const float *x, int64_t n, void *hi_f16, void *lo_f16, voi
 int oryon_x3_range_flag(int *value_out, int reset, void *stream);
 int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,
                        void *stream);
+/* C[M,N] += A W^T + bias (no activation; K >= 64, N % 128 == 0, N * K < 2^30): the towers' residual update x = x + linear(h)
+ * (clip's ResidualAttentionBlock: x + attn(ln_1(x)), x + mlp(ln_2(x)); torchvision's SwinTransformerBlock the same) done by the linear
+ * itself - every element of C receives ONE fire-and-forget fp32 atomic add of its finished sum, i.e. exactly the rounding of the separate
+ * add, in a fixed order (no two lanes touch the same element) - so that the LayerNorm pass which follows reads one tensor, not two.
+ * C must not alias A. */
+int oryon_linear_f16x3_acc(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, float *C,
+                           void *stream);
 
 /* B5  multi-head self-attention of the frozen CLIP image tower (clip's ResidualAttentionBlock.attention reached through
  *     models/vlm.py:46-56; nn.MultiheadAttention without mask) in fp32-grade arithmetic on the fp16 matrix pipe (both products

@@ -98,6 +98,7 @@ _PROTOS = {
     "oryon_kabsch_batched": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "oryon_split_f16x3": (c_int, [_P, c_int64, _P, _P, _P]),
     "oryon_linear_f16x3": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P]),
+    "oryon_linear_f16x3_acc": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "oryon_mha_f16x3": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "oryon_pose_metrics": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     "oryon_pose_bop_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -68,6 +68,7 @@ class PatchEmbed(nn.Conv2d):
 # Inference switch: evaluate the towers' linear layers with the error-compensated fp16x3 kernel (ops.linear_f16x3, B4) instead of
 # torch's fp32 GEMMs.  Results stay fp32-grade (descriptor maps within ~1e-5 of the fp32 evaluation, tests/test_backbone_pins.py).
 FP16X3_LINEAR = False
+ACC_RESIDUAL = True           # fp16x3 path: the blocks' last linears add into the residual stream themselves (same values)
 
 
 def _linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], quick_gelu: bool = False) -> Tensor:
@@ -135,10 +136,24 @@ class _Block(nn.Module):
         x = x + self.attn(self.ln_1(x), self.causal)
         return x + self.mlp(self.ln_2(x))
 
-    def forward_fused(self, x: Tensor, h: Tensor, next_ln: Optional[nn.LayerNorm]):
+    def forward_fused(self, x: Tensor, h: Tensor, next_ln: Optional[nn.LayerNorm], owned: bool = False):
         """Same block with the residual adds fused into the following LayerNorm (ops.add_layernorm): takes the stream x and
         h = ln_1(x), returns the new stream and next_ln(new stream) (None for the last block)."""
         from .. import ops
+        if (owned and FP16X3_LINEAR and not self.causal and x.dtype == torch.float32 and x.shape[-1] == 64 * self.attn.heads
+                and ops.linear_f16x3_acc_supported(h, self.attn.out_proj.weight, x)
+                and ops.linear_f16x3_acc_supported(h.new_empty((1, self.mlp.c_proj.weight.shape[1])), self.mlp.c_proj.weight, x[:1])):
+            # the residual stream is updated IN PLACE by the block's two last linears (oryon_linear_f16x3_acc: one fp32 add per element,
+            # the value `x + linear(...)` has), so each LayerNorm pass reads one tensor instead of two.  `owned`: x is a buffer of this
+            # forward (never the caller's tensor).
+            o = ops.mha_f16x3(_linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias), self.attn.heads)
+            ops.linear_f16x3_acc(o, self.attn.out_proj.weight, self.attn.out_proj.bias, x)
+            _, h = ops.add_layernorm(x, None, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+            h = _linear(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, quick_gelu=True)
+            ops.linear_f16x3_acc(h, self.mlp.c_proj.weight, self.mlp.c_proj.bias, x)
+            if next_ln is None:
+                return x, None
+            return ops.add_layernorm(x, None, next_ln.weight, next_ln.bias, next_ln.eps)
         x, h = ops.add_layernorm(x, self.attn(h, self.causal), self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
         d = self.mlp(h)
         if next_ln is None:
@@ -159,8 +174,11 @@ class _Transformer(nn.Module):
             blocks = list(self.resblocks)
             ln0 = blocks[0].ln_1
             x, h = ops.add_layernorm(x, None, ln0.weight, ln0.bias, ln0.eps)
+            owned = False
+            if FP16X3_LINEAR and x.dtype == torch.float32 and ACC_RESIDUAL:
+                x, owned = x.clone(), True                # the stream the blocks update in place
             for i, blk in enumerate(blocks):
-                x, h = blk.forward_fused(x, h, blocks[i + 1].ln_1 if i + 1 < len(blocks) else None)
+                x, h = blk.forward_fused(x, h, blocks[i + 1].ln_1 if i + 1 < len(blocks) else None, owned)
             return x
         return self.resblocks(x)
 

@@ -188,7 +188,10 @@ struct G3Frags { h8 ah[2], wh[4]; };           // the hi halves are double-buffe
 // WEX ("weights exact"): every weight is exactly representable in fp16 (W_lo would be all zeros - what `clip.load` leaves in the
 // reference's CLIPEncoder, models/vlm.py:19-22: an fp16 checkpoint widened to fp32): the a_hi * w_lo term, its fragments and its DMA
 // are left out - 16 instead of 24 MFMAs per k-step, bit-identical results (the omitted products are exact zeros).
-template <int ACT, bool WEX>
+// ACC ("accumulate"): C += A W^T + bias - the result is ADDED to what C holds with fire-and-forget global_atomic_add_f32 (every element is
+// touched by exactly one lane once: one fp32 addition, same rounding as a separate residual add, deterministic).  The towers' residual
+// stream is updated in place by the out-projection / second MLP linear, and the LayerNorm pass that follows reads ONE tensor instead of two.
+template <int ACT, bool WEX, bool ACC = false>
 __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float *__restrict__ A, int M, int K, const __half *__restrict__ Whi,
                                                                   const __half *__restrict__ Wlo, const float *__restrict__ bias, int N,
                                                                   float *__restrict__ C, int tiles_m, int tiles_n, int sup_n, int sup_rows,
@@ -457,6 +460,10 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
             if (ACT == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
             return v;
         };
+        auto put = [&](float *p_, float v) {
+            if constexpr (ACC) unsafeAtomicAdd(p_, v);
+            else *p_ = v;
+        };
         if (!cols_in) {
         } else if (m0 + G2_BM <= M) {
 #pragma unroll
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
                 for (int r = 0; r < 16; ++r)
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
-                        ctile[(size_t)(a * 32 + (r & 3) + 8 * (r >> 2)) * N + b * 32] = finish(acc[a][b][r], b);
+                        put(ctile + (size_t)(a * 32 + (r & 3) + 8 * (r >> 2)) * N + b * 32, finish(acc[a][b][r], b));
         } else {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void linear_f16x3_stream_kernel(const float
                     const int dm = a * 32 + (r & 3) + 8 * (r >> 2);
                     if (mrow + dm < M) {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) ctile[(size_t)dm * N + b * 32] = finish(acc[a][b][r], b);
+                        for (int b = 0; b < 4; ++b) put(ctile + (size_t)dm * N + b * 32, finish(acc[a][b][r], b));
                     }
                 }
         }
@@ -529,8 +536,24 @@ extern "C" int oryon_split_f16x3(const float *x, int64_t n, void *hi, void *lo, 
     return ORYON_OK;
 }
 
+static int linear_f16x3_impl(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,
+                             bool accumulate, void *stream);
+
 extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act,
                                   float *C, void *stream)
+{
+    return linear_f16x3_impl(A, M, K, W_hi, W_lo, bias, N, act, C, false, stream);
+}
+
+extern "C" int oryon_linear_f16x3_acc(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, float *C,
+                                      void *stream)
+{
+    ORYON_CHECK_ARG(K >= 2 * G2_BK && N % 128 == 0 && (size_t)N * (size_t)K < (1ull << 30));      // the stream kernel's shapes only
+    return linear_f16x3_impl(A, M, K, W_hi, W_lo, bias, N, 0, C, true, stream);
+}
+
+static int linear_f16x3_impl(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,
+                             bool accumulate, void *stream)
 {
     ORYON_CHECK_ARG(A && W_hi && C && M >= 0 && K > 0 && N > 0);
     // W_lo == NULL: the weights are exactly representable in fp16 (stream-kernel shapes only)
@@ -539,7 +562,7 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
     ORYON_CHECK_ARG(N % GX_BN == 0 || (N % 128 == 0 && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)));   // half-wide last column tile: stream kernel only
     if (M == 0) return ORYON_OK;
     static const int variant = dev_env_int("ORYON_GEMM_X3_VARIANT", 2);      // dev: 1 = small-tile kernel
-    if ((variant != 1 || N % GX_BN != 0 || !W_lo) && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)) {
+    if ((variant != 1 || N % GX_BN != 0 || !W_lo || accumulate) && K >= 2 * G2_BK && (size_t)N * (size_t)K < (1ull << 30)) {
         const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
         const int sup_n = (tiles_n + 7) / 8;
         const int sup_cols = (tiles_n + sup_n - 1) / sup_n;
@@ -554,19 +577,22 @@ extern "C" int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi
         if (grid > n_slots) grid = n_slots;
         hipStream_t st2 = as_stream(stream);
         const __half *wh2 = static_cast<const __half *>(W_hi), *wl2 = static_cast<const __half *>(W_lo);
-#define ORYON_LAUNCH_STREAM(ACT, WEX)                                                                                               \
+#define ORYON_LAUNCH_STREAM(ACT, WEX, ACC)                                                                                          \
     do {                                                                                                                            \
-        allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<ACT, WEX>), 2 * G2_STAGE);                      \
-        hipLaunchKernelGGL((linear_f16x3_stream_kernel<ACT, WEX>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2, bias, N, \
-                           C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots, x3_range_flag());                                \
+        allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<ACT, WEX, ACC>), 2 * G2_STAGE);                 \
+        hipLaunchKernelGGL((linear_f16x3_stream_kernel<ACT, WEX, ACC>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2,   \
+                           bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots, x3_range_flag());                       \
     } while (0)
-        if (!wl2) {
-            if (act == 2) ORYON_LAUNCH_STREAM(2, true);
-            else if (act == 1) ORYON_LAUNCH_STREAM(1, true);
-            else ORYON_LAUNCH_STREAM(0, true);
-        } else if (act == 2) ORYON_LAUNCH_STREAM(2, false);
-        else if (act == 1) ORYON_LAUNCH_STREAM(1, false);
-        else ORYON_LAUNCH_STREAM(0, false);
+        if (accumulate) {
+            if (!wl2) ORYON_LAUNCH_STREAM(0, true, true);
+            else ORYON_LAUNCH_STREAM(0, false, true);
+        } else if (!wl2) {
+            if (act == 2) ORYON_LAUNCH_STREAM(2, true, false);
+            else if (act == 1) ORYON_LAUNCH_STREAM(1, true, false);
+            else ORYON_LAUNCH_STREAM(0, true, false);
+        } else if (act == 2) ORYON_LAUNCH_STREAM(2, false, false);
+        else if (act == 1) ORYON_LAUNCH_STREAM(1, false, false);
+        else ORYON_LAUNCH_STREAM(0, false, false);
 #undef ORYON_LAUNCH_STREAM
         ORYON_CHECK_LAUNCH();
         return ORYON_OK;

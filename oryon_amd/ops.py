@@ -751,6 +751,27 @@ def linear_f16x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out.view(*x.shape[:-1], N)
 
 
+def linear_f16x3_acc_supported(x: torch.Tensor, weight: torch.Tensor, out: torch.Tensor) -> bool:
+    return (linear_f16x3_supported(x, weight) and weight.shape[1] >= 64 and weight.shape[0] % 128 == 0 and not X3_GUARD
+            and out.dtype == torch.float32 and out.is_contiguous() and out.shape[-1] == weight.shape[0]
+            and out.numel() // weight.shape[0] == x.numel() // weight.shape[1])
+
+
+@_on_tensor_device
+def linear_f16x3_acc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
+    """out += x @ weight.T + bias, in place (oryon_linear_f16x3_acc): the residual update of a transformer block done by its last linear.
+    Same value per element as `out + linear_f16x3(x, weight, bias)` (one fp32 addition of the finished sum)."""
+    dev = _lib.require_gpu(x.device)
+    K, N = weight.shape[1], weight.shape[0]
+    x2 = x.reshape(-1, K).contiguous()
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == x2.shape[0] * N and out.data_ptr() != x2.data_ptr()
+    hi, lo = _split_weight_f16x3(weight)
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    check(lib().oryon_linear_f16x3_acc(ptr(x2), x2.shape[0], K, ptr(hi), ptr(lo) if lo is not None else None, ptr(b), N, ptr(out),
+                                       stream_ptr(dev)), "oryon_linear_f16x3_acc")
+    return out
+
+
 @_on_tensor_device
 def mha_f16x3(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     """Self-attention on the packed in_proj output qkv [N, L, 3*D] fp32 (head dim 64, no mask) -> [N, L, D] fp32 (B5)."""

@@ -245,6 +245,46 @@ def test_oryon_forward_fast_path_matches_the_fp32_modules():
 
 
 @pytest.mark.gpu
+def test_fp16x3_linear_acc_equals_the_separate_residual_add():
+    """oryon_linear_f16x3_acc (C += A W^T + bias, one fire-and-forget fp32 atomic add per element) gives exactly `x + linear(h)`: general and
+    fp16-valued weights, ragged M, the half-wide last column tile; and the CLIP image tower whose blocks update the residual stream in
+    place (backbone.clip.ACC_RESIDUAL) returns the same bits as the tower with separate adds, leaving its input untouched."""
+    from oryon_amd import ops
+    from oryon_amd.backbone import clip as clip_mod
+    from oryon_amd.backbone.clip import CLIP, CLIPConfig
+    dev = "cuda"
+    torch.set_grad_enabled(False)
+    g = torch.Generator(device=dev).manual_seed(11)
+    for M, K, N, exact in ((577 * 3, 1024, 1024, False), (1000, 4096, 1024, True), (130, 64, 384, False), (1, 128, 128, True)):
+        h = torch.randn(M, K, generator=g, device=dev) * 2.0
+        w = torch.randn(N, K, generator=g, device=dev) * K ** -0.5
+        if exact:
+            w = w.half().float()
+        b = torch.randn(N, generator=g, device=dev)
+        x = torch.randn(M, N, generator=g, device=dev) * 5.0
+        assert ops.linear_f16x3_acc_supported(h, w, x)
+        ref = x + ops.linear_f16x3(h, w, b)
+        buf = x.clone()
+        assert ops.linear_f16x3_acc(h, w, b, buf) is buf and torch.equal(buf, ref), (M, K, N, float((buf - ref).abs().max()))
+    assert not ops.linear_f16x3_acc_supported(torch.zeros(4, 32, device=dev), torch.zeros(256, 32, device=dev), torch.zeros(4, 256, device=dev))  # K < 64
+    cfg = CLIPConfig.vit_l14_336()
+    cfg.v_layers, cfg.t_layers = 3, 1
+    torch.manual_seed(0)
+    m = CLIP(cfg).to(dev).eval()
+    img = torch.randn(2, 3, 336, 336, device=dev)
+    keep = img.clone()
+    clip_mod.FP16X3_LINEAR = True
+    try:
+        clip_mod.ACC_RESIDUAL = False
+        sep = m.patch_tokens(img)
+        clip_mod.ACC_RESIDUAL = True
+        acc = m.patch_tokens(img)
+    finally:
+        clip_mod.FP16X3_LINEAR, clip_mod.ACC_RESIDUAL = False, True
+    assert torch.equal(sep, acc) and torch.equal(img, keep)
+
+
+@pytest.mark.gpu
 def test_fp16x3_linear_with_fp16_exact_weights_is_bit_identical():
     """Weights that are fp16 values in fp32 storage (what `clip.load(...)` + `.to(torch.float32)` leaves in the reference's CLIPEncoder,
     models/vlm.py:19-22) have an all-zero low half: ops.linear_f16x3 detects that once per weight and passes W_lo = NULL - the kernel

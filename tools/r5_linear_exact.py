@@ -29,3 +29,37 @@ for K, N, act in ((1024, 3072, None), (1024, 1024, None), (1024, 4096, "quick"),
         ms = e0.elapsed_time(e1) / 10
         res += [ms, terms * 2.0 * M * K * N / ms / 1e9]
     print(f"| {M} x {K} -> {N} | {act or '-'} | {res[0]:.3f} | {res[1]:.0f} | {res[2]:.3f} | {res[3]:.0f} | {res[0] / res[2]:.2f} |")
+
+print()
+print("| residual update, M x K -> 1024 | weights | linear + add_layernorm(x, delta) ms | linear_acc (in place) + layernorm(x) ms |")
+print("|---|---|---:|---:|")
+lnw, lnb = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
+for K in (1024, 4096):
+    h = torch.randn(M, K, generator=g, device=dev)
+    x = torch.randn(M, 1024, generator=g, device=dev)
+    for kind in ("fp32", "fp16-valued"):
+        w = torch.randn(1024, K, generator=g, device=dev) * K ** -0.5
+        if kind != "fp32":
+            w = w.half().float()
+        b = torch.randn(1024, generator=g, device=dev)
+        ref = x + ops.linear_f16x3(h, w, b)
+        got = ops.linear_f16x3_acc(h, w, b, x.clone())
+        assert torch.equal(ref, got), float((ref - got).abs().max())
+        res = []
+        for mode in (0, 1):
+            xs = x.clone()
+            def run():
+                if mode == 0:
+                    return ops.add_layernorm(xs, ops.linear_f16x3(h, w, b), lnw, lnb, 1e-5)
+                ops.linear_f16x3_acc(h, w, b, xs)
+                return ops.add_layernorm(xs, None, lnw, lnb, 1e-5)
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) / 10)
+        print(f"| {M} x {K} | {kind} | {res[0]:.3f} | {res[1]:.3f} |")
