@@ -141,8 +141,9 @@ class _Block(nn.Module):
         h = ln_1(x), returns the new stream and next_ln(new stream) (None for the last block)."""
         from .. import ops
         if (owned and FP16X3_LINEAR and not self.causal and x.dtype == torch.float32 and x.shape[-1] == 64 * self.attn.heads
-                and ops.linear_f16x3_acc_supported(h, self.attn.out_proj.weight, x)
-                and ops.linear_f16x3_acc_supported(h.new_empty((1, self.mlp.c_proj.weight.shape[1])), self.mlp.c_proj.weight, x[:1])):
+                and h.is_cuda and h.dtype == torch.float32
+                and ops.linear_f16x3_acc_supported(self.attn.out_proj.weight, x) and ops.linear_f16x3_acc_supported(self.mlp.c_proj.weight, x)
+                and ops.linear_f16x3_supported(h, self.attn.in_proj_weight) and ops.linear_f16x3_supported(h, self.mlp.c_fc.weight)):
             # the residual stream is updated IN PLACE by the block's two last linears (oryon_linear_f16x3_acc: one fp32 add per element,
             # the value `x + linear(...)` has), so each LayerNorm pass reads one tensor instead of two.  `owned`: x is a buffer of this
             # forward (never the caller's tensor).

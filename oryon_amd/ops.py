@@ -751,10 +751,11 @@ def linear_f16x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return out.view(*x.shape[:-1], N)
 
 
-def linear_f16x3_acc_supported(x: torch.Tensor, weight: torch.Tensor, out: torch.Tensor) -> bool:
-    return (linear_f16x3_supported(x, weight) and weight.shape[1] >= 64 and weight.shape[0] % 128 == 0 and not X3_GUARD
-            and out.dtype == torch.float32 and out.is_contiguous() and out.shape[-1] == weight.shape[0]
-            and out.numel() // weight.shape[0] == x.numel() // weight.shape[1])
+def linear_f16x3_acc_supported(weight: torch.Tensor, out: torch.Tensor) -> bool:
+    """Can `out += x @ weight.T + bias` run in place (oryon_linear_f16x3_acc)?  x is any fp32 CUDA tensor [..., K] with out's row count."""
+    return (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and weight.dtype == torch.float32 and weight.dim() == 2
+            and not torch.is_grad_enabled() and not X3_GUARD and weight.shape[1] % 32 == 0 and weight.shape[1] >= 64
+            and weight.shape[0] % 128 == 0 and weight.numel() < 2 ** 30 and out.shape[-1] == weight.shape[0])
 
 
 @_on_tensor_device

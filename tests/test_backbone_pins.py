@@ -262,25 +262,31 @@ def test_fp16x3_linear_acc_equals_the_separate_residual_add():
             w = w.half().float()
         b = torch.randn(N, generator=g, device=dev)
         x = torch.randn(M, N, generator=g, device=dev) * 5.0
-        assert ops.linear_f16x3_acc_supported(h, w, x)
+        assert ops.linear_f16x3_acc_supported(w, x)
         ref = x + ops.linear_f16x3(h, w, b)
         buf = x.clone()
         assert ops.linear_f16x3_acc(h, w, b, buf) is buf and torch.equal(buf, ref), (M, K, N, float((buf - ref).abs().max()))
-    assert not ops.linear_f16x3_acc_supported(torch.zeros(4, 32, device=dev), torch.zeros(256, 32, device=dev), torch.zeros(4, 256, device=dev))  # K < 64
+    assert not ops.linear_f16x3_acc_supported(torch.zeros(256, 32, device=dev), torch.zeros(4, 256, device=dev))  # K < 64
     cfg = CLIPConfig.vit_l14_336()
     cfg.v_layers, cfg.t_layers = 3, 1
     torch.manual_seed(0)
     m = CLIP(cfg).to(dev).eval()
     img = torch.randn(2, 3, 336, 336, device=dev)
     keep = img.clone()
+    calls = []
+    real = ops.linear_f16x3_acc
+    ops.linear_f16x3_acc = lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1]
     clip_mod.FP16X3_LINEAR = True
     try:
         clip_mod.ACC_RESIDUAL = False
         sep = m.patch_tokens(img)
+        assert not calls
         clip_mod.ACC_RESIDUAL = True
         acc = m.patch_tokens(img)
     finally:
         clip_mod.FP16X3_LINEAR, clip_mod.ACC_RESIDUAL = False, True
+        ops.linear_f16x3_acc = real
+    assert len(calls) == 2 * cfg.v_layers          # the in-place path was the one that ran
     assert torch.equal(sep, acc) and torch.equal(img, keep)
 
 
