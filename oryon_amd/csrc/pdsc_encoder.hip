@@ -2165,6 +2165,116 @@ __global__ __launch_bounds__(256) void pdsc_normalise_kernel(const float *__rest
     for (int c = lane; c < C; c += 64) o[c] = live ? f[c] / d : 0.0f;
 }
 
+// Confidence head + feature normalisation as ONE launch (round 5; C = 128): conf = W3 relu(W2 relu(W1 feat + b1) + b2) + b3
+// (PointDSC.py:107-113, 128 -> 32 -> 32 -> 1) and feat_n = F.normalize(feat) (PointDSC.py:156) were three pdsc_linear_x3_kernel launches
+// and one pdsc_normalise_kernel launch, 30 us + three launch gaps for 17 MB of reads.  One workgroup keeps a 64-row tile's two hidden
+// activations in LDS.  Every output element is accumulated by exactly the MFMA sequence pdsc_linear_x3_kernel runs for it (same splits,
+// same k order: k-tiles of 32, two 16-steps each, hi*hi then hi*lo then lo*hi) and the normalisation is pdsc_normalise_kernel's loop
+// verbatim, so the results are bit-identical to the four launches (ORYON_PDSC_FUSED_HEAD = 0 in the development build runs those).
+constexpr int HEAD_H = 32;       // hidden width of the confidence head
+__global__ __launch_bounds__(256) void pdsc_head_x3_kernel(const float *__restrict__ feat, const float *__restrict__ W1, const float *__restrict__ b1,
+                                                            const float *__restrict__ W2, const float *__restrict__ b2,
+                                                            const float *__restrict__ W3, const float *__restrict__ b3,
+                                                            const int32_t *__restrict__ n_rows, int n_cap, float *__restrict__ conf,
+                                                            float *__restrict__ feat_n)
+{
+    constexpr int C = 128, XLD = LIN_BK + 8;
+    __shared__ __attribute__((aligned(16))) _Float16 Xh[LIN_ROWS * XLD], Xl[LIN_ROWS * XLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Wh[HEAD_H * XLD], Wl[HEAD_H * XLD];
+    __shared__ float Hs[LIN_ROWS * HEAD_H];
+    const int b = blockIdx.y, m0 = blockIdx.x * LIN_ROWS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int nr = n_rows[b];
+    const float *x = feat + ((size_t)b * n_cap + m0) * C;
+    if (m0 < nr) {                                                   // the linear kernels skip tiles without a live row
+        // one layer of the head: X rows from global (ldx floats apart) or from Hs, W [n_out, K] row-major, result (+ bias, ReLU) into Hs
+        // or, for the last layer, column 0 into conf.  Waves 0 / 1 own the tile's two 32-row blocks; all four stage.
+        auto layer = [&](const float *xg, int ldx, bool from_lds, const float *W, const float *bias, int K, int n_out, bool relu, bool last) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int k0 = 0; k0 < K; k0 += LIN_BK) {
+                float2 xv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = t + 256 * i, row = e >> 4, kk = (e & 15) * 2;
+                    xv[i] = from_lds ? *reinterpret_cast<const float2 *>(Hs + row * HEAD_H + kk)
+                                     : *reinterpret_cast<const float2 *>(xg + (size_t)row * ldx + k0 + kk);
+                }
+                float2 wv[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int e = t + 256 * i, col = e >> 4, kk = (e & 15) * 2;
+                    wv[i] = col < n_out ? *reinterpret_cast<const float2 *>(W + (size_t)col * K + k0 + kk) : make_float2(0.f, 0.f);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = t + 256 * i, row = e >> 4, kk = (e & 15) * 2;
+                    union { _Float16 h[2]; unsigned u; } ph, pl;
+                    split_half(xv[i].x, ph.h[0], pl.h[0]);
+                    split_half(xv[i].y, ph.h[1], pl.h[1]);
+                    *reinterpret_cast<unsigned *>(Xh + row * XLD + kk) = ph.u;
+                    *reinterpret_cast<unsigned *>(Xl + row * XLD + kk) = pl.u;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int e = t + 256 * i, col = e >> 4, kk = (e & 15) * 2;
+                    union { _Float16 h[2]; unsigned u; } ph, pl;
+                    split_half(wv[i].x, ph.h[0], pl.h[0]);
+                    split_half(wv[i].y, ph.h[1], pl.h[1]);
+                    *reinterpret_cast<unsigned *>(Wh + col * XLD + kk) = ph.u;
+                    *reinterpret_cast<unsigned *>(Wl + col * XLD + kk) = pl.u;
+                }
+                __syncthreads();
+                if (wave < 2) {
+#pragma unroll
+                    for (int s_ = 0; s_ < LIN_BK / 16; ++s_) {
+                        const int ko = 16 * s_ + 8 * hi;
+                        const xhalf8 ah = *reinterpret_cast<const xhalf8 *>(Xh + (wave * 32 + l31) * XLD + ko);
+                        const xhalf8 al = *reinterpret_cast<const xhalf8 *>(Xl + (wave * 32 + l31) * XLD + ko);
+                        const xhalf8 bh = *reinterpret_cast<const xhalf8 *>(Wh + l31 * XLD + ko);
+                        const xhalf8 bl = *reinterpret_cast<const xhalf8 *>(Wl + l31 * XLD + ko);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();                                          // Hs (the previous layer's output) has been read by everyone
+            if (wave < 2 && l31 < n_out) {
+                const float bv = bias ? bias[l31] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * 32 + crow(r, hi);
+                    float v = acc[r] + bv;
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    if (last) conf[(size_t)b * n_cap + m0 + row] = v;
+                    else Hs[row * HEAD_H + l31] = v;
+                }
+            }
+            __syncthreads();
+        };
+        layer(x, C, false, W1, b1, C, HEAD_H, true, false);
+        layer(nullptr, 0, true, W2, b2, HEAD_H, HEAD_H, true, false);
+        layer(nullptr, 0, true, W3, b3, HEAD_H, 1, false, true);
+    }
+    // F.normalize of the tile's rows: pdsc_normalise_kernel, one wave per row
+    for (int rr = wave; rr < LIN_ROWS; rr += 4) {
+        const int row = m0 + rr;
+        const float *f = feat + ((size_t)b * n_cap + row) * C;
+        float *o = feat_n + ((size_t)b * n_cap + row) * C;
+        float s = 0.0f;
+        for (int c = lane; c < C; c += 64) s += f[c] * f[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        float d = sqrt_rn(s);
+        d = d < 1e-12f ? 1e-12f : d;
+        const bool live = row < nr;
+        for (int c = lane; c < C; c += 64) o[c] = live ? f[c] / d : 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int launch_linear(bool relu, bool resid, const float *X, int ldx, size_t xb, const float *W, const float *bias,
                          const float *R, int ldr, size_t rb, float *Y, int ldy, size_t yb, int K, int N, int B, int n_cap,
@@ -2326,6 +2436,12 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         if (rc) return rc;
         rc = launch_linear(false, true, ws.h2, H, hb, L.w_m3, L.b_m3, ws.feat1, C, fb, ws.feat, C, fb, H, C, B, n_cap, n_rows, st);
         if (rc) return rc;
+    }
+    static const bool fused_head = dev_env_int("ORYON_PDSC_FUSED_HEAD", 1) != 0;       // dev: 0 = three linears + the normalisation
+    if (fused_head && C == 128 && n_cap % LIN_ROWS == 0) {
+        hipLaunchKernelGGL(pdsc_head_x3_kernel, dim3(n_cap / LIN_ROWS, B), dim3(256), 0, st, ws.feat, M.w_c1, M.b_c1, M.w_c2, M.b_c2, M.w_c3, M.b_c3,
+                           n_rows, n_cap, ws.conf, ws.feat_n);
+        return hipGetLastError() == hipSuccess ? ORYON_OK : ORYON_ERR_HIP;
     }
     // confidence head C -> 32 -> 32 -> 1 (PointDSC.py:107-113)
     rc = launch_linear(true, false, ws.feat, C, fb, M.w_c1, M.b_c1, nullptr, 0, 0, ws.h1, 32, (size_t)n_cap * 32, C, 32, B, n_cap, n_rows, st);
