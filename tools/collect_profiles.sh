@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats -d $D -o bench -- python $R/bench.py --steps 3 
 python $R/tools/rocpd_summary.py $D/bench_results.db --after "distribution_elementwise|index_elementwise" > "$OUT/kernel_stats.md"
 python $R/tools/rocpd_summary.py $D/bench_results.db --between "match_mx6_screen_w4" > "$OUT/kernel_stats_steps_only.md"
 python $R/tools/rocpd_summary.py $D/bench_results.db > "$OUT/kernel_stats_whole_run.md"
-RX='mx6_screen|screen_v2_kernel|gather_q8_v3|gather_mx6_v4|pdsc_att|match_decide|match_resolve|pdsc_linear|pdsc_pcn_qkv|pdsc_mlp3|pdsc_hyp|pdsc_seed'
+RX='mx6_screen|screen_v2_kernel|gather_q8_v3|gather_mx6_v4|pdsc_att|match_decide|match_resolve|pdsc_linear|pdsc_pcn_qkv|pdsc_mlp3|pdsc_hyp|pdsc_seed|pdsc_head'
 {
   echo "# rocprofv3 PMC passes: bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-overlap (2 engine passes, B=64), kernels /$RX/"
   for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
