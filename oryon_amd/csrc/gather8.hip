@@ -585,37 +585,40 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void gather_mx6_v4_kernel(
         // canonical unit rows, k-permuted inside groups of 8 (position 8g + 4h + j holds k = 8g + 2j + h): this wave's 64 channels in four
         // passes of 16 through a wave-private 4 KB stage (64 rows x 64 B), out as 16 rows x 64 bytes per store instruction.  (A 16 KB
         // stage per wave - K0v3's - would leave room for two workgroups per CU only.)
-        char *st32 = lds4 + G4_LDS + wave * G4_STAGE32;
+        // (two passes of 128 bytes per row since the end of round 5: rows 0-31 through this wave's quarter of the still unused mx6 stage,
+        // rows 32-63 through its private 4 KB; 8 rows x 128 B per store instruction instead of 16 x 64 B)
+        char *stA = stage + wave * 4096, *stB = lds4 + G4_LDS + wave * G4_STAGE32;
+        char *my_st = (lane < 32 ? stA : stB) + (lane & 31) * 128;
         float *o32 = out32 + ((size_t)m * rows_cap + row0) * 256 + 64 * wave;
 #pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) {
+        for (int P = 0; P < 2; ++P) {
             WAVE_LDS_ORDER();
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                const int g = 2 * p4 + (sl >> 1), hh = sl & 1;
+            for (int sl = 0; sl < 8; ++sl) {
+                const int g = 4 * P + (sl >> 1), hh = sl & 1;
                 float4 q;
                 q.x = __fdiv_rn(R.get(8 * g + 0 + hh), d);
                 q.y = __fdiv_rn(R.get(8 * g + 2 + hh), d);
                 q.z = __fdiv_rn(R.get(8 * g + 4 + hh), d);
                 q.w = __fdiv_rn(R.get(8 * g + 6 + hh), d);
-                *reinterpret_cast<float4 *>(st32 + lane * 64 + ((sl ^ ((lane >> 1) & 3)) << 4)) = q;
+                *reinterpret_cast<float4 *>(my_st + ((sl ^ (lane & 7)) << 4)) = q;
             }
             WAVE_LDS_ORDER();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = j * 16 + (lane >> 2), sl = lane & 3;
-                const float4 q = *reinterpret_cast<const float4 *>(st32 + t * 64 + ((sl ^ ((t >> 1) & 3)) << 4));
-                *reinterpret_cast<float4 *>(o32 + (size_t)t * 256 + 16 * p4 + sl * 4) = q;
+            for (int j = 0; j < 8; ++j) {
+                const int t = j * 8 + (lane >> 3), sl = lane & 7;
+                const float4 q = *reinterpret_cast<const float4 *>((t < 32 ? stA : stB) + (t & 31) * 128 + ((sl ^ (t & 7)) << 4));
+                *reinterpret_cast<float4 *>(o32 + (size_t)t * 256 + 32 * P + sl * 4) = q;
             }
         }
+        __syncthreads();                                              // the mx6 stage below overlaps the other waves' transposition areas
     }
 
     if constexpr (X3) {
         // FMT = 3 (the engine's K0 pass when recent steps needed the second level): besides the mx6 slots, the canonical unit row
         // u = RN(x / d) as error-compensated float16 halves hi = half(u), lo = half(u - hi) for K1x3 (match_x3.hip) - layout of K0v3:
         // tiles of 32 rows, inside a tile the four 64-channel chunks one after the other, hi array then lo array in `aux`.  This
-        // wave's chunk is chunk `wave`; it leaves in four passes (block 0 hi, lo, block 1 hi, lo) of 64 bytes per row through the
-        // wave-private 4 KB stage, 16 rows x 64 B per store instruction.  The unit values replace the raw ones in place (the fp6
+        // wave's chunk is chunk `wave`; it leaves in two passes (hi, lo) of 128 bytes per row (below).  The unit values replace the raw ones in place (the fp6
         // conversion below then works on them, as K0v3's FMT = 3 does).
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
@@ -625,20 +628,24 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void gather_mx6_v4_kernel(
         float lo2 = 0.0f;
         if (wave * 64 < C) {                                            // chunks beyond the map's channels are not written (readers skip them)
             constexpr size_t HB = 512;                                  // bytes per half row
-            char *st16 = lds4 + G4_LDS + wave * G4_STAGE32;
+            // two passes (hi, lo) of 128 bytes per row: rows 0-31 through this wave's quarter of the (still unused) mx6 stage, rows
+            // 32-63 through its private 4 KB, 16-byte slots XOR-swizzled with the row; out as 8 rows x 128 B = 1 KB contiguous per store
+            // instruction (a 32-row tile of one chunk is 4 KB contiguous in `aux`).  Four passes of 64-byte pieces before: 1.48 -> 1.16 ms for the
+            // query pass of cfg2 (64 x 36 864 rows), outputs unchanged - the half-filled 128-byte lines were what held the pass at 4 TB/s
+            char *stA = stage + wave * 4096, *stB = lds4 + G4_LDS + wave * G4_STAGE32;
+            char *my_st = (lane < 32 ? stA : stB) + (lane & 31) * 128;
             char *ob[2];
             ob[0] = reinterpret_cast<char *>(aux) + ((size_t)m * rows_cap + row0) * HB + wave * 4096;
             ob[1] = ob[0] + (size_t)n_maps * rows_cap * HB;
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int blk = pass >> 1, lo_pass = pass & 1;
+            for (int lo_pass = 0; lo_pass < 2; ++lo_pass) {
                 WAVE_LDS_ORDER();
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
+                for (int sl = 0; sl < 8; ++sl) {                        // channels 8 sl .. 8 sl + 7 of this wave's 64
                     unsigned w[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float u0 = R.get(32 * blk + 8 * sl + 2 * j), u1 = R.get(32 * blk + 8 * sl + 2 * j + 1);
+                        const float u0 = R.get(8 * sl + 2 * j), u1 = R.get(8 * sl + 2 * j + 1);
                         const __half h0 = __float2half_rn(u0), h1 = __float2half_rn(u1);
                         if (lo_pass) {
                             const float d0 = u0 - __half2float(h0), d1 = u1 - __half2float(h1);      // exact: hi is u rounded to 11 bits
@@ -649,18 +656,19 @@ __global__ __launch_bounds__(256, X3 ? 3 : 4) void gather_mx6_v4_kernel(
                             w[j] = (unsigned)__half_as_ushort(h0) | ((unsigned)__half_as_ushort(h1) << 16);
                         }
                     }
-                    *reinterpret_cast<uint4 *>(st16 + lane * 64 + ((sl ^ ((lane >> 1) & 3)) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+                    *reinterpret_cast<uint4 *>(my_st + ((sl ^ (lane & 7)) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
                 WAVE_LDS_ORDER();
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int t = j * 16 + (lane >> 2), sl = lane & 3;
-                    const uint4 q = *reinterpret_cast<const uint4 *>(st16 + t * 64 + ((sl ^ ((t >> 1) & 3)) << 4));
-                    *reinterpret_cast<uint4 *>(ob[lo_pass] + (size_t)(t >> 5) * (32 * HB) + (t & 31) * 128 + blk * 64 + sl * 16) = q;
+                for (int j = 0; j < 8; ++j) {
+                    const int t = j * 8 + (lane >> 3), sl = lane & 7;     // row t of the tile, 16-byte slot sl of its 128 bytes
+                    const uint4 q = *reinterpret_cast<const uint4 *>((t < 32 ? stA : stB) + (t & 31) * 128 + ((sl ^ (t & 7)) << 4));
+                    *reinterpret_cast<uint4 *>(ob[lo_pass] + (size_t)(t >> 5) * (32 * HB) + (t & 31) * 128 + sl * 16) = q;
                 }
             }
         }
         reinterpret_cast<float *>(lds4 + G4_LDS + 4 * G4_STAGE32)[wave * 64 + lane] = lo2;       // per-wave partial |u - hi|^2 of the row
+        __syncthreads();                                                // the mx6 stage below overlaps the other waves' transposition areas
     }
 
     // MX-fp6 slots of this wave's two blocks (arithmetic of K0v3, FMT = 1; FMT = 3: on the unit values)
