@@ -30,7 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from oryon_amd import ops  # noqa: E402
-from oryon_amd.dist import gather_poses, init_from_env  # noqa: E402
+from oryon_amd.dist import gather_pose_windows, gather_poses, init_from_env  # noqa: E402
 from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine  # noqa: E402
 from oryon_amd.pointdsc import PointDSC  # noqa: E402
 from oryon_amd.synth import make_pair  # noqa: E402
@@ -300,8 +300,22 @@ def collation_selftest(a):
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        allp, alls = gather_poses(pose, status, total)
+    if a.collate == "final":
+        # one collective for the whole window: every step's rows staged, step j's pose carries j in its y translation
+        stage = torch.zeros((a.steps, B, 17))
+        for j in range(a.steps):
+            stage[j, :, :16] = pose.reshape(B, 16)
+            stage[j, :, 7] = float(j)
+            stage[j, :, 16] = status.to(torch.float32)
+        allr = gather_pose_windows(stage)
+        if not all(bool((allr[:, j, :, 7] == float(j)).all()) for j in range(a.steps)):
+            raise SystemExit("final collation: step order lost")
+        last = allr[:, a.steps - 1].reshape(total, 17).clone()
+        last[:, 7] = 0.0
+        allp, alls = last[:, :16].reshape(total, 4, 4), last[:, 16].to(torch.int32)
+    else:
+        for _ in range(a.steps):
+            allp, alls = gather_poses(pose, status, total)
     if world > 1:
         dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -311,7 +325,8 @@ def collation_selftest(a):
         bool(torch.equal(alls, torch.arange(total, dtype=torch.int32) % 3))
     if rank == 0:
         print(json.dumps({"metric": "collation selftest (no kernels)", "n_gpus": world, "steps": a.steps, "global_pairs": total,
-                          "collated_in_order": ok, "elapsed_s": float(el.item())}), flush=True)
+                          "collated_in_order": ok, "collate": a.collate, "collectives": 1 if a.collate == "final" else a.steps,
+                          "elapsed_s": float(el.item())}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -361,6 +376,15 @@ def main():
     ap.add_argument("--input-sets", type=int, default=4,
                     help="distinct sets of B synthetic pairs (descriptor maps, masks, depths, poses AND pair keys) the timed steps rotate through: "
                          "step k runs on set k %% N, so no step re-reads the maps its predecessor left in the Infinity Cache / L2 (VERDICT r04)")
+    ap.add_argument("--stream-roles", type=int, default=-1,
+                    help="placement of the engine's four HIP streams on the process's hardware queues (oryon_engine_config_t.stream_roles: four "
+                         "digits = pool positions of match / gather / registration 0 / registration 1).  -1 (default): measure the candidates "
+                         "during warm-up (MatchPoseEngine.tune_stream_roles, outside every timed window) and keep the best; 0: the library "
+                         "default (2301); anything else: that placement")
+    ap.add_argument("--collate", choices=["step", "final"], default="step",
+                    help="N > 1 only.  step (default): one all_gather of [B,17] per step inside the timed region; final: every step's poses are "
+                         "staged on the device and ONE all_gather per timed window collates them (north_star: 'all-gather of per-pair poses ... "
+                         "only for the final collation').  The other mode is measured in extra windows and reported in `multi_gpu` as well")
     ap.add_argument("--no-stage-sets", action="store_true",
                     help="skip the 'decode+match+pose' and 'full' stage sets that the default run measures after the headline")
     ap.add_argument("--collation-selftest", action="store_true",
@@ -411,6 +435,8 @@ def main():
                              native=a.engine == "native", result_views=True)
     engine.native_timing = True           # HIP events around the three sections and the screening kernel of every native step
     engine.native_geometry["screen"] = 1 if a.screen == "mx6" else 0
+    if a.stream_roles > 0:
+        engine.native_geometry["stream_roles"] = a.stream_roles
     key = inputs["key"]
     host = {"submit_s": 0.0, "submits": 0, "rot": 0, "set_of": {}, "last_set": 0}
 
@@ -427,14 +453,40 @@ def main():
         host["set_of"][id(out)] = idx_                      # (not a key of `out`: the engine tells keep steps from ordinary ones by its size)
         return out
 
+    # --collate final: a window's poses are staged in [steps, B, 17] (one small device copy per step: the slot views are re-used six
+    # steps later) and collated by ONE all_gather when the window ends; --collate step: one all_gather per step
+    collate = {"mode": a.collate if world > 1 else "step", "stage": None, "k": 0}
+
     def collect(out):
         host["last_set"] = host["set_of"].pop(id(out), host["last_set"])
         engine.finish(out)
+        if collate["mode"] == "final":
+            st_ = collate["stage"]
+            if st_ is None or st_.shape[0] <= collate["k"]:
+                st_ = collate["stage"] = torch.zeros((max(a.steps, 64), B, 17), dtype=torch.float32, device=dev)
+                collate["k"] = 0
+            row = st_[collate["k"]]
+            row[:, :16].copy_(out["pose"].reshape(B, 16))
+            row[:, 16].copy_(out["status"])
+            collate["k"] += 1
+            return out, out["pose"], out["status"]
         pose, status = gather_poses(out["pose"], out["status"], total)
         return out, pose, status
 
+    def collate_window():
+        """--collate final: the one collective of a timed window - every rank's [k, B, 17] block; returns the LAST step's global poses."""
+        k_ = collate["k"]
+        collate["k"] = 0
+        if collate["mode"] != "final" or k_ == 0:
+            return None
+        allr = gather_pose_windows(collate["stage"][:k_])          # [world, k, B, 17]
+        last = allr[:, k_ - 1].reshape(world * B, 17)              # global pair order: rank-major blocks of B
+        return last[:, :16].reshape(world * B, 4, 4).contiguous(), last[:, 16].to(torch.int32)
+
     def step(keep=False):
-        return collect(submit(keep, which=0))          # the sanity / checksum step: always input set 0
+        res_ = collect(submit(keep, which=0))          # the sanity / checksum step: always input set 0
+        fin_ = collate_window()
+        return res_ if fin_ is None else (res_[0], fin_[0], fin_[1])
 
     def run_steps(n):
         """n complete steps; with overlap the registration of step k runs on a second stream under the matching of step k+1
@@ -447,6 +499,9 @@ def main():
             prev = cur
         if prev is not None:
             res = collect(prev)
+        fin = collate_window()
+        if fin is not None:
+            res = (res[0], fin[0], fin[1])
         return res
 
     def barrier():
@@ -465,6 +520,19 @@ def main():
         run_steps(1)                      # --warmup 0: the first step builds the engine (arena, streams); not a timed step
         barrier()
     native = engine._native if want_native else None
+    # stream placement: measured on THIS process during warm-up (never inside a timed window), unless the command line fixed it
+    roles_rec = None
+    if native is not None and not a.no_overlap:
+        if a.stream_roles < 0:
+            roles_rec = engine.tune_stream_roles(run_steps, steps=12, warm=3)
+            roles_rec["how"] = "tuned during warm-up: 3 + 12 steps per candidate, outside the timed windows (MatchPoseEngine.tune_stream_roles)"
+            if world > 1:
+                # every rank tunes on its own GPU; what rank 0 reports is its own choice, the others' are in multi_gpu.stream_roles_per_rank
+                pass
+        else:
+            roles_rec = {"roles": native.stream_roles(), "ms_per_step": {}, "default": 2301,
+                         "how": "fixed by --stream-roles" if a.stream_roles > 0 else "library default (--stream-roles 0)"}
+        barrier()
 
     def alloc_counters():
         ms = torch.cuda.memory_stats(dev)
@@ -533,15 +601,38 @@ def main():
         mine_ms = torch.tensor([med([w["ms_per_step_rank"] for w in windows])], dtype=torch.float64, device=dev)
         all_ms = [torch.zeros_like(mine_ms) for _ in range(world)]
         dist.all_gather(all_ms, mine_ms)
+        my_roles = torch.tensor([native.stream_roles() if native is not None else 0], dtype=torch.int64, device=dev)
+        all_roles = [torch.zeros_like(my_roles) for _ in range(world)]
+        dist.all_gather(all_roles, my_roles)
+        # the OTHER collation mode in three extra windows of the same length (same engine, same inputs), so that one line carries both
+        other = "final" if collate["mode"] == "step" else "step"
+        keep_mode, collate["mode"] = collate["mode"], other
+        run_steps(3)
+        other_ms = []
+        for _ in range(3):
+            barrier()
+            t0_ = time.perf_counter()
+            run_steps(a.steps)
+            barrier()
+            el_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+            dist.all_reduce(el_, op=dist.ReduceOp.MAX)
+            other_ms.append(float(el_.item()) / a.steps * 1e3)
+        collate["mode"] = keep_mode
+        other_med = sorted(other_ms)[1]
         multi = {"backend": "nccl (RCCL over xGMI)", "rccl_ranks": world, "all_gather_us": ev0.elapsed_time(ev1) / 20 * 1e3,
                  "all_gather_bytes_per_rank": B * 17 * 4, "per_rank_pairs_per_s": [B * 1e3 / float(t.item()) for t in all_ms],
-                 "collectives_per_step": 1}
+                 "collate": keep_mode,
+                 "collectives_per_step": 1 if keep_mode == "step" else 1.0 / a.steps,
+                 f"collate_{other}_ms_per_step": other_med, f"collate_{other}_pairs_per_s": total * 1e3 / other_med,
+                 f"collate_{keep_mode}_ms_per_step": ms_med, f"collate_{keep_mode}_pairs_per_s": total * 1e3 / ms_med,
+                 "stream_roles_per_rank": [int(t.item()) for t in all_roles],
+                 "stream_pool_created_before_process_group": True}
 
     # the dominant kernel WITHOUT the other streams beside it: a few steps of a serial engine (everything on one stream) in this same
     # process, the same HIP events around the same launch.  The pipelined number above is what the kernel costs inside the step (it
     # shares CUs, power and HBM with K0 and the registration); this one is the kernel itself and is what a rocprofv3 kernel trace of
     # this command reports (the profiler serialises kernels of different queues)
-    unshared_ms = None
+    unshared_ms = k0_unshared_ms = None
     if native is not None:
         ser = MatchPoseEngine(engine.solver, engine.cfg, overlap_registration=False, overlap_gather=False, native=True, result_views=True)
         ser.native_timing = True
@@ -552,6 +643,8 @@ def main():
         torch.cuda.synchronize()
         ts_ = [ser._native.timing(k)["screen_kernel_ms"] for k in range(1, 6)]
         unshared_ms = sum(ts_) / len(ts_)
+        tg_ = [ser._native.timing(k)["gather_ms"] for k in range(1, 6)]
+        k0_unshared_ms = sum(tg_) / len(tg_)
         del ser
         torch.cuda.empty_cache()
 
@@ -603,6 +696,24 @@ def main():
                     traffic_src = (f"profiles/{os.path.basename(tpath)} is STALE: the screen kernel source changed since the PMC passes were "
                                    "collected (sha256 mismatch) - re-run tools/collect_profiles.sh + tools/make_traffic_json.py")
                 break
+        # K0 (the one HBM-bound kernel pair of the matcher: gather + normalise + MX-fp6 conversion of the ROI rows, csrc/gather8.hip) against
+        # the 8 TB/s HBM peak.  Algorithmic bytes per step (SURVEY 8d "descriptors actually used" + what the pass has to write):
+        #   reads  4 C (n_a + n_q)                            the ROI rows' fp32 descriptors, once
+        #   writes n_q (256 + 4) + n_a (256 + 4 + 4 c_pad)    mx6 operand row + norm per row; anchors also their fp32 unit row (the exact re-scoring's operand)
+        # `moved` scales that by the ratio the rocprofv3 PMC passes of this workload counted (FETCH_SIZE x 2 + WRITE_SIZE vs algorithmic:
+        # DRAM delivers whole sectors and the ROIs are not dense - DESIGN.md "K0"), source named below
+        k0 = None
+        if k0_unshared_ms is not None and "mx6" in dispatched:
+            k0_alg = float((4.0 * C * (n_a + n_q) + 260.0 * n_q + (260.0 + 4.0 * cp) * n_a).sum())
+            k0_pipe_ms = (sum(t["gather_ms"] for t in sections) / len(sections)) if sections else None
+            K0_MOVED_OVER_ALGORITHMIC = 5.61 / 3.97        # profiles/r05_pmc_counters.md (cfg2, K0v4): 4.51 GB fetched + 1.10 GB written for 3.97 GB
+            k0 = {"kernels": "roi_compact x2 + roi_subsample + gather_mx6_v4_kernel x2 (queries, anchors): the gather-stream section of one step",
+                  "algorithmic_bytes_per_step": k0_alg, "unshared_ms": k0_unshared_ms, "in_pipeline_ms": k0_pipe_ms,
+                  "algorithmic_frac": k0_alg / (k0_unshared_ms * 1e-3) / PEAK_HBM_BYTES,
+                  "moved_frac": k0_alg * K0_MOVED_OVER_ALGORITHMIC / (k0_unshared_ms * 1e-3) / PEAK_HBM_BYTES,
+                  "moved_over_algorithmic": K0_MOVED_OVER_ALGORITHMIC if (B, H, C) == (64, 224, 256) else None,
+                  "moved_source": "profiles/r05_pmc_counters.md / r06_pmc_counters.md (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of the two gather launches)",
+                  "peak_bytes_per_s": PEAK_HBM_BYTES}
         rec = {
             "metric": METRIC, "value": total * a.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -624,6 +735,8 @@ def main():
                                      if sections else None),
                 "step_latency_ms": med([t["registration_end"] for t in sections]) if sections else None,
                 "timed_steps_with_events": len(sections),
+                "stream_roles": roles_rec["roles"] if roles_rec else None,
+                "stream_roles_tuning": roles_rec,
             },
             "config": {
                 "workload": f"{'cfg2' if (H, C) == (224, 256) else 'cfg4 geometry' if (H, C) == (384, 512) else 'custom'}: Batch={B} synthetic {H}x{H} pairs per GPU, C={C} fp32 descriptors given (HIP matcher + lift + "
@@ -651,6 +764,14 @@ def main():
                 "share_of_step": match_ms / (elapsed / a.steps * 1e3),
                 "measured": "HIP events on the launch stream around every launch of the kernel inside the timed windows (pipelined: K0 of the "
                             "next step and the registration of the previous ones run beside it)",
+                # the same figures as scalars (a parser that keeps only scalar entries of `roofline` still sees them)
+                "unshared_avg_launch_ms": unshared_ms,
+                "unshared_frac": None if unshared_ms is None else flops / (unshared_ms * 1e-3) / 1e12 / peak,
+                "frac_of_bare_loop_rate": (flops / (unshared_ms * 1e-3) / 1e12 / BARE_FP6_32x32x64_TFLOPS) if (unshared_ms is not None and "mx6" in dispatched) else None,
+                "k0_algorithmic_frac": k0["algorithmic_frac"] if k0 else None,
+                "k0_moved_frac": k0["moved_frac"] if k0 else None,
+                "k0_unshared_ms": k0_unshared_ms,
+                "k0": k0,
                 "unshared": (None if unshared_ms is None else
                              {"avg_launch_ms": unshared_ms, "achieved": flops / (unshared_ms * 1e-3) / 1e12,
                               "frac": flops / (unshared_ms * 1e-3) / 1e12 / peak,
@@ -745,6 +866,16 @@ def main():
         rec["stages"] = stage_recs or None
         rec["hard_descriptors"] = hard
         rec["sample_first_schedule"] = sfirst
+        # the other measured rates as scalars of `config` (kept by parsers that drop nested records)
+        rec["config"]["hard_pairs_per_s"] = hard["value"] if hard else None
+        rec["config"]["hard_fraction_of_headline"] = hard["fraction_of_headline"] if hard else None
+        full_g = stage_recs.get("full (feat+match+pose), fp16x3 linears")
+        full_c = stage_recs.get("full (feat+match+pose), fp16x3 linears, CLIP weights fp16-valued as `clip.load` leaves them")
+        dec_ = stage_recs.get("decode+match+pose")
+        rec["config"]["full_fp32grade_pairs_per_s"] = full_g["value"] if full_g else None
+        rec["config"]["full_fp32grade_clipload_pairs_per_s"] = full_c["value"] if full_c else None
+        rec["config"]["decode_match_pose_pairs_per_s"] = dec_["value"] if dec_ else None
+        rec["config"]["stream_roles"] = rec["timing"]["stream_roles"]
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

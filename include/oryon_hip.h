@@ -13,7 +13,10 @@
  *   - return value: ORYON_OK or a negative ORYON_ERR_*; nothing throws; oryon_last_error() gives text;
  *   - per-pair outcomes (no mask / no correspondences) are DATA, reported in `status` arrays with the
  *     reference's own failure semantics (pipeline.py:335-350), not error codes;
- *   - thread-safe for distinct streams; no global state besides the last-error string (thread local).
+ *   - thread-safe for distinct streams.  Global state of the library, all of it per device or per thread: the last-error string
+ *     (thread local); the step engine's stream pool (eight HIP streams per device, created under a mutex on first use or by
+ *     oryon_engine_warm_streams, shared by every engine of the process and never destroyed); the fp16x3 range-flag word per device
+ *     (oryon_x3_range_flag); the profile-event pair armed by oryon_profile_events (thread local).
  */
 #ifndef ORYON_HIP_H
 #define ORYON_HIP_H
@@ -421,12 +424,28 @@ typedef struct {
                                 anchors to the second level (n_und, read back through pinned memory without a synchronisation), K0 writes the
                                 query rows' hi / lo halves in its own pass (oryon_gather_mx6_x3) and the matcher skips its second read of the maps
                                 (oryon_match_corrs_mx6_x3).  Results are unchanged; C <= 256 and the MX-fp6 screen only.  0 = never */
+    int stream_roles;        /* which of the device's eight pooled streams (numbered in creation order) serve as match / gather / registration 0 /
+                                registration 1: four decimal digits, each 0..7.  0 = the library's default (2301).  The HIP runtime gives a
+                                process's first streams one hardware queue each in creation order, and the placement alone moves the pipelined
+                                cfg2 step by up to 30 % (DESIGN.md "stream placement"); the digits are positions in THAT order, so a host that
+                                creates other streams first (an RCCL communicator does) calls oryon_engine_warm_streams() before them, and a
+                                host that wants the best placement for its own process measures the candidates with
+                                oryon_engine_set_stream_roles (oryon_amd.engine.MatchPoseEngine.tune_stream_roles does).  Results never
+                                depend on it */
 } oryon_engine_config_t;
 size_t oryon_engine_config_bytes(void);      /* sizeof(oryon_engine_config_t) in the built library: a binding's mirror of the struct must match */
 size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_pointdsc_t *solver);
 int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,
                         size_t arena_bytes);
 void oryon_engine_destroy(oryon_engine_t *handle);
+/* Creates the current device's stream pool now (idempotent, thread-safe): call it once per process BEFORE anything else creates HIP streams
+ * on the device - torch.distributed.init_process_group("nccl", device_id=...) creates RCCL's - so that the engine's streams are the
+ * process's first and cfg.stream_roles means the same placement at N = 1 and under torchrun (run_test.py:31 launches one process per GPU). */
+int oryon_engine_warm_streams(void);
+/* Re-assigns a live engine's streams (same digits as cfg.stream_roles; 0 = default).  Drains the engine's streams first (synchronises
+ * the host with the steps in flight): a tuning aid for warm-up, not for the steady state.  oryon_engine_stream_roles reads the placement. */
+int oryon_engine_set_stream_roles(oryon_engine_t *handle, int roles);
+int oryon_engine_stream_roles(const oryon_engine_t *handle, int *roles);
 int oryon_engine_buffer(const oryon_engine_t *handle, int slot, const char *name, size_t *offset, size_t *bytes);
 int oryon_engine_geometry(const oryon_engine_t *handle, int *cap_a, int *cap_q, int *c_pad, int *n_cap);
 /* feat_* [B,C,FH,FW] fp32 in cfg.layout; mask_* [B,FH*FW] int32 (== 1 selects); depth_* fp32; cam_* [B,9] fp32; pair_key [B] int64 or NULL */
@@ -459,12 +478,23 @@ int oryon_engine_feedback(oryon_engine_t *handle, int64_t *step, int64_t *n_unde
  *     the reference's CLIPEncoder, models/vlm.py:19-22 - an fp16 checkpoint widened to fp32): the Ahi*Wlo products are left out, two
  *     instead of three MFMAs per product, results bit-identical to passing a zero W_lo. */
 int oryon_split_f16x3(const float *x, int64_t n, void *hi_f16, void *lo_f16, void *stream);
-/* Range check of the fp16x3 path (round 5): every fp16x3 kernel of this library (B4 linear, B5 attention, the Swin / fusion window
- * attentions, the 24 x 24 and decoder convolutions) ORs 1 into a per-device flag word when one of its raw accumulators is not a finite
- * value below 60000 in magnitude - which is what an operand beyond float16's range (|x| >= 65520: hi = inf) produces in every product it
- * enters, and what an output that the NEXT kernel could not split looks like.  oryon_x3_range_flag copies the flag to *value_out after
- * everything queued on `stream` (synchronises that stream: call it once per forward, not per layer) and clears it when reset != 0.
- * The Python towers (oryon_amd.net.Oryon.forward) re-evaluate a forward whose flag came back set with the fp32 torch modules. */
+/* Range check of the fp16x3 path (round 5; per stream since round 6).  The PRODUCERS of every tensor the fp16x3 kernels split - the B4
+ * linear (both kernels; the in-place residual form checks its own finished sum, and the residual value its atomics leave in C is
+ * checked by the fused residual-add + LayerNorm pass that reads it next, oryon_add_layernorm_f32), the 24 x 24 and decoder
+ * convolutions / up-convolutions - OR 1 into a flag word when one of their finished values is not a finite value below
+ * 60000 in magnitude: that is what an operand beyond float16's range (|x| >= 65520: hi = inf) produces in every product it enters, and
+ * what an output that the NEXT kernel could not split looks like.  The attention kernels (B5, the Swin / fusion window attentions) and
+ * the single-slab persistent decoder convolutions carry no check of their own: their q | k | v operands are outputs of checked linears
+ * (an overflowing operand has raised the flag already, and their own outputs are convex combinations of checked v rows), the
+ * convolutions' inputs are checked up-convolution outputs and GroupNorm-normalised maps, and whatever they produce goes through a
+ * checked linear / convolution next (tests/test_backbone_pins.py::test_fp16x3_overflow_behind_an_unchecked_kernel_is_flagged_by_the_next executes
+ * that argument).
+ * The word belongs to (device, stream): a launch raises the word of the stream it runs on, oryon_x3_range_flag(stream) reads that word
+ * after everything queued on `stream` (synchronises that stream: once per forward, not per layer) and clears it when reset != 0;
+ * value_out == NULL only queues the clear (and allocates the device's flag table at the first call - make that call at initialisation so
+ * that no launch allocates, e.g. under graph capture).  Forwards on different streams, threads or model instances do not see each
+ * other's flags.  oryon_amd.net.Oryon.forward clears its stream's word before the forward, reads it after, and re-evaluates a flagged
+ * forward with the fp32 torch modules. */
 int oryon_x3_range_flag(int *value_out, int reset, void *stream);
 int oryon_linear_f16x3(const float *A, int M, int K, const void *W_hi, const void *W_lo, const float *bias, int N, int act, float *C,
                        void *stream);

@@ -22,7 +22,7 @@ class OryonError(RuntimeError):
 class EngineConfig(ctypes.Structure):
     _fields_ = [("B", c_int), ("C", c_int), ("FH", c_int), ("FW", c_int), ("HA", c_int), ("WA", c_int), ("HQ", c_int), ("WQ", c_int),
                 ("layout", c_int), ("dist_th", c_float), ("n_corrs", c_int), ("src_sampling", c_int), ("seed", c_uint64),
-                ("round_f16", c_int), ("n_slots", c_int), ("overlap", c_int), ("gather_sets", c_int), ("reg_streams", c_int), ("reg_lag", c_int), ("screen", c_int), ("sample_first", c_int), ("x3_prefetch", c_int)]
+                ("round_f16", c_int), ("n_slots", c_int), ("overlap", c_int), ("gather_sets", c_int), ("reg_streams", c_int), ("reg_lag", c_int), ("screen", c_int), ("sample_first", c_int), ("x3_prefetch", c_int), ("stream_roles", c_int)]
 
 
 class DecoderWeights(ctypes.Structure):
@@ -106,6 +106,9 @@ _PROTOS = {
     "oryon_engine_arena_bytes": (c_size_t, [POINTER(EngineConfig), c_void_p]),
     "oryon_engine_create": (c_int, [POINTER(c_void_p), POINTER(EngineConfig), c_void_p, _P, c_size_t]),
     "oryon_engine_destroy": (None, [c_void_p]),
+    "oryon_engine_warm_streams": (c_int, []),
+    "oryon_engine_set_stream_roles": (c_int, [c_void_p, c_int]),
+    "oryon_engine_stream_roles": (c_int, [c_void_p, POINTER(c_int)]),
     "oryon_engine_buffer": (c_int, [c_void_p, c_int, c_char_p, POINTER(c_size_t), POINTER(c_size_t)]),
     "oryon_engine_geometry": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "oryon_engine_submit": (c_int, [c_void_p, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),

@@ -8,17 +8,23 @@ def enable_fp16x3(flag: bool = True, guard: bool = False) -> None:
     Swin window attention and residual-add + LayerNorm as single fp32 kernels (B3, B2).  Off by default: torch fp32 everywhere.
     Results stay within ~1e-5 of the fp32 evaluation (tests/test_backbone_pins.py); takes effect under torch.no_grad() on CUDA only.
 
-    Range (round 5): the fp16x3 split needs |x| < 65504.  Every fp16x3 linear / convolution kernel raises a per-device flag when one of
-    its pre-activation outputs is not a finite value below 60000 - what an out-of-range operand produces in every product it enters - and
-    `Oryon.forward` reads the flag ONCE per forward (`ops.x3_range_flag`): a forward whose flag came back set is evaluated again with the
-    torch fp32 modules (`net.Oryon.x3_range_fallbacks` counts them).  So the default fast path is range-checked at the cost of one 4-byte
-    read-back per forward, fused kernels included.
+    Range (round 5; per stream since round 6): the fp16x3 split needs |x| < 65504.  Every PRODUCER of a tensor the fp16x3 kernels split
+    (the linears, the convolutions / up-convolutions, the residual-add + LayerNorm pass for the residual stream) raises the flag word of
+    the (device, stream) it runs on when one of its values is not a finite value below 60000 - what an out-of-range operand produces in
+    every product it enters; the attention kernels and the single-slab decoder convolutions carry no check of their own (their operands
+    are checked outputs, and whatever they produce is consumed by a checked kernel: include/oryon_hip.h, oryon_x3_range_flag).
+    `Oryon.forward` clears its stream's word before the forward and reads it ONCE after (`ops.x3_range_reset` / `ops.x3_range_flag`): a
+    forward whose flag came back set is evaluated again with the torch fp32 modules (`net.Oryon.x3_range_fallbacks` counts them).
+    Forwards on other streams / threads / model instances neither raise nor clear it.  Cost: one 4-byte read-back per forward.
 
     guard=True additionally checks every fp16x3 LINEAR's operands on the host before the call (one reduction + a sync per layer) and
     evaluates that layer with torch when they are out of range: the slow, layer-precise mode for a first run with a new checkpoint
     (`ops.x3_guard_fallbacks` counts layers).  The fused kernels stay on in both modes."""
     from . import clip, fusion, swin
     from .. import ops
+    import torch
+    if flag and torch.cuda.is_available():
+        ops.x3_range_reset()                    # allocates the device's flag table now, so that no kernel launch ever does
     ops.X3_GUARD = bool(flag and guard)
     clip.FP16X3_LINEAR = bool(flag)
     fusion.FP16X3_LINEAR = bool(flag)           # guided Swin blocks' linears + the CLIP 1x1 projection of ImageTextFusion

@@ -145,7 +145,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float *__restrict__ x, const float *__restrict__ delta,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                  int64_t rows, int D, float eps, float *__restrict__ x_out,
-                                                                 float *__restrict__ h_out)
+                                                                 float *__restrict__ h_out, unsigned *range_flag)
 {
     constexpr int CH = LPR == 64 ? LN_F32_CHUNKS : 1;
     constexpr int RPB = 256 / LPR;
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float *__r
     const int chunks = (D + LPR * 4 - 1) / (LPR * 4);
     float4 v[CH];
     float sum = 0.0f;
+    unsigned x3m = 0u;
     const float *xr = x + row * D;
     const float *dr = delta ? delta + row * D : nullptr;
 #pragma unroll
@@ -170,8 +171,12 @@ __global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float *__r
             }
             v[c] = a;
             sum += (a.x + a.y) + (a.z + a.w);
+            // the residual stream of the fp16x3 towers is range-checked HERE: whoever updated it (the in-place linear's atomics, the
+            // delta of this very call), this pass reads every element of it before the next fp16x3 kernel splits anything derived from it
+            x3m = max(max(x3m, x3_mag(a.x)), max(max(x3_mag(a.y), x3_mag(a.z)), x3_mag(a.w)));
         }
     }
+    x3_raise(range_flag, x3m);
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / (float)D;
@@ -381,9 +386,11 @@ extern "C" int oryon_add_layernorm_f32(const float *x, const float *delta, const
     ORYON_CHECK_ARG(!delta || x_out);
     ORYON_CHECK_ARG((((uintptr_t)x | (uintptr_t)delta | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)x_out | (uintptr_t)h_out) & 15) == 0);
     if (rows == 0) return ORYON_OK;
+    unsigned *rflag = x3_range_flag(as_stream(stream));
+    if (!rflag) return ORYON_ERR_HIP;
 #define ORYON_LAUNCH_LN32(LPR)                                                                                                     \
     hipLaunchKernelGGL((add_layernorm_f32_kernel<LPR>), dim3((unsigned)((rows + 256 / LPR - 1) / (256 / LPR))), dim3(256), 0,       \
-                       as_stream(stream), x, delta, gamma, beta, rows, D, eps, x_out, h_out)
+                       as_stream(stream), x, delta, gamma, beta, rows, D, eps, x_out, h_out, rflag)
     if (D <= 64) ORYON_LAUNCH_LN32(16);
     else if (D <= 128) ORYON_LAUNCH_LN32(32);
     else ORYON_LAUNCH_LN32(64);

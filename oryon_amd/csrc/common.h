@@ -57,9 +57,10 @@ static inline bool dev_env_set(const char *) { return false; }
 // Range flag of the fp16x3 kernels (round 5).  An fp32 operand of magnitude >= 65520 splits into hi = +-inf (lo = -+inf or NaN) and every
 // product it enters comes out inf or NaN, so a kernel that looks at the magnitude bits of its raw ACCUMULATORS (pre-activation) sees an
 // overflow of any of its inputs - and one that merely produced a value outside float16's range flags it before the next kernel splits
-// it.  The flag is one word per device, set with atomicOr, read (and reset) once per forward by oryon_x3_range_flag.
+// it.  The flag is one word per (device, stream), set with atomicOr, reset at the start and read at the end of a forward on that stream
+// by oryon_x3_range_flag.
 constexpr unsigned X3_RANGE_LIMIT_BITS = 0x476a6000u;            // 60000.0f: below float16's 65504 with room for the rounding of hi
-unsigned *x3_range_flag();                                       // this device's flag word (util.hip)
+unsigned *x3_range_flag(hipStream_t st);                         // the flag word of (current device, stream) (util.hip); nullptr = no memory, error set
 __device__ __forceinline__ unsigned x3_mag(float v) { return __float_as_uint(v) & 0x7fffffffu; }     // NaN / inf compare above any finite value
 __device__ __forceinline__ void x3_raise(unsigned *flag, unsigned mag_max)
 {

@@ -784,7 +784,8 @@ int oryon_decoder_forward(const oryon_decoder_t *d, const float *x, const float 
     const WsLayout L = ws_layout(n_img, h, w);
     ORYON_CHECK_ARG(workspace_bytes >= L.total);
     hipStream_t st = as_stream(stream);
-    unsigned *rflag = x3_range_flag();
+    unsigned *rflag = x3_range_flag(st);
+    if (!rflag) return ORYON_ERR_HIP;
     char *ws = reinterpret_cast<char *>(workspace);
     float *R[3] = {reinterpret_cast<float *>(ws + L.R[0]), reinterpret_cast<float *>(ws + L.R[1]), reinterpret_cast<float *>(ws + L.R[2])};
     float *stats = reinterpret_cast<float *>(ws + L.stats);
@@ -888,7 +889,8 @@ int oryon_conv24_f16x3(const float *x, int n, int cin, const void *image, const 
     ORYON_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)image) & 15) == 0);
     if (n == 0) return ORYON_OK;
     FusConv a{};
-    a.range_flag = x3_range_flag();
+    a.range_flag = x3_range_flag(as_stream(stream));
+    if (!a.range_flag) return ORYON_ERR_HIP;
     a.in = x; a.wimg = reinterpret_cast<const dh8 *>(image); a.bias = bias; a.out = y; a.cin = cin; a.cout = cout; a.relu = relu ? 1 : 0;
     const dim3 grid((unsigned)(n * (cout / 64)));
     if (ksize == 3) {

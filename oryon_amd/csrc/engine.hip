@@ -28,6 +28,17 @@ constexpr int MAX_G_SLOTS = 4;         // K0 output sets (the rows the screening
 constexpr int MAX_REG_STREAMS = 4;
 constexpr int TIMING_RING = 64;        // timing-event sets: the sections of the last 64 steps can be read back
 constexpr int ROW_PAD = 256;
+constexpr int POOL_STREAMS = 8;        // HIP streams per device in the process-wide pool (see acquire_pool)
+constexpr int DEFAULT_ROLES = 2301;    // cfg.stream_roles == 0: the placement measured best on the development boxes (round 5)
+
+// cfg.stream_roles: four decimal digits, each a pool index 0..7 (match / gather / registration 0 / registration 1); 0 = DEFAULT_ROLES
+inline bool roles_valid(int roles)
+{
+    if (roles < 0 || roles > 7777) return false;
+    for (int d = 0, r = roles; d < 4; ++d, r /= 10)
+        if (r % 10 >= POOL_STREAMS) return false;
+    return true;
+}
 
 inline size_t up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
@@ -80,6 +91,7 @@ struct oryon_engine {
     int device;
     hipStream_t sg, sm, sr[MAX_REG_STREAMS];
     int n_reg_streams;
+    int roles;                                // pool positions of match / gather / registration 0 / registration 1 (four digits)
     // ordering events (timing disabled), one set per result slot
     hipEvent_t ev_inputs[MAX_SLOTS], ev_gathered[MAX_SLOTS], ev_matched[MAX_SLOTS], ev_done[MAX_SLOTS];
     // timing events: gather section, match section, screening kernel, registration section
@@ -220,6 +232,7 @@ int check_cfg(const oryon_engine_config_t *c)
     ORYON_CHECK_ARG(c->overlap >= 0 && c->overlap <= 2 && (c->overlap == 0 || c->n_slots >= 2));      // results of step k live until submit k + n_slots
     ORYON_CHECK_ARG((size_t)c->C * (size_t)c->FH * (size_t)c->FW * 4u < (1ull << 32));
     ORYON_CHECK_ARG(c->sample_first >= 0 && (c->x3_prefetch == 0 || c->x3_prefetch == 1));
+    ORYON_CHECK_ARG(roles_valid(c->stream_roles));
     return ORYON_OK;
 }
 }  // namespace
@@ -253,22 +266,53 @@ namespace oryon {
 // build: the same hard cfg2 step ran 5.45 ms on the first engine of a process and 6.4 ms on the third (streams destroyed and re-created
 // in between: two of the new ones shared a queue).  Engines of one process therefore share one set of streams - they do not run
 // concurrently (a second engine's steps simply queue behind the first's), and none of them destroys a stream.
-struct StreamPool { hipStream_t all[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
-static hipError_t pooled_stream(hipStream_t *slot_in_pool)
+// Round 6: the pool's mutex is held while the streams are created (two threads creating engines used to race on the empty slots), the
+// pool is keyed by the device the ARENA lives on, and oryon_engine_warm_streams() lets a host create the pool before anything else of
+// the process creates HIP streams (RCCL's communicator does): the roles below are positions in the process's creation order.
+struct StreamPool { hipStream_t all[POOL_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
+static std::mutex g_pool_mu;
+static StreamPool g_pools[64];
+// copies the device's eight pooled streams into out[], creating the missing ones under the lock
+static hipError_t acquire_pool(int dev, hipStream_t out[POOL_STREAMS])
 {
-    if (*slot_in_pool) return hipSuccess;
-    return hipStreamCreateWithFlags(slot_in_pool, hipStreamNonBlocking);
-}
-static StreamPool &stream_pool()
-{
-    static std::mutex mu;
-    static StreamPool pools[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(mu);
-    return pools[(dev >= 0 && dev < 64) ? dev : 0];
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    StreamPool &pool = g_pools[(dev >= 0 && dev < 64) ? dev : 0];
+    for (int i = 0; i < POOL_STREAMS; ++i) {
+        if (!pool.all[i]) {
+            const hipError_t err = hipStreamCreateWithFlags(&pool.all[i], hipStreamNonBlocking);
+            if (err != hipSuccess) { pool.all[i] = nullptr; return err; }
+        }
+        out[i] = pool.all[i];
+    }
+    return hipSuccess;
 }
 }  // namespace oryon
+
+extern "C" int oryon_engine_warm_streams(void)
+{
+    int dev = 0;
+    ORYON_CHECK_HIP(hipGetDevice(&dev));
+    hipStream_t tmp[POOL_STREAMS];
+    ORYON_CHECK_HIP(acquire_pool(dev, tmp));
+    return ORYON_OK;
+}
+
+namespace {
+// (re)assign the engine's streams from the pool by role digits; the caller has drained the engine's streams when they were in use
+int assign_roles(oryon_engine *e, int roles)
+{
+    hipStream_t pool[POOL_STREAMS];
+    ORYON_CHECK_HIP(acquire_pool(e->device, pool));
+    const int r_m = roles / 1000 % 10, r_g = roles / 100 % 10, r_r0 = roles / 10 % 10, r_r1 = roles % 10;
+    e->sm = e->cfg.overlap >= 1 ? pool[r_m] : nullptr;
+    e->sg = e->cfg.overlap >= 2 ? pool[r_g] : nullptr;
+    for (int s = 0; s < MAX_REG_STREAMS; ++s) e->sr[s] = nullptr;
+    for (int s = 0; s < e->n_reg_streams; ++s)
+        if (e->cfg.overlap >= 1) e->sr[s] = pool[(s == 0 ? r_r0 : s == 1 ? r_r1 : 2 + s) & 7];      // a third / fourth registration stream: pool streams 4, 5
+    e->roles = roles;
+    return ORYON_OK;
+}
+}  // namespace
 
 extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,
                                    size_t arena_bytes)
@@ -287,7 +331,18 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
         delete e;
         return ORYON_ERR_WORKSPACE;
     }
+    // the arena decides the device: the streams come from THAT device's pool, and the calling thread must be on it (every launch of a
+    // submit goes to the current device)
     (void)hipGetDevice(&e->device);
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, arena) == hipSuccess && attr.device != e->device) {
+            set_error("oryon_engine_create: the arena lives on device %d, the calling thread is on device %d", attr.device, e->device);
+            delete e;
+            return ORYON_ERR_INVALID_ARG;
+        }
+        (void)hipGetLastError();
+    }
     e->sg = e->sm = nullptr;
     e->timing = false;
     e->n_submit = 0;
@@ -299,19 +354,18 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     e->host_ns_total = e->host_ns_last = 0.0;
     hipError_t err = hipSuccess;
     auto ok = [&](hipError_t x) { if (err == hipSuccess) err = x; };
-    StreamPool &pool = stream_pool();
     // Which of the pool's 8 consecutively created streams serve as match / gather / registration 0 / registration 1.  The runtime gives
     // the first streams of a process one hardware queue each, in creation order, and the placement matters far more than one would
     // think (cfg2 step, same box, `tools/engine_timeline.py`, two runs each): 0123 (creation order, rounds 3-4) 3.46 ms; 2301 3.33-3.34;
     // 2345 3.34-3.38; 2453 / 2534 / 4523 3.42-3.47; 5670 3.7-3.8; 1357 3.9; 0246 4.07; 3210 / 3456 4.1-4.2 ms.  The two best have the
-    // match stream on the pool's third and the gather stream on its fourth queue.  (dev build: ORYON_ENGINE_ROLES = four digits)
-    static const int roles = dev_env_int("ORYON_ENGINE_ROLES", 2301);
-    const int r_m = roles / 1000 % 10, r_g = roles / 100 % 10, r_r0 = roles / 10 % 10, r_r1 = roles % 10;
-    for (int i = 0; i < 8; ++i) ok(pooled_stream(&pool.all[i]));
-    if (cfg->overlap >= 1) e->sm = pool.all[r_m & 7];
-    if (cfg->overlap >= 2) e->sg = pool.all[r_g & 7];
-    for (int s = 0; s < MAX_REG_STREAMS; ++s) e->sr[s] = nullptr;
+    // match stream on the pool's third and the gather stream on its fourth queue.  cfg.stream_roles names the placement (0 = the
+    // default above); oryon_engine_set_stream_roles changes it on a live engine, which is how a host measures the candidates on ITS
+    // process (oryon_amd.engine.MatchPoseEngine.tune_stream_roles).  (dev build: ORYON_ENGINE_ROLES overrides the default)
+    static const int default_roles = dev_env_int("ORYON_ENGINE_ROLES", DEFAULT_ROLES);
     e->n_reg_streams = cfg->reg_streams;
+    for (int s = 0; s < MAX_REG_STREAMS; ++s) e->sr[s] = nullptr;
+    if (assign_roles(e, cfg->stream_roles > 0 ? cfg->stream_roles : (roles_valid(default_roles) ? default_roles : DEFAULT_ROLES)) != ORYON_OK)
+        err = hipErrorUnknown;
     for (int s = 0; s < MAX_SLOTS; ++s) {
         e->used[s] = false;
         e->ev_inputs[s] = e->ev_gathered[s] = e->ev_matched[s] = e->ev_done[s] = nullptr;
@@ -320,8 +374,6 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
         e->timed[r] = false;
         for (int i = 0; i < 8; ++i) e->tev[r][i] = nullptr;
     }
-    for (int s = 0; s < e->n_reg_streams; ++s)
-        if (cfg->overlap >= 1) e->sr[s] = pool.all[(s == 0 ? r_r0 : s == 1 ? r_r1 : 2 + s) & 7];      // a third / fourth registration stream: pool streams 4, 5
     for (int s = 0; s < cfg->n_slots; ++s) {
         for (hipEvent_t *ev : {&e->ev_inputs[s], &e->ev_gathered[s], &e->ev_matched[s], &e->ev_done[s]})
             ok(hipEventCreateWithFlags(ev, hipEventDisableTiming));
@@ -373,6 +425,25 @@ extern "C" int oryon_engine_set_timing(oryon_engine_t *e, int enable)
 {
     ORYON_CHECK_ARG(e);
     e->timing = enable != 0;
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_set_stream_roles(oryon_engine_t *e, int roles)
+{
+    ORYON_CHECK_ARG(e && roles_valid(roles));
+    if (roles == 0) roles = DEFAULT_ROLES;
+    if (e->cfg.overlap == 0 || roles == e->roles) return ORYON_OK;
+    // steps in flight were ordered with events between the OLD streams: drain them, then every later submit runs on the new ones (the
+    // slot events stay valid - an event recorded on one stream may be waited for on any other)
+    for (hipStream_t st : {e->sm, e->sg, e->sr[0], e->sr[1], e->sr[2], e->sr[3]})
+        if (st) ORYON_CHECK_HIP(hipStreamSynchronize(st));
+    return assign_roles(e, roles);
+}
+
+extern "C" int oryon_engine_stream_roles(const oryon_engine_t *e, int *roles)
+{
+    ORYON_CHECK_ARG(e && roles);
+    *roles = e->roles;
     return ORYON_OK;
 }
 

@@ -576,12 +576,14 @@ static int linear_f16x3_impl(const float *A, int M, int K, const void *W_hi, con
         if (grid < 8) grid = 8;
         if (grid > n_slots) grid = n_slots;
         hipStream_t st2 = as_stream(stream);
+        unsigned *rflag2 = x3_range_flag(st2);
+        if (!rflag2) return ORYON_ERR_HIP;
         const __half *wh2 = static_cast<const __half *>(W_hi), *wl2 = static_cast<const __half *>(W_lo);
 #define ORYON_LAUNCH_STREAM(ACT, WEX, ACC)                                                                                          \
     do {                                                                                                                            \
         allow_dynamic_lds(reinterpret_cast<const void *>(linear_f16x3_stream_kernel<ACT, WEX, ACC>), 2 * G2_STAGE);                 \
         hipLaunchKernelGGL((linear_f16x3_stream_kernel<ACT, WEX, ACC>), dim3(grid), dim3(512), 2 * G2_STAGE, st2, A, M, K, wh2, wl2,   \
-                           bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots, x3_range_flag());                       \
+                           bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, n_slots, rflag2);                       \
     } while (0)
         if (accumulate) {
             if (!wl2) ORYON_LAUNCH_STREAM(0, true, true);
@@ -605,13 +607,15 @@ static int linear_f16x3_impl(const float *A, int M, int K, const void *W_hi, con
     const int supers = ((sup_m * sup_n + 7) / 8) * 8;
     const dim3 grid(supers * 64);
     hipStream_t st = as_stream(stream);
+    unsigned *rflag = x3_range_flag(st);
+    if (!rflag) return ORYON_ERR_HIP;
     const __half *wh = static_cast<const __half *>(W_hi), *wl = static_cast<const __half *>(W_lo);
     if (act == 2)
-        hipLaunchKernelGGL((linear_f16x3_kernel<2>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, x3_range_flag());
+        hipLaunchKernelGGL((linear_f16x3_kernel<2>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, rflag);
     else if (act == 1)
-        hipLaunchKernelGGL((linear_f16x3_kernel<1>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, x3_range_flag());
+        hipLaunchKernelGGL((linear_f16x3_kernel<1>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, rflag);
     else
-        hipLaunchKernelGGL((linear_f16x3_kernel<0>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, x3_range_flag());
+        hipLaunchKernelGGL((linear_f16x3_kernel<0>), grid, dim3(256), 0, st, A, M, K, wh, wl, bias, N, C, tiles_m, tiles_n, sup_n, sup_rows, sup_cols, rflag);
     ORYON_CHECK_LAUNCH();
     return ORYON_OK;
 }

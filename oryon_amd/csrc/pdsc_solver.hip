@@ -167,7 +167,10 @@ __global__ __launch_bounds__(1024) void pdsc_seeds_fused_kernel(const float *__r
     __syncthreads();
     for (int i = t; i < n; i += 1024) {
         const float kv = pt[i].w * ((part_ok[i] & part_ok[n_cap + i]) ? 1.0f : 0.0f);
-        key[i] = kv;
+        // rank counting needs a TOTAL order: a NaN confidence (upstream features overflowed) is neither greater than, equal to nor less
+        // than anything, two rows would share a rank and a seed slot would keep an index of an earlier step.  NaN ranks last (the most
+        // negative finite float; the padding value -inf below stays "neither greater than nor equal to any key").
+        key[i] = (kv != kv) ? -3.402823466e38f : kv;
         key_out[(size_t)b * n_cap + i] = kv;
     }
     __syncthreads();
@@ -596,13 +599,14 @@ __global__ __launch_bounds__(64) void pdsc_power_kernel(const int32_t *__restric
     }
 }
 
-// Round 5: K6b + K7a + K7b as ONE launch per registration (C = 128, n_cap <= 1024): one workgroup per (seed, pair) takes the seed's
+// Round 5: K6b + K7a as ONE launch per registration (C = 128, n_cap <= 1024): one workgroup per (seed, pair) takes the seed's
 // feature distances from pdsc_seed_dist_kernel, selects the k + 1 nearest rows with a WAVE-LEVEL bitonic top-64 - every lane holds EPT
 // (key, row) pairs as 64-bit composites; the 64-element lists are sorted in registers (shuffles, no barrier), merged pairwise by
 // min(a_i, b_63-i) + a 6-stage bitonic merge, across the four waves through LDS with two barriers - i.e. ascending distance, ties by
 // row index: the order of the 45-barrier bitonic sort of all n_cap rows it replaces, hence the same neighbours; then builds the k x k
-// compatibility matrix in LDS and runs the power iteration on it (wave 0; M never goes to memory).  Replaces pdsc_knn_matrix_kernel +
-// pdsc_power_kernel.  Reference: common.py:48-69 (knn), PointDSC.py:257-281 (compatibility), :338-358 (power iteration).
+// compatibility matrix and writes it to M_out for pdsc_power_kernel (the power iteration stays its own launch: inside this kernel one
+// wave iterated while the workgroup's 31 KB of LDS kept all but five workgroups off the CU, +77 us - DESIGN.md round 5).  Replaces
+// pdsc_knn_matrix_kernel.  Reference: common.py:48-69 (knn), PointDSC.py:257-281 (compatibility); :338-358 is pdsc_power_kernel.
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
 {
     const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m);

@@ -13,12 +13,29 @@ import torch
 import torch.distributed as dist
 
 
+def warm_engine_streams(local: int) -> bool:
+    """Create the step engine's stream pool on GPU `local` NOW, before anything else of the process creates HIP streams there.
+
+    Which hardware queue an engine stream sits on moves the pipelined step by up to 30 % (DESIGN.md "stream placement"), the HIP runtime
+    hands queues out in stream-creation order, and `oryon_engine_config_t.stream_roles` names positions in that order.  RCCL's
+    communicator (eager with `device_id=`) creates streams of its own: created first, they would shift every role, and the N > 1 run
+    would not have the placement the N = 1 number was tuned on.  So: pool first, process group second - at every N."""
+    from ._lib import check, lib
+    torch.cuda.set_device(local)
+    check(lib().oryon_engine_warm_streams(), "oryon_engine_warm_streams")
+    return True
+
+
 def init_from_env(device_type: str = "cuda") -> Tuple[int, int, int]:
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world, local_rank).  A single process without those variables is world 1 and needs no group."""
+    Returns (rank, world, local_rank).  A single process without those variables is world 1 and needs no group.
+    On GPUs the step engine's stream pool is created BEFORE the process group (see warm_engine_streams), at world 1 too, so that a
+    rank of an N-GPU run and a single-GPU run give their engine streams the same hardware queues."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device_type == "cuda":
+        warm_engine_streams(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -54,3 +71,17 @@ def gather_poses(pose_local: torch.Tensor, status_local: torch.Tensor, total: in
     dist.all_gather_into_tensor(out, packed)
     out = out[:total]
     return out[:, :16].reshape(total, 4, 4).contiguous(), out[:, 16].to(torch.int32)
+
+
+def gather_pose_windows(staged_local: torch.Tensor) -> torch.Tensor:
+    """Final collation of a whole window (north_star: "all-gather of per-pair poses ... only for the final collation"): every rank staged
+    the [B_r, 17] rows (16 pose values + status) of each of its k steps in `staged_local` [k, B_r, 17] fp32; ONE all_gather returns
+    [world, k, B_r, 17] on every rank - step j of the job in global pair order is out[:, j].reshape(world * B_r, 17).
+    All ranks must pass the same k and B_r (pad short ranks with status rows the reader cuts)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return staged_local.unsqueeze(0)
+    mine = staged_local.contiguous()
+    out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(out.view((world * mine.shape[0],) + tuple(mine.shape[1:])), mine)
+    return out

@@ -69,7 +69,8 @@ class NativeStep:
     }
 
     def __init__(self, solver: PointDSC, cfg: "MatchPoseConfig", key: Tuple, dev: torch.device, overlap: int, n_slots: int = 6,
-                 gather_sets: int = 2, reg_streams: int = 2, reg_lag: int = 0, screen: int = 1, x3_prefetch: int = 1):
+                 gather_sets: int = 2, reg_streams: int = 2, reg_lag: int = 0, screen: int = 1, x3_prefetch: int = 1,
+                 stream_roles: int = 0):
         B, C, FH, FW, HA, WA, HQ, WQ, layout = key
         self.key, self.dev = key, dev
         if overlap >= 2:
@@ -83,7 +84,8 @@ class NativeStep:
                                       gather_sets=min(gather_sets, n_slots), reg_streams=reg_streams,
                                       reg_lag=reg_lag if overlap else 0, screen=screen,
                                       sample_first=int(cfg.sample_first) if cfg.sample_first and cfg.sample_first > 0 else 0,
-                                      x3_prefetch=int(bool(x3_prefetch)) if (C <= 256 and screen == 1) else 0)
+                                      x3_prefetch=int(bool(x3_prefetch)) if (C <= 256 and screen == 1) else 0,
+                                      stream_roles=int(stream_roles))
         self.cfg_sig = (cfg.dist_th, cfg.n_corrs, cfg.src_sampling, cfg.seed, cfg.half_descriptors, overlap, int(cfg.sample_first))
         need = lib().oryon_engine_arena_bytes(ctypes.byref(self.ecfg), solver._handle)
         if need == 0:
@@ -125,6 +127,17 @@ class NativeStep:
 
     def set_timing(self, on: bool) -> None:
         check(lib().oryon_engine_set_timing(self._h, int(on)))
+
+    def stream_roles(self) -> int:
+        """Pool positions (creation order) of the match / gather / registration 0 / registration 1 streams, four digits."""
+        r = ctypes.c_int()
+        check(lib().oryon_engine_stream_roles(self._h, ctypes.byref(r)))
+        return r.value
+
+    def set_stream_roles(self, roles: int) -> None:
+        """Move the live engine to another stream placement (drains the steps in flight: warm-up only)."""
+        with torch.cuda.device(self.dev):
+            check(lib().oryon_engine_set_stream_roles(self._h, int(roles)), "oryon_engine_set_stream_roles")
 
     def timing(self, step: int) -> Dict[str, float]:
         """ms: durations of the gather / match+lift / screening-kernel / registration sections of submit number `step` (0-based, one
@@ -201,7 +214,7 @@ class MatchPoseEngine:
         self.result_views = result_views
         self._native: Optional[NativeStep] = None
         self._inflight: Dict[int, Dict[str, Tensor]] = {}       # slot -> result dict of the native step that last used it
-        self.native_geometry = dict(n_slots=6, gather_sets=2, reg_streams=2, reg_lag=0, screen=1, x3_prefetch=1)      # NativeStep's pipeline depth (see oryon_engine_config_t)
+        self.native_geometry = dict(n_slots=6, gather_sets=2, reg_streams=2, reg_lag=0, screen=1, x3_prefetch=1, stream_roles=0)      # NativeStep's pipeline depth / placement (see oryon_engine_config_t)
         self.native_timing = False          # bracket the sections of every native step with HIP events (NativeStep.timing)
         self._reg_stream = None
         self.reg_streams = 2
@@ -218,6 +231,38 @@ class MatchPoseEngine:
         self._i8_host = None           # pinned buffer, allocated once
         self._i8_frac = 0.0
         self._i8_skipped = 0
+
+    # placements within ~2 % of the best on the development boxes (DESIGN.md "stream placement"): what tune_stream_roles tries
+    ROLE_CANDIDATES = (2301, 2310, 2354, 2345, 2300)
+
+    def tune_stream_roles(self, run_steps, candidates: Optional[Tuple[int, ...]] = None, steps: int = 8, warm: int = 2) -> Dict[str, object]:
+        """Pick the engine's stream placement by MEASUREMENT on this process (warm-up only, never inside a timed region).
+
+        `run_steps(n)` must submit and collect n complete steps of the caller's workload through this engine.  Every candidate gets
+        `warm` untimed steps and `steps` timed ones between two device synchronisations; the fastest stays.  Needs the native engine to
+        exist (run one step first).  Returns {"roles": chosen, "ms_per_step": {candidate: ms}, "default": library default}.
+        Results never depend on the placement - only which hardware queue each engine stream sits on does."""
+        import time
+        nat = self._native
+        if nat is None or nat.ecfg.overlap == 0:
+            return {"roles": None, "ms_per_step": {}, "default": 2301}
+        cands = tuple(candidates or self.ROLE_CANDIDATES)
+        seen: Dict[int, float] = {}
+        for r in cands:
+            nat.set_stream_roles(r)
+            run_steps(warm)
+            torch.cuda.synchronize(nat.dev)
+            t0 = time.perf_counter()
+            run_steps(steps)
+            torch.cuda.synchronize(nat.dev)
+            seen[r] = (time.perf_counter() - t0) / steps * 1e3
+        best = min(seen, key=seen.get)
+        # keep the default unless another placement is clearly (> 1 %) faster: the timing noise of 8 steps is about that
+        if 2301 in seen and seen[2301] <= seen[best] * 1.01:
+            best = 2301
+        nat.set_stream_roles(best)
+        self.native_geometry["stream_roles"] = best          # a rebuilt NativeStep keeps the choice
+        return {"roles": best, "ms_per_step": {str(k): round(v, 4) for k, v in seen.items()}, "default": 2301}
 
     def finish(self, out: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Order the caller's current stream after the registration of `out` (no-op without overlap)."""

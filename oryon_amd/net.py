@@ -164,13 +164,19 @@ class Oryon(nn.Module):
     x3_range_fallbacks = 0          # forwards re-evaluated with the fp32 modules because the fp16x3 range flag came back set
 
     def forward(self, xs: dict) -> Dict[str, Tensor]:
-        out = self._forward(xs)
         from . import backbone
-        t = out["featmap_a"]
-        if t.is_cuda and not torch.is_grad_enabled() and backbone.fp16x3_enabled():
-            # one 4-byte read-back per forward: did any fp16x3 kernel see a value its float16 split cannot hold (|x| >= 65504)?
+        dev = torch.device(self.device)
+        checked = dev.type == "cuda" and not torch.is_grad_enabled() and backbone.fp16x3_enabled()
+        if checked:
+            # the flag word belongs to (device, current stream): cleared here, in stream order, so that nothing launched on this stream
+            # before the forward (a direct ops.linear_f16x3 call, an earlier forward nobody read) is mistaken for this forward's, and
+            # no forward on another stream / thread / model instance can raise or clear it
             from . import ops
-            if ops.x3_range_flag(t.device, reset=True):
+            ops.x3_range_reset(dev)
+        out = self._forward(xs)
+        if checked:
+            # one 4-byte read-back per forward: did any fp16x3 kernel see a value its float16 split cannot hold (|x| >= 65504)?
+            if ops.x3_range_flag(dev, reset=True):
                 Oryon.x3_range_fallbacks += 1
                 with backbone.fp16x3_disabled():
                     out = self._forward(xs)

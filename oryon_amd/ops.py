@@ -683,13 +683,22 @@ x3_guard_fallbacks = 0        # layers evaluated by torch because an operand lef
 
 
 def x3_range_flag(device=None, reset: bool = True) -> bool:
-    """oryon_x3_range_flag: True when an fp16x3 kernel on `device` saw an out-of-range / non-finite pre-activation output since the
-    last reset.  Synchronises the device's current stream: call once per forward."""
+    """oryon_x3_range_flag: True when an fp16x3 kernel launched on `device`'s CURRENT stream saw an out-of-range / non-finite output since
+    that stream's flag was last cleared.  Synchronises that stream: call once per forward.  The flag word belongs to the (device, stream)
+    pair: other streams' launches neither raise nor clear it."""
     dev = _lib.require_gpu(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
     v = ctypes.c_int(0)
     with torch.cuda.device(dev):
         check(lib().oryon_x3_range_flag(ctypes.byref(v), int(bool(reset)), stream_ptr(dev)), "oryon_x3_range_flag")
     return v.value != 0
+
+
+def x3_range_reset(device=None) -> None:
+    """Queue a clear of the current stream's fp16x3 range flag (no synchronisation, no read-back): the start of a forward.  The first
+    call on a device allocates its flag table, so that no kernel launch does."""
+    dev = _lib.require_gpu(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
+    with torch.cuda.device(dev):
+        check(lib().oryon_x3_range_flag(None, 1, stream_ptr(dev)), "oryon_x3_range_flag")
 
 
 def _split_weight_f16x3(weight: torch.Tensor):

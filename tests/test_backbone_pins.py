@@ -495,6 +495,86 @@ def test_fp16x3_device_range_flag():
 
 
 @pytest.mark.gpu
+def test_fp16x3_range_flag_is_per_stream():
+    """the flag word belongs to (device, stream).  An overflow on stream A is seen by a reader of A only; a reader /
+    reset on stream B neither sees nor clears it; `Oryon.forward`-style use (clear, launch, read) on B is undisturbed by A."""
+    from oryon_amd import ops
+    torch.manual_seed(0)
+    w = torch.randn(256, 128, device="cuda") * 0.05
+    b = torch.randn(256, device="cuda")
+    x = torch.randn(300, 128, device="cuda")
+    xb = x.clone(); xb[7, 5] = 7.0e4
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        with torch.cuda.stream(sa):
+            ops.x3_range_reset()
+            ops.linear_f16x3(xb, w, b)                          # raises A's word
+        with torch.cuda.stream(sb):
+            ops.x3_range_reset()                                # B's forward begins: must not clear A's word
+            ops.linear_f16x3(x, w, b)
+            assert ops.x3_range_flag(x.device) is False         # B never overflowed, whatever A did
+        assert ops.x3_range_flag(x.device) is False             # nor did the default stream
+        with torch.cuda.stream(sa):
+            assert ops.x3_range_flag(x.device) is True          # A's flag survived B's reset and B's read
+            assert ops.x3_range_flag(x.device) is False         # ... and was cleared by its own read
+        # a flag left behind on a stream (a direct call nobody read) is cleared by the reset that opens the next forward on that stream
+        ops.linear_f16x3(xb, w, b)
+        ops.x3_range_reset()
+        ops.linear_f16x3(x, w, b)
+        assert ops.x3_range_flag(x.device) is False
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_fp16x3_overflow_behind_an_unchecked_kernel_is_flagged_by_the_next():
+    """The attention kernels carry no range check of their own (include/oryon_hip.h, oryon_x3_range_flag): the argument is that whatever an
+    out-of-range operand makes of their output reaches a CHECKED kernel next.  Executed: an out-of-range v inside the CLIP attention
+    (mha_f16x3) and inside fusion's window attention leaves the flag clear at that kernel and raises it in the projection that consumes
+    the output; a residual value that the in-place linear's atomics push past the range is caught by the LayerNorm pass that reads it."""
+    from oryon_amd import ops
+    torch.manual_seed(1)
+    dev = torch.device("cuda")
+    with torch.no_grad():
+        # (1) CLIP attention -> out projection
+        qkv = torch.randn(2, 77, 3 * 128, device=dev)
+        qkv[1, 5, 2 * 128 + 3] = 7.0e4                          # a v entry beyond float16: hi = inf
+        ops.x3_range_reset()
+        att = ops.mha_f16x3(qkv, heads=2)
+        assert ops.x3_range_flag(dev) is False                  # the attention itself is not instrumented ...
+        assert not torch.isfinite(att[1]).all() and torch.isfinite(att[0]).all()
+        wo = torch.randn(128, 128, device=dev) * 0.05
+        ops.linear_f16x3(att, wo, None)
+        assert ops.x3_range_flag(dev) is True                   # ... the checked linear that consumes its output is
+        # (2) fusion's window attention -> projection
+        qk = torch.randn(1, 24, 24, 256, device=dev)
+        v = torch.randn(1, 24, 24, 128, device=dev)
+        v[0, 4, 4, 9] = 1.0e5
+        ops.x3_range_reset()
+        o = ops.fusion_window_attention(qk, v, heads=4, window=12, shift=0)
+        assert ops.x3_range_flag(dev) is False and not torch.isfinite(o).all()
+        ops.linear_f16x3(o, wo, None)
+        assert ops.x3_range_flag(dev) is True
+        # (3) the residual stream: C and the update are each in range, their sum is not - the in-place linear checks its own finished sum
+        #     only (fire-and-forget atomics), the residual-add + LayerNorm pass that reads C next checks the stream itself
+        x = torch.randn(256, 128, device=dev)
+        w = torch.randn(128, 128, device=dev) * 0.05
+        bias = torch.full((128,), 8.0e3, device=dev)
+        C = torch.full((256, 128), 5.9e4, device=dev)
+        ops.x3_range_reset()
+        if ops.linear_f16x3_acc_supported(w, C):
+            ops.linear_f16x3_acc(x, w, bias, C)
+            assert ops.x3_range_flag(dev) is False and float(C.min()) > 6.55e4
+        else:
+            C += 8.0e3
+        g, be = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+        ops.add_layernorm_f32(C, None, g, be, 1e-5)
+        assert ops.x3_range_flag(dev) is True
+        ops.add_layernorm_f32(torch.randn(256, 128, device=dev), torch.randn(256, 128, device=dev), g, be, 1e-5)
+        assert ops.x3_range_flag(dev) is False
+
+
+@pytest.mark.gpu
 def test_oryon_forward_falls_back_to_fp32_when_the_range_flag_is_raised():
     """Oryon.forward on the fast path reads the flag once per forward; with a decoder weight blown up so that an up-convolution output
     leaves float16's range the forward is evaluated again with the torch fp32 modules: same result as enable_fp16x3(False), counted."""

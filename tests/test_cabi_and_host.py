@@ -147,6 +147,101 @@ def test_collation_gloo_world2(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+WORKER4 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from oryon_amd.dist import init_from_env, shard_range, gather_poses, gather_pose_windows
+rank, world, _ = init_from_env("cpu")
+assert world == 4
+total = 10                                   # not divisible by 4: blocks of 3, 3, 3, 1
+s, e = shard_range(total, rank, world)
+assert (e - s) == (3 if rank < 3 else 1)
+pose = torch.eye(4).repeat(e - s, 1, 1)
+for i in range(e - s):
+    pose[i, 0, 3] = float(s + i)
+status = torch.tensor([(s + i) % 3 for i in range(e - s)], dtype=torch.int32)
+P, S = gather_poses(pose, status, total)
+assert P.shape == (total, 4, 4) and S.tolist() == [i % 3 for i in range(total)], S
+assert P[:, 0, 3].tolist() == [float(i) for i in range(total)]
+# the final collation of a window of k steps: short ranks pad their block to ceil(total / world) rows
+k, per = 5, 3
+stage = torch.zeros((k, per, 17))
+for j in range(k):
+    stage[j, : e - s, :16] = pose.reshape(e - s, 16)
+    stage[j, : e - s, 7] = float(j)
+    stage[j, :, 16] = -1.0
+    stage[j, : e - s, 16] = status.to(torch.float32)
+allr = gather_pose_windows(stage)
+assert allr.shape == (4, k, per, 17)
+for j in range(k):
+    rows = allr[:, j].reshape(4 * per, 17)
+    rows = rows[rows[:, 16] >= 0]            # padding rows cut by their status
+    assert rows.shape[0] == total and rows[:, 3].tolist() == [float(i) for i in range(total)] and bool((rows[:, 7] == j).all())
+    assert rows[:, 16].to(torch.int32).tolist() == [i % 3 for i in range(total)]
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_collation_gloo_world4_total_not_divisible(tmp_path):
+    script = tmp_path / "worker4.py"
+    script.write_text(WORKER4.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr",
+                        "127.0.0.1", "--master-port", "29633", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 4
+
+
+def test_bench_final_collation_selftest_world2():
+    """`bench.py --collate final`: the window's poses are staged and collated by ONE all_gather (the north_star's wording)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "5",
+                        "--collation-selftest", "--collate", "final"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["collated_in_order"] is True and rec["collate"] == "final" and rec["collectives"] == 1
+
+
+def test_stream_pool_is_created_before_the_process_group(monkeypatch):
+    """the engine's stream roles are positions in the process's stream-creation order, so `init_from_env("cuda")` must
+    create the pool (oryon_engine_warm_streams) BEFORE RCCL's communicator creates its streams - at world 1 as well."""
+    import torch.distributed as dist
+    from oryon_amd import dist as odist
+    order = []
+    monkeypatch.setattr(odist, "warm_engine_streams", lambda local: order.append(("warm", local)) or True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: order.append(("set_device", d)))
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **k: order.append(("init_process_group", a[0], k.get("device_id"))))
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert odist.init_from_env("cuda") == (1, 2, 1)
+    kinds = [o[0] for o in order]
+    assert kinds.index("warm") < kinds.index("init_process_group") and order[kinds.index("warm")] == ("warm", 1)
+    assert order[kinds.index("init_process_group")][1] == "nccl"
+    order.clear()
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    assert odist.init_from_env("cuda") == (0, 1, 0) and [o[0] for o in order] == ["warm"]
+
+
+def test_stream_role_entry_points_validate_their_arguments():
+    import ctypes
+    from oryon_amd import _lib
+    L = _lib.lib()
+    assert L.oryon_engine_set_stream_roles(None, 2301) == -1 and L.oryon_engine_stream_roles(None, None) == -1
+    cfg = _lib.EngineConfig(B=1, C=256, FH=8, FW=8, HA=8, WA=8, HQ=8, WQ=8, layout=0, dist_th=0.25, n_corrs=500, src_sampling=5000, seed=1,
+                            round_f16=0, n_slots=6, overlap=2, gather_sets=2, reg_streams=2, reg_lag=0, screen=1, sample_first=0,
+                            x3_prefetch=1, stream_roles=2381)                # 8 is not a pool position
+    assert L.oryon_engine_arena_bytes(ctypes.byref(cfg), ctypes.c_void_p(1)) == 0
+    if not torch.cuda.is_available():
+        assert L.oryon_engine_warm_streams() < 0                             # no device: an error code, not a crash
+
+
 def test_bench_self_launches_for_gpus_2():
     """`python bench.py --gpus 2` (no torchrun, exactly how the driver invokes it) must become its own launcher: two ranks rendezvous on
     127.0.0.1, shard the pairs, run the collation and rank 0 prints ONE JSON line.  --collation-selftest swaps the GPU work for CPU
