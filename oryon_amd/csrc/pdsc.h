@@ -25,8 +25,21 @@ constexpr int PDSC_MLP_W1H = 0, PDSC_MLP_W1L = 16384, PDSC_MLP_W2H = 32768, PDSC
               PDSC_MLP_W3L = 65536, PDSC_MLP_IMG_BYTES = 81920;
 // pdsc_pcn_qkv_x3_kernel: four chunks (PointCN, q, k, v) of [hi: 128 rows x 256 B | lo: the same], slot ^ (row & 15); q|k|v K axis permuted
 constexpr int PDSC_PQ_CHUNK_BYTES = 65536, PDSC_PQ_IMG_BYTES = 5 * PDSC_PQ_CHUNK_BYTES;   // PointCN | q | k | v | PointCN with the permuted K axis
-// K / V image of one 64-key tile (C = 128): Kh | Kl as [64 keys][136 halves] (16-byte row pad), Vh | Vl as [8 octets][128 channels][8 keys]
-constexpr int PDSC_KV_KL = 17408, PDSC_KV_VH = 34816, PDSC_KV_VL = 51200, PDSC_KV_TILE_BYTES = 67584;
+// K / V image of one 64-key tile (C = 128): Kh | Kl as [16 channel octets][64 keys][8 halves], Vh | Vl as [8 key octets][128 channels][8 keys].
+// Round 6 (K): the 16 bytes a lane reads (key, channel octet) sit next to the neighbouring KEYS' 16 bytes, not next to the key's other
+// channels ([64 keys][136 halves] before): a wave's read is 2 x 512 contiguous bytes (conflict-free without the row pad), and the writers'
+// 8-byte pieces (lane = key: 4 channels each, two lanes per octet) fill 512 contiguous bytes = four whole 128-byte lines per store
+// instruction instead of touching 32 lines - the store path takes ~4 cycles per line it touches (DESIGN.md "stores of the per-point chain").
+constexpr int PDSC_KV_KL = 16384, PDSC_KV_VH = 32768, PDSC_KV_VL = 49152, PDSC_KV_TILE_BYTES = 65536;
+// pdsc_att_chain_x3_kernel's LDS: [0, 128 KB) two K / V tiles, later [0, 80 KB) the fc_message image + [80 KB, 146 KB) the key-half merge area /
+// weight areas; behind them the layer's biases (768 floats)
+constexpr int PDSC_AC_BIAS_OFF = PDSC_MLP_IMG_BYTES + 4 * 64 * (128 / 32 * 16 + 2) * 4, PDSC_AC_BIAS_BYTES = 768 * 4;
+// element (half) index inside a K plane of the tile image: key 0..63, channel octet 0..15
+__host__ __device__ constexpr int pdsc_k_img_elem(int key, int octet) { return (octet * 64 + key) * 8; }
+// "G4" row-fragment layout of the one-launch-per-layer path's q and PointCN-output arrays (round 6): [32 channel quads][n_cap rows][4 floats]
+// per pair instead of [n_cap rows][C] - a lane owns (row, quad) pieces (lane = row, accumulator registers 4 g .. 4 g + 3 = one quad), so a
+// float4 access of 32 lanes covers 512 contiguous bytes.  float4 index of (row, quad):
+__host__ __device__ constexpr size_t pdsc_g4_index(int n_cap, int row, int quad) { return (size_t)quad * n_cap + row; }
 
 struct PdscModel {
     oryon_pointdsc_config_t cfg;

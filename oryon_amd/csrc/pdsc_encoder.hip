@@ -378,13 +378,19 @@ __device__ __forceinline__ void split_half(float x, _Float16 &hi, _Float16 &lo)
 // Two values at a time: packed conversions (v_cvt_pk_f16_f32 on gfx950, round-to-nearest-even) - same results as split_half.
 typedef float xf32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 xf16x2 __attribute__((ext_vector_type(2)));
+// Round 6: the residuals x - float(hi) come from v_fma_mix_f32 (hi's half read as the f16 source of an fp32 fma: float(hi) * -1 + x, one
+// rounding of an exactly representable difference - the bits of the subtraction it replaces), four instructions per pair instead of six.
 __device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo)
 {
     const xf32x2 v = {a, b};
     const xf16x2 h = __builtin_convertvector(v, xf16x2);
-    const xf16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, xf32x2), xf16x2);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(b));
+    const xf32x2 lv = {l0, l1};
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, xf16x2));
 }
 
 template <int C>
@@ -636,7 +642,7 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_img_kernel(const float 
     static_assert(C == 128, "tile image geometry");
     constexpr int CB = C / 32;
     constexpr int NS = C / 16;                    // k16 steps of the first product
-    constexpr int KLD = C + 8;                    // halves per K row
+    // (K rows of the tile image: pdsc_k_img_elem, pdsc.h)
     extern __shared__ __attribute__((aligned(1024))) char att_lds[];            // two tile images
     // XCD-aware block map: the query blocks of one pair read the same K / V tile images, so they go to ONE XCD (linear block id mod 8) and
     // share the images through its L2 (with the plain (query block, pair) grid a pair's four blocks landed on four XCDs and each fetched
@@ -722,8 +728,8 @@ __global__ __launch_bounds__(256) void pdsc_attention_x3_img_kernel(const float 
         auto read_k = [&](int s_, int buf) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                kf[buf][kb][0] = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
-                kf[buf][kb][1] = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+                kf[buf][kb][0] = *reinterpret_cast<const xhalf8 *>(Kh + pdsc_k_img_elem(kb * 32 + l31, 2 * s_ + hi));
+                kf[buf][kb][1] = *reinterpret_cast<const xhalf8 *>(Kl + pdsc_k_img_elem(kb * 32 + l31, 2 * s_ + hi));
             }
         };
         read_k(0, 0);
@@ -836,7 +842,6 @@ __global__ __launch_bounds__(512) void pdsc_attention_x3_img8_kernel(const float
     static_assert(C == 128, "tile image geometry");
     constexpr int CB = C / 32;
     constexpr int NS = C / 16;
-    constexpr int KLD = C + 8;
     extern __shared__ __attribute__((aligned(1024))) char att_lds[];
     const int lin = blockIdx.x + gridDim.x * blockIdx.z;
     const int b = (lin / 8 / (int)gridDim.x) * 8 + (lin & 7);
@@ -909,8 +914,8 @@ __global__ __launch_bounds__(512) void pdsc_attention_x3_img8_kernel(const float
         for (int r = 0; r < 16; ++r) s[r] = 0.0f;
         xhalf8 kf[2][2];                              // [buffer][hi | lo]
         auto read_k = [&](int s_, int bf) {
-            kf[bf][0] = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
-            kf[bf][1] = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+            kf[bf][0] = *reinterpret_cast<const xhalf8 *>(Kh + pdsc_k_img_elem(kb * 32 + l31, 2 * s_ + hi));
+            kf[bf][1] = *reinterpret_cast<const xhalf8 *>(Kl + pdsc_k_img_elem(kb * 32 + l31, 2 * s_ + hi));
         };
         read_k(0, 0);
 #pragma unroll
@@ -1102,6 +1107,16 @@ __global__ __launch_bounds__(256) void pdsc_linear_x3_kernel(const float *__rest
 // order.  oryon_pointdsc_finalize stores the three matrices that way (pre-split into fp16 hi / lo, rows swizzled: PDSC_MLP_* image), so the
 // intermediate activations never leave the registers: bias + ReLU + split, next MFMA.  A wave owns 32 points and all channels; a workgroup
 // (4 waves, 128 points) copies the 80 KB weight image into LDS once (LDS-DMA) while its waves fetch and split their input rows.
+// A bias float4 at a WAVE-UNIFORM offset for lane half `hi` (channels off + 4 hi .. + 3): both halves come through the scalar cache
+// (uniform address -> s_load, lgkmcnt) and the lane picks one.  Round 6: as vector loads (address + 16 hi) they sat on the vector-memory
+// counter between the epilogue's stores, and the compiler's s_waitcnt vmcnt(0) in front of each use made every store of the per-point
+// chain wait for the acknowledgement of the one before it - 5 to 8 us per 16 KB of output (the phase clocks of ORYON_PDSC_CLOCKS).
+__device__ __forceinline__ float4 bias4(const float *__restrict__ b, int off, int hi)
+{
+    const float4 lo = *reinterpret_cast<const float4 *>(b + off), up = *reinterpret_cast<const float4 *>(b + off + 4);
+    return hi ? up : lo;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void pdsc_mlp3_x3_kernel(const float *__restrict__ msg, const float *__restrict__ resid,
                                                             const char *__restrict__ img, const float *__restrict__ b1,
@@ -1248,8 +1263,10 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float *__restrict__ feat, const char *__restrict__ img,
                                                                const float *__restrict__ bp, const float *__restrict__ bq,
                                                                const int32_t *__restrict__ n_rows, int n_cap, float *__restrict__ feat1,
-                                                               float *__restrict__ qkv, char *__restrict__ kv_img)
+                                                               float *__restrict__ qkv, char *__restrict__ kv_img, int g4)
 {
+    // g4 != 0: feat1 and q leave in the G4 row-fragment layout (pdsc.h) that pdsc_att_chain_x3_kernel reads and writes (layer 0 of the
+    // one-launch-per-layer path); 0: [row][C] / [row][3 C] rows for the separate attention / fc_message kernels
     constexpr int C = 128, HALF = PDSC_PQ_CHUNK_BYTES / 2;
     extern __shared__ __attribute__((aligned(1024))) char pq_lds[];
     const int b = blockIdx.y, q0 = blockIdx.x * (32 * WAVES);
@@ -1345,11 +1362,12 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
                     const int c = rb * 32 + 8 * (2 * j + g2) + 4 * hi, r0 = 8 * j + 4 * g2;
-                    const float4 bv = *reinterpret_cast<const float4 *>(bp + c);
+                    const float4 bv = bias4(bp, rb * 32 + 8 * (2 * j + g2), hi);
                     float4 v;
                     v.x = fmaxf(acc[i][r0] + bv.x, 0.0f); v.y = fmaxf(acc[i][r0 + 1] + bv.y, 0.0f);
                     v.z = fmaxf(acc[i][r0 + 2] + bv.z, 0.0f); v.w = fmaxf(acc[i][r0 + 3] + bv.w, 0.0f);
-                    *reinterpret_cast<float4 *>(feat1 + prow * C + c) = v;
+                    if (g4) reinterpret_cast<float4 *>(feat1 + (size_t)b * n_cap * C)[pdsc_g4_index(n_cap, q0 + wave * 32 + l31, c >> 2)] = v;
+                    else *reinterpret_cast<float4 *>(feat1 + prow * C + c) = v;
                     split_pair(v.x, v.y, ph[2 * g2], pl[2 * g2]);
                     split_pair(v.z, v.w, ph[2 * g2 + 1], pl[2 * g2 + 1]);
                 }
@@ -1358,6 +1376,10 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float
             }
         }
     }
+    // v's bias is per lane (lane = channel): fetched before the first store (see bias4)
+    float bias_v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias_v[i] = bq[2 * C + i * 32 + l31];
     // q from area 1 while k lands in area 0, k from area 0 while v lands in area 1, v from area 1
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
@@ -1384,7 +1406,7 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int ch = (2 * rp + i) * 32 + l31;
-                    const float bv = bq[2 * C + ch];
+                    const float bv = bias_v[2 * rp + i];
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
                         uint4 uh, ul;
@@ -1403,7 +1425,7 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int cc = (2 * rp + i) * 32 + 8 * g + 4 * hi, c = part * C + cc;
-                        const float4 bv = *reinterpret_cast<const float4 *>(bq + c);
+                        const float4 bv = bias4(bq, part * C + (2 * rp + i) * 32 + 8 * g, hi);
                         float4 o;
                         o.x = acc[i][4 * g + 0] + bv.x; o.y = acc[i][4 * g + 1] + bv.y;
                         o.z = acc[i][4 * g + 2] + bv.z; o.w = acc[i][4 * g + 3] + bv.w;
@@ -1411,9 +1433,11 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float
                             uint2 uh, ul;
                             split_pair(o.x, o.y, uh.x, ul.x);
                             split_pair(o.z, o.w, uh.y, ul.y);
-                            const size_t off = (size_t)((p_pair & 63) + l31) * 272 + cc * 2;
+                            const size_t off = (size_t)pdsc_k_img_elem((p_pair & 63) + l31, cc >> 3) * 2 + (cc & 7) * 2;
                             *reinterpret_cast<uint2 *>(tile + off) = uh;
                             *reinterpret_cast<uint2 *>(tile + PDSC_KV_KL + off) = ul;
+                        } else if (g4 && part == 0) {
+                            reinterpret_cast<float4 *>(qkv + (size_t)b * n_cap * 3 * C)[pdsc_g4_index(n_cap, q0 + wave * 32 + l31, cc >> 2)] = o;
                         } else {
                             *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;
                         }
@@ -1669,7 +1693,7 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_mlp3_pcn_qkv_x3_kernel(const 
                             uint2 uh, ul;
                             split_pair(o.x, o.y, uh.x, ul.x);
                             split_pair(o.z, o.w, uh.y, ul.y);
-                            const size_t off = (size_t)((p_pair & 63) + l31) * 272 + cc * 2;
+                            const size_t off = (size_t)pdsc_k_img_elem((p_pair & 63) + l31, cc >> 3) * 2 + (cc & 7) * 2;
                             *reinterpret_cast<uint2 *>(tile + off) = uh;
                             *reinterpret_cast<uint2 *>(tile + PDSC_KV_KL + off) = ul;
                         } else {
@@ -1686,24 +1710,35 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_mlp3_pcn_qkv_x3_kernel(const 
 // memory either: W1 comes with its K axis in accumulator-register order (second fc_message image).  The four key-half-0 waves run the chain
 // for the workgroup's 128 points; the other four keep moving weights (LDS-DMA) and keep the barriers.  HAS_NEXT = false (last layer): the
 // chain stops after fc_message and writes the features.  One launch per encoder layer instead of three.
-template <int C, bool HAS_NEXT>
+template <int C, bool HAS_NEXT, bool DBG = false>
 __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__restrict__ QKV, const char *__restrict__ kv_img_in,
                                                                  const float *__restrict__ sc, const int32_t *__restrict__ n_rows, int n_cap,
                                                                  float inv_sqrt_c, int n_pairs, const float *resid, const char *__restrict__ mlp_img,
                                                                  const float *__restrict__ b1, const float *__restrict__ b2,
                                                                  const float *__restrict__ b3, const char *__restrict__ pq_img,
                                                                  const float *__restrict__ bp, const float *__restrict__ bq, float *feat1,
-                                                                 float *qkv, char *kv_img, float *__restrict__ feat_out)
+                                                                 float *qkv, char *kv_img, float *__restrict__ feat_out, long long *dbg_clk = nullptr)
 {
     constexpr int WAVES = 8, HALF = PDSC_PQ_CHUNK_BYTES / 2;
+    // development aid (ORYON_PDSC_CLOCKS, dev build only): phase timestamps (100 MHz wall clock) of waves 0 (key half 0) and 4 (key half 1) of workgroup 0
+#define CLK(i) do { if constexpr (DBG) { if (blockIdx.x == 0 && blockIdx.z == 0 && (threadIdx.x & 255) == 0) dbg_clk[(threadIdx.x >> 8) * 16 + (i)] = wall_clock64(); } } while (0)
+    CLK(0);
     constexpr int AREA0 = PDSC_MLP_IMG_BYTES, AREA1 = 0;               // byte offsets of the two 64 KB weight areas (see pdsc_mlp3_pcn_qkv_x3_kernel)
     const char *kv_img_rd = kv_img_in;
 #define kv_img kv_img_rd
     static_assert(C == 128, "tile image geometry");
     constexpr int CB = C / 32;
     constexpr int NS = C / 16;
-    constexpr int KLD = C + 8;
     extern __shared__ __attribute__((aligned(1024))) char att_lds[];
+    // the chain's biases live in LDS (3 KB behind the merge area, filled under the attention tiles): b1 | b2 | b3 | bp | bq as FOUR planes of
+    // 192 floats (plane e = element e of every channel quad), so that a lane's quad is four broadcasting ds_read_b32 - neither the
+    // vector-memory counter its stores sit on nor a cold scalar cache in front of every epilogue (round 6, see bias4)
+    float *lds_bias = reinterpret_cast<float *>(att_lds + PDSC_AC_BIAS_OFF);
+    constexpr int SEG_B1 = 0, SEG_B2 = 64, SEG_B3 = 128, SEG_BP = 256, SEG_BQ = 384;
+    auto bias4l = [&](int seg_off, int hi_) {                       // seg_off: wave-uniform multiple of 8; lane half hi_ -> + 4 channels
+        const int q = (seg_off >> 2) + hi_;
+        return make_float4(lds_bias[q], lds_bias[192 + q], lds_bias[384 + q], lds_bias[576 + q]);
+    };
     const int lin = blockIdx.x + gridDim.x * blockIdx.z;
     const int b = (lin / 8 / (int)gridDim.x) * 8 + (lin & 7);
     const int qblk = (lin / 8) % (int)gridDim.x;
@@ -1714,6 +1749,10 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
     const int t = threadIdx.x, lane = t & 63, wave8 = t >> 6, l31 = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave8);
     const int wave = wave8 & 3, kb = wave8 >> 2;          // query block of the workgroup, key half of every tile
+    for (int i = t; i < (HAS_NEXT ? 768 : 256); i += 512) {
+        const float v = i < SEG_B2 ? b1[i] : i < SEG_B3 ? b2[i - SEG_B2] : i < SEG_BP ? b3[i - SEG_B3] : i < SEG_BQ ? bp[i - SEG_BP] : bq[i - SEG_BQ];
+        lds_bias[(i & 3) * 192 + (i >> 2)] = v;                // (visible behind the first barrier of the tile loop)
+    }
     const int qrow = q0 + wave * 32 + l31;
     const float *base = QKV + (size_t)b * n_cap * 3 * C;
     const char *img = kv_img + (size_t)b * (n_cap / ATT_KT) * PDSC_KV_TILE_BYTES;
@@ -1735,20 +1774,24 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4) scv[v4] = q_live ? sp[(size_t)v4 * 64] : make_float4(-1.f, -1.f, -1.f, -1.f);
     };
+    // round 6: the first tile's DMA and SC rows are requested BEFORE the query rows are split (they used to be issued behind the ~300
+    // instructions of the split, their latency exposed in front of the first tile)
+    dma_tile(0, 0);
+    fetch_sc(0);
     xhalf8 qh[NS], ql[NS];
     {
-        const float4 *qv = reinterpret_cast<const float4 *>(base + (size_t)qrow * 3 * C);
+        // q in the G4 row-fragment layout (pdsc.h): the 8 channels of k-step s_ for lane half hi are the quads 4 s_ + 2 hi, + 1
+        const float4 *qv = reinterpret_cast<const float4 *>(base);
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
-            const float4 a = qv[4 * s_ + 2 * hi], c = qv[4 * s_ + 2 * hi + 1];
-            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                _Float16 h_, l_;
-                split_half(x[e], h_, l_);
-                qh[s_][e] = h_;
-                ql[s_][e] = l_;
-            }
+            const float4 a = qv[pdsc_g4_index(n_cap, qrow, 4 * s_ + 2 * hi)], c = qv[pdsc_g4_index(n_cap, qrow, 4 * s_ + 2 * hi + 1)];
+            uint4 uh, ul;
+            split_pair(a.x, a.y, uh.x, ul.x);
+            split_pair(a.z, a.w, uh.y, ul.y);
+            split_pair(c.x, c.y, uh.z, ul.z);
+            split_pair(c.z, c.w, uh.w, ul.w);
+            qh[s_] = __builtin_bit_cast(xhalf8, uh);
+            ql[s_] = __builtin_bit_cast(xhalf8, ul);
         }
     }
     f32x16 acc_o[CB];
@@ -1758,8 +1801,9 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
         for (int r = 0; r < 16; ++r) acc_o[cb][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
-    dma_tile(0, 0);
-    fetch_sc(0);
+    CLK(1);
+    // every query row of this wave exists: its tiles whose 64 keys all exist need no masking (SC >= 0 there, scores finite)
+    const bool q_full = q0 + wave * 32 + 32 <= n;
     int buf = 0;
     for (int j0 = 0; j0 < n; j0 += ATT_KT, buf ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1775,8 +1819,8 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
         for (int r = 0; r < 16; ++r) s[r] = 0.0f;
         xhalf8 kf[2][2];                              // [buffer][hi | lo]
         auto read_k = [&](int s_, int bf) {
-            kf[bf][0] = *reinterpret_cast<const xhalf8 *>(Kh + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
-            kf[bf][1] = *reinterpret_cast<const xhalf8 *>(Kl + (kb * 32 + l31) * KLD + 16 * s_ + 8 * hi);
+            kf[bf][0] = *reinterpret_cast<const xhalf8 *>(Kh + pdsc_k_img_elem(kb * 32 + l31, 2 * s_ + hi));
+            kf[bf][1] = *reinterpret_cast<const xhalf8 *>(Kl + pdsc_k_img_elem(kb * 32 + l31, 2 * s_ + hi));
         };
         read_k(0, 0);
 #pragma unroll
@@ -1788,6 +1832,44 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[bf][1], qh[s_], s, 0, 0, 0);
         }
         float m_tile = -INFINITY;
+        xhalf8 ph[2], pl[2];
+        if (q_full && j0 + ATT_KT <= n) {
+            // ---- full tile (round 6): every (query, key) of it exists - no mask, no -inf guards (m_new is finite; exp(-inf - m) = 0 on the
+            // first tile).  Same arithmetic per element as the masked path below.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 q4 = scv[r >> 2];
+                const float scq = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+                const float v = scq * (s[r] * inv_sqrt_c);
+                s[r] = v;
+                m_tile = fmaxf(m_tile, v);
+            }
+            if (j0 + ATT_KT < n) fetch_sc(j0 + ATT_KT);
+            m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+            const float m_new = fmaxf(m_run, m_tile);
+            const float alpha = __expf(m_run - m_new);
+            float l_tile = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __expf(s[r] - m_new);
+                const float p1 = __expf(s[r + 1] - m_new);
+                l_tile += p0;
+                l_tile += p1;
+                unsigned uh, ul;
+                split_pair(p0, p1, uh, ul);
+                const xf16x2 h2 = __builtin_bit_cast(xf16x2, uh), l2 = __builtin_bit_cast(xf16x2, ul);
+                ph[r >> 3][r & 7] = h2[0]; ph[r >> 3][(r & 7) + 1] = h2[1];
+                pl[r >> 3][r & 7] = l2[0]; pl[r >> 3][(r & 7) + 1] = l2[1];
+            }
+            l_run = l_run * alpha + l_tile;
+            m_run = m_new;
+            if (__ballot(alpha != 1.0f) != 0ull) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float4 q4 = scv[r >> 2];
@@ -1803,7 +1885,6 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
         // a block whose keys are all masked so far keeps m = -inf: exp(-inf - (-inf)) must not produce NaN
         const float alpha = m_new == -INFINITY ? 1.0f : __expf(m_run - m_new);
         float l_tile = 0.0f;
-        xhalf8 ph[2], pl[2];
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const float p0 = m_new == -INFINITY ? 0.0f : __expf(s[r] - m_new);
@@ -1824,6 +1905,7 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[cb][r] *= alpha;
         }
+        }
         // O^T += V^T P^T over this wave's two key octet pairs
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
@@ -1840,6 +1922,7 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
     }
 #undef kv_img
     // ---- the tiles are done: the fc_message image starts landing at [0, 80 KB) while the two key halves merge through [80 KB, 146 KB)
+    CLK(2);
     float l_all = l_run + __shfl_xor(l_run, 32);
     __syncthreads();
     static_assert((PDSC_MLP_IMG_BYTES / 1024) % WAVES == 0, "pieces per wave");
@@ -1888,6 +1971,7 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
                 xl[cb * 2 + j] = __builtin_bit_cast(xhalf8, ul);
             }
     }
+    CLK(3);
     __syncthreads();                                                    // the merge area is free: PointCN' lands there
     auto dma_chunk = [&](int chunk, int area_off) {                   // 64 pieces of 1 KB, 64 / WAVES per wave
 #pragma unroll
@@ -1895,6 +1979,20 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
             const int piece = wave_u * (64 / WAVES) + j;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pq_img + (size_t)chunk * PDSC_PQ_CHUNK_BYTES + piece * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void *)(att_lds + area_off + piece * 1024), 16, 0, 0);
+        }
+    };
+    // The q | k | v chunks are requested by the four key-half-1 waves alone (16 pieces each): they have no stores, so their
+    // s_waitcnt vmcnt(0) waits for the LDS-DMA only, and the four live waves - whose feat1 / q / k / v stores sit on the same in-order
+    // counter - never wait on it between the parts: their stores drain behind the next part's MFMAs (round 6; with every wave requesting
+    // an eighth and waiting vmcnt(0), each part paid the acknowledgement of its 16 KB of stores)
+    auto dma_chunk_idle = [&](int chunk, int area_off) {
+        if (kb == 1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int piece = (wave_u - 4) * 16 + j;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pq_img + (size_t)chunk * PDSC_PQ_CHUNK_BYTES + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(att_lds + area_off + piece * 1024), 16, 0, 0);
+            }
         }
     };
     if constexpr (HAS_NEXT) dma_chunk(4, AREA0);                       // PointCN with the permuted K axis
@@ -1908,7 +2006,7 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
         const int o = rb * 32 + l31;
         return *reinterpret_cast<const xhalf8 *>(att_lds + base + o * 128 + (((2 * s_ + hi) ^ ((o >> 1) & 7)) << 4));
     };
-    auto next_operand = [&](const f32x16 (&acc)[2], const float *bias, xhalf8 (&oh)[4], xhalf8 (&ol)[4]) {
+    auto next_operand = [&](const f32x16 (&acc)[2], int bias_seg, xhalf8 (&oh)[4], xhalf8 (&ol)[4]) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -1917,7 +2015,7 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
                 unsigned *ph = &uh.x, *pl = &ul.x;
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(bias + rb * 32 + 8 * (2 * j + g2) + 4 * hi);
+                    const float4 bv = bias4l(bias_seg + rb * 32 + 8 * (2 * j + g2), hi);
                     const int r0 = 8 * j + 4 * g2;
                     const float v0 = fmaxf(acc[rb][r0] + bv.x, 0.0f), v1 = fmaxf(acc[rb][r0 + 1] + bv.y, 0.0f);
                     const float v2 = fmaxf(acc[rb][r0 + 2] + bv.z, 0.0f), v3 = fmaxf(acc[rb][r0 + 3] + bv.w, 0.0f);
@@ -1966,24 +2064,41 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
             }
         }
     };
+    CLK(4);
+    // v's bias is per lane (lane = channel in the swapped product): fetched here, long before the first store of the chain - a vector load
+    // issued between stores waits for every earlier store's acknowledgement (s_waitcnt vmcnt is one in-order counter)
+    float bias_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (HAS_NEXT) {
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bias_v[i] = bq[2 * C + i * 32 + l31];
+        }
+    }
     if (live) {
+    // the residual rows (this layer's PointCN output, 32 floats per lane) are requested before W1: behind the W3 blocks, where they used to
+    // be issued, a wave alone on its SIMD waited out their latency twice
+    float4 rv[2][2][4];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                rv[rp][i][g] = reinterpret_cast<const float4 *>(resid + (size_t)b * n_cap * C)[pdsc_g4_index(n_cap, qrow, (2 * rp + i) * 8 + 2 * g + hi)];
     // ---- fc_message of layer l
     f32x16 a1[2];
     two_blocks(w1_frag, PDSC_MLP_W1H, PDSC_MLP_W1L, 0, 8, xh, xl, a1, false);
     xhalf8 h1h[4], h1l[4];
-    next_operand(a1, b1, h1h, h1l);
+    next_operand(a1, SEG_B1, h1h, h1l);
+    CLK(5);
     f32x16 a2[2];
     two_blocks(w23_frag, PDSC_MLP_W2H, PDSC_MLP_W2L, 0, 4, h1h, h1l, a2, false);
     xhalf8 h2h[4], h2l[4];
-    next_operand(a2, b2, h2h, h2l);
+    next_operand(a2, SEG_B2, h2h, h2l);
+    CLK(6);
     // layer 3 + bias + residual = the layer's output features, kept as the 8 B fragments (permuted K order) of the next layer's PointCN
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp) {
-        float4 rv[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) rv[i][g] = *reinterpret_cast<const float4 *>(resid + prow * C + (2 * rp + i) * 32 + 8 * g + 4 * hi);
         f32x16 a3[2];
         two_blocks(w23_frag, PDSC_MLP_W3H, PDSC_MLP_W3L, 2 * rp, 4, h2h, h2l, a3, false);
 #pragma unroll
@@ -1996,9 +2111,9 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
                     const int g = 2 * j + g2;
-                    const float4 bv = *reinterpret_cast<const float4 *>(b3 + rb * 32 + 8 * g + 4 * hi);
-                    const float v0 = a3[i][4 * g + 0] + bv.x + rv[i][g].x, v1 = a3[i][4 * g + 1] + bv.y + rv[i][g].y;
-                    const float v2 = a3[i][4 * g + 2] + bv.z + rv[i][g].z, v3 = a3[i][4 * g + 3] + bv.w + rv[i][g].w;
+                    const float4 bv = bias4l(SEG_B3 + rb * 32 + 8 * g, hi);
+                    const float v0 = a3[i][4 * g + 0] + bv.x + rv[rp][i][g].x, v1 = a3[i][4 * g + 1] + bv.y + rv[rp][i][g].y;
+                    const float v2 = a3[i][4 * g + 2] + bv.z + rv[rp][i][g].z, v3 = a3[i][4 * g + 3] + bv.w + rv[rp][i][g].w;
                     split_pair(v0, v1, ph[2 * g2], pl[2 * g2]);
                     split_pair(v2, v3, ph[2 * g2 + 1], pl[2 * g2 + 1]);
                 }
@@ -2009,20 +2124,21 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = rb * 32 + 8 * g + 4 * hi;
-                    const float4 bv = *reinterpret_cast<const float4 *>(b3 + c);
+                    const float4 bv = bias4l(SEG_B3 + rb * 32 + 8 * g, hi);
                     float4 o;
-                    o.x = a3[i][4 * g + 0] + bv.x + rv[i][g].x; o.y = a3[i][4 * g + 1] + bv.y + rv[i][g].y;
-                    o.z = a3[i][4 * g + 2] + bv.z + rv[i][g].z; o.w = a3[i][4 * g + 3] + bv.w + rv[i][g].w;
+                    o.x = a3[i][4 * g + 0] + bv.x + rv[rp][i][g].x; o.y = a3[i][4 * g + 1] + bv.y + rv[rp][i][g].y;
+                    o.z = a3[i][4 * g + 2] + bv.z + rv[rp][i][g].z; o.w = a3[i][4 * g + 3] + bv.w + rv[rp][i][g].w;
                     if (live) *reinterpret_cast<float4 *>(feat_out + prow * C + c) = o;
                 }
             }
         }
     }
     }
+    CLK(7);
     if constexpr (!HAS_NEXT) return;
     // ---- PointCN + q|k|v of layer l + 1.  The fc_message image is dead once every wave is here: q lands on top of it.
     __syncthreads();
-    dma_chunk(1, AREA1);
+    dma_chunk_idle(1, AREA1);
     auto frag = [&](int base, int rb, int s_) {
         const int o = rb * 32 + l31;
         return *reinterpret_cast<const xhalf8 *>(att_lds + base + o * 256 + (((2 * s_ + hi) ^ (o & 15)) << 4));
@@ -2043,11 +2159,11 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
                     const int c = rb * 32 + 8 * (2 * j + g2) + 4 * hi, r0 = 8 * j + 4 * g2;
-                    const float4 bv = *reinterpret_cast<const float4 *>(bp + c);
+                    const float4 bv = bias4l(SEG_BP + rb * 32 + 8 * (2 * j + g2), hi);
                     float4 v;
                     v.x = fmaxf(acc[i][r0] + bv.x, 0.0f); v.y = fmaxf(acc[i][r0 + 1] + bv.y, 0.0f);
                     v.z = fmaxf(acc[i][r0 + 2] + bv.z, 0.0f); v.w = fmaxf(acc[i][r0 + 3] + bv.w, 0.0f);
-                    if (live) *reinterpret_cast<float4 *>(feat1 + prow * C + c) = v;
+                    if (live) reinterpret_cast<float4 *>(feat1 + (size_t)b * n_cap * C)[pdsc_g4_index(n_cap, qrow, c >> 2)] = v;
                     split_pair(v.x, v.y, ph[2 * g2], pl[2 * g2]);
                     split_pair(v.z, v.w, ph[2 * g2 + 1], pl[2 * g2 + 1]);
                 }
@@ -2058,12 +2174,19 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
     }
     }
     // q from area 1 while k lands in area 0, k from area 0 while v lands in area 1, v from area 1
+    CLK(8);
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
         const int area_off = ((part + 1) & 1) ? AREA1 : AREA0, other_off = ((part + 1) & 1) ? AREA0 : AREA1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this part's chunk has landed (the feat1 stores drain with it)
-        __syncthreads();                                                // every wave is done with the other area; this part's chunk is visible
-        if (part < 2) dma_chunk(part + 2, other_off);
+        CLK(13 + part);
+        // this part's chunk has landed: only the waves that requested it wait for the vector-memory counter; a raw barrier (a
+        // __syncthreads() would fence with vmcnt(0) and make the live waves wait for their stores' acknowledgements)
+        if (kb == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // every wave is done with the other area; this part's chunk is visible
+        asm volatile("" ::: "memory");
+        CLK(9 + part);
+        if (part < 2) dma_chunk_idle(part + 2, other_off);
         const int p_pair = q0 + wave * 32;                           // (wave = query block 0..3 here)
         char *tile = kv_img ? kv_img + ((size_t)b * (n_cap / 64) + (p_pair >> 6)) * PDSC_KV_TILE_BYTES : nullptr;
         const bool as_v = kv_img && part == 2;
@@ -2077,7 +2200,7 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int ch = (2 * rp + i) * 32 + l31;
-                    const float bv = bq[2 * C + ch];
+                    const float bv = bias_v[2 * rp + i];
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
                         uint4 uh, ul;
@@ -2096,7 +2219,7 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int cc = (2 * rp + i) * 32 + 8 * g + 4 * hi, c = part * C + cc;
-                        const float4 bv = *reinterpret_cast<const float4 *>(bq + c);
+                        const float4 bv = bias4l(SEG_BQ + part * C + (2 * rp + i) * 32 + 8 * g, hi);
                         float4 o;
                         o.x = acc[i][4 * g + 0] + bv.x; o.y = acc[i][4 * g + 1] + bv.y;
                         o.z = acc[i][4 * g + 2] + bv.z; o.w = acc[i][4 * g + 3] + bv.w;
@@ -2104,17 +2227,21 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
                             uint2 uh, ul;
                             split_pair(o.x, o.y, uh.x, ul.x);
                             split_pair(o.z, o.w, uh.y, ul.y);
-                            const size_t off = (size_t)((p_pair & 63) + l31) * 272 + cc * 2;
+                            const size_t off = (size_t)pdsc_k_img_elem((p_pair & 63) + l31, cc >> 3) * 2 + (cc & 7) * 2;
                             if (live) *reinterpret_cast<uint2 *>(tile + off) = uh;
                             if (live) *reinterpret_cast<uint2 *>(tile + PDSC_KV_KL + off) = ul;
+                        } else if (part == 0) {
+                            if (live) reinterpret_cast<float4 *>(qkv + (size_t)b * n_cap * 3 * C)[pdsc_g4_index(n_cap, qrow, cc >> 2)] = o;
                         } else {
-                            if (live) *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;
+                            if (live) *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;       // (no image buffer: never on this path)
                         }
                     }
             }
         }
         }
     }
+    CLK(12);
+#undef CLK
 }
 
 // Combine the key-split partials: msg = sum_s e^{m_s - m} O_s / sum_s e^{m_s - m} l_s,  m = max_s m_s.
@@ -2334,7 +2461,10 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
                               (dev_env_int("ORYON_PDSC_WAVES", 8) == 8);
         // K / V images alternate between two buffers when the attention is part of the one-launch-per-layer kernel (its workgroups write
         // layer l + 1's tiles while others still read layer l's)
-        const bool att_chain = chain_ok && fuse_att && ws.kv_img2 != nullptr && L.mlp_img_p &&
+        // (every layer or none: the kernel hands q and the PointCN output from layer to layer in its own G4 layout)
+        bool all_imgs = true;
+        for (const PdscLayer &Lx : M.layers) all_imgs = all_imgs && Lx.mlp_img_p && Lx.mlp_img && Lx.pq_img;
+        const bool att_chain = chain_ok && fuse_att && ws.kv_img2 != nullptr && all_imgs &&
                                (dev_env_int("ORYON_PDSC_ATT8", 1) != 0);
         char *kv_cur = (att_chain && (l & 1)) ? ws.kv_img2 : ws.kv_img, *kv_nxt = (att_chain && !(l & 1)) ? ws.kv_img2 : ws.kv_img;
         if (l > 0 && chain_ok && L.pq_img && M.layers[l - 1].mlp_img) {
@@ -2351,10 +2481,10 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
             use_img = ws.att_splits == 1 && ws.kv_img != nullptr && att_img;
             if (w8)
                 hipLaunchKernelGGL(pdsc_pcn_qkv_x3_kernel<8>, dim3(n_cap / 256, B), dim3(512), 2 * PDSC_PQ_CHUNK_BYTES, st, ws.feat, L.pq_img, L.b_pcn,
-                                   L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, use_img ? ws.kv_img : nullptr);
+                                   L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, use_img ? ws.kv_img : nullptr, (att_chain && use_img) ? 1 : 0);
             else
                 hipLaunchKernelGGL(pdsc_pcn_qkv_x3_kernel<4>, dim3(n_cap / 128, B), dim3(256), 2 * PDSC_PQ_CHUNK_BYTES, st, ws.feat, L.pq_img, L.b_pcn,
-                                   L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, use_img ? ws.kv_img : nullptr);
+                                   L.b_qkv, n_rows, n_cap, ws.feat1, ws.qkv, use_img ? ws.kv_img : nullptr, 0);
             if (hipGetLastError() != hipSuccess) return ORYON_ERR_HIP;
         } else {
             // PointCN: conv + BN + ReLU (BN folded)
@@ -2366,11 +2496,31 @@ int pdsc_run_encoder(const PdscModel &M, const PdscWorkspace &ws, const float *s
         }
         if (att_chain && use_img) {
             // attention + fc_message (+ PointCN + q|k|v of the next layer) in one launch
-            constexpr int AC_LDS = PDSC_MLP_IMG_BYTES + 4 * 64 * (128 / 32 * 16 + 2) * 4 > 2 * PDSC_KV_TILE_BYTES
-                                       ? PDSC_MLP_IMG_BYTES + 4 * 64 * (128 / 32 * 16 + 2) * 4 : 2 * PDSC_KV_TILE_BYTES;
+            constexpr int AC_LDS = PDSC_AC_BIAS_OFF + PDSC_AC_BIAS_BYTES;        // tile buffers / weight areas / merge area, then the biases
+            static_assert(PDSC_AC_BIAS_OFF >= 2 * PDSC_KV_TILE_BYTES && AC_LDS <= 160 * 1024, "att_chain LDS budget");
             const dim3 grid(n_cap / ATT_Q, 1, (B + 7) / 8 * 8);
             if (l + 1 < M.cfg.num_layers && M.layers[l + 1].pq_img) {
                 const PdscLayer &N = M.layers[l + 1];
+#ifdef ORYON_DEV
+                static const int clocks = dev_env_int("ORYON_PDSC_CLOCKS", 0);      // > 0: print the phase clocks of layer `clocks` of every call
+                if (clocks > 0 && l == clocks) {
+                    static long long *dclk = nullptr;
+                    if (!dclk) { (void)hipMalloc(reinterpret_cast<void **>(&dclk), 32 * sizeof(long long)); }
+                    (void)hipMemsetAsync(dclk, 0, 32 * sizeof(long long), st);
+                    allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_att_chain_x3_kernel<128, true, true>), AC_LDS);
+                    hipLaunchKernelGGL((pdsc_att_chain_x3_kernel<128, true, true>), grid, dim3(512), AC_LDS, st, ws.qkv, kv_cur, ws.sc, n_rows, n_cap, inv_sqrt_c, B,
+                                       ws.feat1, L.mlp_img_p, L.b_m1, L.b_m2, L.b_m3, N.pq_img, N.b_pcn, N.b_qkv, ws.feat1, ws.qkv, kv_nxt, ws.feat, dclk);
+                    long long hc[32];
+                    (void)hipMemcpyAsync(hc, dclk, sizeof(hc), hipMemcpyDeviceToHost, st);
+                    (void)hipStreamSynchronize(st);
+                    fprintf(stderr, "att_chain clocks (us since entry) wave0:");
+                    for (int i = 1; i <= 15; ++i) fprintf(stderr, " %.2f", hc[i] ? (hc[i] - hc[0]) * 0.01 : -1.0);
+                    fprintf(stderr, "  wave4:");
+                    for (int i = 1; i <= 12; ++i) fprintf(stderr, " %.2f", hc[16 + i] ? (hc[16 + i] - hc[16]) * 0.01 : -1.0);
+                    fprintf(stderr, "\n");
+                    continue;
+                }
+#endif
                 allow_dynamic_lds(reinterpret_cast<const void *>(pdsc_att_chain_x3_kernel<128, true>), AC_LDS);
                 hipLaunchKernelGGL((pdsc_att_chain_x3_kernel<128, true>), grid, dim3(512), AC_LDS, st, ws.qkv, kv_cur, ws.sc, n_rows, n_cap, inv_sqrt_c, B,
                                    ws.feat1, L.mlp_img_p, L.b_m1, L.b_m2, L.b_m3, N.pq_img, N.b_pcn, N.b_qkv, ws.feat1, ws.qkv, kv_nxt, ws.feat);
