@@ -1509,6 +1509,15 @@ __global__ void match_mask_counts_kernel(int B, const int32_t *__restrict__ n_a,
     n_a_lazy[p] = pair_eager[p] ? 0 : n_a[p];
 }
 
+__global__ void match_cascade_counts_kernel(int B, const int32_t *__restrict__ n_amb_total, const int32_t *__restrict__ n_after,
+                                            const int32_t *__restrict__ n_before, int32_t *__restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const long long tot = n_amb_total[p], nb = n_before[p], na = n_after[p];
+    out[p] = nb > 0 ? (int32_t)(tot * na / nb) : (int32_t)tot;
+}
+
 __global__ void match_sum_counts_kernel(int B, const int32_t *__restrict__ a, const int32_t *__restrict__ b, int32_t *__restrict__ out)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1598,6 +1607,96 @@ __global__ __launch_bounds__(256) void match_list_sampled_amb_kernel(int cap_a, 
         if (a < cap_a && mk[a] != 0) list[(size_t)p * corr_rows + off0++] = a;
     }
     if (t == 255) n_list[p] = off0;
+}
+
+// ---- validity cascade, second pass (round 6; oryon_match_corrs_mx6_x3).  The first screening pass stops a panel once its anchors are all
+// valid for sure and leaves their runner-up open (match_mx6_screen_w4_kernel<.., EXIT>); the sampled ones among them (the list of
+// match_list_sampled_amb_kernel, <= corr_rows per pair) get the COMPLETE screen here: their operand rows compacted into one panel per pair,
+// the same kernel over all query tiles, and the (m1, slice, m2) triples merged back into the per-anchor arrays - a row whose winner turns
+// out unambiguous becomes LZ_VALID (resolved from its winning slice like any other), the others keep LZ_AMB_VALID with their true winning
+// slice as the second level's seed.
+// after the windowed first launch: is every live anchor of a 1024-row panel valid for sure already (its best score over the splits' windows
+// above match_decide_lite_kernel's line)?  Then gate = 0 and its runner-ups read +inf (no margin: a partial scan rules nothing out);
+// otherwise gate = 1: the gated launch scans everything for this panel and overwrites the triples.
+__global__ __launch_bounds__(256) void match_panel_settle_kernel(int cap_a, int T8, int S, const int32_t *__restrict__ n_a,
+                                                                  const float *__restrict__ ws_m1, float *__restrict__ ws_m2,
+                                                                  const float *__restrict__ a_err, const float *__restrict__ q_err,
+                                                                  float cut0, int32_t *__restrict__ gate)
+{
+    __shared__ int bad;
+    const int p = blockIdx.y, panel = blockIdx.x, t = threadIdx.x;
+    const int na = n_a[p], a0 = panel * 1024;
+    if (a0 >= na) return;
+    if (t == 0) bad = 0;
+    __syncthreads();
+    const float ea = a_err[p], eq = q_err[p];
+    const float delta = ea + eq + ea * eq + 1.2e-4f;
+    const float thr = delta < 0.2f ? cut0 + delta + 2e-5f : INFINITY;      // (match_decide_lite_kernel: m1 > cut0 + delta + 1e-5)
+    int mine = 0;
+    for (int a = a0 + t; a < a0 + 1024 && a < na; a += 256) {
+        float m1 = -INFINITY;
+        for (int s_ = 0; s_ < S; ++s_) m1 = fmaxf(m1, ws_m1[((size_t)p * S + s_) * cap_a + a]);
+        mine |= !(m1 > thr);
+    }
+    if (mine) atomicOr(&bad, 1);
+    __syncthreads();
+    const int open = bad;
+    if (t == 0) gate[p * T8 + panel] = open;
+    if (!open)
+        for (int a = a0 + t; a < a0 + 1024 && a < na; a += 256)
+            for (int s_ = 0; s_ < S; ++s_) ws_m2[((size_t)p * S + s_) * cap_a + a] = INFINITY;
+}
+
+__global__ __launch_bounds__(256) void match_compact_rows_kernel(const uint8_t *__restrict__ rows, int row_bytes, int cap_a, int cap_c,
+                                                                  const int32_t *__restrict__ count, const int32_t *__restrict__ idx,
+                                                                  int idx_stride, uint8_t *__restrict__ out)
+{
+    // 16 lanes per 256-byte row (uint4 each); rows [count, cap_c) are zero rows (exponent byte 0: finite scores nobody reads)
+    const int p = blockIdx.y, sl = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    if (sl >= cap_c) return;
+    const int n = count[p] < cap_c ? count[p] : cap_c;
+    uint4 *d = reinterpret_cast<uint4 *>(out + ((size_t)p * cap_c + sl) * row_bytes);
+    if (sl >= n) {
+        for (int i = l; i < row_bytes / 16; i += 16) d[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const uint4 *src = reinterpret_cast<const uint4 *>(rows + ((size_t)p * cap_a + idx[(size_t)p * idx_stride + sl]) * row_bytes);
+    for (int i = l; i < row_bytes / 16; i += 16) d[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void match_decide_sampled_kernel(int cap_a, int cap_c, int S, const int32_t *__restrict__ count,
+                                                                    const int32_t *__restrict__ idx, int idx_stride,
+                                                                    const float *__restrict__ ws_m1, const int32_t *__restrict__ ws_i1,
+                                                                    const float *__restrict__ ws_m2, const float *__restrict__ a_err,
+                                                                    const float *__restrict__ q_err, float *__restrict__ m_final,
+                                                                    int32_t *__restrict__ sid_final, float *__restrict__ margin_out,
+                                                                    uint8_t *__restrict__ state, int32_t *__restrict__ mark,
+                                                                    int32_t *__restrict__ count_before)
+{
+    const int p = blockIdx.y, sl = blockIdx.x * 256 + threadIdx.x;
+    const int n = count[p] < cap_c ? count[p] : cap_c;
+    if (sl == 0) count_before[p] = n;
+    if (sl >= n) return;
+    const int a = idx[(size_t)p * idx_stride + sl];
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int sid = 0;
+    for (int s = 0; s < S; ++s) {
+        const size_t o = ((size_t)p * S + s) * cap_c + sl;
+        const float x1 = ws_m1[o], x2 = ws_m2[o];
+        m2 = fmaxf(fminf(m1, x1), fmaxf(m2, x2));
+        if (x1 > m1) { m1 = x1; sid = ws_i1[o]; }
+    }
+    const float ea = a_err[p], eq = q_err[p];
+    const float delta = ea + eq + ea * eq + 1.2e-4f;                  // match_decide_lite_kernel, fmt 1
+    const float margin = delta < 0.2f ? 2.0f * delta + 2e-7f : INFINITY;
+    const size_t arow = (size_t)p * cap_a + a;
+    m_final[arow] = m1;                                                // the complete scan's maximum (>= the partial one that settled validity)
+    sid_final[arow] = sid;
+    margin_out[arow] = margin;
+    if (m1 - m2 > margin) {                                            // unambiguous after all: no second level for this row
+        state[arow] = LZ_VALID;
+        mark[arow] = 0;
+    }
 }
 
 // Exact resolution of ONE unambiguous anchor by one wave: candidates = rows of the winning 16-row slice within the int8 margin of its
@@ -1805,6 +1904,11 @@ struct LazyWs {
     uint8_t *x3_va_o;
     void *x3_scratch;
     uint8_t *state;
+    // validity cascade (hard route, C_pad 256): the sampled anchors' mx6 rows as one 512-row panel per pair + the second pass's triples
+    uint8_t *cs_panel;
+    float *cs_max, *cs_m2;
+    int32_t *cs_i1;
+    int32_t *n_ambv0, *cs_gate;
     size_t bytes, zero_off, zero_bytes;
 };
 
@@ -1837,6 +1941,14 @@ LazyWs carve_lazy(void *base, int B, int C, int cap_a, int cap_q, int S, int cor
     const size_t o_xam = take((size_t)B * cap_s * sizeof(int32_t));
     const size_t o_xva = take((size_t)B * cap_s);
     const size_t o_xsc = take(match_x3_scratch_bytes(B, cap_s, 8, cap_q));
+    const bool cascade = C == 256 && corr_rows <= MX6_SAMPLED_PANEL;
+    const int csS = mx6_sampled_splits(B);
+    const size_t o_csp = take(cascade ? (size_t)B * MX6_SAMPLED_PANEL * C : 16);
+    const size_t o_csm = take(cascade ? (size_t)B * csS * MX6_SAMPLED_PANEL * sizeof(float) : 16);
+    const size_t o_cs2 = take(cascade ? (size_t)B * csS * MX6_SAMPLED_PANEL * sizeof(float) : 16);
+    const size_t o_csi = take(cascade ? (size_t)B * csS * MX6_SAMPLED_PANEL * sizeof(int32_t) : 16);
+    const size_t o_na0 = take((size_t)B * sizeof(int32_t));
+    const size_t o_gat = take((size_t)B * mx6_panels_per_pair(cap_a) * sizeof(int32_t));
     w.zero_off = off;
     const size_t o_pe = take((size_t)B * sizeof(int32_t));
     const size_t o_nu = take((size_t)B * sizeof(int32_t));
@@ -1868,6 +1980,12 @@ LazyWs carve_lazy(void *base, int B, int C, int cap_a, int cap_q, int S, int cor
     w.x3_am_o = reinterpret_cast<int32_t *>(at(o_xam));
     w.x3_va_o = reinterpret_cast<uint8_t *>(at(o_xva));
     w.x3_scratch = at(o_xsc);
+    w.cs_panel = cascade ? reinterpret_cast<uint8_t *>(at(o_csp)) : nullptr;
+    w.cs_max = reinterpret_cast<float *>(at(o_csm));
+    w.cs_m2 = reinterpret_cast<float *>(at(o_cs2));
+    w.cs_i1 = reinterpret_cast<int32_t *>(at(o_csi));
+    w.n_ambv0 = reinterpret_cast<int32_t *>(at(o_na0));
+    w.cs_gate = reinterpret_cast<int32_t *>(at(o_gat));
     w.n_ambu = reinterpret_cast<int32_t *>(at(o_nau));
     w.n_ambv = reinterpret_cast<int32_t *>(at(o_nav));
     w.need_f32_lazy = reinterpret_cast<int32_t *>(at(o_nfl));
@@ -1976,9 +2094,22 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     // ORYON_AMB_X3=0 keeps the exact scan (the tests run both settings).
     static const bool x3_env = dev_env_int("ORYON_AMB_X3", 1) != 0;
     const int use_x3 = (x3_env && C == 256 && !force_eager) ? 1 : 0;
+    // validity cascade (round 6): on the route the engine takes once its feedback says "hard" (q_hi_lo given: K0 wrote the hi / lo rows),
+    // the screen stops a panel whose anchors are all valid for sure, and a second, complete pass serves the sampled anchors only
+    static const bool cascade_env = dev_env_int("ORYON_CASCADE", 1) != 0;
+    const bool cascade = cascade_env && fmt == 1 && use_x3 && q_hi_lo != nullptr && lw.cs_panel != nullptr;
     if (fmt == 1) {
         const uint8_t *a6 = reinterpret_cast<const uint8_t *>(a_i8), *q6 = reinterpret_cast<const uint8_t *>(q_i8);
         profile_begin(st, screen_mx6_name(C));
+        if (cascade) {
+            // first pass of the cascade: two tiles per (panel, split) near the panel's own place in the map, then the complete scan for the
+            // panels that still hold an anchor whose validity is open (device-gated: the others return at once)
+            const int T8 = mx6_panels_per_pair(cap_a);
+            launch_screen_mx6(C, groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2, C_true, 1, nullptr, 2);
+            hipLaunchKernelGGL(match_panel_settle_kernel, dim3(T8, B), dim3(256), 0, st, cap_a, T8, S, n_a, w.ws_max, w.ws_m2, a_scale, q_eps_max,
+                               cut0, lw.cs_gate);
+            launch_screen_mx6(C, groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2, C_true, 1, lw.cs_gate, 0);
+        } else
         launch_screen_mx6(C, groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, w.ws_max, w.ws_i1, w.ws_m2, C_true);
         profile_end(st);
     } else {
@@ -2065,6 +2196,20 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
     const int cap_s = cap_s0 < cap_a ? cap_s0 : cap_a;           // distinct sampled rows <= min(max_corrs, n_a)
     hipLaunchKernelGGL(match_list_sampled_amb_kernel, dim3(B), dim3(256), 0, st, cap_a, lw.state, lw.pair_eager, n_sel, lw.sel_rows, corr_rows,
                        lw.mark, lw.n_ambv, lw.ambv_idx);
+    if (cascade) {
+        // second pass: the complete screen for the listed rows (one 512-row panel per pair), triples merged back, list rebuilt
+        const int csS = mx6_sampled_splits(B);
+        hipLaunchKernelGGL(match_compact_rows_kernel, dim3(MX6_SAMPLED_PANEL / 16, B), dim3(256), 0, st, reinterpret_cast<const uint8_t *>(a_i8), C,
+                           cap_a, MX6_SAMPLED_PANEL, lw.n_ambv, lw.ambv_idx, corr_rows, lw.cs_panel);
+        launch_screen_mx6_sampled(st, lw.cs_panel, reinterpret_cast<const uint8_t *>(q_i8), B, cap_q, lw.n_ambv, n_q, csS, lw.cs_max, lw.cs_i1,
+                                  lw.cs_m2, C_true);
+        hipLaunchKernelGGL(match_decide_sampled_kernel, dim3((MX6_SAMPLED_PANEL + 255) / 256, B), dim3(256), 0, st, cap_a, MX6_SAMPLED_PANEL, csS,
+                           lw.n_ambv, lw.ambv_idx, corr_rows, lw.cs_max, lw.cs_i1, lw.cs_m2, a_scale, q_eps_max, w.m_final, lw.sid_final,
+                           lw.margin, lw.state, lw.mark, lw.n_ambv0);
+        hipLaunchKernelGGL(match_list_sampled_amb_kernel, dim3(B), dim3(256), 0, st, cap_a, lw.state, lw.pair_eager, n_sel, lw.sel_rows, corr_rows,
+                           lw.mark, lw.n_ambv, lw.ambv_idx);
+        ORYON_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(match_compact_f32_kernel, dim3((cap_s + 63) / 64, B), dim3(256), 0, st, a_hat, C, cap_a, cap_s, lw.n_ambv, lw.ambv_idx,
                        corr_rows, w8.a_hat_c);
     ORYON_CHECK_LAUNCH();
@@ -2107,6 +2252,12 @@ static int match_corrs_lazy_impl(const float *a_hat, const int8_t *a_i8, const f
 #undef RESOLVE_S
 #undef RESOLVE_S2
     ORYON_CHECK_LAUNCH();
+    if (n_undecided && cascade) {
+        // cascade: the first pass calls every anchor of a panel that stopped early "ambiguous"; the feedback the engine steers by is that
+        // count scaled by the share of the SAMPLED ambiguous rows which the complete second pass left ambiguous
+        hipLaunchKernelGGL(match_cascade_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, lw.n_amb_total, lw.n_ambv, lw.n_ambv0, n_undecided);
+        ORYON_CHECK_LAUNCH();
+    } else
     if (n_undecided) {       // anchors the int8 stage could not fully decide: the fp16-stage anchors of eager pairs + the ambiguous anchors of lazy pairs
         hipLaunchKernelGGL(match_sum_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, w.n_amb, lw.n_amb_total, n_undecided);
         ORYON_CHECK_LAUNCH();

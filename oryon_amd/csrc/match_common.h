@@ -34,6 +34,13 @@ void match_x3_scatter_ovf(int B, int cap_s, const int32_t *n_ovf, const int32_t 
 const char *screen_mx6_name(int C);
 // screen_mx6.hip: K1s6 launch (C = 256 / 512); groups / T as sized for 256-anchor panels by the caller
 void launch_screen_mx6(int C, int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q,
-                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int C_true);
+                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int C_true,
+                       int cascade = 0, const int32_t *gate = nullptr, int win = 0);
+inline int mx6_panels_per_pair(int cap_a) { return (cap_a + 1023) / 1024; }     // panels of the 8-wave C_pad 256 screen (the cascade's gate is [B, that])
+// second pass of the validity cascade: one 512-row panel of compacted anchor rows per pair, S query splits (C_pad 256)
+void launch_screen_mx6_sampled(hipStream_t st, const uint8_t *a6_panel, const uint8_t *q6, int B, int cap_q, const int32_t *n_rows,
+                               const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int C_true);
+constexpr int MX6_SAMPLED_PANEL = 512;          // rows of that panel (>= the sampled rows of a pair: corr_rows <= 512 on this route)
+inline int mx6_sampled_splits(int B) { int s = (512 + B - 1) / B; return s < 1 ? 1 : s > 16 ? 16 : s; }      // ~512 four-wave workgroups
 
 }  // namespace oryon

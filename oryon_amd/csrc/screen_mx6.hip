@@ -429,6 +429,213 @@ __global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_scree
     }
 }
 
+// The validity cascade of the hard route (round 6; oryon_match_corrs_mx6_x3) runs the screen in two launches of this copy of the kernel
+// above (same loop, two more scalar arguments; the headline's kernel itself is untouched):
+//   win > 0  : every (panel, split) multiplies only `win` query tiles, placed in its split where the panel sits in its own map - on smooth
+//              maps (every anchor matches a near-by query and its neighbours almost as well) that settles the VALIDITY of every anchor
+//              of the panel ("some query within the threshold" needs one witness) at a few percent of the multiply-accumulates;
+//   gate     : the complete scan, for the panels match_panel_settle_kernel found an unsettled anchor in; panels that were settled keep
+//              their partial triples with m2 = +inf (no margin: argmin open, which is what every anchor of such maps is anyway), and
+//              the SAMPLED anchors get the complete screen in a second pass over one 512-row panel per pair (match_corrs_lazy_impl).
+// (An in-loop early exit was built first: the break cost the loop its register allocation - 161 spilled registers, six times slower per tile.)
+template <int CP, int WAVES, int KL = CP / 64>
+__global__ __launch_bounds__(64 * WAVES, CP == 512 ? 1 : 2) void match_mx6_screen_w4_win_kernel(
+    const uint8_t *__restrict__ a6, const uint8_t *__restrict__ q6, int B, int cap_a, int cap_q, const int32_t *__restrict__ n_a,
+    const int32_t *__restrict__ n_q, int T, int S, float *__restrict__ ws_max, int32_t *__restrict__ ws_i1, float *__restrict__ ws_m2,
+    const int32_t *__restrict__ gate /* [B, T] or NULL: only panels with a non-zero entry run */, int win /* > 0: that many tiles of the split */)
+{
+    static_assert(CP == 256 || (CP == 512 && WAVES == 4), "geometries: C_pad 256 with 4 / 8 waves, C_pad 512 with 4 waves");
+    constexpr int RB = CP, NAB = 4;
+    constexpr int TILE_BYTES = screen8_tile_bytes(CP);
+    constexpr int ROWS = 128, NQB = 4;
+    constexpr int NKS = CP / 64;
+    constexpr int NI = TILE_BYTES / (1024 * WAVES);
+    constexpr int LPR = RB / 256;
+    char *smem;
+    if constexpr (2 * TILE_BYTES > 65536) {
+        extern __shared__ __attribute__((aligned(256))) char smem_dyn_w4w[];
+        smem = smem_dyn_w4w;
+    } else {
+        __shared__ __attribute__((aligned(256))) char smem_st_w4w[2 * TILE_BYTES];
+        smem = smem_st_w4w;
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int unit = (slot / T) * 8 + xcd;
+    if (unit >= B * S) return;
+    const int panel = slot % T;
+    const int p = unit / S, split = unit % S;
+    const int na = n_a[p], nq = n_q[p];
+    const int a0 = panel * (32 * NAB * WAVES);
+    if (a0 >= na) return;
+    if (gate && gate[p * T + panel] == 0) return;
+    const int nqt = (nq + ROWS - 1) / ROWS;
+    const int qt_per = (nqt + S - 1) / S;
+    int qt_begin = split * qt_per;
+    int qt_end = (qt_begin + qt_per < nqt) ? qt_begin + qt_per : nqt;
+    if (win > 0 && qt_end - qt_begin > win) {
+        // the window sits in the split where the panel sits among the pair's panels (smooth maps match near-by pixels)
+        const int cnt = qt_end - qt_begin, panels = (na + 32 * NAB * WAVES - 1) / (32 * NAB * WAVES);
+        int k0 = (int)(((long long)(2 * panel + 1) * cnt) / (2 * panels)) - win / 2;
+        k0 = k0 < 0 ? 0 : (k0 > cnt - win ? cnt - win : k0);
+        qt_begin += k0;
+        qt_end = qt_begin + win;
+    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const char *qp = reinterpret_cast<const char *>(q6) + (size_t)p * cap_q * RB;
+
+    // stationary B operands: slot (2 s + hi) of k-step s of the lane's anchor row in each of the four blocks; the four exponent bytes of a
+    // block packed into one register (the instruction picks the byte by op_sel)
+    i32x8 breg[NAB][NKS];
+    int bsc[NAB][NKS / 4];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const int arow_i = a0 + wave * (32 * NAB) + ab * 32 + l31;
+        const char *arow = reinterpret_cast<const char *>(a6) + ((size_t)p * cap_a + (arow_i < cap_a ? arow_i : cap_a - 1)) * RB + 32 * hi;
+        unsigned sc[NKS / 4];
+#pragma unroll
+        for (int w = 0; w < NKS / 4; ++w) sc[w] = 0;
+#pragma unroll
+        for (int s = 0; s < KL; ++s) {
+            const i32x4 lo = *reinterpret_cast<const i32x4 *>(arow + 64 * s), up = *reinterpret_cast<const i32x4 *>(arow + 64 * s + 16);
+            breg[ab][s] = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, -1, -1);   // the fp6 format reads six dwords
+            sc[s >> 2] |= ((unsigned)up[2] & 0xffu) << (8 * (s & 3));
+        }
+#pragma unroll
+        for (int w = 0; w < NKS / 4; ++w) bsc[ab][w] = (int)sc[w];
+    }
+    // DMA instruction j of a wave moves the four 256-byte lines (wave NI + j) 4 .. + 3 of the tile (4 / LPR rows); rows 16 apart share the
+    // swizzle, so instructions j and j + DJ (DJ = 4 LPR) differ by 16 rows - in the scalar base, not in another pair of address registers
+    constexpr int DJ = 4 * LPR;
+    static_assert(NI % DJ == 0 || NI == DJ, "DMA instructions per wave and tile");
+    unsigned dma_off[DJ];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+        const int line = (wave * NI + j) * 4 + (lane >> 4), sl = lane & 15;
+        const int row = line / LPR;
+        dma_off[j] = (unsigned)(row * RB + (((line % LPR) * 16 + (sl ^ (row & 15))) << 4));
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_one = [&](int qt, int buf, int j) {
+        const char *qb = qp + (size_t)qt * TILE_BYTES + (j / DJ) * (16 * RB);
+        char *dst = smem + buf * TILE_BYTES + (wave_u * NI + j) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + dma_off[j % DJ]),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    unsigned koff[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) koff[c][e] = (unsigned)(l31 * RB) + ((((unsigned)(4 * c + 2 * hi + e)) ^ (unsigned)(l31 & 15)) << 4);
+    // A operand of one k-step: 16 + 12 bytes of the lane's slot (dword 6 = exponent byte, the scale operand)
+    auto rd = [&](int s, int qb, unsigned tile) -> i32x8 {
+        const unsigned base = tile + (unsigned)(qb * 32 * RB + (s >> 2) * 256);
+        const i32x4 lo = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][0] + base);
+        const i32x4 up = *reinterpret_cast<const i32x4 *>(smem + koff[s & 3][1] + base);
+        return __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, -1);
+    };
+
+    float runmax[NAB], run2[NAB];
+    int runidx[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) { runmax[ab] = -INFINITY; run2[ab] = -INFINITY; runidx[ab] = 0; }
+    auto reduce_block = [&](const f32x16s &c, int sid, int ab) {
+        const float m0 = fmaxf(fmaxf(c[0], c[1]), c[2]), m1 = fmaxf(fmaxf(c[3], c[4]), c[5]), m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
+        const float m3 = fmaxf(fmaxf(c[9], c[10]), c[11]), m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+        const float x = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
+        const bool improved = x > runmax[ab];
+        run2[ab] = __builtin_amdgcn_fmed3f(runmax[ab], run2[ab], x);              // run2 <= runmax: the median is the second largest
+        runmax[ab] = __builtin_amdgcn_fmed3f(runmax[ab], x, INFINITY);           // = max (no NaNs here); as the intrinsic it needs no operand
+        runidx[ab] = improved ? sid : runidx[ab];                                // canonicalisation (v_max x, x) of the loop-carried state
+    };
+    const f32x16s zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    if (qt_end > qt_begin) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) issue_one(qt_begin, 0, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    i32x8 areg[NKS];
+#pragma unroll
+    for (int s = 0; s < KL; ++s) areg[s] = rd(s, 0, 0u);
+    f32x16s acc[NAB];
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ab][r] = -3.0e38f;           // "previous block" of the pairs before the first one: never wins
+    int sid01 = 0, sid23 = 0;                                         // slice ids of the blocks acc[0..1] / acc[2..3] currently hold
+
+    // one MFMA: k-step SC (a compile-time constant: it is also the op_sel byte of the packed B exponents) of anchor block ab
+    auto mfma = [&](f32x16s &d, int ab, auto SC) {
+        constexpr int s_ = decltype(SC)::value;
+        d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(areg[s_], breg[ab][s_], s_ == 0 ? zero16 : d, 2, 2, 0, areg[s_][6], s_ & 3,
+                                                            bsc[ab][s_ >> 2]);
+    };
+    int buf = 0;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        const unsigned tile = buf * TILE_BYTES;
+        const int qt_next = qt + 1 < qt_end ? qt + 1 : qt;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            const int sid = (qt * NQB + qb) * 2 + hi;
+            if (qb == 0) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) issue_one(qt_next, buf ^ 1, j);
+            }
+            // first half: the VALU reduces the previous block of anchor blocks 2 / 3, the matrix pipe starts this block for 0 / 1
+            reduce_block(acc[2], sid23, 2);
+            reduce_block(acc[3], sid23, 3);
+            // (the reductions read acc[2..3] before the second half overwrites them: program order)
+            mx6_static_for<0, KL>([&](auto SC) { mfma(acc[0], 0, SC); mfma(acc[1], 1, SC); });
+#pragma unroll
+            for (int i = 0; i < 2 * KL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16 / KL, 0);
+            }
+            // second half: this block for 2 / 3 while the VALU reduces what 0 / 1 just finished; next A operand behind its last use
+            mx6_static_for<0, KL>([&](auto SC) {
+                constexpr int s_ = decltype(SC)::value;
+                mfma(acc[2], 2, SC); mfma(acc[3], 3, SC);
+                if (qb + 1 < NQB) areg[s_] = rd(s_, qb + 1, tile);
+            });
+            reduce_block(acc[0], sid, 0);
+            reduce_block(acc[1], sid, 1);
+#pragma unroll
+            for (int i = 0; i < 2 * KL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16 / KL, 0);
+                if (qb + 1 < NQB && (i & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            sid01 = sid;
+            sid23 = sid;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+#pragma unroll
+        for (int s = 0; s < KL; ++s) areg[s] = rd(s, 0, buf * TILE_BYTES);
+    }
+    (void)sid01;
+    reduce_block(acc[2], sid23, 2);
+    reduce_block(acc[3], sid23, 3);
+#pragma unroll
+    for (int ab = 0; ab < NAB; ++ab) {
+        const float om1 = __shfl_xor(runmax[ab], 32), om2 = __shfl_xor(run2[ab], 32);
+        const int oi1 = __shfl_xor(runidx[ab], 32);
+        const float m1 = fmaxf(runmax[ab], om1);
+        const float m2 = fmaxf(fminf(runmax[ab], om1), fmaxf(run2[ab], om2));
+        const int i1 = (om1 > runmax[ab]) ? oi1 : runidx[ab];
+        const int a = a0 + wave * (32 * NAB) + ab * 32 + l31;
+        if (hi == 0 && a < cap_a) {
+            const size_t o = ((size_t)p * S + split) * cap_a + a;
+            ws_max[o] = m1;
+            ws_i1[o] = i1;
+            ws_m2[o] = m2;
+        }
+    }
+}
+
 // ORYON_MX6_DEBUG=1 (development aid; synchronises): per-workgroup wall-clock records of the screen launch -> how many workgroups were
 // resident over the launch, i.e. whether the dispatcher keeps the CUs full (the K1x3 scan's were not: match_x3.hip)
 static void mx6_debug_report(const long long *dbg_dev, int groups, hipStream_t st)
@@ -471,7 +678,8 @@ static int mx6_var()
 namespace {
 template <int CP>
 void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q, const int32_t *n_a,
-                       const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int kl = 0)
+                       const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int kl = 0, bool gate_or_win = false,
+                       const int32_t *gate = nullptr, int win = 0)
 {
     // C_pad 256: 512-anchor panels (8 waves; `groups` was sized for 256-anchor panels, T of them per unit).  C_pad 512: the stationary
     // operand is 128 registers, so 4 waves per workgroup and one workgroup per CU (512 registers per wave), as the int8 kernel
@@ -493,6 +701,17 @@ void launch_screen_mx6_t(int groups, int T, hipStream_t st, const uint8_t *a6, c
             const int g8 = groups / T * T8;
             if (dbg && !dbg_wg) (void)hipMalloc(&dbg_wg, (size_t)65536 * 4 * sizeof(long long));
             if (dbg && dbg_wg && g8 <= 65536) (void)hipMemsetAsync(dbg_wg, 0, (size_t)g8 * 4 * sizeof(long long), st);
+            if (gate_or_win) {
+                // the cascade's launches: windowed (win > 0) or gated (gate != NULL) copy of the kernel
+#define ORYON_LAUNCH_WIN(KLV)                                                                                                         \
+    hipLaunchKernelGGL((match_mx6_screen_w4_win_kernel<CP, 8, KLV>), dim3(g8), dim3(512), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, T8, S,   \
+                       ws_max, ws_i1, ws_m2, gate, win)
+                if (kl == 1) ORYON_LAUNCH_WIN(1);
+                else if (kl == 2) ORYON_LAUNCH_WIN(2);
+                else ORYON_LAUNCH_WIN(4);
+#undef ORYON_LAUNCH_WIN
+                return;
+            }
             if (kl == 1)
                 hipLaunchKernelGGL((match_mx6_screen_w4_kernel<CP, 8, 1>), dim3(g8), dim3(512), 0, st, a6, q6, B, cap_a, cap_q, n_a, n_q, T8, S,
                                    ws_max, ws_i1, ws_m2, (dbg && g8 <= 65536) ? dbg_wg : nullptr);
@@ -533,12 +752,33 @@ const char *screen_mx6_name(int C)
 }
 
 void launch_screen_mx6(int C, int groups, int T, hipStream_t st, const uint8_t *a6, const uint8_t *q6, int B, int cap_a, int cap_q,
-                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int C_true)
+                       const int32_t *n_a, const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int C_true,
+                       int cascade, const int32_t *gate, int win)
 {
     // live k-steps of narrow maps (1 for C <= 64, 2 for C <= 128; otherwise all four): see match_mx6_screen_w4_kernel
     const int kl = (C == 256 && C_true > 0 && C_true <= 64) ? 1 : (C == 256 && C_true > 0 && C_true <= 128) ? 2 : 0;
-    if (C == 256) launch_screen_mx6_t<256>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, ws_max, ws_i1, ws_m2, kl);
+    // cascade != 0 (C_pad 256 only): the windowed / gated launches of the validity cascade (match_mx6_screen_w4_win_kernel)
+    if (C == 256) launch_screen_mx6_t<256>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, ws_max, ws_i1, ws_m2, kl, cascade != 0, gate, win);
     else launch_screen_mx6_t<512>(groups, T, st, a6, q6, B, cap_a, cap_q, n_a, n_q, S, ws_max, ws_i1, ws_m2);
+}
+
+// Second pass of the validity cascade: the complete screen over ONE 512-row panel per pair (the sampled anchors whose argmin is open,
+// compacted by match_compact_rows_kernel), the query tiles of a pair dealt to S workgroups of four waves (two per CU): a tenth of the
+// first pass's multiply-accumulates, spread over the whole chip.  Same kernel, same scores, same slice ids as the full screen.
+void launch_screen_mx6_sampled(hipStream_t st, const uint8_t *a6_panel, const uint8_t *q6, int B, int cap_q, const int32_t *n_rows,
+                               const int32_t *n_q, int S, float *ws_max, int32_t *ws_i1, float *ws_m2, int C_true)
+{
+    const int groups = ((B * S + 7) / 8) * 8;                      // T = 1 panel per (pair, split) unit
+    const int kl = (C_true > 0 && C_true <= 64) ? 1 : (C_true > 0 && C_true <= 128) ? 2 : 0;
+    if (kl == 1)
+        hipLaunchKernelGGL((match_mx6_screen_w4_kernel<256, 4, 1>), dim3(groups), dim3(256), 0, st, a6_panel, q6, B, 512, cap_q, n_rows, n_q, 1, S,
+                           ws_max, ws_i1, ws_m2, static_cast<long long *>(nullptr));
+    else if (kl == 2)
+        hipLaunchKernelGGL((match_mx6_screen_w4_kernel<256, 4, 2>), dim3(groups), dim3(256), 0, st, a6_panel, q6, B, 512, cap_q, n_rows, n_q, 1, S,
+                           ws_max, ws_i1, ws_m2, static_cast<long long *>(nullptr));
+    else
+        hipLaunchKernelGGL((match_mx6_screen_w4_kernel<256, 4>), dim3(groups), dim3(256), 0, st, a6_panel, q6, B, 512, cap_q, n_rows, n_q, 1, S,
+                           ws_max, ws_i1, ws_m2, static_cast<long long *>(nullptr));
 }
 
 }  // namespace oryon
