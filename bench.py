@@ -643,7 +643,7 @@ def main():
         torch.cuda.synchronize()
         ts_ = [ser._native.timing(k)["screen_kernel_ms"] for k in range(1, 6)]
         unshared_ms = sum(ts_) / len(ts_)
-        tg_ = [ser._native.timing(k)["gather_ms"] for k in range(1, 6)]
+        tg_ = [ser._native.gather_ms(k) for k in range(1, 6)]             # the two gather launches (ROI kernels excluded)
         k0_unshared_ms = sum(tg_) / len(tg_)
         del ser
         torch.cuda.empty_cache()
@@ -705,10 +705,10 @@ def main():
         k0 = None
         if k0_unshared_ms is not None and "mx6" in dispatched:
             k0_alg = float((4.0 * C * (n_a + n_q) + 260.0 * n_q + (260.0 + 4.0 * cp) * n_a).sum())
-            k0_pipe_ms = (sum(t["gather_ms"] for t in sections) / len(sections)) if sections else None
+            k0_pipe_ms = (sum(t["gather_ms"] for t in sections) / len(sections)) if sections else None     # (whole section, ROI kernels included)
             K0_MOVED_OVER_ALGORITHMIC = 5.61 / 3.97        # profiles/r05_pmc_counters.md (cfg2, K0v4): 4.51 GB fetched + 1.10 GB written for 3.97 GB
-            k0 = {"kernels": "roi_compact x2 + roi_subsample + gather_mx6_v4_kernel x2 (queries, anchors): the gather-stream section of one step",
-                  "algorithmic_bytes_per_step": k0_alg, "unshared_ms": k0_unshared_ms, "in_pipeline_ms": k0_pipe_ms,
+            k0 = {"kernels": "gather_mx6_v4_kernel x2 (queries, anchors) of one step, HIP events around the two launches on a serial engine",
+                  "algorithmic_bytes_per_step": k0_alg, "unshared_ms": k0_unshared_ms, "gather_section_in_pipeline_ms": k0_pipe_ms,
                   "algorithmic_frac": k0_alg / (k0_unshared_ms * 1e-3) / PEAK_HBM_BYTES,
                   "moved_frac": k0_alg * K0_MOVED_OVER_ALGORITHMIC / (k0_unshared_ms * 1e-3) / PEAK_HBM_BYTES,
                   "moved_over_algorithmic": K0_MOVED_OVER_ALGORITHMIC if (B, H, C) == (64, 224, 256) else None,

@@ -250,7 +250,16 @@ int oryon_match_corrs_mx6(const float *a_hat, const uint8_t *a_mx6, const float 
  * row u) for its fp16x3 second level - a second read of the maps inside oryon_match_corrs_mx6.  oryon_gather_mx6_x3 writes them in the same
  * pass as the mx6 slots (replaces the same reference lines as oryon_gather_mx6, utils/pcd.py:192-193, :28-29): hi_lo_f16 = [2][n_maps,
  * rows_cap, 256] halves (all hi rows, then all lo rows), lo_sq_max [n_maps] = largest |u - hi|^2 of the map's rows.  C_pad = 256 only.
- * oryon_match_corrs_mx6_x3 = oryon_match_corrs_mx6 that takes those rows instead of making them: same results bit for bit. */
+ * oryon_match_corrs_mx6_x3 = oryon_match_corrs_mx6 that takes those rows instead of making them: same corrs / n_valid / n_sel / status /
+ * valid, bit for bit.  Since round 6 its screen runs as a VALIDITY CASCADE (this is the route of maps on which every anchor is valid and
+ * ambiguous, where the full screen bought nothing but validity): (1) a windowed launch - two query tiles per (1024-anchor panel, query
+ * split), placed where the panel sits in its own map; a panel all of whose anchors are thereby valid for sure (one witness above
+ * 1 - 2 thr + the proven bound suffices: utils/pcd.py:204 is "min over queries < threshold") is settled, its runner-ups read "open";
+ * (2) the complete scan for the other panels only (device-gated); (3) after the sampling, the complete screen for the <= max_corrs
+ * sampled rows whose argmin is open (one 512-row panel per pair), which gives them their true winning slice - rows that turn out
+ * unambiguous are resolved from it, the others go to the fp16x3 second level with it as their seed.  corr_rows <= 512.  min_dist of rows
+ * that were neither sampled nor resolved holds the estimate of the scan that settled them (here possibly a partial one); n_undecided =
+ * the first pass's count scaled by the share of sampled rows that stayed ambiguous after (3) (the engine's route feedback). */
 int oryon_gather_mx6_x3(const float *feat, int n_maps, int C, int HW, int layout, const int32_t *roi, int roi_stride, const int32_t *count,
                         int rows_cap, int C_pad, uint8_t *out_mx6, float *err_max, float *row_norm, void *hi_lo_f16, float *lo_sq_max,
                         int round_f16, void *stream);
@@ -458,6 +467,9 @@ int oryon_engine_timing(oryon_engine_t *handle, int64_t step, float *out8);
 /* ms from timing event `event_a` of step `step_a` to event `event_b` of step `step_b` (events per step: 0/1 gather begin / end,
  * 2/3 match + lift begin / end, 4/5 screening kernel begin / end, 6/7 registration begin / end): timelines across steps. */
 int oryon_engine_elapsed(oryon_engine_t *handle, int64_t step_a, int event_a, int64_t step_b, int event_b, float *ms);
+/* ms the two K0 gather launches (queries, anchors: the HBM-bound kernels of the matcher) of step `step` took, i.e. the gather section
+ * without the ROI kernels in front of it (timing must have been on; the step must have completed) */
+int oryon_engine_gather_ms(oryon_engine_t *handle, int64_t step, float *ms);
 int oryon_engine_host_stats(const oryon_engine_t *handle, int64_t *n_submit, double *submit_ms_total, double *submit_ms_last);
 /* number of submits so far whose K0 pass wrote the hi / lo rows (cfg.x3_prefetch) */
 int oryon_engine_x3_steps(const oryon_engine_t *handle, int64_t *n_steps);

@@ -116,6 +116,7 @@ _PROTOS = {
     "oryon_engine_set_timing": (c_int, [c_void_p, c_int]),
     "oryon_engine_timing": (c_int, [c_void_p, c_int64, POINTER(c_float)]),
     "oryon_engine_elapsed": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, POINTER(c_float)]),
+    "oryon_engine_gather_ms": (c_int, [c_void_p, c_int64, POINTER(c_float)]),
     "oryon_engine_config_bytes": (c_size_t, []),
     "oryon_engine_host_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "oryon_engine_x3_steps": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -95,7 +95,7 @@ struct oryon_engine {
     // ordering events (timing disabled), one set per result slot
     hipEvent_t ev_inputs[MAX_SLOTS], ev_gathered[MAX_SLOTS], ev_matched[MAX_SLOTS], ev_done[MAX_SLOTS];
     // timing events: gather section, match section, screening kernel, registration section
-    hipEvent_t tev[TIMING_RING][8];           // per step: gather begin / end, match begin / end, screen begin / end, registration begin / end
+    hipEvent_t tev[TIMING_RING][9];           // per step: gather begin / end, match begin / end, screen begin / end, registration begin / end, [8] = first gather launch (behind the ROI kernels)
     bool timed[TIMING_RING];
     bool used[MAX_SLOTS];
     bool timing;
@@ -372,14 +372,14 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     }
     for (int r = 0; r < TIMING_RING; ++r) {
         e->timed[r] = false;
-        for (int i = 0; i < 8; ++i) e->tev[r][i] = nullptr;
+        for (int i = 0; i < 9; ++i) e->tev[r][i] = nullptr;
     }
     for (int s = 0; s < cfg->n_slots; ++s) {
         for (hipEvent_t *ev : {&e->ev_inputs[s], &e->ev_gathered[s], &e->ev_matched[s], &e->ev_done[s]})
             ok(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     for (int r = 0; r < TIMING_RING; ++r)
-        for (int i = 0; i < 8; ++i) ok(hipEventCreate(&e->tev[r][i]));
+        for (int i = 0; i < 9; ++i) ok(hipEventCreate(&e->tev[r][i]));
     if (cfg->x3_prefetch && e->L.c_pad == 256) {
         ok(hipHostMalloc(reinterpret_cast<void **>(&e->fb_host), (size_t)MAX_SLOTS * 2 * cfg->B * sizeof(int32_t), hipHostMallocDefault));
         for (int s = 0; s < cfg->n_slots; ++s) ok(hipEventCreateWithFlags(&e->ev_fb[s], hipEventDisableTiming));
@@ -411,7 +411,7 @@ extern "C" void oryon_engine_destroy(oryon_engine_t *e)
             if (ev) (void)hipEventDestroy(ev);
     }
     for (int r = 0; r < TIMING_RING; ++r)
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 9; ++i)
             if (e->tev[r][i]) (void)hipEventDestroy(e->tev[r][i]);
     if (e->sm) (void)hipStreamSynchronize(e->sm);
     if (e->sg) (void)hipStreamSynchronize(e->sg);
@@ -560,6 +560,7 @@ extern "C" int oryon_engine_submit(oryon_engine_t *e, const float *feat_a, const
         }
         x3_pre = e->hard_mode && !sf && g.q_hilo != nullptr;
     }
+    if (timing) ORYON_CHECK_HIP(hipEventRecord(tev[8], sg));          // the ROI kernels are behind us: K0's gather launches start here
     if (ablate & 1) {
     } else if (mx6) {
         // the row buffers hold 32-byte mx6 slots instead of int8 rows (same size); the per-map error norms go where eps_max went
@@ -720,6 +721,15 @@ extern "C" int oryon_engine_timing(oryon_engine_t *e, int64_t step, float *out8)
             return ORYON_ERR_STATE;
         }
     }
+    return ORYON_OK;
+}
+
+extern "C" int oryon_engine_gather_ms(oryon_engine_t *e, int64_t step, float *ms)
+{
+    ORYON_CHECK_ARG(e && ms && step >= 0 && step < e->n_submit && step >= e->n_submit - TIMING_RING);
+    if (!e->timed[step % TIMING_RING]) { set_error("oryon_engine_gather_ms: step %lld was submitted with timing off", (long long)step); return ORYON_ERR_STATE; }
+    const hipError_t err = hipEventElapsedTime(ms, e->tev[step % TIMING_RING][8], e->tev[step % TIMING_RING][1]);
+    if (err != hipSuccess) { set_error("oryon_engine_gather_ms: %s (step still running?)", hipGetErrorString(err)); return ORYON_ERR_STATE; }
     return ORYON_OK;
 }
 

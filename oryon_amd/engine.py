@@ -154,6 +154,12 @@ class NativeStep:
         check(lib().oryon_engine_elapsed(self._h, int(step_a), event_a, int(step_b), event_b, ctypes.byref(ms)), "oryon_engine_elapsed")
         return float(ms.value)
 
+    def gather_ms(self, step: int) -> float:
+        """ms of the two K0 gather launches of submit `step` (the gather section without the ROI kernels)."""
+        ms = ctypes.c_float()
+        check(lib().oryon_engine_gather_ms(self._h, int(step), ctypes.byref(ms)), "oryon_engine_gather_ms")
+        return float(ms.value)
+
     def x3_steps(self) -> int:
         """Submits so far whose K0 pass also wrote the second level's hi / lo rows (oryon_engine_config_t.x3_prefetch)."""
         n = ctypes.c_int64()

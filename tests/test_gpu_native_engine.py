@@ -224,3 +224,39 @@ def test_native_x3_prefetch_gives_identical_results_on_smooth_fields():
         for k in ("pose", "status", "n_valid", "n_lifted"):
             assert torch.equal(outs[0][i][k], outs[1][i][k]), (i, k)
             assert torch.equal(outs[1][i][k], outs[1][0][k]), (i, k)
+
+
+@pytest.mark.gpu
+def test_validity_cascade_with_unsettled_panels_gives_identical_results():
+    """Round 6: on the route the engine takes once its feedback says "hard" (oryon_match_corrs_mx6_x3) the screen runs as a cascade - a
+    windowed first launch that settles the validity of whole panels, the complete scan only for panels with an open anchor, a complete
+    second pass for the sampled anchors.  A batch of two smooth pairs (every panel settles in the window) and one pair of the generator's
+    Gaussian descriptors (anchors without a counterpart: its panels never settle and take the gated complete scan) must give, bit for
+    bit, what the engine gives without the cascade (x3_prefetch off: the plain full screen) - poses, statuses, counts."""
+    from oryon_amd.engine import MatchPoseConfig, MatchPoseEngine
+    from oryon_amd.synth import make_pair
+    solver = _solver()
+    pairs = [make_pair(700, 96, 96, 256, device="cuda", smooth=0.02), make_pair(701, 96, 96, 256, device="cuda", smooth=0.02),
+             make_pair(702, 96, 96, 256, device="cuda")]
+    st = lambda k: torch.stack([p[k] for p in pairs]).contiguous()
+    cam = st("camera").reshape(3, 9).float().cuda().contiguous()
+    ins = (st("feat_a"), st("feat_q"), st("mask_a"), st("mask_q"), st("depth_a"), st("depth_q"), cam, cam)
+    key = torch.arange(3, device="cuda")
+    outs = {}
+    for pre in (0, 1):
+        eng = MatchPoseEngine(solver, MatchPoseConfig(), overlap_registration=True, overlap_gather=True, native=True)
+        eng.native_geometry["x3_prefetch"] = pre
+        res = []
+        for _ in range(6):
+            o = eng.finish(eng.run(*ins, key, keep=False))
+            torch.cuda.synchronize()
+            res.append({k: o[k].clone() for k in ("pose", "status", "n_valid", "n_lifted")})
+        outs[pre] = res
+        if pre:
+            assert eng._native.x3_steps() >= 4             # two thirds of the anchors are "undecided": the feedback switched the route
+        assert res[0]["status"].tolist() == [0, 0, 0]
+    for i in range(6):
+        for k in ("pose", "status", "n_valid", "n_lifted"):
+            assert torch.equal(outs[0][i][k], outs[1][i][k]), (i, k)
+    # the Gaussian pair has anchors without a counterpart: fewer valid rows than anchors, i.e. its panels could not settle in the window
+    assert int(outs[1][5]["n_valid"][2]) < int(outs[1][5]["n_valid"][0])
