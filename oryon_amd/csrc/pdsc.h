@@ -29,7 +29,7 @@ constexpr int PDSC_PQ_CHUNK_BYTES = 65536, PDSC_PQ_IMG_BYTES = 5 * PDSC_PQ_CHUNK
 // Round 6 (K): the 16 bytes a lane reads (key, channel octet) sit next to the neighbouring KEYS' 16 bytes, not next to the key's other
 // channels ([64 keys][136 halves] before): a wave's read is 2 x 512 contiguous bytes (conflict-free without the row pad), and the writers'
 // 8-byte pieces (lane = key: 4 channels each, two lanes per octet) fill 512 contiguous bytes = four whole 128-byte lines per store
-// instruction instead of touching 32 lines - the store path takes ~4 cycles per line it touches (DESIGN.md "stores of the per-point chain").
+// instruction instead of touching 32 lines - the store path takes ~4 cycles per line it touches (DESIGN.md "PointDSC encoder: what round 6 found").
 constexpr int PDSC_KV_KL = 16384, PDSC_KV_VH = 32768, PDSC_KV_VL = 49152, PDSC_KV_TILE_BYTES = 65536;
 // pdsc_att_chain_x3_kernel's LDS: [0, 128 KB) two K / V tiles, later [0, 80 KB) the fc_message image + [80 KB, 146 KB) the key-half merge area /
 // weight areas; behind them the layer's biases (768 floats)

@@ -57,6 +57,16 @@ def test_two_gpu_run_over_rccl_equals_single_gpu_bit_for_bit():
     assert m["rccl_ranks"] == 2 and m["all_gather_us"] > 0 and len(m["per_rank_pairs_per_s"]) == 2 and m["collectives_per_step"] == 1
     assert one["multi_gpu"] is None and two["scaling"] == "weak"
     assert abs(two["value"] - 16 * 1e3 / two["ms_per_step"]) < 1e-6 * two["value"]
+    # round 6: both collation modes are in the line, the stream pool was created before the process group, every rank reports its placement
+    assert m["collate"] == "step" and m["collate_final_pairs_per_s"] > 0 and m["collate_step_pairs_per_s"] > 0
+    assert m["stream_pool_created_before_process_group"] is True and len(m["stream_roles_per_rank"]) == 2
+    final = _run("--gpus", "2", "--batch", "8", "--collate", "final", *common)
+    assert final["config"]["pose_sha256"] == one["config"]["pose_sha256"] and final["multi_gpu"]["collectives_per_step"] < 1
+    # the N = 2 ranks inherit what the N = 1 line was tuned on: each rank's own rate within 10 % of a single-GPU run of the SAME per-GPU
+    # batch on the same box (weak scaling; the placement of the engine's streams is the thing a late pool creation used to break)
+    same = _run("--gpus", "1", "--batch", "8", *common)
+    for r in m["per_rank_pairs_per_s"]:
+        assert abs(r - same["value"]) < 0.10 * same["value"], (m["per_rank_pairs_per_s"], same["value"])
 
 
 def test_line_carries_timing_diagnostics():
@@ -68,6 +78,13 @@ def test_line_carries_timing_diagnostics():
     assert set(t["stream_busy_ms_per_step"]) == {"gather_ms", "match_ms", "screen_kernel_ms", "registration_ms"}
     assert rec["roofline"]["kernel"].startswith("match_mx6_screen_w4_kernel<256, 8>") and rec["roofline"]["peak"] == 10000.0
     assert 0 < rec["roofline"]["unshared"]["frac"] < 1
+    # round 6: the same figures as scalars, K0 against the HBM peak, and the stream placement the run was measured with
+    roof = rec["roofline"]
+    assert abs(roof["unshared_frac"] - roof["unshared"]["frac"]) < 1e-12 and 0 < roof["frac_of_bare_loop_rate"] < 1.2
+    assert 0 < roof["k0_algorithmic_frac"] < roof["k0_moved_frac"] < 1 and roof["k0_unshared_ms"] > 0
+    assert t["stream_roles"] in (2301, 2310, 2354, 2345, 2300) and len(t["stream_roles_tuning"]["ms_per_step"]) == 5
+    fixed = _run("--steps", "2", "--warmup", "1", "--batch", "8", "--reps", "1", "--no-cpu-baseline", "--no-stage-sets", "--stream-roles", "2345")
+    assert fixed["timing"]["stream_roles"] == 2345 and fixed["config"]["pose_sha256"] == rec["config"]["pose_sha256"]      # placement never changes results
     rec8 = _run("--steps", "2", "--warmup", "1", "--batch", "8", "--reps", "1", "--no-cpu-baseline", "--no-stage-sets", "--screen", "int8")
     assert rec8["roofline"]["kernel"].startswith("match_i8_screen_v2_kernel<256, 0, 8>") and rec8["roofline"]["peak"] == 5000.0
     assert rec8["config"]["pose_sha256"] == _run("--steps", "2", "--warmup", "1", "--batch", "8", "--reps", "1", "--no-cpu-baseline",
