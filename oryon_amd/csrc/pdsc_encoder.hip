@@ -2067,12 +2067,10 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
     CLK(4);
     // v's bias is per lane (lane = channel in the swapped product): fetched here, long before the first store of the chain - a vector load
     // issued between stores waits for every earlier store's acknowledgement (s_waitcnt vmcnt is one in-order counter)
-    float bias_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float bias_v[2] = {0.0f, 0.0f};                                  // (round 6: a wave computes the row blocks 2 kb, 2 kb + 1 of q | k | v)
     if constexpr (HAS_NEXT) {
-        if (live) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bias_v[i] = bq[2 * C + i * 32 + l31];
-        }
+        for (int i = 0; i < 2; ++i) bias_v[i] = bq[2 * C + (2 * kb + i) * 32 + l31];
     }
     if (live) {
     // the residual rows (this layer's PointCN output, 32 floats per lane) are requested before W1: behind the W3 blocks, where they used to
@@ -2173,26 +2171,53 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
         }
     }
     }
-    // q from area 1 while k lands in area 0, k from area 0 while v lands in area 1, v from area 1
+    // q from area 1 while k lands in area 0, k from area 0 while v lands in area 1, v from area 1.
+    // Round 6: BOTH waves of a query block compute q | k | v - wave (qb, kb) the output row blocks 2 kb, 2 kb + 1 of each part - so the
+    // 288 of the chain's 504 MFMAs and their stores run at two waves per SIMD.  The PointCN output (the B operand: 16 fragments per lane)
+    // goes from the wave that made it to its partner through the query block's 16 KB slice of the dead PointCN weight area.
     CLK(8);
+    CLK(13);
+    if (kb == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the q chunk (requested by these waves) has landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // ... and every wave is done with the PointCN weights (area 0)
+    asm volatile("" ::: "memory");
+    {
+        xhalf8 *ex = reinterpret_cast<xhalf8 *>(att_lds + AREA0 + wave * 16384);
+        if (live) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) { ex[f * 64 + lane] = fh[f]; ex[(8 + f) * 64 + lane] = fl[f]; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!live) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) { fh[f] = ex[f * 64 + lane]; fl[f] = ex[(8 + f) * 64 + lane]; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slice is read: this wave's own DMA pieces may overwrite it
+        }
+    }
+    CLK(9);
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
         const int area_off = ((part + 1) & 1) ? AREA1 : AREA0, other_off = ((part + 1) & 1) ? AREA0 : AREA1;
-        CLK(13 + part);
-        // this part's chunk has landed: only the waves that requested it wait for the vector-memory counter; a raw barrier (a
-        // __syncthreads() would fence with vmcnt(0) and make the live waves wait for their stores' acknowledgements)
-        if (kb == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                   // every wave is done with the other area; this part's chunk is visible
-        asm volatile("" ::: "memory");
-        CLK(9 + part);
+        if (part > 0) {
+            CLK(13 + part);
+            // this part's chunk has landed: the key-half-1 waves requested it BEFORE their previous part's stores (>= 8 of them), and the
+            // vector-memory counter retires in order - vmcnt(8) covers the DMA without waiting for the stores' acknowledgements; the other
+            // waves never wait on it.  Raw barrier (a __syncthreads() would fence with vmcnt(0)).
+            if (kb == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // every wave is done with the other area; this part's chunk is visible
+            asm volatile("" ::: "memory");
+            CLK(9 + part);
+        }
         if (part < 2) dma_chunk_idle(part + 2, other_off);
         const int p_pair = q0 + wave * 32;                           // (wave = query block 0..3 here)
         char *tile = kv_img ? kv_img + ((size_t)b * (n_cap / 64) + (p_pair >> 6)) * PDSC_KV_TILE_BYTES : nullptr;
         const bool as_v = kv_img && part == 2;
-        if (live) {
-#pragma unroll
-        for (int rp = 0; rp < 2; ++rp) {
+        {
+        const int rp = kb;
+        {
             f32x16 acc[2];
             two_blocks(frag, area_off, area_off + HALF, 2 * rp, 8, fh, fl, acc, as_v);
             if (as_v) {
@@ -2200,7 +2225,7 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int ch = (2 * rp + i) * 32 + l31;
-                    const float bv = bias_v[2 * rp + i];
+                    const float bv = bias_v[i];
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
                         uint4 uh, ul;
@@ -2209,8 +2234,8 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
                         split_pair(acc[i][8 * t2 + 4] + bv, acc[i][8 * t2 + 5] + bv, uh.z, ul.z);
                         split_pair(acc[i][8 * t2 + 6] + bv, acc[i][8 * t2 + 7] + bv, uh.w, ul.w);
                         const int oct = (kb * 2 + t2) * 2 + hi;
-                        if (live) *reinterpret_cast<uint4 *>(tile + PDSC_KV_VH + ((size_t)oct * C + ch) * 16) = uh;
-                        if (live) *reinterpret_cast<uint4 *>(tile + PDSC_KV_VL + ((size_t)oct * C + ch) * 16) = ul;
+                        *reinterpret_cast<uint4 *>(tile + PDSC_KV_VH + ((size_t)oct * C + ch) * 16) = uh;
+                        *reinterpret_cast<uint4 *>(tile + PDSC_KV_VL + ((size_t)oct * C + ch) * 16) = ul;
                     }
                 }
             } else {
@@ -2228,12 +2253,12 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
                             split_pair(o.x, o.y, uh.x, ul.x);
                             split_pair(o.z, o.w, uh.y, ul.y);
                             const size_t off = (size_t)pdsc_k_img_elem((p_pair & 63) + l31, cc >> 3) * 2 + (cc & 7) * 2;
-                            if (live) *reinterpret_cast<uint2 *>(tile + off) = uh;
-                            if (live) *reinterpret_cast<uint2 *>(tile + PDSC_KV_KL + off) = ul;
+                            *reinterpret_cast<uint2 *>(tile + off) = uh;
+                            *reinterpret_cast<uint2 *>(tile + PDSC_KV_KL + off) = ul;
                         } else if (part == 0) {
-                            if (live) reinterpret_cast<float4 *>(qkv + (size_t)b * n_cap * 3 * C)[pdsc_g4_index(n_cap, qrow, cc >> 2)] = o;
+                            reinterpret_cast<float4 *>(qkv + (size_t)b * n_cap * 3 * C)[pdsc_g4_index(n_cap, qrow, cc >> 2)] = o;
                         } else {
-                            if (live) *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;       // (no image buffer: never on this path)
+                            *reinterpret_cast<float4 *>(qkv + prow * 3 * C + c) = o;       // (no image buffer: never on this path)
                         }
                     }
             }
