@@ -418,6 +418,14 @@ def main():
         return bench_full(a, rank, world, dev)
     # N distinct input sets: set s holds the global pairs [s * world * B, (s + 1) * world * B), this rank its block of B of them
     n_sets = max(1, a.input_sets)
+    # the rotating input sets must leave room for the engine's arena (K0 outputs, six result slots): at most ~40 % of the device for the maps
+    # (cfg2: 4 sets = 26 GB; the cfg4 shard - 128 pairs at 384^2, C = 512 - is 77 GB per set: one set)
+    set_bytes = 2 * B * C * H * H * 4 + 4 * B * H * H * 4
+    n_fit = max(1, int(0.40 * torch.cuda.get_device_properties(dev).total_memory // set_bytes))
+    if n_sets > n_fit:
+        if rank == 0:
+            print(f"bench.py: {n_sets} input sets of {set_bytes / 2**30:.0f} GiB do not fit beside the engine's arena: using {n_fit}", file=sys.stderr)
+        n_sets = n_fit
     total = B * world
     sets = []
     for s_ in range(n_sets):

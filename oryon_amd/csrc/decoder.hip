@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256, (WREG ? 2 : (NB == 1 ? 3 : 2))) void dec_conv3
                 s1 += v;
                 v += bv;
                 if (a.relu) v = fmaxf(v, 0.0f);
-                if (co < a.cout) a.out[(((size_t)img * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co] = v;
+                // (WREG: cout == 32 == the block: no predicate - with one the compiler waits for every store's acknowledgement (s_waitcnt
+                //  vmcnt(0) in front of the next predicated store), 32 memory round trips per tile and wave: round 6)
+                if (WREG || co < a.cout) a.out[(((size_t)img * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co] = v;
             }
         if (a.stats) {
             // GroupNorm statistics without cancellation: (sum, sum of squared deviations from the WAVE's own group mean) per wave, merged
@@ -669,7 +671,7 @@ void launch_conv(hipStream_t st, const DecConv &a, int n)
 {
     const int tiles = (a.H / 16) * (a.W / 16), total = tiles * n;
     if constexpr (NB == 1 && !IN_NCHW) {
-        if (a.cin == 32 && total > 512) {                   // single slab: persistent workgroups, weights in registers
+        if (a.cin == 32 && a.cout == 32 && total > 512) {   // single slab, one full 32-channel output block: persistent workgroups, weights in registers
             hipLaunchKernelGGL((dec_conv3x3_kernel<1, false, IN_GN, true>), dim3(512), dim3(256), 0, st, a, tiles, total);
             return;
         }

@@ -2205,7 +2205,8 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
             // this part's chunk has landed: the key-half-1 waves requested it BEFORE their previous part's stores (>= 8 of them), and the
             // vector-memory counter retires in order - vmcnt(8) covers the DMA without waiting for the stores' acknowledgements; the other
             // waves never wait on it.  Raw barrier (a __syncthreads() would fence with vmcnt(0)).
-            if (kb == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // (behind the q part: its 8 float4 stores; behind the k part: its 16 eight-byte stores - one instruction each, none mergeable)
+            if (kb == 1) { if (part == 1 || !kv_img) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                               // every wave is done with the other area; this part's chunk is visible
             asm volatile("" ::: "memory");
