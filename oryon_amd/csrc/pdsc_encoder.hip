@@ -1301,7 +1301,13 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float
             xl[s_] = __builtin_bit_cast(xhalf8, ul);
         }
     }
+    // v's bias is per lane (lane = channel): fetched here, with the inputs, so that the wait below covers it - a load waited for between the
+    // parts' stores would be waited for with vmcnt(0), i.e. behind every earlier store's acknowledgement
+    float bias_v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias_v[i] = bq[2 * C + i * 32 + l31];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(bias_v[0]), "v"(bias_v[1]), "v"(bias_v[2]), "v"(bias_v[3]));
     __syncthreads();
     auto frag = [&](int base, int rb, int s_) {
         const int o = rb * 32 + l31;
@@ -1376,21 +1382,19 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_pcn_qkv_x3_kernel(const float
             }
         }
     }
-    // v's bias is per lane (lane = channel): fetched before the first store (see bias4)
-    float bias_v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bias_v[i] = bq[2 * C + i * 32 + l31];
     // q from area 1 while k lands in area 0, k from area 0 while v lands in area 1, v from area 1
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
         const int area = (part + 1) & 1;
-        if (part > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this part's chunk has landed (requested one part ago)
-        if (part < 2) {
-            __syncthreads();                                                     // every wave is done with the other area; part's chunk visible
-            dma_chunk(part + 2, area ^ 1);
-        } else {
-            __syncthreads();
-        }
+        // this part's chunk has landed: it was requested one part ago, BEFORE that part's stores (16 float4 for q, 32 eight-byte pieces for k
+        // with the tile image), and the vector-memory counter retires in order - a counted wait covers the DMA without waiting for the
+        // stores' acknowledgements; a raw barrier (a __syncthreads() would fence with vmcnt(0)).  Round 6, see pdsc_att_chain_x3_kernel.
+        if (part == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (part == 2) { if (kv_img) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                            // every wave is done with the other area; part's chunk visible
+        asm volatile("" ::: "memory");
+        if (part < 2) dma_chunk(part + 2, area ^ 1);
         // q (and k, v without an image buffer): fp32 rows of the q|k|v array.  With `kv_img`: k and v leave as the attention kernel's LDS
         // tile image, already split into fp16 hi / lo - k rows [key][136 halves] from the transposed product (lane = key: 8-byte pieces),
         // v from the un-transposed one (lane = channel, registers 8 t2 .. 8 t2 + 7 = the 8 keys of octet (kb, t2, hi): 16-byte pieces).
@@ -2134,6 +2138,10 @@ __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__r
     }
     CLK(7);
     if constexpr (!HAS_NEXT) return;
+    // v's bias registers are "used" here, before the chain's first store: the compiler waits for their loads at the first use, and behind
+    // this kernel's hand-written counted waits it can only do so with vmcnt(0) - in the v part that meant every wave waiting for the
+    // acknowledgement of its k stores
+    asm volatile("" ::"v"(bias_v[0]), "v"(bias_v[1]));
     // ---- PointCN + q|k|v of layer l + 1.  The fc_message image is dead once every wave is here: q lands on top of it.
     __syncthreads();
     dma_chunk_idle(1, AREA1);
