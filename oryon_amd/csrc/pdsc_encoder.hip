@@ -1711,9 +1711,17 @@ __global__ __launch_bounds__(64 * WAVES) void pdsc_mlp3_pcn_qkv_x3_kernel(const 
 
 // Attention + fc_message of layer l + PointCN + q|k|v of layer l + 1 as ONE kernel (round 4): the merged attention output of a query block
 // already sits in the accumulator layout the per-point chain consumes (lane = point, registers = channels), so the message never goes to
-// memory either: W1 comes with its K axis in accumulator-register order (second fc_message image).  The four key-half-0 waves run the chain
-// for the workgroup's 128 points; the other four keep moving weights (LDS-DMA) and keep the barriers.  HAS_NEXT = false (last layer): the
-// chain stops after fc_message and writes the features.  One launch per encoder layer instead of three.
+// memory either: W1 comes with its K axis in accumulator-register order (second fc_message image).  The four key-half-0 waves run
+// fc_message and PointCN for the workgroup's 128 points; q | k | v are shared by both waves of a query block (round 6); the key-half-1 waves
+// request the q | k | v weight chunks (LDS-DMA).  HAS_NEXT = false (last layer): the chain stops after fc_message and writes the features.
+// One launch per encoder layer instead of three.
+// Round 6 (DESIGN.md "PointDSC encoder: what round 6 found"; phase clocks: DBG / ORYON_PDSC_CLOCKS in the development build):
+//   * nothing on the vector-memory counter between the chain's stores: biases in LDS (bias4l), v's per-lane bias and the residual rows
+//     fetched before the first store, chunk DMA by waves that wait with counted vmcnt, raw s_barrier between the parts - vmcnt is ONE
+//     in-order counter, and a vector load between stores makes every store wait for the acknowledgement of the one before it;
+//   * every store whole 128-byte lines: K tile image [channel octet][key][8 halves], q and the PointCN output in the G4 row-fragment layout
+//     (pdsc.h) - the store path costs ~4 cycles per line a store instruction touches;
+//   * q / resid / feat1 in G4, so this kernel's only partners on those arrays are itself and pdsc_pcn_qkv_x3_kernel<8>(g4 = 1) for layer 0.
 template <int C, bool HAS_NEXT, bool DBG = false>
 __global__ __launch_bounds__(512) void pdsc_att_chain_x3_kernel(const float *__restrict__ QKV, const char *__restrict__ kv_img_in,
                                                                  const float *__restrict__ sc, const int32_t *__restrict__ n_rows, int n_cap,
