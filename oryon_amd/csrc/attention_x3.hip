@@ -21,6 +21,22 @@ typedef float af32x16 __attribute__((ext_vector_type(16)));
 constexpr int MHA_D = 64, MHA_KT = 64, MHA_Q = 128;
 constexpr int MHA_KLD = MHA_D + 8;
 
+// Two values at a time (round 6): packed conversion for hi, x - float(hi) as ONE v_fma_mix_f32 (hi's half read as the f16 source of an fp32
+// fma), packed conversion for lo - four instructions per pair where mha_split takes four per ELEMENT plus the packing; the same bits
+// (tools/probe_cvt_pk_f16.hip).  The kernel's VALU and MFMA instructions do not overlap on this part, so the split is wave time.
+typedef float mha_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 mha_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mha_split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const mha_f32x2 v = {a, b};
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, mha_f16x2));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(b));
+    const mha_f32x2 lv = {l0, l1};
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, mha_f16x2));
+}
 __device__ __forceinline__ void mha_split(float x, _Float16 &hi, _Float16 &lo)
 {
     hi = (_Float16)x;
@@ -98,20 +114,22 @@ __global__ __launch_bounds__(256, 2) void mha_x3_kernel(const float *__restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (int)krow0 + 16 * i;
-            union { _Float16 h[4]; uint2 u; } ph, pl;
-            mha_split(kv[i].x, ph.h[0], pl.h[0]); mha_split(kv[i].y, ph.h[1], pl.h[1]);
-            mha_split(kv[i].z, ph.h[2], pl.h[2]); mha_split(kv[i].w, ph.h[3], pl.h[3]);
-            *reinterpret_cast<uint2 *>(Kh + row * MHA_KLD + 4 * (int)kc4) = ph.u;
-            *reinterpret_cast<uint2 *>(Kl + row * MHA_KLD + 4 * (int)kc4) = pl.u;
+            uint2 ph, pl;
+            mha_split2(kv[i].x, kv[i].y, ph.x, pl.x);
+            mha_split2(kv[i].z, kv[i].w, ph.y, pl.y);
+            *reinterpret_cast<uint2 *>(Kh + row * MHA_KLD + 4 * (int)kc4) = ph;
+            *reinterpret_cast<uint2 *>(Kl + row * MHA_KLD + 4 * (int)kc4) = pl;
         }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const int oct = wave + 4 * o;
-            union { _Float16 h[8]; uint4 u; } ph, pl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) mha_split(vv[o * 8 + e], ph.h[e], pl.h[e]);
-            *reinterpret_cast<uint4 *>(Vh + ((size_t)oct * C + lane) * 8) = ph.u;
-            *reinterpret_cast<uint4 *>(Vl + ((size_t)oct * C + lane) * 8) = pl.u;
+            uint4 ph, pl;
+            mha_split2(vv[o * 8 + 0], vv[o * 8 + 1], ph.x, pl.x);
+            mha_split2(vv[o * 8 + 2], vv[o * 8 + 3], ph.y, pl.y);
+            mha_split2(vv[o * 8 + 4], vv[o * 8 + 5], ph.z, pl.z);
+            mha_split2(vv[o * 8 + 6], vv[o * 8 + 7], ph.w, pl.w);
+            *reinterpret_cast<uint4 *>(Vh + ((size_t)oct * C + lane) * 8) = ph;
+            *reinterpret_cast<uint4 *>(Vl + ((size_t)oct * C + lane) * 8) = pl;
         }
     };
 
@@ -122,14 +140,13 @@ __global__ __launch_bounds__(256, 2) void mha_x3_kernel(const float *__restrict_
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             const float4 a = qv[4 * s_ + 2 * hi], c = qv[4 * s_ + 2 * hi + 1];
-            const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                _Float16 h_, l_;
-                mha_split(x[e] * scale, h_, l_);         // scale = 2^-3 for head dim 64: exact
-                qh[s_][e] = h_;
-                ql[s_][e] = l_;
-            }
+            uint4 uh, ul;                                 // scale = 2^-3 for head dim 64: exact
+            mha_split2(a.x * scale, a.y * scale, uh.x, ul.x);
+            mha_split2(a.z * scale, a.w * scale, uh.y, ul.y);
+            mha_split2(c.x * scale, c.y * scale, uh.z, ul.z);
+            mha_split2(c.z * scale, c.w * scale, uh.w, ul.w);
+            qh[s_] = __builtin_bit_cast(ahalf8, uh);
+            ql[s_] = __builtin_bit_cast(ahalf8, ul);
         }
     }
     af32x16 acc_o[CB];
@@ -187,13 +204,15 @@ __global__ __launch_bounds__(256, 2) void mha_x3_kernel(const float *__restrict_
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __expf(s[kb][r] - m_new);
-                l_tile += p;
-                _Float16 h_, l_;
-                mha_split(p, h_, l_);
-                ph[kb][r >> 3][r & 7] = h_;
-                pl[kb][r >> 3][r & 7] = l_;
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __expf(s[kb][r] - m_new), p1 = __expf(s[kb][r + 1] - m_new);
+                l_tile += p0;
+                l_tile += p1;
+                unsigned uh, ul;
+                mha_split2(p0, p1, uh, ul);
+                const mha_f16x2 h2 = __builtin_bit_cast(mha_f16x2, uh), l2 = __builtin_bit_cast(mha_f16x2, ul);
+                ph[kb][r >> 3][r & 7] = h2[0]; ph[kb][r >> 3][(r & 7) + 1] = h2[1];
+                pl[kb][r >> 3][r & 7] = l2[0]; pl[kb][r >> 3][(r & 7) + 1] = l2[1];
             }
         l_run += l_tile;
 #pragma unroll

@@ -32,15 +32,24 @@ constexpr int GX_LD = GX_BK + 8;                 // halves per LDS row (80 bytes
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// x = hi + lo with two packed conversions per pair (v_cvt_pk_f16_f32 on gfx950, round-to-nearest-even)
+// x = hi + lo with two packed conversions per pair (v_cvt_pk_f16_f32 on gfx950, round-to-nearest-even) and - round 6 - the residuals
+// x - float(hi) as one v_fma_mix_f32 each (hi's half read as the f16 source of an fp32 fma: the bits of the subtraction it replaces,
+// tools/probe_cvt_pk_f16.hip): four instructions per pair instead of six.  VALU and MFMA do not overlap on this part.
+__device__ __forceinline__ void split2(float x, float y, unsigned &hi, unsigned &lo)
+{
+    const f32x2 a = {x, y};
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(a, f16x2));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(y));
+    const f32x2 lv = {l0, l1};
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, f16x2));
+}
 __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo)
 {
-    const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
-    const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-    const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), f16x2);
-    const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
-    hi.x = __builtin_bit_cast(unsigned, ha); hi.y = __builtin_bit_cast(unsigned, hb);
-    lo.x = __builtin_bit_cast(unsigned, la); lo.y = __builtin_bit_cast(unsigned, lb);
+    split2(v.x, v.y, hi.x, lo.x);
+    split2(v.z, v.w, hi.y, lo.y);
 }
 
 template <int ACT>
