@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 from oryon_amd import _lib  # noqa: E402
 
-_DEV = os.path.join(os.path.dirname(_lib.LIB_PATH), "liboryon_hip_dev.so")
+_DEV = os.environ.get("ORYON_DEVLIB") or os.path.join(os.path.dirname(_lib.LIB_PATH), "liboryon_hip_dev.so")
 if os.path.exists(_DEV):
     _lib.LIB_PATH = _DEV
 else:
