@@ -380,11 +380,15 @@ def main():
                     help="placement of the engine's four HIP streams on the process's hardware queues (oryon_engine_config_t.stream_roles: four "
                          "digits = pool positions of match / gather / registration 0 / registration 1).  -1 (default): measure the candidates "
                          "during warm-up (MatchPoseEngine.tune_stream_roles, outside every timed window) and keep the best; 0: the library "
-                         "default (2301); anything else: that placement")
+                         "default (2345); anything else: that placement")
     ap.add_argument("--collate", choices=["step", "final"], default="step",
                     help="N > 1 only.  step (default): one all_gather of [B,17] per step inside the timed region; final: every step's poses are "
                          "staged on the device and ONE all_gather per timed window collates them (north_star: 'all-gather of per-pair poses ... "
                          "only for the final collation').  The other mode is measured in extra windows and reported in `multi_gpu` as well")
+    ap.add_argument("--process-group", action="store_true",
+                    help="--gpus 1 only: create the RCCL process group all the same (one rank) and collate every step through it - the part of "
+                         "the multi-GPU path a single-GPU box can execute (communicator created after the engine's stream pool, "
+                         "all_gather_into_tensor of the [B,17] rows inside the timed region); reported in `multi_gpu`")
     ap.add_argument("--no-stage-sets", action="store_true",
                     help="skip the 'decode+match+pose' and 'full' stage sets that the default run measures after the headline")
     ap.add_argument("--collation-selftest", action="store_true",
@@ -408,7 +412,8 @@ def main():
 
     if a.collation_selftest:
         return collation_selftest(a)
-    rank, world, local = init_from_env("cuda")
+    rank, world, local = init_from_env("cuda", force_group=a.process_group and a.gpus == 1)
+    grouped = dist.is_initialized()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
@@ -463,7 +468,7 @@ def main():
 
     # --collate final: a window's poses are staged in [steps, B, 17] (one small device copy per step: the slot views are re-used six
     # steps later) and collated by ONE all_gather when the window ends; --collate step: one all_gather per step
-    collate = {"mode": a.collate if world > 1 else "step", "stage": None, "k": 0}
+    collate = {"mode": a.collate if grouped else "step", "stage": None, "k": 0}
 
     def collect(out):
         host["last_set"] = host["set_of"].pop(id(out), host["last_set"])
@@ -514,7 +519,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -538,7 +543,7 @@ def main():
                 # every rank tunes on its own GPU; what rank 0 reports is its own choice, the others' are in multi_gpu.stream_roles_per_rank
                 pass
         else:
-            roles_rec = {"roles": native.stream_roles(), "ms_per_step": {}, "default": 2301,
+            roles_rec = {"roles": native.stream_roles(), "ms_per_step": {}, "default": 2345,
                          "how": "fixed by --stream-roles" if a.stream_roles > 0 else "library default (--stream-roles 0)"}
         barrier()
 
@@ -562,7 +567,7 @@ def main():
             barrier()
             elapsed = time.perf_counter() - t0
             el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            if world > 1:
+            if grouped:
                 dist.all_reduce(el, op=dist.ReduceOp.MAX)
             a1 = alloc_counters()
             w = {"ms_per_step": float(el.item()) / a.steps * 1e3, "ms_per_step_rank": elapsed / a.steps * 1e3,
@@ -595,7 +600,7 @@ def main():
     import hashlib
     pose_sha = hashlib.sha256(pose[:total].contiguous().cpu().numpy().tobytes() + status[:total].contiguous().cpu().numpy().tobytes()).hexdigest()
     multi = None
-    if world > 1:
+    if grouped:
         # the only collective of the path: one all_gather of [B_r,17] fp32 per step (pose + status), timed on its own with HIP events;
         # and every rank's own throughput over the median window
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -627,7 +632,8 @@ def main():
             other_ms.append(float(el_.item()) / a.steps * 1e3)
         collate["mode"] = keep_mode
         other_med = sorted(other_ms)[1]
-        multi = {"backend": "nccl (RCCL over xGMI)", "rccl_ranks": world, "all_gather_us": ev0.elapsed_time(ev1) / 20 * 1e3,
+        multi = {"backend": "nccl (RCCL over xGMI)" if world > 1 else "nccl (RCCL, ONE rank: --process-group on a single-GPU box; no link is crossed)",
+                 "rccl_ranks": world, "all_gather_us": ev0.elapsed_time(ev1) / 20 * 1e3,
                  "all_gather_bytes_per_rank": B * 17 * 4, "per_rank_pairs_per_s": [B * 1e3 / float(t.item()) for t in all_ms],
                  "collate": keep_mode,
                  "collectives_per_step": 1 if keep_mode == "step" else 1.0 / a.steps,
@@ -805,7 +811,7 @@ def main():
         sout, spose, sstatus = run_steps(SF_STEPS)
         barrier()
         sel = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if grouped:
             dist.all_reduce(sel, op=dist.ReduceOp.MAX)
         engine.cfg.sample_first = 0
         if rank == 0:
@@ -841,7 +847,7 @@ def main():
         hout, _, hstatus = run_steps(HARD_STEPS)
         barrier()
         hel = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if grouped:
             dist.all_reduce(hel, op=dist.ReduceOp.MAX)
         if rank == 0:
             hard = {"descriptors": "smooth rank-8 fields + 1-2 % noise (anchor map = query map + noise): the int8 bound settles every anchor's VALIDITY "
@@ -885,7 +891,7 @@ def main():
         rec["config"]["decode_match_pose_pairs_per_s"] = dec_["value"] if dec_ else None
         rec["config"]["stream_roles"] = rec["timing"]["stream_roles"]
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -434,12 +434,14 @@ typedef struct {
                                 query rows' hi / lo halves in its own pass (oryon_gather_mx6_x3) and the matcher skips its second read of the maps
                                 (oryon_match_corrs_mx6_x3).  Results are unchanged; C <= 256 and the MX-fp6 screen only.  0 = never */
     int stream_roles;        /* which of the device's eight pooled streams (numbered in creation order) serve as match / gather / registration 0 /
-                                registration 1: four decimal digits, each 0..7.  0 = the library's default (2301).  The HIP runtime gives a
-                                process's first streams one hardware queue each in creation order, and the placement alone moves the pipelined
-                                cfg2 step by up to 30 % (DESIGN.md "stream placement"); the digits are positions in THAT order, so a host that
-                                creates other streams first (an RCCL communicator does) calls oryon_engine_warm_streams() before them, and a
-                                host that wants the best placement for its own process measures the candidates with
-                                oryon_engine_set_stream_roles (oryon_amd.engine.MatchPoseEngine.tune_stream_roles does).  Results never
+                                registration 1: four decimal digits, each 0..7.  0 = the library's default (2345).  The HIP runtime multiplexes a
+                                process's streams onto a few hardware queues and streams in one queue wait for each other's barrier packets:
+                                the placement alone moves the pipelined step by up to 30 % at 64 pairs and 70 % at 16, and which placements
+                                are good depends on what else the process created first (DESIGN.md "stream placement": the default is
+                                the one that stayed within 2 % of the best both in a plain process and behind an RCCL communicator).  A
+                                host calls oryon_engine_warm_streams() before it creates other streams, and measures the candidates on its
+                                own process with oryon_engine_set_stream_roles (oryon_amd.engine.MatchPoseEngine.tune_stream_roles does).
+                                Results never
                                 depend on it */
 } oryon_engine_config_t;
 size_t oryon_engine_config_bytes(void);      /* sizeof(oryon_engine_config_t) in the built library: a binding's mirror of the struct must match */

@@ -29,7 +29,7 @@ constexpr int MAX_REG_STREAMS = 4;
 constexpr int TIMING_RING = 64;        // timing-event sets: the sections of the last 64 steps can be read back
 constexpr int ROW_PAD = 256;
 constexpr int POOL_STREAMS = 8;        // HIP streams per device in the process-wide pool (see acquire_pool)
-constexpr int DEFAULT_ROLES = 2301;    // cfg.stream_roles == 0: the placement measured best on the development boxes (round 5)
+constexpr int DEFAULT_ROLES = 2345;    // cfg.stream_roles == 0 (round 6; round 5: 2301 - see oryon_engine_create)
 
 // cfg.stream_roles: four decimal digits, each a pool index 0..7 (match / gather / registration 0 / registration 1); 0 = DEFAULT_ROLES
 inline bool roles_valid(int roles)
@@ -269,6 +269,7 @@ namespace oryon {
 // Round 6: the pool's mutex is held while the streams are created (two threads creating engines used to race on the empty slots), the
 // pool is keyed by the device the ARENA lives on, and oryon_engine_warm_streams() lets a host create the pool before anything else of
 // the process creates HIP streams (RCCL's communicator does): the roles below are positions in the process's creation order.
+__global__ void pool_touch_kernel() {}
 struct StreamPool { hipStream_t all[POOL_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
 static std::mutex g_pool_mu;
 static StreamPool g_pools[64];
@@ -279,8 +280,13 @@ static hipError_t acquire_pool(int dev, hipStream_t out[POOL_STREAMS])
     StreamPool &pool = g_pools[(dev >= 0 && dev < 64) ? dev : 0];
     for (int i = 0; i < POOL_STREAMS; ++i) {
         if (!pool.all[i]) {
-            const hipError_t err = hipStreamCreateWithFlags(&pool.all[i], hipStreamNonBlocking);
+            hipError_t err = hipStreamCreateWithFlags(&pool.all[i], hipStreamNonBlocking);
             if (err != hipSuccess) { pool.all[i] = nullptr; return err; }
+            // An empty kernel binds the stream's hardware queue here, in pool order (the runtime may create it lazily, at the first
+            // command): pool position i then means "queue i mod 4 counted from the pool's first", whatever is used first later.
+            hipLaunchKernelGGL(pool_touch_kernel, dim3(1), dim3(64), 0, pool.all[i]);
+            err = hipStreamSynchronize(pool.all[i]);
+            if (err != hipSuccess) return err;
         }
         out[i] = pool.all[i];
     }
@@ -354,12 +360,14 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     e->host_ns_total = e->host_ns_last = 0.0;
     hipError_t err = hipSuccess;
     auto ok = [&](hipError_t x) { if (err == hipSuccess) err = x; };
-    // Which of the pool's 8 consecutively created streams serve as match / gather / registration 0 / registration 1.  The runtime gives
-    // the first streams of a process one hardware queue each, in creation order, and the placement matters far more than one would
-    // think (cfg2 step, same box, `tools/engine_timeline.py`, two runs each): 0123 (creation order, rounds 3-4) 3.46 ms; 2301 3.33-3.34;
-    // 2345 3.34-3.38; 2453 / 2534 / 4523 3.42-3.47; 5670 3.7-3.8; 1357 3.9; 0246 4.07; 3210 / 3456 4.1-4.2 ms.  The two best have the
-    // match stream on the pool's third and the gather stream on its fourth queue.  cfg.stream_roles names the placement (0 = the
-    // default above); oryon_engine_set_stream_roles changes it on a live engine, which is how a host measures the candidates on ITS
+    // Which of the pool's 8 streams serve as match / gather / registration 0 / registration 1.  The runtime multiplexes a process's streams
+    // onto a few hardware queues, two streams in one queue wait for each other's barrier packets, and the placement matters far more
+    // than one would think (cfg2 step, round 5, same box, two runs each: 0123 3.46 ms; 2301 3.33-3.34; 2345 3.34-3.38; 5670 3.7-3.8; 1357
+    // 3.9; 0246 4.07; 3210 / 3456 4.1-4.2 ms).  Round 6 (tools/pg_probe4.py; 16 placements, 16 pairs per step): what ELSE the process
+    // created before its first tensor shifts the picture - with a one-rank RCCL communicator created first (every rank of an N > 1 run
+    // has one) registration 0 on pool stream 0 loses the pipeline (2301: 1.47 -> 2.42 ms), 2345 / 2341 / 6345 / 6341 stay at 1.44-1.47 in
+    // both cases; in a plain process the gather on pool stream 7 costs 13 %.  Hence the default 2345.  cfg.stream_roles names the placement
+    // (0 = that default); oryon_engine_set_stream_roles changes it on a live engine, which is how a host measures the candidates on ITS
     // process (oryon_amd.engine.MatchPoseEngine.tune_stream_roles).  (dev build: ORYON_ENGINE_ROLES overrides the default)
     static const int default_roles = dev_env_int("ORYON_ENGINE_ROLES", DEFAULT_ROLES);
     e->n_reg_streams = cfg->reg_streams;

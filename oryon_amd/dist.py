@@ -26,9 +26,11 @@ def warm_engine_streams(local: int) -> bool:
     return True
 
 
-def init_from_env(device_type: str = "cuda") -> Tuple[int, int, int]:
+def init_from_env(device_type: str = "cuda", force_group: bool = False) -> Tuple[int, int, int]:
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world, local_rank).  A single process without those variables is world 1 and needs no group.
+    Returns (rank, world, local_rank).  A single process without those variables is world 1 and needs no group;
+    `force_group` creates one all the same (a one-rank RCCL communicator: the collation then runs through the same collectives as at
+    N > 1 - what a single-GPU box can execute of the multi-GPU path, `bench.py --process-group`).
     On GPUs the step engine's stream pool is created BEFORE the process group (see warm_engine_streams), at world 1 too, so that a
     rank of an N-GPU run and a single-GPU run give their engine streams the same hardware queues."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -36,9 +38,13 @@ def init_from_env(device_type: str = "cuda") -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if device_type == "cuda":
         warm_engine_streams(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sock:                  # (only a process that was not launched by torchrun gets here: it is alone)
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1]) if world == 1 else "29500"
         if device_type == "cuda":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -59,7 +65,7 @@ def gather_poses(pose_local: torch.Tensor, status_local: torch.Tensor, total: in
     (pose [total,4,4], status [total]) on every rank.  Ranks may hold fewer than ceil(total/world) pairs: rows are
     padded to equal size for the collective and cut afterwards."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return pose_local[:total], status_local[:total]
     per = (total + world - 1) // world
     dev = pose_local.device
@@ -79,7 +85,7 @@ def gather_pose_windows(staged_local: torch.Tensor) -> torch.Tensor:
     [world, k, B_r, 17] on every rank - step j of the job in global pair order is out[:, j].reshape(world * B_r, 17).
     All ranks must pass the same k and B_r (pad short ranks with status rows the reader cuts)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return staged_local.unsqueeze(0)
     mine = staged_local.contiguous()
     out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)

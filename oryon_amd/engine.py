@@ -238,8 +238,15 @@ class MatchPoseEngine:
         self._i8_frac = 0.0
         self._i8_skipped = 0
 
-    # placements within ~2 % of the best on the development boxes (DESIGN.md "stream placement"): what tune_stream_roles tries
-    ROLE_CANDIDATES = (2301, 2310, 2354, 2345, 2300)
+    # What tune_stream_roles tries (digits: matcher, gather, registration 0, registration 1 = positions in the stream pool).  The runtime
+    # multiplexes a process's streams onto a few hardware queues and two streams in one queue wait for each other's barrier packets, so
+    # which pool stream plays which role decides whether the pipeline overlaps at all - and the good choices depend on what ELSE the
+    # process created before its first tensor.  Measured at 16 pairs per step over 16 placements each (tools/pg_probe4.py):
+    # plain process - gather on pool stream 7 costs 13 %, everything else within 2 %; with a one-rank RCCL communicator created first (what
+    # every rank of an N > 1 run has) - registration 0 on pool stream 0 costs 70 % (1.44 -> 2.43 ms; round 5's default 2301 did that).
+    # The candidates avoid both; 2345 is the library default since round 6.
+    DEFAULT_ROLES = 2345
+    ROLE_CANDIDATES = (2345, 6345, 2341, 6341, 2301)
 
     def tune_stream_roles(self, run_steps, candidates: Optional[Tuple[int, ...]] = None, steps: int = 8, warm: int = 2) -> Dict[str, object]:
         """Pick the engine's stream placement by MEASUREMENT on this process (warm-up only, never inside a timed region).
@@ -251,7 +258,7 @@ class MatchPoseEngine:
         import time
         nat = self._native
         if nat is None or nat.ecfg.overlap == 0:
-            return {"roles": None, "ms_per_step": {}, "default": 2301}
+            return {"roles": None, "ms_per_step": {}, "default": self.DEFAULT_ROLES}
         cands = tuple(candidates or self.ROLE_CANDIDATES)
         seen: Dict[int, float] = {}
         for r in cands:
@@ -264,11 +271,11 @@ class MatchPoseEngine:
             seen[r] = (time.perf_counter() - t0) / steps * 1e3
         best = min(seen, key=seen.get)
         # keep the default unless another placement is clearly (> 1 %) faster: the timing noise of 8 steps is about that
-        if 2301 in seen and seen[2301] <= seen[best] * 1.01:
-            best = 2301
+        if self.DEFAULT_ROLES in seen and seen[self.DEFAULT_ROLES] <= seen[best] * 1.01:
+            best = self.DEFAULT_ROLES
         nat.set_stream_roles(best)
         self.native_geometry["stream_roles"] = best          # a rebuilt NativeStep keeps the choice
-        return {"roles": best, "ms_per_step": {str(k): round(v, 4) for k, v in seen.items()}, "default": 2301}
+        return {"roles": best, "ms_per_step": {str(k): round(v, 4) for k, v in seen.items()}, "default": self.DEFAULT_ROLES}
 
     def finish(self, out: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Order the caller's current stream after the registration of `out` (no-op without overlap)."""

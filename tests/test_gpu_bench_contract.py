@@ -69,6 +69,25 @@ def test_two_gpu_run_over_rccl_equals_single_gpu_bit_for_bit():
         assert abs(r - same["value"]) < 0.10 * same["value"], (m["per_rank_pairs_per_s"], same["value"])
 
 
+def test_one_rank_rccl_group_on_a_single_gpu_gives_the_same_poses_and_rate():
+    """What a 1-GPU box can execute of the N > 1 path: `bench.py --process-group` creates the RCCL communicator (one rank) AFTER the
+    engine's stream pool and collates every step through `all_gather_into_tensor` inside the timed region.  The collated poses equal the
+    plain run's bit for bit, both collation modes run, and the communicator's own streams do not disturb the engine's placement:
+    the step rate stays within 10 % of the plain run on the same box (the concern VERDICT r05 raised for the first multi-GPU run)."""
+    common = ("--steps", "10", "--warmup", "2", "--reps", "3", "--batch", "16", "--no-cpu-baseline", "--no-stage-sets", "--stream-roles", "0")
+    plain = _run(*common)
+    grp = _run("--process-group", *common)
+    assert plain["multi_gpu"] is None
+    m = grp["multi_gpu"]
+    assert m["rccl_ranks"] == 1 and "RCCL" in m["backend"] and m["all_gather_us"] > 0 and m["collectives_per_step"] == 1
+    assert m["stream_pool_created_before_process_group"] is True and m["stream_roles_per_rank"] == [plain["timing"]["stream_roles"]]
+    assert m["collate_final_pairs_per_s"] > 0 and m["collate_step_pairs_per_s"] > 0
+    assert grp["config"]["pose_sha256"] == plain["config"]["pose_sha256"] and grp["config"]["pairs_ok"] == 16
+    assert abs(grp["value"] - plain["value"]) < 0.10 * plain["value"], (grp["value"], plain["value"])
+    final = _run("--process-group", "--collate", "final", *common)
+    assert final["config"]["pose_sha256"] == plain["config"]["pose_sha256"] and final["multi_gpu"]["collectives_per_step"] < 1
+
+
 def test_line_carries_timing_diagnostics():
     rec = _run("--steps", "3", "--warmup", "1", "--batch", "8", "--reps", "3", "--no-cpu-baseline", "--no-stage-sets")
     t = rec["timing"]
@@ -82,9 +101,9 @@ def test_line_carries_timing_diagnostics():
     roof = rec["roofline"]
     assert abs(roof["unshared_frac"] - roof["unshared"]["frac"]) < 1e-12 and 0 < roof["frac_of_bare_loop_rate"] < 1.2
     assert 0 < roof["k0_algorithmic_frac"] < roof["k0_moved_frac"] < 1 and roof["k0_unshared_ms"] > 0
-    assert t["stream_roles"] in (2301, 2310, 2354, 2345, 2300) and len(t["stream_roles_tuning"]["ms_per_step"]) == 5
-    fixed = _run("--steps", "2", "--warmup", "1", "--batch", "8", "--reps", "1", "--no-cpu-baseline", "--no-stage-sets", "--stream-roles", "2345")
-    assert fixed["timing"]["stream_roles"] == 2345 and fixed["config"]["pose_sha256"] == rec["config"]["pose_sha256"]      # placement never changes results
+    assert t["stream_roles"] in (2345, 6345, 2341, 6341, 2301) and len(t["stream_roles_tuning"]["ms_per_step"]) == 5
+    fixed = _run("--steps", "2", "--warmup", "1", "--batch", "8", "--reps", "1", "--no-cpu-baseline", "--no-stage-sets", "--stream-roles", "2301")
+    assert fixed["timing"]["stream_roles"] == 2301 and fixed["config"]["pose_sha256"] == rec["config"]["pose_sha256"]      # placement never changes results
     rec8 = _run("--steps", "2", "--warmup", "1", "--batch", "8", "--reps", "1", "--no-cpu-baseline", "--no-stage-sets", "--screen", "int8")
     assert rec8["roofline"]["kernel"].startswith("match_i8_screen_v2_kernel<256, 0, 8>") and rec8["roofline"]["peak"] == 5000.0
     assert rec8["config"]["pose_sha256"] == _run("--steps", "2", "--warmup", "1", "--batch", "8", "--reps", "1", "--no-cpu-baseline",
