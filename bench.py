@@ -273,16 +273,38 @@ def run_stage_set(a, rank, world, dev, stage, steps, warmup, backbone_dtype="fp3
     }
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner through C stdio - fully buffered when stdout is a pipe, so it used to come out when the process exits,
+    BEHIND the JSON line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:           # (no libc handle: nothing buffered that we could flush)
+        pass
+    sys.stdout.flush()
+
+
+def emit_line(rec, rank, grouped):
+    """The ONE JSON line, as the last thing the job writes to stdout: every rank flushes what C stdio still holds (the banner was already
+    flushed once behind init_process_group), a barrier makes sure they all have, rank 0 prints, and only then the group is torn down."""
+    flush_c_stdio()
+    if grouped:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if grouped:
+        dist.barrier()
+        dist.destroy_process_group()
+    flush_c_stdio()
+
+
 def bench_full(a, rank, world, dev):
     """`--stages full|decode`: that stage set alone, as its own JSON line (never mixed into the headline `value`)."""
     rec = run_stage_set(a, rank, world, dev, a.stages, a.steps, a.warmup, a.backbone_dtype)
     if rank == 0:
         rec.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                     "config": {"workload": f"Batch={a.batch} synthetic 224x224 RGB-D pairs per GPU, stage set {a.stages}", "stages": a.stages}})
-        print(json.dumps(rec), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    emit_line(rec if rank == 0 else None, rank, world > 1)
 
 
 def collation_selftest(a):
@@ -414,6 +436,7 @@ def main():
         return collation_selftest(a)
     rank, world, local = init_from_env("cuda", force_group=a.process_group and a.gpus == 1)
     grouped = dist.is_initialized()
+    flush_c_stdio()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
@@ -890,10 +913,7 @@ def main():
         rec["config"]["full_fp32grade_clipload_pairs_per_s"] = full_c["value"] if full_c else None
         rec["config"]["decode_match_pose_pairs_per_s"] = dec_["value"] if dec_ else None
         rec["config"]["stream_roles"] = rec["timing"]["stream_roles"]
-        print(json.dumps(rec), flush=True)
-    if grouped:
-        dist.barrier()
-        dist.destroy_process_group()
+    emit_line(rec if rank == 0 else None, rank, grouped)
 
 
 if __name__ == "__main__":

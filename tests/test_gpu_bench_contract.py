@@ -15,6 +15,8 @@ def _run(*flags):
                          cwd=ROOT).stdout
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out
+    # the JSON line is the LAST thing on stdout (RCCL's version banner, written through C stdio, used to come out behind it at exit)
+    assert [ln for ln in out.splitlines() if ln.strip()][-1] == lines[0], out[-2000:]
     return json.loads(lines[0])
 
 
