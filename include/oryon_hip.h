@@ -449,9 +449,10 @@ size_t oryon_engine_arena_bytes(const oryon_engine_config_t *cfg, const oryon_po
 int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_config_t *cfg, oryon_pointdsc_t *solver, void *arena,
                         size_t arena_bytes);
 void oryon_engine_destroy(oryon_engine_t *handle);
-/* Creates the current device's stream pool now (idempotent, thread-safe): call it once per process BEFORE anything else creates HIP streams
- * on the device - torch.distributed.init_process_group("nccl", device_id=...) creates RCCL's - so that the engine's streams are the
- * process's first and cfg.stream_roles means the same placement at N = 1 and under torchrun (run_test.py:31 launches one process per GPU). */
+/* Creates the current device's stream pool now (idempotent, thread-safe; every new stream runs one empty kernel, which binds its hardware
+ * queue): call it once per process BEFORE anything else creates HIP streams on the device - torch.distributed.init_process_group("nccl",
+ * device_id=...) creates RCCL's - so that the engine's streams are the process's first (run_test.py:31 launches one process per GPU).
+ * That alone does not make every placement equally good behind a communicator (measured, see cfg.stream_roles): the default one is. */
 int oryon_engine_warm_streams(void);
 /* Re-assigns a live engine's streams (same digits as cfg.stream_roles; 0 = default).  Drains the engine's streams first (synchronises
  * the host with the steps in flight): a tuning aid for warm-up, not for the steady state.  oryon_engine_stream_roles reads the placement. */
