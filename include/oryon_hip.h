@@ -435,7 +435,7 @@ typedef struct {
                                 (oryon_match_corrs_mx6_x3).  Results are unchanged; C <= 256 and the MX-fp6 screen only.  0 = never */
     int stream_roles;        /* which of the device's eight pooled streams (numbered in creation order) serve as match / gather / registration 0 /
                                 registration 1: four decimal digits, each 0..7.  0 = the library's default (2345).  The HIP runtime multiplexes a
-                                process's streams onto a few hardware queues and streams in one queue wait for each other's barrier packets:
+                                process's streams onto a few hardware queues (the arbitration between them is undocumented; found by measurement):
                                 the placement alone moves the pipelined step by up to 30 % at 64 pairs and 70 % at 16, and which placements
                                 are good depends on what else the process created first (DESIGN.md "stream placement": the default is
                                 the one that stayed within 2 % of the best both in a plain process and behind an RCCL communicator).  A

@@ -361,7 +361,7 @@ extern "C" int oryon_engine_create(oryon_engine_t **handle, const oryon_engine_c
     hipError_t err = hipSuccess;
     auto ok = [&](hipError_t x) { if (err == hipSuccess) err = x; };
     // Which of the pool's 8 streams serve as match / gather / registration 0 / registration 1.  The runtime multiplexes a process's streams
-    // onto a few hardware queues, two streams in one queue wait for each other's barrier packets, and the placement matters far more
+    // onto a few hardware queues (the arbitration between them is not documented), and the placement matters far more
     // than one would think (cfg2 step, round 5, same box, two runs each: 0123 3.46 ms; 2301 3.33-3.34; 2345 3.34-3.38; 5670 3.7-3.8; 1357
     // 3.9; 0246 4.07; 3210 / 3456 4.1-4.2 ms).  Round 6 (tools/pg_probe4.py; 16 placements, 16 pairs per step): what ELSE the process
     // created before its first tensor shifts the picture - with a one-rank RCCL communicator created first (every rank of an N > 1 run

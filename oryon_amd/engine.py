@@ -239,7 +239,7 @@ class MatchPoseEngine:
         self._i8_skipped = 0
 
     # What tune_stream_roles tries (digits: matcher, gather, registration 0, registration 1 = positions in the stream pool).  The runtime
-    # multiplexes a process's streams onto a few hardware queues and two streams in one queue wait for each other's barrier packets, so
+    # multiplexes a process's streams onto a few hardware queues (how the command processor arbitrates between them is not documented), so
     # which pool stream plays which role decides whether the pipeline overlaps at all - and the good choices depend on what ELSE the
     # process created before its first tensor.  Measured at 16 pairs per step over 16 placements each (tools/pg_probe4.py):
     # plain process - gather on pool stream 7 costs 13 %, everything else within 2 %; with a one-rank RCCL communicator created first (what
