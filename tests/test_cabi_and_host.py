@@ -317,3 +317,18 @@ def test_engine_config_struct_matches_the_library():
         if m:
             decl += [x.strip() for x in m.group(1).split(",")]
     assert decl == names, (decl, names)
+
+
+def test_default_stream_placement_is_the_same_in_python_header_and_library_source():
+    """The placement the library falls back to (cfg.stream_roles == 0) is named in three places - they must agree, and the tuner must try it."""
+    import re
+    from oryon_amd.engine import MatchPoseEngine
+    src = open(os.path.join(ROOT, "oryon_amd", "csrc", "engine.hip")).read()
+    c_default = int(re.search(r"constexpr int DEFAULT_ROLES = (\d+);", src).group(1))
+    header = open(os.path.join(ROOT, "include", "oryon_hip.h")).read()
+    h_default = int(re.search(r"0 = the library's default \((\d+)\)", header).group(1))
+    assert c_default == h_default == MatchPoseEngine.DEFAULT_ROLES
+    assert MatchPoseEngine.DEFAULT_ROLES in MatchPoseEngine.ROLE_CANDIDATES
+    for r in MatchPoseEngine.ROLE_CANDIDATES:                      # four digits, each a pool position
+        assert 0 < r <= 7777 and all(int(d) < 8 for d in str(r))
+
