@@ -345,13 +345,9 @@ def collation_selftest(a):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ok = bool(torch.equal(allp[:, 0, 3], torch.arange(total, dtype=torch.float32))) and \
         bool(torch.equal(alls, torch.arange(total, dtype=torch.int32) % 3))
-    if rank == 0:
-        print(json.dumps({"metric": "collation selftest (no kernels)", "n_gpus": world, "steps": a.steps, "global_pairs": total,
-                          "collated_in_order": ok, "collate": a.collate, "collectives": 1 if a.collate == "final" else a.steps,
-                          "elapsed_s": float(el.item())}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    emit_line({"metric": "collation selftest (no kernels)", "n_gpus": world, "steps": a.steps, "global_pairs": total,
+               "collated_in_order": ok, "collate": a.collate, "collectives": 1 if a.collate == "final" else a.steps,
+               "elapsed_s": float(el.item())}, rank, world > 1)           # (the same exit sequence as the measured runs)
     if not ok:
         raise SystemExit(1)
 

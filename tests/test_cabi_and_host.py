@@ -253,6 +253,7 @@ def test_bench_self_launches_for_gpus_2():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
+    assert [l for l in r.stdout.splitlines() if l.strip()][-1] == lines[0], r.stdout        # ... and it is the LAST thing on stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["global_pairs"] == 10 and rec["collated_in_order"] is True
 
